@@ -1,0 +1,37 @@
+"""Shared helpers for the parity tests: rebuild the synthetic weights a fixture was made with."""
+import json
+
+import numpy as np
+
+from gaudi_amd import synth
+
+TINY = dict(nf=32, n_layers=2)
+TINY_P = dict(nf=36, n_layers=3)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def cfg_of(fix, name):
+    return json.loads(str(fix[name + "_cfg"]))
+
+
+def edm_from_cfg(cfg, **extra):
+    over = dict(cfg.get("over", {}))
+    over.update(extra)
+    args = synth.edm_args(dataset=cfg["dataset"], **over)
+    F = synth.num_node_features(cfg["dataset"])
+    sd = synth.synth_edm_state_dict(args, F, seed=cfg.get("wseed", cfg.get("eseed")), amplify_coord=cfg.get("amp", False))
+    return args, sd
+
+
+def pred_from_cfg(cfg, K=5, **extra):
+    over = dict(cfg.get("over", {}))
+    over.update(extra)
+    args = synth.pred_args(dataset=cfg["dataset"], **over)
+    F = synth.num_node_features(cfg["dataset"])
+    sd = synth.synth_predictor_state_dict(args, F, K, seed=cfg.get("wseed", cfg.get("pseed")), amplify_coord=cfg.get("amp", False))
+    return args, sd

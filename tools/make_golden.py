@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (read-only, /root/reference) on CPU.
+
+Runs only in the build container (the GPU box has no /root/reference).  Nothing from the
+reference is copied: it is imported, fed seeded synthetic weights (gaudi_amd.synth) and
+injected noise, and only numeric inputs/outputs are stored.  Recipe = SURVEY.md Appendix A.
+
+    python tools/make_golden.py            # rewrites every fixture
+"""
+import json
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+for m in ["rdkit", "rdkit.Chem", "rdkit.Chem.Draw", "rdkit.Chem.rdmolops", "rdkit.Chem.rdchem",
+          "rdkit.Chem.AllChem", "imageio", "torch.utils.tensorboard"]:
+    sys.modules[m] = MagicMock()
+
+import torch  # noqa: E402
+
+import models_edm  # noqa: E402  (reference)
+import sampling_edm as ref_sampling  # noqa: E402  (reference)
+from cond_prediction.train_cond_predictor import get_cond_predictor_model  # noqa: E402
+from cond_prediction.prediction_args import PredictionArgs  # noqa: E402
+from utils.args_edm import Args_EDM  # noqa: E402
+from utils.helpers import switch_grad_off  # noqa: E402
+
+from gaudi_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+META = dict(torch=torch.__version__, numpy=np.__version__, threads=torch.get_num_threads())
+
+
+class FakeDataset:
+    def __init__(self, F, K):
+        self.num_node_features = F
+        self.num_targets = K
+        self.mean = torch.zeros(K)
+        self.std = torch.ones(K)
+
+
+class FakeLoader:
+    def __init__(self, F, K):
+        self.dataset = FakeDataset(F, K)
+
+
+class InjectNoise:
+    """Replace torch.randn by a queue of pre-drawn tensors (call order: x-noise then h-noise)."""
+
+    def __init__(self, eps_list):
+        # eps_list: list of [B,N,3+F] arrays, one per sample_combined_position_feature_noise call
+        self.q = []
+        for e in eps_list:
+            e = torch.from_numpy(np.ascontiguousarray(e))
+            self.q.append(e[:, :, :3].contiguous())
+            self.q.append(e[:, :, 3:].contiguous())
+        self.orig = None
+
+    def __enter__(self):
+        self.orig = torch.randn
+
+        def fake(size, device=None, **kw):
+            t = self.q.pop(0)
+            assert tuple(t.shape) == tuple(size), (t.shape, size)
+            return t.clone()
+
+        torch.randn = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.randn = self.orig
+        assert not self.q, f"{len(self.q)} injected tensors unused"
+
+
+def build_ref_edm(dataset, sd_np, **over):
+    a = Args_EDM().parse_args([])
+    a.device = torch.device("cpu")
+    a.dp = False
+    a.restore = None
+    a.dataset = dataset
+    for k, v in over.items():
+        setattr(a, k, v)
+    F = synth.num_node_features(dataset)
+    model, _, prop = models_edm.get_model(a, FakeLoader(F, 5), only_norm=True)
+    full = model.state_dict()
+    for k, v in sd_np.items():
+        assert k in full and tuple(full[k].shape) == v.shape, k
+        full[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(full)
+    switch_grad_off([model])
+    return a, model
+
+
+def build_ref_pred(dataset, sd_np, K=5, **over):
+    a = PredictionArgs().parse_args([])
+    a.device = torch.device("cpu")
+    a.dp = False
+    a.restore = None
+    a.dataset = dataset
+    for k, v in over.items():
+        setattr(a, k, v)
+    F = synth.num_node_features(dataset)
+    pred = get_cond_predictor_model(a, FakeDataset(F, K))
+    full = pred.state_dict()
+    assert set(full.keys()) == set(sd_np.keys()), set(full.keys()) ^ set(sd_np.keys())
+    pred.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    switch_grad_off([pred])
+    return a, pred
+
+
+def masks(dataset, nodesxsample, max_nodes):
+    """Reference mask construction, run through the reference's own code by calling
+    sample_guidance / sample_pos_edm with a recording fake model."""
+    rec = {}
+
+    class Rec:
+        def sample(self, B, n_nodes, node_mask, edge_mask, std=1.0):
+            rec.update(node_mask=node_mask.numpy().copy(), edge_mask=edge_mask.numpy().copy())
+            x = torch.zeros(B, n_nodes, 3)
+            return x, {"categorical": torch.zeros(B, n_nodes, 1)}
+
+        def sample_guidance(self, B, tf, node_mask, edge_mask, scale, fix_noise=False, std=1.0):
+            rec.update(node_mask=node_mask.numpy().copy(), edge_mask=edge_mask.numpy().copy())
+            x = torch.zeros(B, node_mask.shape[1], 3)
+            return x, {"categorical": torch.zeros(B, node_mask.shape[1], 1)}
+
+    class A:
+        pass
+
+    a = A()
+    a.device = torch.device("cpu")
+    a.dataset = dataset
+    a.max_nodes = max_nodes
+    n = torch.tensor(nodesxsample).long()
+    if max_nodes is None:
+        ref_sampling.sample_guidance(a, Rec(), None, n)
+    else:
+        ref_sampling.sample_pos_edm(a, Rec(), n)
+    return rec["node_mask"], rec["edge_mask"]
+
+
+def rng_noise(seed, shape):
+    return np.random.Generator(np.random.Philox(key=seed)).standard_normal(shape).astype(np.float32)
+
+
+def save(name, **arrs):
+    arrs["meta"] = np.array(json.dumps(META))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------------------
+def g1_schedule():
+    out = {}
+    for T in (50, 1000):
+        sd = synth.synth_edm_state_dict(synth.edm_args(nf=8, n_layers=1), 1, seed=0)
+        a, model = build_ref_edm("cata", sd, nf=8, n_layers=1, diffusion_steps=T)
+        gamma = model.gamma.gamma.numpy().copy()
+        out[f"gamma_T{T}"] = gamma
+        rows = []
+        for s in ([0, 1, T // 2, T - 2, T - 1]):
+            st = torch.full((1, 1), s) / T
+            tt = (torch.full((1, 1), s) + 1) / T
+            gs, gt = model.gamma(st), model.gamma(tt)
+            zt = torch.zeros(1, 1, 1)
+            s2, s_ts, a_ts = model.sigma_and_alpha_t_given_s(gt, gs, zt)
+            sig_s, sig_t = model.sigma(gs, zt), model.sigma(gt, zt)
+            rows.append([s, a_ts.item(), s2.item(), (s2 / a_ts / sig_t).item(), (s_ts * sig_s / sig_t).item(),
+                         sig_s.item(), sig_t.item(), tt.item()])
+        out[f"coef_T{T}"] = np.array(rows, dtype=np.float64)
+    save("g1_schedule", **out)
+
+
+def g2_masks():
+    out = {}
+    nm, em = masks("cata", [4, 11, 7, 1], 11)
+    out["cata_n"] = np.array([4, 11, 7, 1])
+    out["cata_node_mask"], out["cata_edge_mask"] = nm, em
+    nm, em = masks("hetro", [3, 5, 10, 7], 10)
+    out["hetro_pos_n"] = np.array([3, 5, 10, 7])
+    out["hetro_pos_node_mask"], out["hetro_pos_edge_mask"] = nm, em
+    nm, em = masks("hetro", [3, 5, 9, 7], None)  # sample_guidance pads to batch max (9 -> N=18)
+    out["hetro_guid_n"] = np.array([3, 5, 9, 7])
+    out["hetro_guid_node_mask"], out["hetro_guid_edge_mask"] = nm, em
+    nm, em = masks("cata", [6, 8, 8], None)
+    out["cata_guid_n"] = np.array([6, 8, 8])
+    out["cata_guid_node_mask"], out["cata_guid_edge_mask"] = nm, em
+    save("g2_masks", **out)
+
+
+TINY = dict(nf=32, n_layers=2)
+TINY_P = dict(nf=36, n_layers=3)  # 36: not a multiple of 16 -> exercises feature padding
+
+
+def case_inputs(dataset, nodes, max_nodes, seed, guidance_pad=False):
+    nm, em = masks(dataset, nodes, None if guidance_pad else max_nodes)
+    B, N, _ = nm.shape
+    F = synth.num_node_features(dataset)
+    z = rng_noise(seed, (B, N, 3 + F)) * nm
+    z[:, :, :3] -= (z[:, :, :3].sum(1, keepdims=True) / np.maximum(nm.sum(1, keepdims=True), 1)) * nm
+    return nm, em, z.astype(np.float32)
+
+
+def g3_phi():
+    out = {}
+    cases = [
+        ("cata_tiny", "cata", [4, 11, 7, 1, 11], 11, TINY, False),
+        ("cata_tiny_amp", "cata", [4, 11, 7, 2, 11], 11, TINY, True),
+        ("hetro_tiny_amp", "hetro", [3, 5, 10, 7], 10, TINY, True),
+        ("cata_tiny_sub2_amp", "cata", [5, 9, 11], 11, dict(nf=32, n_layers=2, inv_sublayers=2,
+                                                            normalization_factor=3.0, norm_constant=0.5), True),
+        ("cata_full", "cata", [11, 8, 11], 11, dict(nf=192, n_layers=9), False),
+        ("hetro_full_amp", "hetro", [10, 6], 10, dict(nf=192, n_layers=9), True),
+    ]
+    for i, (name, ds, nodes, mx, over, amp) in enumerate(cases):
+        F = synth.num_node_features(ds)
+        args = synth.edm_args(dataset=ds, **over)
+        sd = synth.synth_edm_state_dict(args, F, seed=100 + i, amplify_coord=amp)
+        a, model = build_ref_edm(ds, sd, **over)
+        nm, em, z = case_inputs(ds, nodes, mx, seed=200 + i)
+        B = z.shape[0]
+        t = np.linspace(0.05, 0.95, B).astype(np.float32).reshape(B, 1)
+        with torch.no_grad():
+            eps = model.phi(torch.from_numpy(z), torch.from_numpy(t), torch.from_numpy(nm),
+                            torch.from_numpy(em), None).numpy()
+        out[name + "_cfg"] = np.array(json.dumps(dict(dataset=ds, over=over, amp=amp, wseed=100 + i)))
+        out[name + "_z"], out[name + "_t"] = z, t
+        out[name + "_node_mask"], out[name + "_edge_mask"] = nm, em
+        out[name + "_eps"] = eps
+    save("g3_phi", **out)
+
+
+TARGETS = {
+    "gap": lambda pred, prop: -pred[:, 1],
+    "opv": lambda pred, prop: (lambda u: u[:, 3] + u[:, 2] + 3 * u[:, 0])(pred * prop["std"] + prop["mean"]),
+}
+
+
+def g4_predictor():
+    out = {}
+    cases = [
+        ("cata_tiny_amp", "cata", [4, 11, 7, 1, 11], 11, TINY_P, True, False),
+        ("hetro_tiny_amp", "hetro", [3, 5, 9, 7], None, TINY_P, True, True),
+        ("cata_full", "cata", [11, 9], 11, dict(nf=196, n_layers=12), False, False),
+        ("hetro_full_amp", "hetro", [10, 4], 10, dict(nf=196, n_layers=12), True, False),
+    ]
+    prop = dict(mean=torch.tensor([0.3, -1.0, 0.5, 2.0, 0.1]), std=torch.tensor([1.5, 0.7, 2.0, 0.9, 1.1]))
+    for i, (name, ds, nodes, mx, over, amp, gpad) in enumerate(cases):
+        F = synth.num_node_features(ds)
+        pargs = synth.pred_args(dataset=ds, **over)
+        sd = synth.synth_predictor_state_dict(pargs, F, 5, seed=300 + i, amplify_coord=amp)
+        a, pred = build_ref_pred(ds, sd, **over)
+        nm, em, z = case_inputs(ds, nodes, mx, seed=400 + i, guidance_pad=gpad)
+        B = z.shape[0]
+        t = np.full((B, 1), 0.37, np.float32)
+        zt = torch.from_numpy(z).requires_grad_()
+        p = pred(zt, torch.from_numpy(nm), torch.from_numpy(em), torch.from_numpy(t))
+        out[name + "_pred"] = p.detach().numpy()
+        for tn, tf in TARGETS.items():
+            energy = (0.6 * tf(p, prop)).sum()
+            g = torch.autograd.grad(energy, zt, retain_graph=True)[0]
+            out[f"{name}_grad_{tn}"] = g.numpy()
+        out[name + "_cfg"] = np.array(json.dumps(dict(dataset=ds, over=over, amp=amp, wseed=300 + i)))
+        out[name + "_z"], out[name + "_t"] = z, t
+        out[name + "_node_mask"], out[name + "_edge_mask"] = nm, em
+    out["prop_mean"], out["prop_std"] = prop["mean"].numpy(), prop["std"].numpy()
+    out["scale"] = np.float32(0.6)
+    save("g4_predictor", **out)
+
+
+def g5_steps():
+    """Teacher-forced reverse steps (unguided + guided) at several t, tiny configs."""
+    out = {}
+    T = 1000
+    for ci, (name, ds, nodes) in enumerate([("cata", "cata", [4, 11, 7, 11]), ("hetro", "hetro", [3, 9, 6])]):
+        F = synth.num_node_features(ds)
+        eargs = synth.edm_args(dataset=ds, **TINY)
+        esd = synth.synth_edm_state_dict(eargs, F, seed=500 + ci, amplify_coord=True)
+        a, model = build_ref_edm(ds, esd, **TINY)
+        pargs = synth.pred_args(dataset=ds, **TINY_P)
+        psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=510 + ci, amplify_coord=True)
+        pa, pred = build_ref_pred(ds, psd, **TINY_P)
+        nm, em, z = case_inputs(ds, nodes, None, seed=520 + ci, guidance_pad=True)
+        B, N, D = z.shape
+        tnm, tem = torch.from_numpy(nm), torch.from_numpy(em)
+
+        def tf_gap(_in, _nm, _em, _t):
+            return -pred(_in, _nm, _em, _t)[:, 1]
+
+        out[f"{name}_z"], out[f"{name}_node_mask"], out[f"{name}_edge_mask"] = z, nm, em
+        for s in (0, 1, 500, 998, 999):
+            eps = rng_noise(600 + 10 * ci + s % 7, (B, N, D))
+            st = torch.full((B, 1), s) / T
+            tt = (torch.full((B, 1), s) + 1) / T
+            with InjectNoise([eps]), torch.no_grad():
+                zs = model.sample_p_zs_given_zt(st, tt, torch.from_numpy(z), tnm, tem, None).numpy()
+            out[f"{name}_s{s}_eps"] = eps
+            out[f"{name}_s{s}_zs_unguided"] = zs
+            for scale in (0.6, 400.0):  # 400: forces the ||g||>10 clip branch
+                with InjectNoise([eps]), torch.no_grad():
+                    zg = model.sample_p_zs_given_zt_guidance(st, tt, torch.from_numpy(z), tnm, tem, tf_gap,
+                                                             scale).numpy()
+                out[f"{name}_s{s}_zs_guided_scale{scale}"] = zg
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, eseed=500 + ci, pseed=510 + ci, T=T)))
+    save("g5_steps", **out)
+
+
+def g6_decode():
+    out = {}
+    for ci, (name, ds, nodes) in enumerate([("cata", "cata", [4, 11, 7]), ("hetro", "hetro", [3, 9, 6])]):
+        F = synth.num_node_features(ds)
+        esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **TINY), F, seed=700 + ci, amplify_coord=True)
+        a, model = build_ref_edm(ds, esd, **TINY)
+        nm, em, z = case_inputs(ds, nodes, None, seed=720 + ci, guidance_pad=True)
+        eps = rng_noise(730 + ci, z.shape)
+        with InjectNoise([eps]), torch.no_grad():
+            x, h = model.sample_p_xh_given_z0(torch.from_numpy(z), torch.from_numpy(nm), torch.from_numpy(em), None)
+        out[f"{name}_z"], out[f"{name}_node_mask"], out[f"{name}_edge_mask"], out[f"{name}_eps"] = z, nm, em, eps
+        out[f"{name}_x"], out[f"{name}_h"] = x.numpy(), h["categorical"].numpy().astype(np.float32)
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, eseed=700 + ci)))
+    save("g6_decode", **out)
+
+
+def g7_end_to_end():
+    """C1: cata, 4 rings padded to 11, B=8, T=50, unguided, default architecture and default
+    init (+ tiny guided T=50 variants).  Entry points: the reference's sample_pos_edm /
+    sample_guidance with torch.randn injected."""
+    out = {}
+    # --- C1 (full default architecture, default init, std=1.0)
+    T = 50
+    over = dict(diffusion_steps=T)
+    eargs = synth.edm_args(**over)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=0)
+    a, model = build_ref_edm("cata", esd, **over)
+    a.max_nodes = 11
+    B, N, D = 8, 11, 4
+    noise = rng_noise(1, (T + 2, B, N, D))
+    with InjectNoise(list(noise)):
+        x, h, nm, em = ref_sampling.sample_pos_edm(a, model, torch.tensor([4] * B), std=1.0)
+    out["c1_noise"], out["c1_x"], out["c1_h"] = noise, x.numpy(), h.numpy().astype(np.float32)
+    out["c1_node_mask"], out["c1_edge_mask"] = nm.numpy(), em.numpy()
+    out["c1_cfg"] = np.array(json.dumps(dict(dataset="cata", T=T, eseed=0, nodes=[4] * B, std=1.0)))
+
+    # --- tiny guided / unguided chains, amplified coordinate heads, T=50
+    for ci, (name, ds, nodes, amp) in enumerate([("cata_tiny", "cata", [6, 8, 8, 3], False),
+                                                 ("hetro_tiny", "hetro", [3, 5, 4], False),
+                                                 ("cata_tiny_amp", "cata", [6, 8, 8, 3], True)]):
+        F = synth.num_node_features(ds)
+        over = dict(diffusion_steps=T, **TINY)
+        esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=800 + ci, amplify_coord=amp)
+        a, model = build_ref_edm(ds, esd, **over)
+        psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **TINY_P), F, 5, seed=810 + ci,
+                                               amplify_coord=amp)
+        pa, pred = build_ref_pred(ds, psd, **TINY_P)
+
+        def tf_gap(_in, _nm, _em, _t):
+            return -pred(_in, _nm, _em, _t)[:, 1]
+
+        n = torch.tensor(nodes)
+        Nn = max(nodes) * (2 if ds != "cata" else 1)
+        noise = rng_noise(820 + ci, (T + 2, len(nodes), Nn, 3 + F))
+        with InjectNoise(list(noise)):
+            x, h, nm, em = ref_sampling.sample_guidance(a, model, tf_gap, n, scale=0.6, std=1.0)
+        out[f"{name}_noise"] = noise
+        out[f"{name}_x_guided"], out[f"{name}_h_guided"] = x.numpy(), h.numpy().astype(np.float32)
+        out[f"{name}_node_mask"], out[f"{name}_edge_mask"] = nm.numpy(), em.numpy()
+        a.max_nodes = max(nodes)
+        with InjectNoise(list(noise)):
+            x, h, nm2, em2 = ref_sampling.sample_pos_edm(a, model, n, std=0.7)
+        assert np.array_equal(nm2.numpy(), nm.numpy())
+        out[f"{name}_x_unguided"], out[f"{name}_h_unguided"] = x.numpy(), h.numpy().astype(np.float32)
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, T=T, eseed=800 + ci, pseed=810 + ci,
+                                                      nodes=nodes, amp=amp)))
+    save("g7_end_to_end", **out)
+
+
+def g8_checkpoint_roundtrip():
+    """The reference's own loader must accept checkpoints written by gaudi_amd.synth.write_checkpoint
+    (args.txt + model.pt, with and without the ``module.`` prefix).  Stores nothing but a marker."""
+    import tempfile
+    from utils.helpers import get_edm_args
+
+    for dp in (True, False):
+        with tempfile.TemporaryDirectory() as d:
+            args = synth.edm_args(dp=dp, **TINY)
+            sd = synth.synth_edm_state_dict(args, 1, seed=5)
+            a0, m0 = build_ref_edm("cata", sd, **TINY)
+            sd["gamma.gamma"] = m0.gamma.gamma.numpy().copy()
+            synth.write_checkpoint(d, args, sd)
+            a = get_edm_args(d)
+            a.device = torch.device("cpu")
+            model, _, _ = models_edm.get_model(a, FakeLoader(1, 5), only_norm=True)
+            got = model.state_dict()
+            pre = "module." if dp else ""
+            for k, v in sd.items():
+                assert np.array_equal(got[pre + k].numpy(), v), k
+    print("g8: reference loader accepts synth checkpoints (dp=True/False)")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip)
+    for w in which:
+        fns[w]()
