@@ -1,0 +1,88 @@
+"""ctypes binding of libgaudi_hip.so (include/gaudi_hip.h).  There is NO CPU fallback: if the HIP
+library is missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgaudi_hip.so")
+
+
+class GaudiError(RuntimeError):
+    pass
+
+
+class EdmConfig(C.Structure):
+    _fields_ = [("in_node_nf", C.c_int32), ("hidden_nf", C.c_int32), ("n_layers", C.c_int32),
+                ("inv_sublayers", C.c_int32), ("attention", C.c_int32), ("tanh", C.c_int32),
+                ("coords_range", C.c_float), ("norm_constant", C.c_float), ("normalization_factor", C.c_float),
+                ("diffusion_steps", C.c_int32), ("noise_power", C.c_float), ("noise_precision", C.c_float),
+                ("norm_values", C.c_float * 3)]
+
+
+class PredConfig(C.Structure):
+    _fields_ = [("in_nf", C.c_int32), ("out_nf", C.c_int32), ("hidden_nf", C.c_int32), ("n_layers", C.c_int32),
+                ("attention", C.c_int32), ("tanh", C.c_int32), ("coords_range", C.c_float)]
+
+
+class Diag(C.Structure):
+    _fields_ = [("max_masked_leak", C.c_float), ("max_cog_rel", C.c_float), ("max_cog_abs", C.c_float),
+                ("nan_count", C.c_int32), ("reprojected", C.c_int32)]
+
+
+FP = C.POINTER(C.c_float)
+EXPORTS = {
+    "gaudi_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "gaudi_destroy": (None, [C.c_void_p]),
+    "gaudi_last_error": (C.c_char_p, [C.c_void_p]),
+    "gaudi_load_edm": (C.c_int, [C.c_void_p, C.POINTER(EdmConfig), C.c_int, C.POINTER(C.c_char_p), C.POINTER(FP),
+                                 C.POINTER(C.c_int64)]),
+    "gaudi_load_predictor": (C.c_int, [C.c_void_p, C.POINTER(PredConfig), C.c_int, C.POINTER(C.c_char_p),
+                                       C.POINTER(FP), C.POINTER(C.c_int64)]),
+    "gaudi_get_gamma": (C.c_int, [C.c_void_p, FP]),
+    "gaudi_get_step_coefficients": (C.c_int, [C.c_void_p, FP]),
+    "gaudi_phi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, FP, FP, FP]),
+    "gaudi_predictor_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, FP, FP, FP]),
+    "gaudi_predictor_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, FP, FP, FP, FP, FP]),
+    "gaudi_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, FP, FP, FP, FP, FP, C.c_float, FP]),
+    "gaudi_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, FP, FP, FP, FP]),
+    "gaudi_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, FP,
+                               C.c_float, FP, FP, FP, C.POINTER(Diag)]),
+    "gaudi_philox_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, FP]),
+    "gaudi_profile_reset": (C.c_int, [C.c_void_p, C.c_int]),
+    "gaudi_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "gaudi_set_steps_per_launch": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree library and bind every symbol of include/gaudi_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GaudiError(f"{LIB_PATH} not found: build it with `python -m gaudi_amd.build` "
+                         "(there is no CPU fallback for the sampler)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def fptr(a: np.ndarray | None):
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(FP)
+
+
+def f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))

@@ -1,0 +1,305 @@
+// device_common.h -- shared device helpers for the gfx950 GaUDI sampler kernels.
+//
+// Execution model: ONE workgroup (4 waves, 256 threads) owns ONE molecule for the
+// whole launch.  All dense contractions run on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 fma chains, same peak as the vector ALUs) in the
+// orientation   D[feature][col] += W[feature][k] * act[k][col]
+// i.e. weights are the MFMA A operand (streamed from L2 in a tile-packed layout, 1 KiB
+// contiguous per wave-instruction) and activations are the B operand with graph NODES or EDGES
+// on the 16 MFMA columns (= lanes & 15).  In this orientation the C/D layout of one GEMM
+// (lane = column, 4 regs = 4 consecutive features 16t+4g..) is exactly the B layout the next
+// GEMM needs, so per-edge MLP chains never leave registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gaudi {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 4;
+constexpr int kThreads = 256;
+constexpr int kPF = 4;  // weight-tile prefetch depth (float4 per lane each)
+
+__host__ __device__ constexpr int align16(int n) { return (n + 15) & ~15; }
+__host__ __device__ constexpr int pad_hidden(int h) { return (h + 15) & ~15; }
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+// d/dx silu(x) = s * (1 + x * (1 - s))
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = sigmoid_f(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ f4 silu4(f4 u) {
+  f4 r;
+  r[0] = silu_f(u[0]); r[1] = silu_f(u[1]); r[2] = silu_f(u[2]); r[3] = silu_f(u[3]);
+  return r;
+}
+__device__ __forceinline__ f4 splat(float v) { return (f4){v, v, v, v}; }
+
+__device__ __forceinline__ f4 mfma4(f4 w, f4 b, f4 acc) {
+  // 4 k-steps: the A fragment holds W[row = lane&15][k = 4*(lane>>4) + q], the B fragment the
+  // activation of column lane&15 at the same k (k order inside a 16-chunk is permuted
+  // consistently on both operands, which only changes the summation order).
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], b[3], acc, 0, 0, 0);
+  return acc;
+}
+
+// sum over the 4 lane groups g = lane>>4 (same column), result in every lane
+__device__ __forceinline__ float reduce_groups(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving
+  // LDS accesses across and drains the LDS queue.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node-level GEMM:  Y[n][o] = epi( sum_k Wa[o][k] Xa[n][k] (+ sum_k Wb[o][k] Xb[n][k]) + bias[o] )
+// X*, Y live in LDS ([N][LD] row major, LD = HP+4).  W* are tile-packed [HP/16][HP/16][16][16].
+// Wave w produces output-feature tiles t = w, w+4, ... for every node tile, so every weight
+// element is fetched by exactly one wave of the workgroup.
+// ---------------------------------------------------------------------------------------------
+enum NodeEpi { EPI_NONE = 0, EPI_SILU = 1, EPI_RESIDUAL_MASK = 2 };
+
+template <int HP, int EPI>
+__device__ __forceinline__ void node_gemm(const float* __restrict__ Wa, const float* sXa,
+                                          const float* __restrict__ Wb, const float* sXb,
+                                          const float* __restrict__ bias, float* sY, const float* sRes,
+                                          const float* sMask, int N, int wave, int lane) {
+  constexpr int T = HP / 16;
+  constexpr int LD = HP + 4;
+  constexpr int UT = (T + kWaves - 1) / kWaves;
+  const int c = lane & 15, g = lane >> 4;
+  const int n_tiles = (N + 15) >> 4;
+  for (int nt = 0; nt < n_tiles; ++nt) {
+    const int node = nt * 16 + c;
+    const int nclamp = node < N ? node : N - 1;
+    f4 acc[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int t = wave + kWaves * u;
+      acc[u] = (bias != nullptr && t < T) ? *(const f4*)(bias + 16 * t + 4 * g) : splat(0.f);
+    }
+#pragma unroll
+    for (int src = 0; src < 2; ++src) {
+      const float* __restrict__ W = src == 0 ? Wa : Wb;
+      const float* sX = src == 0 ? sXa : sXb;
+      if (W == nullptr) continue;
+      const f4* W4 = (const f4*)W + c * 4 + g;
+      const float* xrow = sX + nclamp * LD + 4 * g;
+#pragma unroll 4
+      for (int cc = 0; cc < T; ++cc) {
+        const f4 b4 = *(const f4*)(xrow + 16 * cc);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          const int t = wave + kWaves * u;
+          if (t < T) {
+            const f4 w4 = W4[(cc * T + t) * 64];
+            acc[u] = mfma4(w4, b4, acc[u]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int t = wave + kWaves * u;
+      if (t < T && node < N) {
+        f4 y = acc[u];
+        float* dst = sY + node * LD + 16 * t + 4 * g;
+        if (EPI == EPI_SILU) y = silu4(y);
+        if (EPI == EPI_RESIDUAL_MASK) {
+          const f4 r = *(const f4*)(sRes + node * LD + 16 * t + 4 * g);
+          y = (r + y) * sMask[node];
+        }
+        *(f4*)dst = y;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Edge-level GEMM core for TWO 16-edge tiles owned by one wave:
+//   acc[e][t] (features 16t+4g+q of edge column c) = b2 + W2 . silu(u_e)
+//   u_e[f] = P[i_e][f] + Q[j_e][f] + cr[f] * r_e + cd[f] * d0_e        (b1 is folded into P)
+// which is Linear(2H+2 -> H) of [h_i | h_j | r | d0] factorised per node (exact algebra; only the
+// fp32 summation order differs from the reference's concat+Linear: egnn_new.py:42-47,119-129;
+// egnn_predictor/gcl.py:225-231).  U (optional) receives u for the backward pass.
+// ---------------------------------------------------------------------------------------------
+struct EdgeCols {
+  int i0, j0, i1, j1;        // node indices of the lane's edge column in tile 0 / tile 1
+  float r0, d00, r1, d01;    // radial (current x) and d0 (input x) of those edges
+};
+
+template <int HP>
+__device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[2][HP / 16], const float* __restrict__ W2p,
+                                                  const float* __restrict__ b2, const float* __restrict__ cr,
+                                                  const float* __restrict__ cd, const float* sP, const float* sQ,
+                                                  const EdgeCols& ec, int lane) {
+  constexpr int T = HP / 16;
+  constexpr int LD = HP + 4;
+  constexpr int PF = kPF < T ? kPF : T;
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const f4 b = *(const f4*)(b2 + 16 * t + 4 * g);
+    acc[0][t] = b;
+    acc[1][t] = b;
+  }
+  const float* p0 = sP + ec.i0 * LD + 4 * g;
+  const float* q0 = sQ + ec.j0 * LD + 4 * g;
+  const float* p1 = sP + ec.i1 * LD + 4 * g;
+  const float* q1 = sQ + ec.j1 * LD + 4 * g;
+  const float* crg = cr + 4 * g;
+  const float* cdg = cd + 4 * g;
+  auto gen = [&](int cc, f4& o0, f4& o1) {
+    const f4 crv = *(const f4*)(crg + 16 * cc);
+    const f4 cdv = *(const f4*)(cdg + 16 * cc);
+    const f4 u0 = *(const f4*)(p0 + 16 * cc) + *(const f4*)(q0 + 16 * cc) + crv * ec.r0 + cdv * ec.d00;
+    const f4 u1 = *(const f4*)(p1 + 16 * cc) + *(const f4*)(q1 + 16 * cc) + crv * ec.r1 + cdv * ec.d01;
+    o0 = silu4(u0);
+    o1 = silu4(u1);
+  };
+  const f4* W4 = (const f4*)W2p + c * 4 + g;
+  f4 wq[PF];
+#pragma unroll
+  for (int p = 0; p < PF; ++p) wq[p] = W4[p * 64];
+  f4 bin0, bin1;
+  gen(0, bin0, bin1);
+  // K loop stays rolled (one 16-feature chunk per trip): the weight tiles of the next chunk are
+  // prefetched by the tail of this one (rotating queue) and the next chunk's activations are
+  // generated under this chunk's MFMAs.
+#pragma unroll 1
+  for (int cc = 0; cc < T; ++cc) {
+    f4 nb0 = bin0, nb1 = bin1;
+    const f4* Wc = W4 + (size_t)cc * T * 64;
+    f4 r[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) r[p] = wq[p];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const f4 w = r[t % PF];
+      // tile index cc*T + t + PF (clamped at the end of the matrix; the surplus loads are unused)
+      const int nxt = (cc * T + t + PF < T * T) ? (t + PF) : t;
+      r[t % PF] = Wc[nxt * 64];
+      acc[0][t] = mfma4(w, bin0, acc[0][t]);
+      acc[1][t] = mfma4(w, bin1, acc[1][t]);
+      if (t == 0 && cc + 1 < T) gen(cc + 1, nb0, nb1);
+    }
+#pragma unroll
+    for (int p = 0; p < PF; ++p) wq[p] = r[(p + T) % PF];
+    bin0 = nb0;
+    bin1 = nb1;
+  }
+}
+
+// Edge-level GEMM whose input already sits in registers in C/B layout (chained MLP layer):
+//   out[e][t] = init[t] + W . in[e]      in[e][cc] = features 16cc+4g+q of edge column c
+template <int HP>
+__device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[2][HP / 16], const f4 (&in)[2][HP / 16],
+                                                    const float* __restrict__ Wp, const float* __restrict__ bias,
+                                                    int lane) {
+  constexpr int T = HP / 16;
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const f4 b = bias != nullptr ? *(const f4*)(bias + 16 * t + 4 * g) : splat(0.f);
+    out[0][t] = b;
+    out[1][t] = b;
+  }
+  const f4* W4 = (const f4*)Wp + c * 4 + g;
+  f4 wq[kPF];
+#pragma unroll
+  for (int p = 0; p < kPF; ++p) wq[p] = W4[p * 64];
+#pragma unroll
+  for (int idx = 0; idx < T * T; ++idx) {
+    const int cc = idx / T, t = idx % T;
+    const f4 w = wq[idx % kPF];
+    if (idx + kPF < T * T) wq[idx % kPF] = W4[(idx + kPF) * 64];
+    out[0][t] = mfma4(w, in[0][cc], out[0][t]);
+    out[1][t] = mfma4(w, in[1][cc], out[1][t]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Segmented edge->node sum ("scatter_add over row", egnn_new.py:403-414): the wave owns every
+// edge of the nodes it serves and its edge list is sorted by receiving node, so the sum is a
+// run-length reduction: the 16x HP tile is bounced through the wave's private LDS scratch and
+// lanes 0..HP/4-1 accumulate 4 features each down the 16 edge slots, flushing a node's sum
+// when the (wave-uniform) node id changes.  No atomics, fixed order (ascending j like the
+// reference's CPU scatter).
+// ---------------------------------------------------------------------------------------------
+template <int HP>
+struct SegSum {
+  f4 run;
+  int cur;
+  __device__ __forceinline__ void init() { run = splat(0.f); cur = -1; }
+  __device__ __forceinline__ void flush(float* sOut, float div, int lane) {
+    constexpr int LD = HP + 4;
+    if (cur >= 0 && lane < HP / 4) *(f4*)(sOut + cur * LD + 4 * lane) = run / div;
+  }
+  // scr: [16][LD] tile written as scr[col][feature]; node_of_col: value held by lane k = node of column k
+  __device__ __forceinline__ void add_tile(const float* scr, int node_of_col, float* sOut, float div, int lane) {
+    constexpr int LD = HP + 4;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int nk = __builtin_amdgcn_readlane(node_of_col, k);
+      if (nk != cur) {
+        flush(sOut, div, lane);
+        run = splat(0.f);
+        cur = nk;
+      }
+      if (lane < HP / 4) run += *(const f4*)(scr + k * LD + 4 * lane);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG + Box-Muller.  One call -> 4 standard normals.
+// key = seed, counter = (quad index inside the sample's [N*D] draw, draw index, global sample lo/hi)
+// so the stream is independent of batch sharding.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ inline f4 philox_normal4(uint64_t seed, uint64_t sample, uint32_t draw, uint32_t quad) {
+  uint32_t r[4];
+  philox4x32_10(quad, draw, (uint32_t)sample, (uint32_t)(sample >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const float k2m32 = 2.3283064365386963e-10f;  // 2^-32
+  const float u1 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+  const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+  const float u3 = ((float)(r[2] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u4 = (float)(r[3] >> 8) * (1.0f / 16777216.0f);
+  (void)k2m32;
+  const float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
+  float sa, ca, sb, cb;
+  sincosf(6.283185307179586f * u2, &sa, &ca);
+  sincosf(6.283185307179586f * u4, &sb, &cb);
+  return (f4){ra * ca, ra * sa, rb * cb, rb * sb};
+}
+
+}  // namespace gaudi

@@ -1,0 +1,289 @@
+// edm_device.h -- EGNN_dynamics._forward (edm/egnn/models.py:83-152, edm/egnn/egnn_new.py) for one
+// molecule held by one workgroup.  Input z and output eps_hat live in LDS.
+#pragma once
+#include "device_common.h"
+
+namespace gaudi {
+
+// Packed EDM weight buffer (floats).  HP = hidden padded to 16, PK = HP*HP (tile-packed matrix).
+//   head : emb_w [HP][F1] | emb_b [HP] | out_w [F1][HP] | out_b [16]
+//   block: S x GCL { A, Bm, W2, Wn1h, Wn1a, Wn2 (6 PK) | cr, cd, b1, b2, wa, bn1, bn2 (7 HP) | ba (16) }
+//          EqU     { A, Bm, W2 (3 PK) | cr, cd, b1, b2, w3 (5 HP) }
+// A/Bm/cr/cd are the column blocks of Linear(2H+2 -> H): W1 = [A | Bm | cr | cd].
+struct EdmLayout {
+  int HP, F1, L, S;
+  __host__ __device__ int pk() const { return HP * HP; }
+  __host__ __device__ int emb_w() const { return 0; }
+  __host__ __device__ int emb_b() const { return align16(HP * F1); }
+  __host__ __device__ int out_w() const { return emb_b() + HP; }
+  __host__ __device__ int out_b() const { return out_w() + align16(F1 * HP); }
+  __host__ __device__ int blocks() const { return out_b() + 16; }
+  __host__ __device__ int gcl_size() const { return 6 * pk() + 7 * HP + 16; }
+  __host__ __device__ int equ_size() const { return 3 * pk() + 5 * HP; }
+  __host__ __device__ int block_size() const { return S * gcl_size() + equ_size(); }
+  __host__ __device__ int gcl(int l, int s) const { return blocks() + l * block_size() + s * gcl_size(); }
+  __host__ __device__ int equ(int l) const { return blocks() + l * block_size() + S * gcl_size(); }
+  __host__ __device__ int total() const { return blocks() + L * block_size(); }
+};
+
+struct EdmDev {
+  const float* w;
+  int F, L, S, attention, use_tanh;
+  float coords_range, norm_constant, normf;
+};
+
+// Per-molecule graph metadata prepared on the host (gaudi_hip.hip: build_meta) and staged in LDS.
+struct MolGraph {
+  int N, D, EW;           // nodes (padded), 3+F, per-wave edge-slot capacity (multiple of 32)
+  const float* mask;      // LDS [N]
+  const uint32_t* edge;   // LDS [4][EW]  i | j<<8
+  const float* em;        // LDS [4][EW]  edge_mask value (0 for padding slots)
+  const uint32_t* seg;    // LDS [N]      wave<<30 | start<<15 | len  (edge run of node n)
+  int npairs;             // 32-edge passes of THIS wave
+};
+
+// LDS working set of one network evaluation
+template <int HP>
+struct NetSmem {
+  float *h, *p, *q, *agg;  // [N][HP+4]
+  float* scr;              // [4][16][HP+4]  per-wave transposition scratch
+  float *x, *x0;           // [N][4]
+  f4* geo;                 // [4][EW] (r, dhat)
+  float* d0;               // [4][EW]
+  float* trans;            // [4][EW][4]
+  __device__ static int floats(int N, int EW) {
+    return 4 * N * (HP + 4) + kWaves * 16 * (HP + 4) + 8 * N + kWaves * EW * 9;
+  }
+  __device__ void carve(float* base, int N, int EW) {
+    constexpr int LD = HP + 4;
+    h = base; base += N * LD;
+    p = base; base += N * LD;
+    q = base; base += N * LD;
+    agg = base; base += N * LD;
+    scr = base; base += kWaves * 16 * LD;
+    x = base; base += 4 * N;
+    x0 = base; base += 4 * N;
+    geo = (f4*)base; base += kWaves * EW * 4;
+    d0 = base; base += kWaves * EW;
+    trans = base;
+  }
+};
+
+__device__ __forceinline__ void edge_ij(uint32_t e, int& i, int& j) { i = e & 255; j = (e >> 8) & 255; }
+
+// r = |x_i - x_j|^2, dhat = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn_new.py:394-400)
+template <int HP>
+__device__ __forceinline__ void compute_geo(const NetSmem<HP>& sm, const MolGraph& mg, float norm_constant, int wave,
+                                            int lane, bool write_d0) {
+  for (int slot = lane; slot < mg.npairs * 32; slot += 64) {
+    int i, j;
+    edge_ij(mg.edge[wave * mg.EW + slot], i, j);
+    const float dx = sm.x[4 * i + 0] - sm.x[4 * j + 0];
+    const float dy = sm.x[4 * i + 1] - sm.x[4 * j + 1];
+    const float dz = sm.x[4 * i + 2] - sm.x[4 * j + 2];
+    const float r = dx * dx + dy * dy + dz * dz;
+    if (write_d0) {
+      sm.d0[wave * mg.EW + slot] = r;
+    } else {
+      const float inv = 1.0f / (sqrtf(r + 1e-8f) + norm_constant);
+      sm.geo[wave * mg.EW + slot] = (f4){r, dx * inv, dy * inv, dz * inv};
+    }
+  }
+}
+
+template <int HP>
+__device__ __forceinline__ EdgeCols load_cols(const NetSmem<HP>& sm, const MolGraph& mg, int wave, int tp, int c,
+                                              float& m0, float& m1, f4& g0, f4& g1) {
+  const int s0 = wave * mg.EW + tp * 32 + c, s1 = s0 + 16;
+  EdgeCols ec;
+  edge_ij(mg.edge[s0], ec.i0, ec.j0);
+  edge_ij(mg.edge[s1], ec.i1, ec.j1);
+  m0 = mg.em[s0];
+  m1 = mg.em[s1];
+  g0 = sm.geo[s0];
+  g1 = sm.geo[s1];
+  ec.r0 = g0[0];
+  ec.r1 = g1[0];
+  ec.d00 = sm.d0[s0];
+  ec.d01 = sm.d0[s1];
+  return ec;
+}
+
+// x <- (x + sum_j trans_ij / normf) * mask     (egnn_new.py:132-155), fixed ascending-j order
+template <int HP>
+__device__ __forceinline__ void coord_update(const NetSmem<HP>& sm, const MolGraph& mg, float normf, int tid) {
+  if (tid < mg.N * 3) {
+    const int n = tid / 3, d = tid % 3;
+    const uint32_t sg = mg.seg[n];
+    const int w = sg >> 30, st = (sg >> 15) & 0x7fff, len = sg & 0x7fff;
+    float s = 0.f;
+    for (int k = 0; k < len; ++k) s += sm.trans[(w * mg.EW + st + k) * 4 + d];
+    sm.x[4 * n + d] = (sm.x[4 * n + d] + s / normf) * mg.mask[n];
+  }
+}
+
+// eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
+template <int HP>
+__device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP>& sm, const float* sZ, float* sEps,
+                            float* sMean /* [4] */, float t_val, int tid) {
+  constexpr int LD = HP + 4;
+  constexpr int T = HP / 16;
+  const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1;
+  EdmLayout lay{HP, F1, W.L, W.S};
+  const float* __restrict__ w = W.w;
+
+  // ---- input split + masking (models.py:88-105): x = z[:, :3]*m ; h = [z[:, 3:]*m , t]
+  for (int idx = tid; idx < N * 3; idx += kThreads) {
+    const int n = idx / 3, d = idx % 3;
+    const float v = sZ[n * D + d] * mg.mask[n];
+    sm.x[4 * n + d] = v;
+    sm.x0[4 * n + d] = v;
+  }
+  // ---- embedding Linear(F+1 -> H)  (egnn_new.py:304)
+  {
+    const float* ew = w + lay.emb_w();
+    const float* eb = w + lay.emb_b();
+    for (int idx = tid; idx < N * HP; idx += kThreads) {
+      const int n = idx / HP, f = idx % HP;
+      float acc = 0.f;
+      const float m = mg.mask[n];
+      for (int k = 0; k < F; ++k) acc += ew[f * F1 + k] * (sZ[n * D + 3 + k] * m);
+      acc += ew[f * F1 + F] * t_val;
+      sm.h[n * LD + f] = acc + eb[f];
+    }
+  }
+  __syncthreads();
+  compute_geo<HP>(sm, mg, 0.f, wave, lane, true);  // d0 of the input coordinates (egnn_new.py:301)
+
+  for (int l = 0; l < W.L; ++l) {
+    compute_geo<HP>(sm, mg, W.norm_constant, wave, lane, false);  // egnn_new.py:216
+    for (int s = 0; s < W.S; ++s) {
+      // ------------------------------------------------------------------ GCL (egnn_new.py:42-89)
+      const float* G = w + lay.gcl(l, s);
+      const int PK = HP * HP;
+      const float* V = G + 6 * PK;
+      const float *cr = V, *cd = V + HP, *b1 = V + 2 * HP, *b2 = V + 3 * HP, *wa = V + 4 * HP, *bn1 = V + 5 * HP,
+                  *bn2 = V + 6 * HP;
+      const float ba = V[7 * HP];
+      node_gemm<HP, EPI_NONE>(G, sm.h, nullptr, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_NONE>(G + PK, sm.h, nullptr, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane);
+      for (int idx = tid; idx < N * LD; idx += kThreads) sm.agg[idx] = 0.f;
+      __syncthreads();
+      {
+        SegSum<HP> ss;
+        ss.init();
+        float* scr = sm.scr + wave * 16 * LD;
+        for (int tp = 0; tp < mg.npairs; ++tp) {
+          float m0, m1;
+          f4 g0, g1;
+          const EdgeCols ec = load_cols<HP>(sm, mg, wave, tp, c, m0, m1, g0, g1);
+          f4 acc[2][T];
+          edge_gemm_from_pq<HP>(acc, G + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const f4 m = silu4(acc[e][t]);
+              acc[e][t] = m;
+              const f4 wv = *(const f4*)(wa + 16 * t + 4 * g);
+              sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
+            }
+            float a = 1.f;
+            if (W.attention) a = sigmoid_f(reduce_groups(sdot) + ba);
+            const float mk = e ? m1 : m0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) *(f4*)(scr + c * LD + 16 * t + 4 * g) = acc[e][t] * a * mk;
+            wave_lds_fence();
+            ss.add_tile(scr, e ? ec.i1 : ec.i0, sm.agg, W.normf, lane);
+            wave_lds_fence();
+          }
+        }
+        ss.flush(sm.agg, W.normf, lane);
+      }
+      __syncthreads();
+      node_gemm<HP, EPI_SILU>(G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, N, wave, lane);
+      __syncthreads();
+      node_gemm<HP, EPI_RESIDUAL_MASK>(G + 5 * PK, sm.p, nullptr, nullptr, bn2, sm.h, sm.h, mg.mask, N, wave, lane);
+      __syncthreads();
+    }
+    // -------------------------------------------------------- EquivariantUpdate (egnn_new.py:119-155)
+    {
+      const float* E = w + lay.equ(l);
+      const int PK = HP * HP;
+      const float* V = E + 3 * PK;
+      const float *cr = V, *cd = V + HP, *b1 = V + 2 * HP, *b2 = V + 3 * HP, *w3 = V + 4 * HP;
+      node_gemm<HP, EPI_NONE>(E, sm.h, nullptr, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_NONE>(E + PK, sm.h, nullptr, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane);
+      __syncthreads();
+      for (int tp = 0; tp < mg.npairs; ++tp) {
+        float m0, m1;
+        f4 g0, g1;
+        const EdgeCols ec = load_cols<HP>(sm, mg, wave, tp, c, m0, m1, g0, g1);
+        f4 acc[2][T];
+        edge_gemm_from_pq<HP>(acc, E + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float sdot = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const f4 m = silu4(acc[e][t]);
+            const f4 wv = *(const f4*)(w3 + 16 * t + 4 * g);
+            sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
+          }
+          const float phi = reduce_groups(sdot);
+          const float tau = W.use_tanh ? tanhf(phi) * W.coords_range : phi;
+          const f4 gg = e ? g1 : g0;
+          const float mk = e ? m1 : m0;
+          if (g == 0) {
+            const int slot = wave * mg.EW + tp * 32 + e * 16 + c;
+            *(f4*)(sm.trans + 4 * slot) = (f4){gg[1] * tau * mk, gg[2] * tau * mk, gg[3] * tau * mk, 0.f};
+          }
+        }
+      }
+      __syncthreads();
+      coord_update<HP>(sm, mg, W.normf, tid);
+      __syncthreads();
+    }
+  }
+
+  // ---- head: embedding_out * mask (egnn_new.py:316-318); vel = (x - x_in) * mask, NaN -> 0,
+  //      masked mean removal (models.py:116-152); the time column of h is dropped.
+  {
+    const float* ow = w + lay.out_w();
+    const float* ob = w + lay.out_b();
+    for (int idx = tid; idx < N * D; idx += kThreads) {
+      const int n = idx / D, d = idx % D;
+      const float m = mg.mask[n];
+      float v;
+      if (d < 3) {
+        v = (sm.x[4 * n + d] - sm.x0[4 * n + d]) * m;
+        if (v != v) v = 0.f;
+      } else {
+        const int o = d - 3;
+        float acc = 0.f;
+        for (int k = 0; k < HP; ++k) acc += ow[o * HP + k] * sm.h[n * LD + k];
+        v = (acc + ob[o]) * m;
+      }
+      sEps[idx] = v;
+    }
+    __syncthreads();
+    if (tid < 3) {
+      float s = 0.f, cnt = 0.f;
+      for (int n = 0; n < N; ++n) {
+        s += sEps[n * D + tid];
+        cnt += mg.mask[n];
+      }
+      sMean[tid] = s / fmaxf(cnt, 1.0f);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
+      sEps[n * D + d] = sEps[n * D + d] - sMean[d] * mg.mask[n];
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace gaudi

@@ -1,0 +1,729 @@
+// gaudi_hip.hip -- host side of libgaudi_hip.so: the C ABI declared in include/gaudi_hip.h.
+// Builds the noise-schedule tables, packs reference-format checkpoints into the kernels' tile
+// layout, turns (node_mask, edge_mask) into per-wave edge lists and launches the per-molecule
+// persistent kernel (sampler_kernel.h) on the handle's own HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gaudi_hip.h"
+#include "sampler_kernel.h"
+
+using namespace gaudi;
+
+// -------------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return (T*)p; }
+};
+
+struct gaudi_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool has_edm = false, has_pred = false;
+  gaudi_edm_config ecfg{};
+  gaudi_pred_config pcfg{};
+  int HPE = 0, HPP = 0;
+  DevBuf edm_w, pred_w, coef_d;
+  std::vector<float> gamma, coef;
+  // per-call workspaces
+  DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
+      d_pred, d_tw, d_stash;
+  int steps_per_launch = 25;
+  // profiling
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  long long prof_steps = 0;
+};
+
+#define HIPCHECK(h, call)                                                                         \
+  do {                                                                                            \
+    hipError_t e__ = (call);                                                                      \
+    if (e__ != hipSuccess) {                                                                      \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                              \
+      return GAUDI_E_HIP;                                                                         \
+    }                                                                                             \
+  } while (0)
+
+static int fail(gaudi_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+// -------------------------------------------------------------------------------------------------
+// noise schedule: PredefinedNoiseSchedule / polynomial_schedule / clip_noise_schedule
+// (edm/equivariant_diffusion/en_diffusion.py:32-61, 191-218), float64 like the reference's numpy.
+static std::vector<float> make_gamma(int T, double power, double precision) {
+  const int steps = T + 1;
+  std::vector<double> a2(steps);
+  const double step = (double)steps / (double)(steps - 1);  // np.linspace(0, steps, steps)
+  for (int i = 0; i < steps; ++i) {
+    double x = (i == steps - 1) ? (double)steps : i * step;
+    double v = 1.0 - std::pow(x / steps, power);
+    a2[i] = v * v;
+  }
+  // clip_noise_schedule: ratios alpha2[i]/alpha2[i-1] clipped to [1e-3, 1], cumulative product
+  std::vector<double> out(steps);
+  double prev = 1.0, cum = 1.0;
+  for (int i = 0; i < steps; ++i) {
+    double r = a2[i] / prev;
+    r = std::min(std::max(r, 0.001), 1.0);
+    cum *= r;
+    out[i] = cum;
+    prev = a2[i];
+  }
+  std::vector<float> g(steps);
+  const double pr = 1.0 - 2.0 * precision;
+  for (int i = 0; i < steps; ++i) {
+    double a = pr * out[i] + precision;
+    g[i] = (float)(-(std::log(a) - std::log(1.0 - a)));
+  }
+  return g;
+}
+
+static inline float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+static inline float logsigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+static inline float sigmoid_host(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// en_diffusion.py:433-457 (sigma_and_alpha_t_given_s), :365-373 (sigma), :843-849 (mu / sigma of p(z_s|z_t))
+static void make_coef(const std::vector<float>& g, int T, std::vector<float>& coef) {
+  coef.resize((size_t)T * 4);
+  for (int s = 0; s < T; ++s) {
+    const float gs = g[s], gt = g[s + 1];
+    const float sigma2 = -expm1f(softplus_f(gs) - softplus_f(gt));
+    const float alpha_ts = expf(0.5f * (logsigmoid_f(-gt) - logsigmoid_f(-gs)));
+    const float sigma_ts = sqrtf(sigma2);
+    const float sigma_s = sqrtf(sigmoid_host(gs)), sigma_t = sqrtf(sigmoid_host(gt));
+    coef[4 * s + 0] = alpha_ts;
+    coef[4 * s + 1] = sigma2 / alpha_ts / sigma_t;
+    coef[4 * s + 2] = sigma_ts * sigma_s / sigma_t;
+    coef[4 * s + 3] = (float)(s + 1) / (float)T;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// checkpoint packing
+struct Tensors {
+  std::map<std::string, std::pair<const float*, int64_t>> m;
+  std::string missing;
+  const float* get(const std::string& k, int64_t numel) {
+    auto it = m.find(k);
+    if (it == m.end() || it->second.second != numel) {
+      if (missing.empty())
+        missing = k + (it == m.end() ? " (absent)" : " (numel " + std::to_string(it->second.second) + " != " +
+                                                         std::to_string(numel) + ")");
+      return nullptr;
+    }
+    return it->second.first;
+  }
+};
+
+// W[o][col0 + k] (row stride ldw), o,k < H  ->  tile-packed [HP/16][HP/16][16][16]: dst[((k/16*T + o/16)*16 + o%16)*16 + k%16]
+static void pack_matrix(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
+  const int T = HP / 16;
+  for (int o = 0; o < H; ++o)
+    for (int k = 0; k < H; ++k) {
+      const float v = transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k];
+      dst[(((size_t)(k / 16) * T + o / 16) * 16 + o % 16) * 16 + k % 16] = v;
+    }
+}
+static void pack_vec(float* dst, const float* v, int n) { std::memcpy(dst, v, sizeof(float) * n); }
+static void pack_col(float* dst, const float* W, int H, int ldw, int col) {
+  for (int o = 0; o < H; ++o) dst[o] = W[(size_t)o * ldw + col];
+}
+
+// -------------------------------------------------------------------------------------------------
+// graph metadata: live edges of each molecule, receiving nodes dealt to the 4 waves (LPT), each
+// wave's edge list sorted by receiving node and padded to 32 ("bucketed by degree").
+struct Meta {
+  int EW = 32;
+  std::vector<int> order, npairs;
+  std::vector<uint32_t> edges, seg;
+  std::vector<float> emask;
+};
+
+static int build_meta(int B, int N, const float* node_mask, const float* edge_mask, Meta& M, std::string& err) {
+  if (N > 255) {
+    err = "N > 255 unsupported";
+    return GAUDI_E_CAPACITY;
+  }
+  struct Mol {
+    std::vector<std::vector<std::pair<int, float>>> nbr;  // per receiving node: (j, mask)
+    int owner[256];
+    int total = 0;
+  };
+  std::vector<Mol> mols(B);
+  int maxlen = 0;
+  std::vector<std::vector<int>> wl(B * kWaves);
+  for (int b = 0; b < B; ++b) {
+    Mol& m = mols[b];
+    m.nbr.resize(N);
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        const float v = edge_mask[((size_t)b * N + i) * N + j];
+        if (v != 0.f) {
+          m.nbr[i].push_back({j, v});
+          ++m.total;
+        }
+      }
+    // longest-processing-time assignment of receiving nodes to waves
+    std::vector<int> idx(N);
+    for (int i = 0; i < N; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return m.nbr[a].size() > m.nbr[c].size(); });
+    int load[kWaves] = {0, 0, 0, 0};
+    for (int i : idx) {
+      int w = 0;
+      for (int k = 1; k < kWaves; ++k)
+        if (load[k] < load[w]) w = k;
+      m.owner[i] = w;
+      load[w] += (int)m.nbr[i].size();
+    }
+    for (int w = 0; w < kWaves; ++w) maxlen = std::max(maxlen, load[w]);
+  }
+  M.EW = std::max(32, (maxlen + 31) / 32 * 32);
+  if (M.EW > 0x7fff) {
+    err = "too many edges per wave";
+    return GAUDI_E_CAPACITY;
+  }
+  const int EW = M.EW;
+  M.edges.assign((size_t)B * kWaves * EW, 0);
+  M.emask.assign((size_t)B * kWaves * EW, 0.f);
+  M.npairs.assign((size_t)B * kWaves, 0);
+  M.seg.assign((size_t)B * N, 0);
+  for (int b = 0; b < B; ++b) {
+    Mol& m = mols[b];
+    int fill[kWaves] = {0, 0, 0, 0};
+    int last_i[kWaves] = {0, 0, 0, 0};
+    for (int i = 0; i < N; ++i) {
+      const int w = m.owner[i];
+      const int st = fill[w];
+      for (auto& e : m.nbr[i]) {
+        const size_t s = ((size_t)b * kWaves + w) * EW + fill[w]++;
+        M.edges[s] = (uint32_t)i | ((uint32_t)e.first << 8);
+        M.emask[s] = e.second;
+      }
+      if (!m.nbr[i].empty()) last_i[w] = i;
+      M.seg[(size_t)b * N + i] = ((uint32_t)w << 30) | ((uint32_t)st << 15) | (uint32_t)m.nbr[i].size();
+    }
+    for (int w = 0; w < kWaves; ++w) {
+      const int padded = (fill[w] + 31) / 32 * 32;
+      for (int s = fill[w]; s < padded; ++s)  // padding slots: same receiving node, mask 0
+        M.edges[((size_t)b * kWaves + w) * EW + s] = (uint32_t)last_i[w] | ((uint32_t)last_i[w] << 8);
+      M.npairs[(size_t)b * kWaves + w] = padded / 32;
+    }
+  }
+  M.order.resize(B);
+  for (int b = 0; b < B; ++b) M.order[b] = b;
+  std::stable_sort(M.order.begin(), M.order.end(), [&](int a, int c) { return mols[a].total > mols[c].total; });
+  (void)node_mask;
+  return GAUDI_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// kernel table
+typedef void (*kernel_fn)(const KParams);
+#define GAUDI_EDM_ONLY(X) X(32) X(48) X(64) X(128) X(192) X(208) X(256)
+
+static kernel_fn pick_kernel(int hpe, int hpp) {
+#define X(E) \
+  if (hpe == E && hpp == 0) return sampler_kernel<E, 0>;
+  GAUDI_EDM_ONLY(X)
+#undef X
+  return nullptr;
+}
+
+static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW) {
+  size_t net = 0;
+  if (hpe) net = std::max(net, (size_t)(4 * N * (hpe + 4) + kWaves * 16 * (hpe + 4) + 8 * N + kWaves * EW * 9));
+  (void)hpp;
+  return sizeof(float) * (common_floats(N, D, EW) + net);
+}
+
+static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
+  kernel_fn fn = pick_kernel(hpe, hpp);
+  if (!fn)
+    return fail(h, GAUDI_E_INVALID,
+                "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")");
+  const size_t lds = lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW);
+  if (lds > 160 * 1024)
+    return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
+  HIPCHECK(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->prof) {
+    HIPCHECK(h, hipEventCreate(&e0));
+    HIPCHECK(h, hipEventCreate(&e1));
+    HIPCHECK(h, hipEventRecord(e0, h->stream));
+  }
+  hipLaunchKernelGGL(fn, dim3(P.B), dim3(kThreads), lds, h->stream, P);
+  HIPCHECK(h, hipGetLastError());
+  if (h->prof) {
+    HIPCHECK(h, hipEventRecord(e1, h->stream));
+    h->prof_events.push_back({e0, e1});
+    h->prof_steps += steps;
+  }
+  return GAUDI_OK;
+}
+
+// upload masks + metadata, fill the graph part of KParams
+static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P) {
+  if (B <= 0 || N <= 0) return fail(h, GAUDI_E_INVALID, "B and N must be positive");
+  Meta M;
+  std::string err;
+  int rc = build_meta(B, N, node_mask, edge_mask, M, err);
+  if (rc) return fail(h, rc, err);
+  HIPCHECK(h, h->d_mask.reserve(sizeof(float) * B * N));
+  HIPCHECK(h, h->d_order.reserve(sizeof(int) * B));
+  HIPCHECK(h, h->d_edges.reserve(sizeof(uint32_t) * M.edges.size()));
+  HIPCHECK(h, h->d_emask.reserve(sizeof(float) * M.emask.size()));
+  HIPCHECK(h, h->d_npairs.reserve(sizeof(int) * M.npairs.size()));
+  HIPCHECK(h, h->d_seg.reserve(sizeof(uint32_t) * M.seg.size()));
+  HIPCHECK(h, hipMemcpyAsync(h->d_mask.p, node_mask, sizeof(float) * B * N, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(h->d_order.p, M.order.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(h->d_edges.p, M.edges.data(), sizeof(uint32_t) * M.edges.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(h->d_emask.p, M.emask.data(), sizeof(float) * M.emask.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(h->d_npairs.p, M.npairs.data(), sizeof(int) * M.npairs.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(h->d_seg.p, M.seg.data(), sizeof(uint32_t) * M.seg.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));  // M goes out of scope
+  P.B = B;
+  P.N = N;
+  P.EW = M.EW;
+  P.node_mask = h->d_mask.as<float>();
+  P.order = h->d_order.as<int>();
+  P.edges = h->d_edges.as<uint32_t>();
+  P.emask = h->d_emask.as<float>();
+  P.npairs = h->d_npairs.as<int>();
+  P.seginfo = h->d_seg.as<uint32_t>();
+  return GAUDI_OK;
+}
+
+static void fill_edm(gaudi_handle* h, KParams& P) {
+  const gaudi_edm_config& c = h->ecfg;
+  P.F = c.in_node_nf;
+  P.T = c.diffusion_steps;
+  P.edm.w = h->edm_w.as<float>();
+  P.edm.F = c.in_node_nf;
+  P.edm.L = c.n_layers;
+  P.edm.S = c.inv_sublayers;
+  P.edm.attention = c.attention;
+  P.edm.use_tanh = c.tanh;
+  P.edm.coords_range = c.coords_range;
+  P.edm.norm_constant = c.norm_constant;
+  P.edm.normf = c.normalization_factor;
+  P.coef = h->coef_d.as<float>();
+  const float g0 = h->gamma[0];
+  P.alpha0 = sqrtf(sigmoid_host(-g0));
+  P.sigma0 = sqrtf(sigmoid_host(g0));
+  P.sigma_x = expf(0.5f * g0);  // SNR(-0.5*gamma_0), en_diffusion.py:538
+  P.nv0 = c.norm_values[0];
+  P.nv1 = c.norm_values[1];
+}
+
+// -------------------------------------------------------------------------------------------------
+extern "C" {
+
+int gaudi_create(int device, gaudi_handle** out) {
+  if (!out) return GAUDI_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return GAUDI_E_HIP;
+  gaudi_handle* h = new gaudi_handle();
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return GAUDI_E_HIP;
+  }
+  *out = h;
+  return GAUDI_OK;
+}
+
+void gaudi_destroy(gaudi_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& p : h->prof_events) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
+                    &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
+                    &h->d_pred, &h->d_tw, &h->d_stash};
+  for (DevBuf* b : bufs) b->release();
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* gaudi_last_error(const gaudi_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const char* const* names,
+                   const float* const* tensors, const int64_t* numel) {
+  if (!h || !cfg) return GAUDI_E_INVALID;
+  HIPCHECK(h, hipSetDevice(h->device));
+  const int H = cfg->hidden_nf, F = cfg->in_node_nf, F1 = F + 1, L = cfg->n_layers, S = cfg->inv_sublayers;
+  if (H <= 0 || H > 256) return fail(h, GAUDI_E_INVALID, "hidden_nf must be in 1..256");
+  if (F < 1 || F > 15) return fail(h, GAUDI_E_INVALID, "in_node_nf must be in 1..15");
+  if (L < 1 || S < 1 || cfg->diffusion_steps < 1) return fail(h, GAUDI_E_INVALID, "bad n_layers/inv_sublayers/diffusion_steps");
+  if (!(cfg->normalization_factor > 0.f)) return fail(h, GAUDI_E_INVALID, "normalization_factor must be > 0");
+  int HP = pad_hidden(H);
+  if (!pick_kernel(HP, 0)) {  // round up to the next instantiated size
+    static const int sizes[] = {32, 48, 64, 128, 192, 208, 256};
+    for (int s : sizes)
+      if (s >= HP) { HP = s; break; }
+  }
+  Tensors T;
+  for (int i = 0; i < n; ++i) T.m[names[i]] = {tensors[i], numel[i]};
+  EdmLayout lay{HP, F1, L, S};
+  std::vector<float> w((size_t)lay.total(), 0.f);
+  const std::string p = "dynamics.egnn.";
+  const int PK = HP * HP;
+  {
+    const float* ew = T.get(p + "embedding.weight", (int64_t)H * F1);
+    const float* eb = T.get(p + "embedding.bias", H);
+    const float* ow = T.get(p + "embedding_out.weight", (int64_t)F1 * H);
+    const float* ob = T.get(p + "embedding_out.bias", F1);
+    if (ew && eb && ow && ob) {
+      for (int f = 0; f < H; ++f)
+        for (int k = 0; k < F1; ++k) w[lay.emb_w() + f * F1 + k] = ew[f * F1 + k];
+      pack_vec(&w[lay.emb_b()], eb, H);
+      for (int o = 0; o < F1; ++o)
+        for (int k = 0; k < H; ++k) w[lay.out_w() + o * HP + k] = ow[o * H + k];
+      pack_vec(&w[lay.out_b()], ob, F1);
+    }
+  }
+  const int ld1 = 2 * H + 2;
+  for (int l = 0; l < L; ++l) {
+    for (int s = 0; s < S; ++s) {
+      const std::string q = p + "e_block_" + std::to_string(l) + ".gcl_" + std::to_string(s) + ".";
+      float* G = &w[lay.gcl(l, s)];
+      float* V = G + 6 * PK;
+      const float* W1 = T.get(q + "edge_mlp.0.weight", (int64_t)H * ld1);
+      const float* b1 = T.get(q + "edge_mlp.0.bias", H);
+      const float* W2 = T.get(q + "edge_mlp.2.weight", (int64_t)H * H);
+      const float* b2 = T.get(q + "edge_mlp.2.bias", H);
+      const float* Wn1 = T.get(q + "node_mlp.0.weight", (int64_t)H * 2 * H);
+      const float* bn1 = T.get(q + "node_mlp.0.bias", H);
+      const float* Wn2 = T.get(q + "node_mlp.2.weight", (int64_t)H * H);
+      const float* bn2 = T.get(q + "node_mlp.2.bias", H);
+      const float *wa = nullptr, *ba = nullptr;
+      if (cfg->attention) {
+        wa = T.get(q + "att_mlp.0.weight", H);
+        ba = T.get(q + "att_mlp.0.bias", 1);
+      }
+      if (!(W1 && b1 && W2 && b2 && Wn1 && bn1 && Wn2 && bn2) || (cfg->attention && !(wa && ba))) continue;
+      pack_matrix(G, W1, H, ld1, 0, HP);
+      pack_matrix(G + PK, W1, H, ld1, H, HP);
+      pack_matrix(G + 2 * PK, W2, H, H, 0, HP);
+      pack_matrix(G + 3 * PK, Wn1, H, 2 * H, 0, HP);
+      pack_matrix(G + 4 * PK, Wn1, H, 2 * H, H, HP);
+      pack_matrix(G + 5 * PK, Wn2, H, H, 0, HP);
+      pack_col(V, W1, H, ld1, 2 * H);
+      pack_col(V + HP, W1, H, ld1, 2 * H + 1);
+      pack_vec(V + 2 * HP, b1, H);
+      pack_vec(V + 3 * HP, b2, H);
+      if (wa) pack_vec(V + 4 * HP, wa, H);
+      pack_vec(V + 5 * HP, bn1, H);
+      pack_vec(V + 6 * HP, bn2, H);
+      if (ba) V[7 * HP] = ba[0];
+    }
+    const std::string q = p + "e_block_" + std::to_string(l) + ".gcl_equiv.";
+    float* E = &w[lay.equ(l)];
+    float* V = E + 3 * PK;
+    const float* W1 = T.get(q + "coord_mlp.0.weight", (int64_t)H * ld1);
+    const float* b1 = T.get(q + "coord_mlp.0.bias", H);
+    const float* W2 = T.get(q + "coord_mlp.2.weight", (int64_t)H * H);
+    const float* b2 = T.get(q + "coord_mlp.2.bias", H);
+    const float* w3 = T.get(q + "coord_mlp.4.weight", H);
+    if (!(W1 && b1 && W2 && b2 && w3)) continue;
+    pack_matrix(E, W1, H, ld1, 0, HP);
+    pack_matrix(E + PK, W1, H, ld1, H, HP);
+    pack_matrix(E + 2 * PK, W2, H, H, 0, HP);
+    pack_col(V, W1, H, ld1, 2 * H);
+    pack_col(V + HP, W1, H, ld1, 2 * H + 1);
+    pack_vec(V + 2 * HP, b1, H);
+    pack_vec(V + 3 * HP, b2, H);
+    pack_vec(V + 4 * HP, w3, H);
+  }
+  if (!T.missing.empty()) return fail(h, GAUDI_E_MISSING, "EDM checkpoint tensor missing or mis-shaped: " + T.missing);
+  HIPCHECK(h, h->edm_w.reserve(sizeof(float) * w.size()));
+  HIPCHECK(h, hipMemcpy(h->edm_w.p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
+  h->gamma = make_gamma(cfg->diffusion_steps, cfg->noise_power, cfg->noise_precision);
+  make_coef(h->gamma, cfg->diffusion_steps, h->coef);
+  HIPCHECK(h, h->coef_d.reserve(sizeof(float) * h->coef.size()));
+  HIPCHECK(h, hipMemcpy(h->coef_d.p, h->coef.data(), sizeof(float) * h->coef.size(), hipMemcpyHostToDevice));
+  h->ecfg = *cfg;
+  h->HPE = HP;
+  h->has_edm = true;
+  return GAUDI_OK;
+}
+
+int gaudi_get_gamma(gaudi_handle* h, float* gamma_out) {
+  if (!h || !gamma_out) return GAUDI_E_INVALID;
+  if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
+  std::memcpy(gamma_out, h->gamma.data(), sizeof(float) * h->gamma.size());
+  return GAUDI_OK;
+}
+
+int gaudi_get_step_coefficients(gaudi_handle* h, float* coef_out) {
+  if (!h || !coef_out) return GAUDI_E_INVALID;
+  if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
+  std::memcpy(coef_out, h->coef.data(), sizeof(float) * h->coef.size());
+  return GAUDI_OK;
+}
+
+int gaudi_phi(gaudi_handle* h, int B, int N, const float* z, const float* t, const float* node_mask,
+              const float* edge_mask, float* eps_out) {
+  if (!h || !z || !t || !node_mask || !edge_mask || !eps_out) return GAUDI_E_INVALID;
+  if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
+  HIPCHECK(h, hipSetDevice(h->device));
+  KParams P{};
+  int rc = stage_graph(h, B, N, node_mask, edge_mask, P);
+  if (rc) return rc;
+  fill_edm(h, P);
+  const size_t zb = sizeof(float) * B * N * (3 + P.F);
+  HIPCHECK(h, h->d_zin.reserve(zb));
+  HIPCHECK(h, h->d_zout.reserve(zb));
+  HIPCHECK(h, h->d_t.reserve(sizeof(float) * B));
+  HIPCHECK(h, hipMemcpyAsync(h->d_zin.p, z, zb, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(h->d_t.p, t, sizeof(float) * B, hipMemcpyHostToDevice, h->stream));
+  P.mode = MODE_PHI;
+  P.z_in = h->d_zin.as<float>();
+  P.z_out = h->d_zout.as<float>();
+  P.t_in = h->d_t.as<float>();
+  rc = launch(h, P, h->HPE, 0, 0);
+  if (rc) return rc;
+  HIPCHECK(h, hipMemcpyAsync(eps_out, h->d_zout.p, zb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  return GAUDI_OK;
+}
+
+static int fill_pred(gaudi_handle* h, KParams& P, const float* target_w, int B, int N);  // pred_host.inc
+
+// shared by gaudi_step / gaudi_decode / gaudi_sample
+static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, const float* z_in,
+                     bool do_init, int s_hi, int s_lo, bool do_decode, const float* noise, int draw_base, int n_draws,
+                     uint64_t seed, int64_t sample_offset, float std0, const float* target_w, float scale,
+                     float* z_out, float* x_out, float* onehot_out, int* nan_count) {
+  if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
+  if (target_w && !h->has_pred) return fail(h, GAUDI_E_STATE, "guided sampling needs predictor weights");
+  HIPCHECK(h, hipSetDevice(h->device));
+  KParams P{};
+  int rc = stage_graph(h, B, N, node_mask, edge_mask, P);
+  if (rc) return rc;
+  fill_edm(h, P);
+  const int D = 3 + P.F, T = P.T;
+  if (s_hi >= T || s_lo < 0) return fail(h, GAUDI_E_INVALID, "step index out of range");
+  const size_t zb = sizeof(float) * B * N * D;
+  HIPCHECK(h, h->d_zin.reserve(zb));
+  HIPCHECK(h, h->d_zout.reserve(zb));
+  HIPCHECK(h, h->d_x.reserve(sizeof(float) * B * N * 3));
+  HIPCHECK(h, h->d_h.reserve(sizeof(float) * B * N * P.F));
+  HIPCHECK(h, h->d_nan.reserve(sizeof(int)));
+  HIPCHECK(h, hipMemsetAsync(h->d_nan.p, 0, sizeof(int), h->stream));
+  if (z_in) HIPCHECK(h, hipMemcpyAsync(h->d_zin.p, z_in, zb, hipMemcpyHostToDevice, h->stream));
+  if (noise) {
+    HIPCHECK(h, h->d_noise.reserve(zb * (size_t)n_draws));
+    HIPCHECK(h, hipMemcpyAsync(h->d_noise.p, noise, zb * (size_t)n_draws, hipMemcpyHostToDevice, h->stream));
+    P.noise = h->d_noise.as<float>();
+  }
+  P.draw_base = draw_base;
+  P.draw_stride = (long long)B * N * D;
+  P.seed = seed;
+  P.sample_offset = sample_offset;
+  P.std0 = std0;
+  P.mode = MODE_SAMPLE;
+  P.x_out = h->d_x.as<float>();
+  P.h_out = h->d_h.as<float>();
+  P.nan_count = h->d_nan.as<int>();
+  P.guided = target_w != nullptr;
+  P.scale = scale;
+  int hpp = 0;
+  if (target_w) {
+    rc = fill_pred(h, P, target_w, B, N);
+    if (rc) return rc;
+    hpp = h->HPP;
+  }
+  // chunk the chain into launches of steps_per_launch steps; z ping-pongs zout -> zin
+  bool first = true;
+  int s = s_hi;
+  const bool any_steps = s_hi >= s_lo;
+  float* zin = h->d_zin.as<float>();
+  float* zout = h->d_zout.as<float>();
+  do {
+    const int lo = any_steps ? std::max(s_lo, s - h->steps_per_launch + 1) : s + 1;
+    P.s_hi = s;
+    P.s_lo = lo;
+    P.do_init = first && do_init;
+    P.do_decode = do_decode && lo <= s_lo;
+    P.z_in = zin;
+    P.z_out = zout;
+    rc = launch(h, P, h->HPE, hpp, any_steps ? (s - lo + 1) : 0);
+    if (rc) return rc;
+    std::swap(zin, zout);
+    first = false;
+    s = lo - 1;
+  } while (any_steps && s >= s_lo);
+  // after the swap, `zin` holds the latest z
+  if (z_out) HIPCHECK(h, hipMemcpyAsync(z_out, zin, zb, hipMemcpyDeviceToHost, h->stream));
+  if (do_decode) {
+    HIPCHECK(h, hipMemcpyAsync(x_out, h->d_x.p, sizeof(float) * B * N * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(onehot_out, h->d_h.p, sizeof(float) * B * N * P.F, hipMemcpyDeviceToHost, h->stream));
+  }
+  int nanc = 0;
+  HIPCHECK(h, hipMemcpyAsync(&nanc, h->d_nan.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (nan_count) *nan_count = nanc;
+  return GAUDI_OK;
+}
+
+int gaudi_step(gaudi_handle* h, int B, int N, int s_idx, const float* z_t, const float* node_mask,
+               const float* edge_mask, const float* eps_raw, const float* target_w, float scale, float* zs_out) {
+  if (!h || !z_t || !node_mask || !edge_mask || !eps_raw || !zs_out) return GAUDI_E_INVALID;
+  if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
+  const int T = h->ecfg.diffusion_steps;
+  return run_chain(h, B, N, node_mask, edge_mask, z_t, false, s_idx, s_idx, false, eps_raw, T - s_idx, 1, 0, 0, 1.0f,
+                   target_w, scale, zs_out, nullptr, nullptr, nullptr);
+}
+
+int gaudi_decode(gaudi_handle* h, int B, int N, const float* z0, const float* node_mask, const float* edge_mask,
+                 const float* eps_raw, float* x_out, float* onehot_out) {
+  if (!h || !z0 || !node_mask || !edge_mask || !eps_raw || !x_out || !onehot_out) return GAUDI_E_INVALID;
+  if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
+  const int T = h->ecfg.diffusion_steps;
+  return run_chain(h, B, N, node_mask, edge_mask, z0, false, -1, 0, true, eps_raw, T + 1, 1, 0, 0, 1.0f, nullptr, 0.f,
+                   nullptr, x_out, onehot_out, nullptr);
+}
+
+int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                 int64_t sample_offset, const float* noise, float std, const float* target_w, float scale,
+                 float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag) {
+  if (!h || !node_mask || !edge_mask || !x_out || !onehot_out) return GAUDI_E_INVALID;
+  if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
+  const int T = h->ecfg.diffusion_steps, F = h->ecfg.in_node_nf;
+  int nanc = 0;
+  int rc = run_chain(h, B, N, node_mask, edge_mask, nullptr, true, T - 1, 0, true, noise, 0, T + 2, seed, sample_offset,
+                     std, target_w, scale, z0_out, x_out, onehot_out, &nanc);
+  if (rc) return rc;
+  (void)F;
+  // diagnostics replacing assert_correctly_masked / assert_mean_zero_with_mask (utils.py:52-65) and the
+  // CoG re-projection of en_diffusion.py:1000-1006 (batch-wide condition -> host side)
+  float leak = 0.f, cog = 0.f, big = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float s[3] = {0, 0, 0};
+    for (int n = 0; n < N; ++n)
+      for (int d = 0; d < 3; ++d) {
+        const float v = x_out[((size_t)b * N + n) * 3 + d];
+        s[d] += v;
+        big = std::max(big, std::fabs(v));
+        leak = std::max(leak, std::fabs(v * (1.f - node_mask[b * N + n])));
+      }
+    for (int d = 0; d < 3; ++d) cog = std::max(cog, std::fabs(s[d]));
+  }
+  int reproj = 0;
+  if (cog > 5e-2f) {
+    reproj = 1;
+    for (int b = 0; b < B; ++b) {
+      float cnt = 0.f;
+      for (int n = 0; n < N; ++n) cnt += node_mask[b * N + n];
+      cnt = std::max(cnt, 1.f);
+      for (int d = 0; d < 3; ++d) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += x_out[((size_t)b * N + n) * 3 + d];
+        const float mean = s / cnt;
+        for (int n = 0; n < N; ++n) x_out[((size_t)b * N + n) * 3 + d] -= mean * node_mask[b * N + n];
+      }
+    }
+  }
+  if (diag) {
+    diag->max_masked_leak = leak;
+    diag->max_cog_abs = cog;
+    diag->max_cog_rel = cog / (big + 1e-10f);
+    diag->nan_count = nanc;
+    diag->reprojected = reproj;
+  }
+  return GAUDI_OK;
+}
+
+__global__ void philox_kernel(unsigned long long seed, long long sample_offset, int B, int n_elem, int draw0, int n_draws,
+                              float* out) {
+  const long long total = (long long)n_draws * B * n_elem;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % n_elem);
+    const int b = (int)((i / n_elem) % B);
+    const int dr = (int)(i / ((long long)n_elem * B));
+    const f4 v = philox_normal4(seed, (uint64_t)(sample_offset + b), (uint32_t)(draw0 + dr), (uint32_t)(e >> 2));
+    out[i] = v[e & 3];
+  }
+}
+
+int gaudi_philox_normal(gaudi_handle* h, uint64_t seed, int64_t sample_offset, int B, int n_elem, int draw0, int n_draws,
+                        float* out) {
+  if (!h || !out || B <= 0 || n_elem <= 0 || n_draws <= 0) return GAUDI_E_INVALID;
+  HIPCHECK(h, hipSetDevice(h->device));
+  const size_t bytes = sizeof(float) * (size_t)B * n_elem * n_draws;
+  HIPCHECK(h, h->d_noise.reserve(bytes));
+  hipLaunchKernelGGL(philox_kernel, dim3(256), dim3(256), 0, h->stream, seed, sample_offset, B, n_elem, draw0, n_draws,
+                     h->d_noise.as<float>());
+  HIPCHECK(h, hipGetLastError());
+  HIPCHECK(h, hipMemcpyAsync(out, h->d_noise.p, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  return GAUDI_OK;
+}
+
+int gaudi_profile_reset(gaudi_handle* h, int enable) {
+  if (!h) return GAUDI_E_INVALID;
+  for (auto& p : h->prof_events) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  h->prof_events.clear();
+  h->prof_steps = 0;
+  h->prof = enable != 0;
+  return GAUDI_OK;
+}
+
+int gaudi_profile_get(gaudi_handle* h, int32_t* n_launches, double* total_ms, int64_t* steps_done) {
+  if (!h) return GAUDI_E_INVALID;
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  for (auto& p : h->prof_events) {
+    float ms = 0.f;
+    HIPCHECK(h, hipEventElapsedTime(&ms, p.first, p.second));
+    tot += ms;
+  }
+  if (n_launches) *n_launches = (int32_t)h->prof_events.size();
+  if (total_ms) *total_ms = tot;
+  if (steps_done) *steps_done = h->prof_steps;
+  return GAUDI_OK;
+}
+
+int gaudi_set_steps_per_launch(gaudi_handle* h, int steps) {
+  if (!h || steps < 1) return GAUDI_E_INVALID;
+  h->steps_per_launch = steps;
+  return GAUDI_OK;
+}
+
+}  // extern "C"
+
+#include "pred_host.inc"

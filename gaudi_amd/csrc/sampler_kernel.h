@@ -1,0 +1,223 @@
+// sampler_kernel.h -- the per-molecule persistent workgroup kernel: runs reverse-diffusion steps
+// s_hi..s_lo (EDM denoiser + z update [+ predictor forward/backward + guidance]) for one molecule
+// without leaving the CU, plus the unit-test modes (phi / predictor / decode).
+#pragma once
+#include "edm_device.h"
+#include "pred_device.h"
+
+namespace gaudi {
+
+enum Mode { MODE_PHI = 0, MODE_SAMPLE = 1, MODE_PRED_FWD = 2, MODE_PRED_GRAD = 3 };
+
+struct KParams {
+  int mode, B, N, F, EW;
+  int do_init, do_decode, guided;
+  int s_hi, s_lo, T;
+  // graph metadata (device)
+  const float* node_mask;   // [B][N]
+  const int* order;         // [B] block -> molecule (heaviest first)
+  const uint32_t* edges;    // [B][4][EW]
+  const float* emask;       // [B][4][EW]
+  const int* npairs;        // [B][4]
+  const uint32_t* seginfo;  // [B][N]
+  // tensors (device)
+  const float* z_in;        // [B][N][D]
+  float* z_out;             // [B][N][D]
+  const float* t_in;        // [B]
+  float* x_out;             // [B][N][3]
+  float* h_out;             // [B][N][F]
+  const float* noise;       // injected raw draws or nullptr
+  int draw_base;
+  long long draw_stride;
+  unsigned long long seed;
+  long long sample_offset;
+  float std0;
+  const float* coef;        // [T][4] alpha_ts, eps_coef, sigma, t
+  float alpha0, sigma0, sigma_x, nv0, nv1;
+  int* nan_count;
+  EdmDev edm;
+  PredDev pred;
+  const float* dpred_in;    // [B][K]  (MODE_PRED_GRAD) or nullptr
+  const float* target_w;    // [K]     (guided sampling)
+  float scale;
+  float* pred_out;          // [B][K]
+  float* stash;             // predictor activation stash, [B] x stash_stride floats
+  long long stash_stride;
+  float readout_div;        // padded N the predictor readout divides by
+};
+
+__host__ __device__ inline int common_floats(int N, int D, int EW) {
+  return 3 * align16(N * D) + align16(N) + 16 + 2 * kWaves * EW + align16(N);
+}
+
+template <int HPE, int HPP>
+__global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int b = P.order[blockIdx.x];
+  const int N = P.N, D = 3 + P.F, EW = P.EW;
+
+  // ---- carve the common region
+  float* base = smem;
+  float* sZ = base; base += align16(N * D);
+  float* sEps = base; base += align16(N * D);
+  float* sNz = base; base += align16(N * D);
+  float* sMask = base; base += align16(N);
+  float* sMean = base; base += 16;
+  uint32_t* sEdge = (uint32_t*)base; base += kWaves * EW;
+  float* sEm = base; base += kWaves * EW;
+  uint32_t* sSeg = (uint32_t*)base; base += align16(N);
+  float* net = base;
+
+  for (int i = tid; i < N; i += kThreads) {
+    sMask[i] = P.node_mask[b * N + i];
+    sSeg[i] = P.seginfo[b * N + i];
+  }
+  for (int i = tid; i < kWaves * EW; i += kThreads) {
+    sEdge[i] = P.edges[(size_t)b * kWaves * EW + i];
+    sEm[i] = P.emask[(size_t)b * kWaves * EW + i];
+  }
+  MolGraph mg;
+  mg.N = N; mg.D = D; mg.EW = EW;
+  mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg;
+  mg.npairs = P.npairs[b * kWaves + wave];
+
+  const uint64_t gsample = (uint64_t)(P.sample_offset + b);
+  // locals (not references into the kernarg struct) so nothing forces P onto the stack
+  const float* const noise_p = P.noise ? P.noise + (size_t)b * N * D : nullptr;
+  const long long draw_stride = P.draw_stride;
+  const int draw_base = P.draw_base;
+  const unsigned long long seed = P.seed;
+  auto raw_noise = [=](int draw, int e) -> float {
+    if (noise_p != nullptr) return noise_p[(size_t)(draw - draw_base) * draw_stride + e];
+    const f4 v = philox_normal4(seed, gsample, (uint32_t)draw, (uint32_t)(e >> 2));
+    return v[e & 3];
+  };
+  // masked mean over nodes of column d (<3) of an LDS [N][D] array -> sMean[d]
+  auto col_means = [=](const float* a) {
+    if (tid < 3) {
+      float s = 0.f, cnt = 0.f;
+      for (int n = 0; n < N; ++n) { s += a[n * D + tid]; cnt += sMask[n]; }
+      sMean[tid] = s / fmaxf(cnt, 1.0f);
+    }
+  };
+  // sNz <- sample_combined_position_feature_noise (en_diffusion.py:937-956) from raw draw `draw`
+  auto combined_noise = [=](int draw, float std) {
+    for (int e = tid; e < N * D; e += kThreads) sNz[e] = raw_noise(draw, e) * std * sMask[e / D];
+    __syncthreads();
+    col_means(sNz);
+    __syncthreads();
+    for (int e = tid; e < N * 3; e += kThreads) {
+      const int n = e / 3, d = e % 3;
+      sNz[n * D + d] = sNz[n * D + d] - sMean[d] * sMask[n];
+    }
+    __syncthreads();
+  };
+
+  const int mode = P.mode;
+  if (mode == MODE_SAMPLE && P.do_init) {
+    __syncthreads();
+    combined_noise(0, P.std0);
+    for (int e = tid; e < N * D; e += kThreads) sZ[e] = sNz[e];
+  } else {
+    for (int e = tid; e < N * D; e += kThreads) sZ[e] = P.z_in[(size_t)b * N * D + e];
+  }
+  __syncthreads();
+
+  if constexpr (HPE > 0) {
+    if (mode == MODE_PHI || mode == MODE_SAMPLE) {
+      NetSmem<HPE> sm;
+      sm.carve(net, N, EW);
+      const EdmDev edm = P.edm;
+      const int guided = P.guided, T = P.T, s_hi = P.s_hi;
+      const int n_steps = mode == MODE_SAMPLE ? (s_hi - P.s_lo + 1) : 0;
+      const int n_pass = mode == MODE_PHI ? 1 : n_steps + (P.do_decode ? 1 : 0);
+      int nan_local = 0;
+      // one EDM evaluation per pass: reverse steps s_hi..s_lo, then (optionally) the decode pass
+      for (int pass = 0; pass < n_pass; ++pass) {
+        const bool is_step = mode == MODE_SAMPLE && pass < n_steps;
+        const int s = s_hi - pass;
+        f4 cf = splat(0.f);
+        if (is_step) cf = *(const f4*)(P.coef + 4 * s);
+        const float t_val = mode == MODE_PHI ? P.t_in[b] : cf[3];  // decode: t = 0
+        if (is_step == false && mode == MODE_SAMPLE)               // z_0 is final: publish it
+          for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
+        edm_forward<HPE>(edm, mg, sm, sZ, sEps, sMean, t_val, tid);
+        if (mode == MODE_PHI) {
+          for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
+        } else if (is_step) {
+          // ---- z_s = z_t/alpha_ts - c*eps + sigma*noise ; x part mean-removed (en_diffusion.py:831-852)
+          combined_noise(T - s, 1.0f);
+          for (int e = tid; e < N * D; e += kThreads) {
+            float ep = sEps[e];
+            if (guided) {  // eps_t.nan_to_num(0.)  (en_diffusion.py:881)
+              if (ep != ep) { ep = 0.f; ++nan_local; }
+              ep = fminf(fmaxf(ep, -3.4028234663852886e38f), 3.4028234663852886e38f);
+            }
+            const float mu = sZ[e] / cf[0] - cf[1] * ep;
+            sZ[e] = mu + cf[2] * sNz[e];
+          }
+          __syncthreads();
+          if constexpr (HPP > 0) {
+            if (guided) {
+              // guidance (en_diffusion.py:899-920): predictor at (z_s, t), clip, project, apply
+              guidance_update<HPP>(P.pred, mg, net, sZ, sEps /* grad */, sNz /* scratch */, sMean, cf[3], cf[2],
+                                   P.target_w, P.scale, nullptr, P.readout_div,
+                                   P.stash + (size_t)b * P.stash_stride, tid);
+            }
+          }
+          col_means(sZ);
+          __syncthreads();
+          for (int e = tid; e < N * 3; e += kThreads) {
+            const int n = e / 3, d = e % 3;
+            sZ[n * D + d] = sZ[n * D + d] - sMean[d] * sMask[n];
+          }
+          __syncthreads();
+          if (guided) {  // zs.nan_to_num(0.) (en_diffusion.py:933-934)
+            for (int e = tid; e < N * D; e += kThreads) {
+              float v = sZ[e];
+              if (v != v) { v = 0.f; ++nan_local; }
+              sZ[e] = v;
+            }
+            __syncthreads();
+          }
+        } else {
+          // ---- decode: sample_p_xh_given_z0 (en_diffusion.py:533-560) + unnormalize (:406-415)
+          combined_noise(T + 1, 1.0f);
+          const float inv_a = 1.0f / P.alpha0;
+          const float sigma0 = P.sigma0, sigma_x = P.sigma_x, nv0 = P.nv0, nv1 = P.nv1;
+          const int F = P.F;
+          for (int e = tid; e < N * 3; e += kThreads) {
+            const int n = e / 3, d = e % 3;
+            const float mu = inv_a * (sZ[n * D + d] - sigma0 * sEps[n * D + d]);
+            P.x_out[(size_t)b * N * 3 + e] = (mu + sigma_x * sNz[n * D + d]) * nv0;
+          }
+          for (int n = tid; n < N; n += kThreads) {
+            int best = 0;
+            float bv = (sZ[n * D + 3] * nv1 + 0.0f) * sMask[n];
+            for (int k = 1; k < F; ++k) {
+              const float v = (sZ[n * D + 3 + k] * nv1 + 0.0f) * sMask[n];
+              if (v > bv) { bv = v; best = k; }
+            }
+            for (int k = 0; k < F; ++k) P.h_out[((size_t)b * N + n) * F + k] = (k == best ? 1.0f : 0.0f) * sMask[n];
+          }
+        }
+      }
+      if (mode == MODE_SAMPLE && !P.do_decode)
+        for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
+      if (nan_local) atomicAdd(P.nan_count, nan_local);
+      return;
+    }
+  }
+  if constexpr (HPP > 0) {
+    if (P.mode == MODE_PRED_FWD || P.mode == MODE_PRED_GRAD) {
+      const float* dp = P.dpred_in ? P.dpred_in + (size_t)b * P.pred.K : nullptr;
+      predictor_entry<HPP>(P.pred, mg, net, sZ, sEps, sNz, sMean, P.t_in[b], dp, P.mode == MODE_PRED_GRAD,
+                           P.pred_out + (size_t)b * P.pred.K, P.readout_div, P.stash + (size_t)b * P.stash_stride, tid);
+      if (P.mode == MODE_PRED_GRAD)
+        for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
+    }
+  }
+}
+
+}  // namespace gaudi

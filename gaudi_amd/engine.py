@@ -1,0 +1,215 @@
+"""Thin object wrapper over the C ABI: one Engine = one gaudi_handle = one GPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Diag, EdmConfig, GaudiError, PredConfig, f32, fptr
+
+
+def _strip(sd: dict) -> dict:
+    """Checkpoints saved with dp=True carry a ``module.`` prefix (models_edm.py:98-102)."""
+    out = {}
+    for k, v in sd.items():
+        if hasattr(v, "detach"):
+            v = v.detach().cpu().numpy()
+        out[k[7:] if k.startswith("module.") else k] = f32(v)
+    return out
+
+
+def _noise_power(schedule: str) -> float:
+    parts = schedule.split("_")
+    if len(parts) != 2 or parts[0] != "polynomial":
+        raise GaudiError(f"unsupported diffusion_noise_schedule {schedule!r}: only 'polynomial_<p>' is implemented "
+                         "(the 'learned'/'cosine' schedules are training-only in the reference)")
+    return float(parts[1])
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.gaudi_create(int(device), C.byref(self.h))
+        if rc != 0:
+            raise GaudiError(f"gaudi_create(device={device}) failed with code {rc} (no usable HIP device?)")
+        self.device = device
+        self.edm_args = None
+        self.pred_args = None
+        self.F = None
+        self.K = None
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.gaudi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.gaudi_last_error(self.h)
+            raise GaudiError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _tensor_args(self, sd: dict):
+        names = list(sd.keys())
+        arrs = [sd[k] for k in names]
+        n = len(names)
+        c_names = (C.c_char_p * n)(*[k.encode() for k in names])
+        c_ptrs = (_lib.FP * n)(*[fptr(a) for a in arrs])
+        c_numel = (C.c_int64 * n)(*[a.size for a in arrs])
+        return n, c_names, c_ptrs, c_numel, arrs
+
+    # ------------------------------------------------------------------ weights
+    def load_edm(self, args: dict, state_dict: dict):
+        """args: the checkpoint's args.txt namespace (utils/args_edm.py); state_dict: model.pt."""
+        if args.get("sin_embedding", False):
+            raise GaudiError("sin_embedding=True checkpoints are not supported")
+        if args.get("aggregation_method", "sum") != "sum":
+            raise GaudiError("only aggregation_method='sum' is supported")
+        sd = _strip(state_dict)
+        emb = sd.get("dynamics.egnn.embedding.weight")
+        if emb is None:
+            raise GaudiError("state dict has no dynamics.egnn.embedding.weight (mode='gnn_dynamics' is unsupported)")
+        F = emb.shape[1] - 1  # in_node_nf is not stored: recover it
+        nv = args.get("normalize_factors", [1, 1, 1])
+        cfg = EdmConfig(F, int(args["nf"]), int(args["n_layers"]), int(args.get("inv_sublayers", 1)),
+                        int(bool(args["attention"])), int(bool(args["tanh"])), float(args["coords_range"]),
+                        float(args["norm_constant"]), float(args.get("normalization_factor", 1)),
+                        int(args["diffusion_steps"]), _noise_power(args["diffusion_noise_schedule"]),
+                        float(args["diffusion_noise_precision"]), (C.c_float * 3)(*[float(v) for v in nv]))
+        n, c_names, c_ptrs, c_numel, keep = self._tensor_args(sd)
+        self._check(self.lib.gaudi_load_edm(self.h, C.byref(cfg), n, c_names, c_ptrs, c_numel), "gaudi_load_edm")
+        self.edm_args, self.F, self.T = dict(args), F, int(args["diffusion_steps"])
+
+    def load_predictor(self, args: dict, state_dict: dict):
+        sd = _strip(state_dict)
+        emb = sd["egnn.embedding.weight"]
+        F = emb.shape[1] - 1
+        K = sd["egnn.embedding_out.weight"].shape[0]
+        cfg = PredConfig(F, K, int(args["nf"]), int(args["n_layers"]), int(bool(args["attention"])),
+                         int(bool(args["tanh"])), float(args["coords_range"]))
+        n, c_names, c_ptrs, c_numel, keep = self._tensor_args(sd)
+        self._check(self.lib.gaudi_load_predictor(self.h, C.byref(cfg), n, c_names, c_ptrs, c_numel),
+                    "gaudi_load_predictor")
+        self.pred_args, self.K = dict(args), K
+
+    # ------------------------------------------------------------------ tables
+    def gamma(self) -> np.ndarray:
+        g = np.empty(self.T + 1, np.float32)
+        self._check(self.lib.gaudi_get_gamma(self.h, fptr(g)), "gaudi_get_gamma")
+        return g
+
+    def step_coefficients(self) -> np.ndarray:
+        c = np.empty((self.T, 4), np.float32)
+        self._check(self.lib.gaudi_get_step_coefficients(self.h, fptr(c)), "gaudi_get_step_coefficients")
+        return c
+
+    # ------------------------------------------------------------------ unit entry points
+    @staticmethod
+    def _masks(node_mask, edge_mask, B, N):
+        nm = f32(node_mask).reshape(B, N)
+        em = f32(edge_mask).reshape(B, N, N)
+        return nm, em
+
+    def phi(self, z, t, node_mask, edge_mask) -> np.ndarray:
+        z = f32(z)
+        B, N, D = z.shape
+        nm, em = self._masks(node_mask, edge_mask, B, N)
+        t = f32(np.broadcast_to(np.asarray(t, np.float32).reshape(-1), (B,)))
+        out = np.empty_like(z)
+        self._check(self.lib.gaudi_phi(self.h, B, N, fptr(z), fptr(t), fptr(nm), fptr(em), fptr(out)), "gaudi_phi")
+        return out
+
+    def predictor_fwd(self, z, t, node_mask, edge_mask) -> np.ndarray:
+        z = f32(z)
+        B, N, D = z.shape
+        nm, em = self._masks(node_mask, edge_mask, B, N)
+        t = f32(np.broadcast_to(np.asarray(t, np.float32).reshape(-1), (B,)))
+        out = np.empty((B, self.K), np.float32)
+        self._check(self.lib.gaudi_predictor_fwd(self.h, B, N, fptr(z), fptr(t), fptr(nm), fptr(em), fptr(out)),
+                    "gaudi_predictor_fwd")
+        return out
+
+    def predictor_grad(self, z, t, node_mask, edge_mask, dpred):
+        z = f32(z)
+        B, N, D = z.shape
+        nm, em = self._masks(node_mask, edge_mask, B, N)
+        t = f32(np.broadcast_to(np.asarray(t, np.float32).reshape(-1), (B,)))
+        dp = f32(np.broadcast_to(np.asarray(dpred, np.float32), (B, self.K)))
+        pred = np.empty((B, self.K), np.float32)
+        grad = np.empty_like(z)
+        self._check(self.lib.gaudi_predictor_grad(self.h, B, N, fptr(z), fptr(t), fptr(nm), fptr(em), fptr(dp),
+                                                  fptr(pred), fptr(grad)), "gaudi_predictor_grad")
+        return pred, grad
+
+    def step(self, s_idx, z_t, node_mask, edge_mask, eps_raw, target_w=None, scale=1.0) -> np.ndarray:
+        z = f32(z_t)
+        B, N, D = z.shape
+        nm, em = self._masks(node_mask, edge_mask, B, N)
+        eps = f32(eps_raw)
+        tw = None if target_w is None else f32(target_w)
+        out = np.empty_like(z)
+        self._check(self.lib.gaudi_step(self.h, B, N, int(s_idx), fptr(z), fptr(nm), fptr(em), fptr(eps), fptr(tw),
+                                        float(scale), fptr(out)), "gaudi_step")
+        return out
+
+    def decode(self, z0, node_mask, edge_mask, eps_raw):
+        z = f32(z0)
+        B, N, D = z.shape
+        nm, em = self._masks(node_mask, edge_mask, B, N)
+        eps = f32(eps_raw)
+        x = np.empty((B, N, 3), np.float32)
+        h = np.empty((B, N, D - 3), np.float32)
+        self._check(self.lib.gaudi_decode(self.h, B, N, fptr(z), fptr(nm), fptr(em), fptr(eps), fptr(x), fptr(h)),
+                    "gaudi_decode")
+        return x, h
+
+    # ------------------------------------------------------------------ whole chain
+    def sample(self, node_mask, edge_mask, *, seed=0, sample_offset=0, noise=None, std=1.0, target_w=None, scale=1.0,
+               return_z0=False):
+        nm = f32(node_mask)
+        B, N = nm.shape[0], nm.shape[1]
+        nm, em = self._masks(nm, edge_mask, B, N)
+        D = 3 + self.F
+        nz = None
+        if noise is not None:
+            nz = f32(noise)
+            if nz.shape != (self.T + 2, B, N, D):
+                raise GaudiError(f"noise must be [T+2,B,N,3+F] = {(self.T + 2, B, N, D)}, got {nz.shape}")
+        tw = None if target_w is None else f32(target_w)
+        x = np.empty((B, N, 3), np.float32)
+        h = np.empty((B, N, self.F), np.float32)
+        z0 = np.empty((B, N, D), np.float32) if return_z0 else None
+        diag = Diag()
+        self._check(self.lib.gaudi_sample(self.h, B, N, fptr(nm), fptr(em), int(seed), int(sample_offset), fptr(nz),
+                                          float(std), fptr(tw), float(scale), fptr(x), fptr(h), fptr(z0),
+                                          C.byref(diag)), "gaudi_sample")
+        d = dict(max_masked_leak=diag.max_masked_leak, max_cog_rel=diag.max_cog_rel, max_cog_abs=diag.max_cog_abs,
+                 nan_count=diag.nan_count, reprojected=diag.reprojected)
+        return (x, h, d, z0) if return_z0 else (x, h, d)
+
+    def philox_normal(self, seed, sample_offset, B, n_elem, draw0, n_draws) -> np.ndarray:
+        out = np.empty((n_draws, B, n_elem), np.float32)
+        self._check(self.lib.gaudi_philox_normal(self.h, int(seed), int(sample_offset), B, n_elem, draw0, n_draws,
+                                                 fptr(out)), "gaudi_philox_normal")
+        return out
+
+    # ------------------------------------------------------------------ profiling
+    def profile_reset(self, enable=True):
+        self._check(self.lib.gaudi_profile_reset(self.h, int(enable)), "gaudi_profile_reset")
+
+    def profile_get(self):
+        n = C.c_int32()
+        ms = C.c_double()
+        steps = C.c_int64()
+        self._check(self.lib.gaudi_profile_get(self.h, C.byref(n), C.byref(ms), C.byref(steps)), "gaudi_profile_get")
+        return n.value, ms.value, steps.value
+
+    def set_steps_per_launch(self, k: int):
+        self._check(self.lib.gaudi_set_steps_per_launch(self.h, int(k)), "gaudi_set_steps_per_launch")

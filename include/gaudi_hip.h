@@ -1,0 +1,144 @@
+/*
+ * gaudi_hip.h -- C ABI of libgaudi_hip.so: MI355X (gfx950) guided-diffusion sampler for GaUDI.
+ *
+ * The reference (tomer196/GaUDI) has no FFI/plugin layer: its boundary for this path is a set
+ * of Python call signatures plus an on-disk checkpoint.  This header is
+ * therefore the boundary a maintainer would bind with ctypes; each entry
+ * point names the reference function it replaces.  Conventions:
+ *   - every function returns 0 on success or a negative GAUDI_E_* code; nothing throws across
+ *     the ABI; gaudi_last_error(h) returns a human-readable message for the last failure;
+ *   - all pointers are HOST pointers to caller-owned, contiguous fp32/int buffers; the handle
+ *     owns all device memory and one HIP stream; one handle per device, not thread-safe;
+ *   - tensors use the reference's layouts: z/eps/grad [B,N,3+F] (x first), node_mask [B,N],
+ *     edge_mask [B,N,N] (row i = receiving node, as edm/egnn/models.py:154-175).
+ */
+#ifndef GAUDI_HIP_H
+#define GAUDI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAUDI_OK 0
+#define GAUDI_E_INVALID (-1)   /* bad argument / unsupported configuration      */
+#define GAUDI_E_HIP (-2)       /* HIP runtime error                              */
+#define GAUDI_E_STATE (-3)     /* e.g. sampling before weights are loaded        */
+#define GAUDI_E_MISSING (-4)   /* a required checkpoint tensor was not supplied  */
+#define GAUDI_E_CAPACITY (-5)  /* problem does not fit the kernel's LDS budget   */
+
+typedef struct gaudi_handle gaudi_handle;
+
+/* Architecture of EnVariationalDiffusion(EGNN_dynamics): models_edm.py:67-96 / utils/args_edm.py. */
+typedef struct {
+  int32_t in_node_nf;          /* F: dataset.num_node_features (cata 1, hetro 12)            */
+  int32_t hidden_nf;           /* args.nf                                                      */
+  int32_t n_layers;            /* args.n_layers (EquivariantBlocks)                            */
+  int32_t inv_sublayers;       /* args.inv_sublayers (GCLs per block)                          */
+  int32_t attention;           /* args.attention                                               */
+  int32_t tanh;                /* args.tanh                                                    */
+  float coords_range;          /* args.coords_range (NOT divided by n_layers, egnn_new.py:290) */
+  float norm_constant;         /* args.norm_constant                                           */
+  float normalization_factor;  /* args.normalization_factor ("sum" aggregation only)           */
+  int32_t diffusion_steps;     /* args.diffusion_steps (T)                                     */
+  float noise_power;           /* p of "polynomial_<p>" (en_diffusion.py:47-61)                */
+  float noise_precision;       /* args.diffusion_noise_precision                               */
+  float norm_values[3];        /* args.normalize_factors                                       */
+} gaudi_edm_config;
+
+/* Architecture of EGNN_predictor: cond_prediction/train_cond_predictor.py:183-196. */
+typedef struct {
+  int32_t in_nf;        /* F                                                      */
+  int32_t out_nf;       /* K = dataset.num_targets                                */
+  int32_t hidden_nf;    /* args.nf                                                */
+  int32_t n_layers;     /* args.n_layers                                          */
+  int32_t attention;
+  int32_t tanh;
+  float coords_range;   /* divided by n_layers inside (egnn_predictor/models.py:515) */
+} gaudi_pred_config;
+
+/* Per-call diagnostics replacing the reference's per-step asserts
+ * (edm/equivariant_diffusion/utils.py:52-65, sampling_edm.py:167-168,222-223). */
+typedef struct {
+  float max_masked_leak;   /* max |x * (1-node_mask)|                     */
+  float max_cog_rel;       /* max |sum_n x| / (max|x| + 1e-10)            */
+  float max_cog_abs;       /* max |sum_n x| before the final re-projection */
+  int32_t nan_count;       /* NaNs scrubbed inside the chain              */
+  int32_t reprojected;     /* 1 if the 5e-2 CoG re-projection fired (en_diffusion.py:1000-1006) */
+} gaudi_diag;
+
+int gaudi_create(int device, gaudi_handle** out);
+void gaudi_destroy(gaudi_handle* h);
+const char* gaudi_last_error(const gaudi_handle* h);
+
+/* Load a state dict (reference key names WITHOUT the "module." prefix).
+ * names[i] is the key, tensors[i] its fp32 data, numel[i] its element count.  Unknown keys are
+ * ignored ("buffer", "gamma.gamma": the schedule is rebuilt from the config exactly as
+ * PredefinedNoiseSchedule does); missing ones fail with GAUDI_E_MISSING.
+ * Replaces models_edm.get_model / load_state_dict (models_edm.py:61-104). */
+int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const char* const* names,
+                   const float* const* tensors, const int64_t* numel);
+/* Replaces get_cond_predictor_model (cond_prediction/train_cond_predictor.py:183-203). */
+int gaudi_load_predictor(gaudi_handle* h, const gaudi_pred_config* cfg, int n, const char* const* names,
+                         const float* const* tensors, const int64_t* numel);
+
+/* gamma table [T+1] as PredefinedNoiseSchedule builds it (en_diffusion.py:191-218). */
+int gaudi_get_gamma(gaudi_handle* h, float* gamma_out /* [T+1] */);
+/* Per-step scalars (en_diffusion.py:433-457, 811-821): coef_out[s] = {alpha_t|s, sigma2_t|s/alpha_t|s/sigma_t,
+ * sigma_t|s*sigma_s/sigma_t, t=(s+1)/T} for s in [0,T). */
+int gaudi_get_step_coefficients(gaudi_handle* h, float* coef_out /* [T][4] */);
+
+/* eps_hat = EGNN_dynamics._forward(t, z, node_mask, edge_mask)  (edm/egnn/models.py:83-152). */
+int gaudi_phi(gaudi_handle* h, int B, int N, const float* z, const float* t /* [B] */,
+              const float* node_mask, const float* edge_mask, float* eps_out);
+
+/* pred = EGNN_predictor.forward(z, node_mask, edge_mask, t)  (edm/egnn_predictor/models.py:433-457). */
+int gaudi_predictor_fwd(gaudi_handle* h, int B, int N, const float* z, const float* t /* [B] */,
+                        const float* node_mask, const float* edge_mask, float* pred_out /* [B,K] */);
+/* grad = d(sum_b dpred[b].pred[b])/dz: the hand-written reverse pass replacing
+ * torch.autograd.grad at en_diffusion.py:900-903. */
+int gaudi_predictor_grad(gaudi_handle* h, int B, int N, const float* z, const float* t, const float* node_mask,
+                         const float* edge_mask, const float* dpred /* [B,K] */, float* pred_out /* [B,K] or NULL */,
+                         float* grad_out /* [B,N,3+F] */);
+
+/* One teacher-forced reverse step z_t -> z_s with s = s_idx/T, t = (s_idx+1)/T:
+ * sample_p_zs_given_zt (en_diffusion.py:807-852) when target_w == NULL, else
+ * sample_p_zs_given_zt_guidance (:854-935) for the target  T(pred) = target_w . pred  scaled by `scale`.
+ * eps_raw [B,N,3+F] are the raw N(0,1) draws (x part first). */
+int gaudi_step(gaudi_handle* h, int B, int N, int s_idx, const float* z_t, const float* node_mask,
+               const float* edge_mask, const float* eps_raw, const float* target_w /* [K] or NULL */,
+               float scale, float* zs_out);
+
+/* x, one_hot = sample_p_xh_given_z0(z0)  (en_diffusion.py:533-560 + unnormalize :406-415). */
+int gaudi_decode(gaudi_handle* h, int B, int N, const float* z0, const float* node_mask, const float* edge_mask,
+                 const float* eps_raw, float* x_out /* [B,N,3] */, float* onehot_out /* [B,N,F] */);
+
+/* Whole chain: EnVariationalDiffusion.sample (en_diffusion.py:958-1008) when target_w == NULL, else
+ * .sample_guidance (:1010-1067).  noise: NULL -> on-device Philox4x32-10 keyed by
+ * (seed, sample_offset + b, draw, element) so results do not depend on how samples are sharded;
+ * otherwise injected raw N(0,1) draws [T+2,B,N,3+F] (draw 0 -> z_T, 1+k -> k-th step, T+1 -> decode).
+ * n_pad_readout: the N the predictor readout divides by (0 -> N); shards of one logical batch pass the
+ * global padded N (egnn_predictor/models.py:457). */
+int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                 int64_t sample_offset, const float* noise, float std, const float* target_w /* [K] or NULL */,
+                 float scale, float* x_out /* [B,N,3] */, float* onehot_out /* [B,N,F] */,
+                 float* z0_out /* [B,N,3+F] or NULL */, gaudi_diag* diag /* or NULL */);
+
+/* Device Philox stream used when noise == NULL, exposed for tests: out[draw][b][e], e < n_elem. */
+int gaudi_philox_normal(gaudi_handle* h, uint64_t seed, int64_t sample_offset, int B, int n_elem, int draw0,
+                        int n_draws, float* out);
+
+/* Kernel timing with HIP events on the handle's own stream (bench.py roofline).
+ * gaudi_profile_reset enables collection; gaudi_profile_get returns the number of step-kernel
+ * launches since the reset and their summed duration. */
+int gaudi_profile_reset(gaudi_handle* h, int enable);
+int gaudi_profile_get(gaudi_handle* h, int32_t* n_launches, double* total_ms, int64_t* steps_done);
+
+/* Tuning knob: reverse steps fused into one kernel launch (default 25). */
+int gaudi_set_steps_per_launch(gaudi_handle* h, int steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAUDI_HIP_H */
