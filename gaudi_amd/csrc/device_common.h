@@ -71,7 +71,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Wave w produces output-feature tiles t = w, w+4, ... for every node tile, so every weight
 // element is fetched by exactly one wave of the workgroup.
 // ---------------------------------------------------------------------------------------------
-enum NodeEpi { EPI_NONE = 0, EPI_SILU = 1, EPI_RESIDUAL_MASK = 2 };
+enum NodeEpi { EPI_NONE = 0, EPI_SILU = 1, EPI_RESIDUAL_MASK = 2, EPI_MUL_DSILU = 3, EPI_ACCUM = 4 };
 
 template <int HP, int EPI>
 __device__ __forceinline__ void node_gemm(const float* __restrict__ Wa, const float* sXa,
@@ -123,6 +123,11 @@ __device__ __forceinline__ void node_gemm(const float* __restrict__ Wa, const fl
           const f4 r = *(const f4*)(sRes + node * LD + 16 * t + 4 * g);
           y = (r + y) * sMask[node];
         }
+        if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
+          const f4 r = *(const f4*)(sRes + node * LD + 16 * t + 4 * g);
+          y = (f4){y[0] * dsilu_f(r[0]), y[1] * dsilu_f(r[1]), y[2] * dsilu_f(r[2]), y[3] * dsilu_f(r[3])};
+        }
+        if (EPI == EPI_ACCUM) y = *(const f4*)(sRes + node * LD + 16 * t + 4 * g) + y;
         *(f4*)dst = y;
       }
     }
@@ -137,16 +142,24 @@ __device__ __forceinline__ void node_gemm(const float* __restrict__ Wa, const fl
 // fp32 summation order differs from the reference's concat+Linear: egnn_new.py:42-47,119-129;
 // egnn_predictor/gcl.py:225-231).  U (optional) receives u for the backward pass.
 // ---------------------------------------------------------------------------------------------
-struct EdgeCols {
-  int i0, j0, i1, j1;        // node indices of the lane's edge column in tile 0 / tile 1
-  float r0, d00, r1, d01;    // radial (current x) and d0 (input x) of those edges
+struct EdgeCol {
+  int i, j;      // receiving / sending node of the lane's edge column
+  float r, d0;   // radial (current x) and d0 (input x) of that edge
 };
 
-template <int HP>
-__device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[2][HP / 16], const float* __restrict__ W2p,
+// u[f] for f = 16cc+4g+q of one edge column
+__device__ __forceinline__ f4 edge_u(const float* p, const float* q, const float* crg, const float* cdg, int cc,
+                                     float r, float d0) {
+  const f4 crv = *(const f4*)(crg + 16 * cc);
+  const f4 cdv = *(const f4*)(cdg + 16 * cc);
+  return *(const f4*)(p + 16 * cc) + *(const f4*)(q + 16 * cc) + crv * r + cdv * d0;
+}
+
+template <int HP, int NE>
+__device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const float* __restrict__ W2p,
                                                   const float* __restrict__ b2, const float* __restrict__ cr,
                                                   const float* __restrict__ cd, const float* sP, const float* sQ,
-                                                  const EdgeCols& ec, int lane) {
+                                                  const EdgeCol (&ec)[NE], int lane) {
   constexpr int T = HP / 16;
   constexpr int LD = HP + 4;
   constexpr int PF = kPF < T ? kPF : T;
@@ -154,35 +167,33 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[2][HP / 16], const f
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const f4 b = *(const f4*)(b2 + 16 * t + 4 * g);
-    acc[0][t] = b;
-    acc[1][t] = b;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[e][t] = b;
   }
-  const float* p0 = sP + ec.i0 * LD + 4 * g;
-  const float* q0 = sQ + ec.j0 * LD + 4 * g;
-  const float* p1 = sP + ec.i1 * LD + 4 * g;
-  const float* q1 = sQ + ec.j1 * LD + 4 * g;
+  const float* pp[NE];
+  const float* qq[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    pp[e] = sP + ec[e].i * LD + 4 * g;
+    qq[e] = sQ + ec[e].j * LD + 4 * g;
+  }
   const float* crg = cr + 4 * g;
   const float* cdg = cd + 4 * g;
-  auto gen = [&](int cc, f4& o0, f4& o1) {
-    const f4 crv = *(const f4*)(crg + 16 * cc);
-    const f4 cdv = *(const f4*)(cdg + 16 * cc);
-    const f4 u0 = *(const f4*)(p0 + 16 * cc) + *(const f4*)(q0 + 16 * cc) + crv * ec.r0 + cdv * ec.d00;
-    const f4 u1 = *(const f4*)(p1 + 16 * cc) + *(const f4*)(q1 + 16 * cc) + crv * ec.r1 + cdv * ec.d01;
-    o0 = silu4(u0);
-    o1 = silu4(u1);
-  };
   const f4* W4 = (const f4*)W2p + c * 4 + g;
   f4 wq[PF];
 #pragma unroll
   for (int p = 0; p < PF; ++p) wq[p] = W4[p * 64];
-  f4 bin0, bin1;
-  gen(0, bin0, bin1);
+  f4 bin[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) bin[e] = silu4(edge_u(pp[e], qq[e], crg, cdg, 0, ec[e].r, ec[e].d0));
   // K loop stays rolled (one 16-feature chunk per trip): the weight tiles of the next chunk are
   // prefetched by the tail of this one (rotating queue) and the next chunk's activations are
   // generated under this chunk's MFMAs.
 #pragma unroll 1
   for (int cc = 0; cc < T; ++cc) {
-    f4 nb0 = bin0, nb1 = bin1;
+    f4 nb[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) nb[e] = bin[e];
     const f4* Wc = W4 + (size_t)cc * T * 64;
     f4 r[PF];
 #pragma unroll
@@ -193,42 +204,48 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[2][HP / 16], const f
       // tile index cc*T + t + PF (clamped at the end of the matrix; the surplus loads are unused)
       const int nxt = (cc * T + t + PF < T * T) ? (t + PF) : t;
       r[t % PF] = Wc[nxt * 64];
-      acc[0][t] = mfma4(w, bin0, acc[0][t]);
-      acc[1][t] = mfma4(w, bin1, acc[1][t]);
-      if (t == 0 && cc + 1 < T) gen(cc + 1, nb0, nb1);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) acc[e][t] = mfma4(w, bin[e], acc[e][t]);
+      if (t == 0 && cc + 1 < T) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], crg, cdg, cc + 1, ec[e].r, ec[e].d0));
+      }
     }
 #pragma unroll
     for (int p = 0; p < PF; ++p) wq[p] = r[(p + T) % PF];
-    bin0 = nb0;
-    bin1 = nb1;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) bin[e] = nb[e];
   }
 }
 
 // Edge-level GEMM whose input already sits in registers in C/B layout (chained MLP layer):
-//   out[e][t] = init[t] + W . in[e]      in[e][cc] = features 16cc+4g+q of edge column c
-template <int HP>
-__device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[2][HP / 16], const f4 (&in)[2][HP / 16],
+//   out[e][t] = init + W . in[e]      in[e][cc] = features 16cc+4g+q of edge column c
+// init = bias[16t+4g..] (global, may be null) + per-column LDS rows rowinit[e] (may be null).
+template <int HP, int NE>
+__device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[NE][HP / 16], const f4 (&in)[NE][HP / 16],
                                                     const float* __restrict__ Wp, const float* __restrict__ bias,
-                                                    int lane) {
+                                                    const float* const (&rowinit)[NE], int lane) {
   constexpr int T = HP / 16;
+  constexpr int PF = kPF < T ? kPF : T;
   const int c = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const f4 b = bias != nullptr ? *(const f4*)(bias + 16 * t + 4 * g) : splat(0.f);
-    out[0][t] = b;
-    out[1][t] = b;
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      out[e][t] = rowinit[e] != nullptr ? b + *(const f4*)(rowinit[e] + 16 * t + 4 * g) : b;
   }
   const f4* W4 = (const f4*)Wp + c * 4 + g;
-  f4 wq[kPF];
+  f4 wq[PF];
 #pragma unroll
-  for (int p = 0; p < kPF; ++p) wq[p] = W4[p * 64];
+  for (int p = 0; p < PF; ++p) wq[p] = W4[p * 64];
 #pragma unroll
   for (int idx = 0; idx < T * T; ++idx) {
     const int cc = idx / T, t = idx % T;
-    const f4 w = wq[idx % kPF];
-    if (idx + kPF < T * T) wq[idx % kPF] = W4[(idx + kPF) * 64];
-    out[0][t] = mfma4(w, in[0][cc], out[0][t]);
-    out[1][t] = mfma4(w, in[1][cc], out[1][t]);
+    const f4 w = wq[idx % PF];
+    if (idx + PF < T * T) wq[idx % PF] = W4[(idx + PF) * 64];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) out[e][t] = mfma4(w, in[e][cc], out[e][t]);
   }
 }
 

@@ -40,6 +40,7 @@ struct MolGraph {
   const float* em;        // LDS [4][EW]  edge_mask value (0 for padding slots)
   const uint32_t* seg;    // LDS [N]      wave<<30 | start<<15 | len  (edge run of node n)
   int npairs;             // 32-edge passes of THIS wave
+  int npairs_all[kWaves]; // ... of every wave of the workgroup (lock-step loops of the reverse pass)
 };
 
 // LDS working set of one network evaluation
@@ -72,8 +73,8 @@ struct NetSmem {
 __device__ __forceinline__ void edge_ij(uint32_t e, int& i, int& j) { i = e & 255; j = (e >> 8) & 255; }
 
 // r = |x_i - x_j|^2, dhat = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn_new.py:394-400)
-template <int HP>
-__device__ __forceinline__ void compute_geo(const NetSmem<HP>& sm, const MolGraph& mg, float norm_constant, int wave,
+template <class SM>
+__device__ __forceinline__ void compute_geo(const SM& sm, const MolGraph& mg, float norm_constant, int wave,
                                             int lane, bool write_d0) {
   for (int slot = lane; slot < mg.npairs * 32; slot += 64) {
     int i, j;
@@ -91,27 +92,23 @@ __device__ __forceinline__ void compute_geo(const NetSmem<HP>& sm, const MolGrap
   }
 }
 
-template <int HP>
-__device__ __forceinline__ EdgeCols load_cols(const NetSmem<HP>& sm, const MolGraph& mg, int wave, int tp, int c,
-                                              float& m0, float& m1, f4& g0, f4& g1) {
-  const int s0 = wave * mg.EW + tp * 32 + c, s1 = s0 + 16;
-  EdgeCols ec;
-  edge_ij(mg.edge[s0], ec.i0, ec.j0);
-  edge_ij(mg.edge[s1], ec.i1, ec.j1);
-  m0 = mg.em[s0];
-  m1 = mg.em[s1];
-  g0 = sm.geo[s0];
-  g1 = sm.geo[s1];
-  ec.r0 = g0[0];
-  ec.r1 = g1[0];
-  ec.d00 = sm.d0[s0];
-  ec.d01 = sm.d0[s1];
-  return ec;
+template <class SM, int NE>
+__device__ __forceinline__ void load_cols(const SM& sm, const MolGraph& mg, int wave, int first_slot, int c,
+                                          EdgeCol (&ec)[NE], float (&mk)[NE], f4 (&geo)[NE]) {
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int s = wave * mg.EW + first_slot + 16 * e + c;
+    edge_ij(mg.edge[s], ec[e].i, ec[e].j);
+    mk[e] = mg.em[s];
+    geo[e] = sm.geo[s];
+    ec[e].r = geo[e][0];
+    ec[e].d0 = sm.d0[s];
+  }
 }
 
 // x <- (x + sum_j trans_ij / normf) * mask     (egnn_new.py:132-155), fixed ascending-j order
-template <int HP>
-__device__ __forceinline__ void coord_update(const NetSmem<HP>& sm, const MolGraph& mg, float normf, int tid) {
+template <class SM>
+__device__ __forceinline__ void coord_update(const SM& sm, const MolGraph& mg, float normf, int tid) {
   if (tid < mg.N * 3) {
     const int n = tid / 3, d = tid % 3;
     const uint32_t sg = mg.seg[n];
@@ -154,10 +151,10 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
     }
   }
   __syncthreads();
-  compute_geo<HP>(sm, mg, 0.f, wave, lane, true);  // d0 of the input coordinates (egnn_new.py:301)
+  compute_geo(sm, mg, 0.f, wave, lane, true);  // d0 of the input coordinates (egnn_new.py:301)
 
   for (int l = 0; l < W.L; ++l) {
-    compute_geo<HP>(sm, mg, W.norm_constant, wave, lane, false);  // egnn_new.py:216
+    compute_geo(sm, mg, W.norm_constant, wave, lane, false);  // egnn_new.py:216
     for (int s = 0; s < W.S; ++s) {
       // ------------------------------------------------------------------ GCL (egnn_new.py:42-89)
       const float* G = w + lay.gcl(l, s);
@@ -175,11 +172,12 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
         ss.init();
         float* scr = sm.scr + wave * 16 * LD;
         for (int tp = 0; tp < mg.npairs; ++tp) {
-          float m0, m1;
-          f4 g0, g1;
-          const EdgeCols ec = load_cols<HP>(sm, mg, wave, tp, c, m0, m1, g0, g1);
+          EdgeCol ec[2];
+          float mk2[2];
+          f4 geo2[2];
+          load_cols<NetSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
           f4 acc[2][T];
-          edge_gemm_from_pq<HP>(acc, G + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+          edge_gemm_from_pq<HP, 2>(acc, G + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             float sdot = 0.f;
@@ -192,11 +190,11 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
             }
             float a = 1.f;
             if (W.attention) a = sigmoid_f(reduce_groups(sdot) + ba);
-            const float mk = e ? m1 : m0;
+            const float mk = mk2[e];
 #pragma unroll
             for (int t = 0; t < T; ++t) *(f4*)(scr + c * LD + 16 * t + 4 * g) = acc[e][t] * a * mk;
             wave_lds_fence();
-            ss.add_tile(scr, e ? ec.i1 : ec.i0, sm.agg, W.normf, lane);
+            ss.add_tile(scr, ec[e].i, sm.agg, W.normf, lane);
             wave_lds_fence();
           }
         }
@@ -218,11 +216,12 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
       node_gemm<HP, EPI_NONE>(E + PK, sm.h, nullptr, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane);
       __syncthreads();
       for (int tp = 0; tp < mg.npairs; ++tp) {
-        float m0, m1;
-        f4 g0, g1;
-        const EdgeCols ec = load_cols<HP>(sm, mg, wave, tp, c, m0, m1, g0, g1);
+        EdgeCol ec[2];
+        float mk2[2];
+        f4 geo2[2];
+        load_cols<NetSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
         f4 acc[2][T];
-        edge_gemm_from_pq<HP>(acc, E + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+        edge_gemm_from_pq<HP, 2>(acc, E + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           float sdot = 0.f;
@@ -234,8 +233,8 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
           }
           const float phi = reduce_groups(sdot);
           const float tau = W.use_tanh ? tanhf(phi) * W.coords_range : phi;
-          const f4 gg = e ? g1 : g0;
-          const float mk = e ? m1 : m0;
+          const f4 gg = geo2[e];
+          const float mk = mk2[e];
           if (g == 0) {
             const int slot = wave * mg.EW + tp * 32 + e * 16 + c;
             *(f4*)(sm.trans + 4 * slot) = (f4){gg[1] * tau * mk, gg[2] * tau * mk, gg[3] * tau * mk, 0.f};
@@ -243,7 +242,7 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
         }
       }
       __syncthreads();
-      coord_update<HP>(sm, mg, W.normf, tid);
+      coord_update(sm, mg, W.normf, tid);
       __syncthreads();
     }
   }

@@ -53,6 +53,7 @@ struct gaudi_handle {
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
       d_pred, d_tw, d_stash;
   int steps_per_launch = 25;
+  int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -243,22 +244,36 @@ static int build_meta(int B, int N, const float* node_mask, const float* edge_ma
 }
 
 // -------------------------------------------------------------------------------------------------
-// kernel table
+// kernel table: the instantiations live in kern_*.hip (compiled in parallel), each exporting a lookup
 typedef void (*kernel_fn)(const KParams);
-#define GAUDI_EDM_ONLY(X) X(32) X(48) X(64) X(128) X(192) X(208) X(256)
+#define GAUDI_KERNEL_TUS(X)                                                                            \
+  X(edm_small) X(edm_192) X(edm_208) X(edm_256) X(pred_small) X(pred_192) X(pred_208) X(pred_256)      \
+  X(fused_tiny) X(fused_128_128) X(fused_192_192) X(fused_192_208) X(fused_208_208) X(fused_256_256)
+#define X(name) kernel_fn gaudi_kern_##name(int hpe, int hpp);
+GAUDI_KERNEL_TUS(X)
+#undef X
 
 static kernel_fn pick_kernel(int hpe, int hpp) {
-#define X(E) \
-  if (hpe == E && hpp == 0) return sampler_kernel<E, 0>;
-  GAUDI_EDM_ONLY(X)
+  kernel_fn f = nullptr;
+#define X(name) \
+  if (!f) f = gaudi_kern_##name(hpe, hpp);
+  GAUDI_KERNEL_TUS(X)
 #undef X
-  return nullptr;
+  return f;
+}
+
+// smallest instantiated padded hidden size >= H (0 if none)
+static int round_hidden(int H) {
+  static const int sizes[] = {32, 48, 64, 128, 192, 208, 256};
+  for (int s : sizes)
+    if (s >= H) return s;
+  return 0;
 }
 
 static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW) {
   size_t net = 0;
   if (hpe) net = std::max(net, (size_t)(4 * N * (hpe + 4) + kWaves * 16 * (hpe + 4) + 8 * N + kWaves * EW * 9));
-  (void)hpp;
+  if (hpp) net = std::max(net, (size_t)(5 * N * (hpp + 4) + kWaves * 16 * (hpp + 4) + 12 * N + kWaves * EW * 10 + 32));
   return sizeof(float) * (common_floats(N, D, EW) + net);
 }
 
@@ -386,12 +401,8 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   if (F < 1 || F > 15) return fail(h, GAUDI_E_INVALID, "in_node_nf must be in 1..15");
   if (L < 1 || S < 1 || cfg->diffusion_steps < 1) return fail(h, GAUDI_E_INVALID, "bad n_layers/inv_sublayers/diffusion_steps");
   if (!(cfg->normalization_factor > 0.f)) return fail(h, GAUDI_E_INVALID, "normalization_factor must be > 0");
-  int HP = pad_hidden(H);
-  if (!pick_kernel(HP, 0)) {  // round up to the next instantiated size
-    static const int sizes[] = {32, 48, 64, 128, 192, 208, 256};
-    for (int s : sizes)
-      if (s >= HP) { HP = s; break; }
-  }
+  const int HP = round_hidden(H);
+  if (!HP) return fail(h, GAUDI_E_INVALID, "no kernel instantiated for this hidden size");
   Tensors T;
   for (int i = 0; i < n; ++i) T.m[names[i]] = {tensors[i], numel[i]};
   EdmLayout lay{HP, F1, L, S};

@@ -1,0 +1,10 @@
+// kern_edm_256.hip -- sampler_kernel instantiations [(256, 0)] (own translation unit so the
+// instantiations compile in parallel; looked up by gaudi_hip.hip through gaudi_kern_edm_256).
+#include "sampler_kernel.h"
+
+typedef void (*kernel_fn)(const gaudi::KParams);
+
+kernel_fn gaudi_kern_edm_256(int hpe, int hpp) {
+  if (hpe == 256 && hpp == 0) return gaudi::sampler_kernel<256, 0>;
+  return nullptr;
+}

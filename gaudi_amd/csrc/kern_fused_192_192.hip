@@ -1,0 +1,10 @@
+// kern_fused_192_192.hip -- sampler_kernel instantiations [(192, 192)] (own translation unit so the
+// instantiations compile in parallel; looked up by gaudi_hip.hip through gaudi_kern_fused_192_192).
+#include "sampler_kernel.h"
+
+typedef void (*kernel_fn)(const gaudi::KParams);
+
+kernel_fn gaudi_kern_fused_192_192(int hpe, int hpp) {
+  if (hpe == 192 && hpp == 192) return gaudi::sampler_kernel<192, 192>;
+  return nullptr;
+}

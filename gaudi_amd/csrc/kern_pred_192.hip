@@ -1,0 +1,10 @@
+// kern_pred_192.hip -- sampler_kernel instantiations [(0, 192)] (own translation unit so the
+// instantiations compile in parallel; looked up by gaudi_hip.hip through gaudi_kern_pred_192).
+#include "sampler_kernel.h"
+
+typedef void (*kernel_fn)(const gaudi::KParams);
+
+kernel_fn gaudi_kern_pred_192(int hpe, int hpp) {
+  if (hpe == 0 && hpp == 192) return gaudi::sampler_kernel<0, 192>;
+  return nullptr;
+}

@@ -1,9 +1,29 @@
-// pred_device.h -- EGNN_predictor forward + hand-written reverse pass (guidance gradient).
+// pred_device.h -- EGNN_predictor (edm/egnn_predictor/models.py:433-457,543-560; gcl.py:225-316):
+// forward with a small per-layer activation stash (h, agg, x per node -- edge activations are
+// recomputed), the hand-written reverse pass that replaces torch.autograd.grad at
+// en_diffusion.py:900-903, and the guidance epilogue (:905-920).  One workgroup = one molecule.
 #pragma once
 #include "device_common.h"
 #include "edm_device.h"
 
 namespace gaudi {
+
+// Packed predictor weights (floats), HP = padded hidden, PK = HP*HP:
+//   head : emb_w [HP][F1] | emb_b [HP] | out_w [K][HP] | out_b [16]
+//   layer: A, Bm, W2, Wc1, Wn1h, Wn1a, Wn2  and their transposes (14 PK)
+//          | cr, cd, b1, b2, wa, bc1, wc2, bn1, bn2 (9 HP) | ba (16)
+struct PredLayout {
+  int HP, F1, K, L;
+  __host__ __device__ int pk() const { return HP * HP; }
+  __host__ __device__ int emb_w() const { return 0; }
+  __host__ __device__ int emb_b() const { return align16(HP * F1); }
+  __host__ __device__ int out_w() const { return emb_b() + HP; }
+  __host__ __device__ int out_b() const { return out_w() + align16(K * HP); }
+  __host__ __device__ int layers() const { return out_b() + 16; }
+  __host__ __device__ int layer_size() const { return 14 * pk() + 9 * HP + 16; }
+  __host__ __device__ int layer(int l) const { return layers() + l * layer_size(); }
+  __host__ __device__ int total() const { return layers() + L * layer_size(); }
+};
 
 struct PredDev {
   const float* w;
@@ -12,13 +32,487 @@ struct PredDev {
 };
 
 template <int HP>
-__device__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
-                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
-                                float* pred_out, float readout_div, float* stash, int tid);
+struct PredSmem {
+  float *b0, *b1, *b2, *b3, *b4;  // [N][HP+4] node buffers (roles change per phase, see below)
+  float* scr;                     // [4][16][HP+4]
+  float *x, *x0, *dx;             // [N][4]
+  f4* geo;                        // [4][EW]
+  float *d0, *trans, *dd0;        // [4][EW], [4][EW][4], [4][EW]
+  float* pred;                    // [16] pred | [16] dpred
+  __host__ __device__ static int floats(int N, int EW) {
+    return 5 * N * (HP + 4) + kWaves * 16 * (HP + 4) + 12 * N + kWaves * EW * 10 + 32;
+  }
+  __device__ void carve(float* base, int N, int EW) {
+    constexpr int LD = HP + 4;
+    b0 = base; base += N * LD;
+    b1 = base; base += N * LD;
+    b2 = base; base += N * LD;
+    b3 = base; base += N * LD;
+    b4 = base; base += N * LD;
+    scr = base; base += kWaves * 16 * LD;
+    x = base; base += 4 * N;
+    x0 = base; base += 4 * N;
+    dx = base; base += 4 * N;
+    geo = (f4*)base; base += kWaves * EW * 4;
+    d0 = base; base += kWaves * EW;
+    trans = base; base += kWaves * EW * 4;
+    dd0 = base; base += kWaves * EW;
+    pred = base;
+  }
+};
 
+__device__ __forceinline__ f4 dsilu4(f4 u) {
+  return (f4){dsilu_f(u[0]), dsilu_f(u[1]), dsilu_f(u[2]), dsilu_f(u[3])};
+}
+__device__ __forceinline__ float dot4(f4 a, f4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
+struct PredLayerW {
+  const float *A, *Bm, *W2, *Wc1, *Wn1h, *Wn1a, *Wn2, *At, *Bmt, *W2t, *Wc1t, *Wn1ht, *Wn1at, *Wn2t;
+  const float *cr, *cd, *b1, *b2, *wa, *bc1, *wc2, *bn1, *bn2;
+  float ba;
+  __device__ PredLayerW(const float* L0, int HP) {
+    const int PK = HP * HP;
+    A = L0; Bm = L0 + PK; W2 = L0 + 2 * PK; Wc1 = L0 + 3 * PK; Wn1h = L0 + 4 * PK; Wn1a = L0 + 5 * PK;
+    Wn2 = L0 + 6 * PK; At = L0 + 7 * PK; Bmt = L0 + 8 * PK; W2t = L0 + 9 * PK; Wc1t = L0 + 10 * PK;
+    Wn1ht = L0 + 11 * PK; Wn1at = L0 + 12 * PK; Wn2t = L0 + 13 * PK;
+    const float* V = L0 + 14 * PK;
+    cr = V; cd = V + HP; b1 = V + 2 * HP; b2 = V + 3 * HP; wa = V + 4 * HP; bc1 = V + 5 * HP; wc2 = V + 6 * HP;
+    bn1 = V + 7 * HP; bn2 = V + 8 * HP;
+    ba = V[9 * HP];
+  }
+};
+
+// stash per layer: h [N][HP] | agg [N][HP] | x [N][4]
+__host__ __device__ inline long long pred_stash_floats(int N, int HP, int L) {
+  return (long long)L * (2LL * N * HP + 4LL * N);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: pred[K] -> sm.pred[0..K)
+// buffers: h = b0, P = b1, Q = b2, agg = b3
+// ---------------------------------------------------------------------------------------------
+template <int HP>
+__device__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* sZ, float t_val,
+                             float* stash, float readout_div, int tid) {
+  constexpr int LD = HP + 4;
+  constexpr int T = HP / 16;
+  const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1, K = W.K;
+  PredLayout lay{HP, F1, K, W.L};
+  const float* __restrict__ w = W.w;
+  float *h = sm.b0, *p = sm.b1, *q = sm.b2, *agg = sm.b3;
+
+  for (int idx = tid; idx < N * 3; idx += kThreads) {  // models.py:439
+    const int n = idx / 3, d = idx % 3;
+    const float v = sZ[n * D + d] * mg.mask[n];
+    sm.x[4 * n + d] = v;
+    sm.x0[4 * n + d] = v;
+  }
+  {
+    const float* ew = w + lay.emb_w();
+    const float* eb = w + lay.emb_b();
+    for (int idx = tid; idx < N * HP; idx += kThreads) {
+      const int n = idx / HP, f = idx % HP;
+      float acc = 0.f;
+      const float m = mg.mask[n];
+      for (int k = 0; k < F; ++k) acc += ew[f * F1 + k] * (sZ[n * D + 3 + k] * m);
+      acc += ew[f * F1 + F] * t_val;
+      h[n * LD + f] = acc + eb[f];
+    }
+  }
+  __syncthreads();
+  compute_geo(sm, mg, 0.f, wave, lane, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
+
+  for (int l = 0; l < W.L; ++l) {
+    const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
+    const PredLayerW Lw(w + lay.layer(l), HP);
+    float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
+    for (int idx = tid; idx < N * HP; idx += kThreads) st[idx] = h[(idx / HP) * LD + idx % HP];
+    for (int idx = tid; idx < N * 4; idx += kThreads) st[2 * N * HP + idx] = sm.x[idx];
+    compute_geo(sm, mg, 1.0f, wave, lane, false);  // gcl.py:308-316
+    node_gemm<HP, EPI_NONE>(Lw.A, h, nullptr, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(Lw.Bm, h, nullptr, nullptr, nullptr, q, nullptr, nullptr, N, wave, lane);
+    for (int idx = tid; idx < N * LD; idx += kThreads) agg[idx] = 0.f;
+    __syncthreads();
+    {
+      SegSum<HP> ss;
+      ss.init();
+      float* scr = sm.scr + wave * 16 * LD;
+      for (int tp = 0; tp < mg.npairs; ++tp) {
+        EdgeCol ec[2];
+        float mk2[2];
+        f4 geo2[2];
+        load_cols<PredSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
+        f4 acc[2][T];
+        edge_gemm_from_pq<HP, 2>(acc, Lw.W2, Lw.b2, Lw.cr, Lw.cd, p, q, ec, lane);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float sdot = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const f4 m = silu4(acc[e][t]);
+            acc[e][t] = m;
+            sdot += dot4(m, *(const f4*)(Lw.wa + 16 * t + 4 * g));
+          }
+          float a = 1.f;
+          if (W.attention) a = sigmoid_f(reduce_groups(sdot) + Lw.ba);
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            acc[e][t] = acc[e][t] * a * mk2[e];  // e_ij (gcl.py:231-237)
+            *(f4*)(scr + c * LD + 16 * t + 4 * g) = acc[e][t];
+          }
+          wave_lds_fence();
+          ss.add_tile(scr, ec[e].i, agg, 1.0f, lane);
+          wave_lds_fence();
+        }
+        if (!last) {  // coord_model (gcl.py:252-278): trans = dhat * tanh(wc2 . silu(Wc1 e + bc1)) * R * mask
+          f4 cp[2][T];
+          const float* const noinit[2] = {nullptr, nullptr};
+          edge_gemm_from_regs<HP, 2>(cp, acc, Lw.Wc1, Lw.bc1, noinit, lane);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) sdot += dot4(silu4(cp[e][t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
+            const float phi = reduce_groups(sdot);
+            const float tau = W.use_tanh ? tanhf(phi) * W.coords_range_layer : phi;
+            if (g == 0) {
+              const int slot = wave * mg.EW + tp * 32 + e * 16 + c;
+              const f4 gg = geo2[e];
+              *(f4*)(sm.trans + 4 * slot) = (f4){gg[1] * tau * mk2[e], gg[2] * tau * mk2[e], gg[3] * tau * mk2[e], 0.f};
+            }
+          }
+        }
+      }
+      ss.flush(agg, 1.0f, lane);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < N * HP; idx += kThreads) st[N * HP + idx] = agg[(idx / HP) * LD + idx % HP];
+    node_gemm<HP, EPI_SILU>(Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane);
+    __syncthreads();
+    node_gemm<HP, EPI_RESIDUAL_MASK>(Lw.Wn2, p, nullptr, nullptr, Lw.bn2, h, h, mg.mask, N, wave, lane);
+    if (!last) coord_update(sm, mg, 1.0f, tid);
+    __syncthreads();
+  }
+  // readout: mean over the PADDED node count of (embedding_out(h) * mask)   (models.py:553-557, :457)
+  {
+    const float* ow = w + lay.out_w();
+    const float* ob = w + lay.out_b();
+    for (int idx = tid; idx < N * K; idx += kThreads) {
+      const int n = idx / K, k = idx % K;
+      float acc = 0.f;
+      for (int f = 0; f < HP; ++f) acc += ow[k * HP + f] * h[n * LD + f];
+      p[idx] = (acc + ob[k]) * mg.mask[n];
+    }
+    __syncthreads();
+    if (tid < K) {
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s += p[n * K + tid];
+      sm.pred[tid] = s / readout_div;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reverse pass: sGrad[N][D] = d( sum_k dpred[k] * pred[k] ) / dz      (dpred in sm.pred[16..16+K))
+// buffer roles per layer:  B0 = b0: h_l -> dagg      B1 = b1: agg_l -> Q
+//                          B2 = b2: P -> dP (in place, rows owned by the wave that reduces them)
+//                          B3 = b3: dh (running)     B4 = b4: npre -> dnpre -> dQ accumulator
+// ---------------------------------------------------------------------------------------------
+template <int HP>
+__device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
+                              float* sGrad, float readout_div, int tid) {
+  constexpr int LD = HP + 4;
+  constexpr int T = HP / 16;
+  const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1, K = W.K, EW = mg.EW;
+  PredLayout lay{HP, F1, K, W.L};
+  const float* __restrict__ w = W.w;
+  float *B0 = sm.b0, *B1 = sm.b1, *B2 = sm.b2, *dh = sm.b3, *B4 = sm.b4;
+  const float* dpred = sm.pred + 16;
+  int ntmax = 0;
+#pragma unroll
+  for (int k = 0; k < kWaves; ++k) ntmax = max(ntmax, 2 * mg.npairs_all[k]);
+  const int nt_me = 2 * mg.npairs;
+
+  // readout backward: dh = mask * (dpred / N_pad) . W_out
+  {
+    const float* ow = w + lay.out_w();
+    for (int idx = tid; idx < N * HP; idx += kThreads) {
+      const int n = idx / HP, f = idx % HP;
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc += (dpred[k] / readout_div) * ow[k * HP + f];
+      dh[n * LD + f] = acc * mg.mask[n];
+    }
+    for (int idx = tid; idx < N * 4; idx += kThreads) sm.dx[idx] = 0.f;
+    for (int idx = tid; idx < kWaves * EW; idx += kThreads) sm.dd0[idx] = 0.f;
+  }
+  __syncthreads();
+
+  for (int l = W.L - 1; l >= 0; --l) {
+    const bool last = l == W.L - 1;
+    const PredLayerW Lw(w + lay.layer(l), HP);
+    const float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
+    // (a) reload h_l, agg_l, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
+    for (int idx = tid; idx < N * HP; idx += kThreads) {
+      const int n = idx / HP, f = idx % HP;
+      B0[n * LD + f] = st[idx];
+      B1[n * LD + f] = st[N * HP + idx];
+      dh[n * LD + f] *= mg.mask[n];
+    }
+    for (int idx = tid; idx < N * 4; idx += kThreads) {
+      sm.x[idx] = st[2 * N * HP + idx];
+      sm.dx[idx] *= mg.mask[idx >> 2];
+    }
+    __syncthreads();
+    compute_geo(sm, mg, 1.0f, wave, lane, false);
+    // (b1) npre = Wn1h h + Wn1a agg + bn1 -> B4
+    node_gemm<HP, EPI_NONE>(Lw.Wn1h, B0, Lw.Wn1a, B1, Lw.bn1, B4, nullptr, nullptr, N, wave, lane);
+    __syncthreads();
+    // (b2) P -> B2, Q -> B1 (agg is dead)
+    node_gemm<HP, EPI_NONE>(Lw.A, B0, nullptr, nullptr, Lw.b1, B2, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(Lw.Bm, B0, nullptr, nullptr, nullptr, B1, nullptr, nullptr, N, wave, lane);
+    // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
+    node_gemm<HP, EPI_MUL_DSILU>(Lw.Wn2t, dh, nullptr, nullptr, nullptr, B4, B4, nullptr, N, wave, lane);
+    __syncthreads();
+    // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
+    node_gemm<HP, EPI_ACCUM>(Lw.Wn1ht, B4, nullptr, nullptr, nullptr, dh, dh, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(Lw.Wn1at, B4, nullptr, nullptr, nullptr, B0, nullptr, nullptr, N, wave, lane);
+    __syncthreads();
+    for (int idx = tid; idx < N * LD; idx += kThreads) B4[idx] = 0.f;  // dQ accumulator
+    __syncthreads();
+    // (e) edge pass, all four waves in lock step (one 16-edge tile per round)
+    {
+      SegSum<HP> ss;
+      ss.init();
+      float* scr = sm.scr + wave * 16 * LD;
+      for (int tile = 0; tile < ntmax; ++tile) {
+        const bool active = tile < nt_me;
+        int my_i = 0;
+        if (active) {
+          EdgeCol ec[1];
+          float mk1[1];
+          f4 geo1[1];
+          load_cols<PredSmem<HP>, 1>(sm, mg, wave, tile * 16, c, ec, mk1, geo1);
+          const int i = ec[0].i, j = ec[0].j;
+          my_i = i;
+          const float mk = mk1[0];
+          const f4 gg = geo1[0];
+          f4 v[1][T];
+          edge_gemm_from_pq<HP, 1>(v, Lw.W2, Lw.b2, Lw.cr, Lw.cd, B2, B1, ec, lane);
+          f4 ev[1][T];
+          float sdot = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const f4 m = silu4(v[0][t]);
+            ev[0][t] = m;
+            sdot += dot4(m, *(const f4*)(Lw.wa + 16 * t + 4 * g));
+          }
+          float a = 1.f;
+          if (W.attention) a = sigmoid_f(reduce_groups(sdot) + Lw.ba);
+#pragma unroll
+          for (int t = 0; t < T; ++t) ev[0][t] = ev[0][t] * a * mk;
+          f4 de[1][T];
+          float tau = 0.f;
+          const float dtx = sm.dx[4 * i + 0], dty = sm.dx[4 * i + 1], dtz = sm.dx[4 * i + 2];  // dtrans = dx'_i
+          if (!last) {
+            f4 cp[1][T];
+            const float* const noinit[1] = {nullptr};
+            edge_gemm_from_regs<HP, 1>(cp, ev, Lw.Wc1, Lw.bc1, noinit, lane);
+            float sd2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) sd2 += dot4(silu4(cp[0][t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
+            const float phi = reduce_groups(sd2);
+            const float th = tanhf(phi);
+            tau = W.use_tanh ? th * W.coords_range_layer : phi;
+            const float dtau = (dtx * gg[1] + dty * gg[2] + dtz * gg[3]) * mk;
+            const float dphi = W.use_tanh ? dtau * W.coords_range_layer * (1.0f - th * th) : dtau;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {  // dcpre = dphi * wc2 * silu'(cpre)
+              const f4 wv = *(const f4*)(Lw.wc2 + 16 * t + 4 * g);
+              cp[0][t] = wv * dphi * dsilu4(cp[0][t]);
+            }
+            const float* const rowinit[1] = {B0 + i * LD};  // + dagg_i (from agg_i = sum_j e_ij)
+            edge_gemm_from_regs<HP, 1>(de, cp, Lw.Wc1t, nullptr, rowinit, lane);
+          } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) de[0][t] = *(const f4*)(B0 + i * LD + 16 * t + 4 * g);
+          }
+          // e = m * a * mask ; a = sigmoid(wa . m + ba)
+          float dadot = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) dadot += dot4(de[0][t], silu4(v[0][t]));
+          const float da = reduce_groups(dadot) * mk;
+          const float ds = W.attention ? da * a * (1.0f - a) : 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {  // dv = (de*a*mask + ds*wa) * silu'(v)
+            const f4 wv = *(const f4*)(Lw.wa + 16 * t + 4 * g);
+            de[0][t] = (de[0][t] * a * mk + wv * ds) * dsilu4(v[0][t]);
+          }
+          f4 dt1[1][T];
+          {
+            const float* const noinit[1] = {nullptr};
+            edge_gemm_from_regs<HP, 1>(dt1, de, Lw.W2t, nullptr, noinit, lane);
+          }
+          // du = dt1 * silu'(u) -> scratch ; dr = cr . du ; dd0 = cd . du
+          const float* pp = B2 + i * LD + 4 * g;
+          const float* qq = B1 + j * LD + 4 * g;
+          float drdot = 0.f, dd0dot = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const f4 u = edge_u(pp, qq, Lw.cr + 4 * g, Lw.cd + 4 * g, t, ec[0].r, ec[0].d0);
+            const f4 du = dt1[0][t] * dsilu4(u);
+            drdot += dot4(du, *(const f4*)(Lw.cr + 16 * t + 4 * g));
+            dd0dot += dot4(du, *(const f4*)(Lw.cd + 16 * t + 4 * g));
+            *(f4*)(scr + c * LD + 16 * t + 4 * g) = du;
+          }
+          const float dr = reduce_groups(drdot), dd0v = reduce_groups(dd0dot);
+          if (g == 0) {
+            // d/d(diff) of r = |diff|^2 and dhat = diff / (sqrt(r + 1e-8) + 1)   (gcl.py:308-316)
+            const float fx = sm.x[4 * i + 0] - sm.x[4 * j + 0];
+            const float fy = sm.x[4 * i + 1] - sm.x[4 * j + 1];
+            const float fz = sm.x[4 * i + 2] - sm.x[4 * j + 2];
+            const float nrm = sqrtf(gg[0] + 1e-8f), den = nrm + 1.0f;
+            const float cx = dtx * tau * mk, cy = dty * tau * mk, cz = dtz * tau * mk;  // d(dhat)
+            const float k1 = (cx * fx + cy * fy + cz * fz) / (den * den * nrm);
+            const int slot = wave * EW + tile * 16 + c;
+            sm.trans[4 * slot + 0] = cx / den - fx * k1 + 2.0f * fx * dr;
+            sm.trans[4 * slot + 1] = cy / den - fy * k1 + 2.0f * fy * dr;
+            sm.trans[4 * slot + 2] = cz / den - fz * k1 + 2.0f * fz * dr;
+            sm.dd0[slot] += dd0v;
+          }
+        }
+        wave_lds_fence();
+        __syncthreads();  // every wave's du tile of this round is in its scratch
+        if (active) ss.add_tile(scr, my_i, B2, 1.0f, lane);  // dP_i = sum_j du_ij  (overwrites P_i: dead)
+        // dQ_j = sum_i du_ij : the wave owning node j folds the matching rows of all four tiles
+#pragma unroll 1
+        for (int w2 = 0; w2 < kWaves; ++w2) {
+          if (tile >= 2 * mg.npairs_all[w2]) continue;
+          const float* scr2 = sm.scr + w2 * 16 * LD;
+          for (int k = 0; k < 16; ++k) {
+            const int jj = __builtin_amdgcn_readfirstlane((int)((mg.edge[w2 * EW + tile * 16 + k] >> 8) & 255));
+            const int owner = __builtin_amdgcn_readfirstlane((int)(mg.seg[jj] >> 30));
+            if (owner == wave && lane < HP / 4) {
+              f4* dst = (f4*)(B4 + jj * LD + 4 * lane);
+              *dst = *dst + *(const f4*)(scr2 + k * LD + 4 * lane);
+            }
+          }
+        }
+        wave_lds_fence();
+        __syncthreads();  // scratch may be overwritten
+      }
+      if (nt_me > 0) ss.flush(B2, 1.0f, lane);
+    }
+    __syncthreads();
+    // nodes without live edges never had their P row replaced by dP = 0
+    for (int idx = tid; idx < N * LD; idx += kThreads) {
+      const int n = idx / LD;
+      if ((mg.seg[n] & 0x7fff) == 0) B2[idx] = 0.f;
+    }
+    // dx <- dx*mask + sum_{e: i=n} ddiff_e - sum_{e: j=n} ddiff_e   (fixed slot order)
+    if (tid < N * 3) {
+      const int n = tid / 3, d = tid % 3;
+      float acc = sm.dx[4 * n + d];
+      for (int w2 = 0; w2 < kWaves; ++w2)
+        for (int s = 0; s < 32 * mg.npairs_all[w2]; ++s) {
+          const uint32_t e = mg.edge[w2 * EW + s];
+          const float v = sm.trans[4 * (w2 * EW + s) + d];
+          if ((int)(e & 255) == n) acc += v;
+          if ((int)((e >> 8) & 255) == n) acc -= v;
+        }
+      sm.dx[4 * n + d] = acc;
+    }
+    __syncthreads();
+    // (f) dh += A^T dP + Bm^T dQ
+    node_gemm<HP, EPI_ACCUM>(Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, N, wave, lane);
+    __syncthreads();
+  }
+
+  // embedding backward (time column dropped), d0 backward, input masking
+  {
+    const float* ew = w + lay.emb_w();
+    if (tid < N * 3) {
+      const int n = tid / 3, d = tid % 3;
+      float acc = sm.dx[4 * n + d];
+      for (int w2 = 0; w2 < kWaves; ++w2)
+        for (int s = 0; s < 32 * mg.npairs_all[w2]; ++s) {
+          const uint32_t e = mg.edge[w2 * EW + s];
+          const int i = e & 255, j = (e >> 8) & 255;
+          const float v = 2.0f * (sm.x0[4 * i + d] - sm.x0[4 * j + d]) * sm.dd0[w2 * EW + s];
+          if (i == n) acc += v;
+          if (j == n) acc -= v;
+        }
+      sGrad[n * D + d] = acc * mg.mask[n];
+    }
+    for (int idx = tid; idx < N * F; idx += kThreads) {
+      const int n = idx / F, k = idx % F;
+      float acc = 0.f;
+      for (int f = 0; f < HP; ++f) acc += dh[n * LD + f] * ew[f * F1 + k];
+      sGrad[n * D + 3 + k] = acc * mg.mask[n];
+    }
+  }
+  __syncthreads();
+}
+
+// unit-test entry: pred (and optionally grad into sGrad) for z in sZ
 template <int HP>
 __device__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                 float* sMean, float t_val, const float* dpred, bool want_grad, float* pred_out,
-                                float readout_div, float* stash, int tid);
+                                float readout_div, float* stash, int tid) {
+  (void)sTmp; (void)sMean;
+  PredSmem<HP> sm;
+  sm.carve(net, mg.N, mg.EW);
+  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid);
+  if (tid < W.K) {
+    if (pred_out) pred_out[tid] = sm.pred[tid];
+    sm.pred[16 + tid] = dpred ? dpred[tid] : 0.f;
+  }
+  __syncthreads();
+  if (want_grad) pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, tid);
+}
+
+// guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
+template <int HP>
+__device__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
+                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
+                                float* pred_out, float readout_div, float* stash, int tid) {
+  (void)sTmp;
+  const int N = mg.N, D = mg.D;
+  PredSmem<HP> sm;
+  sm.carve(net, N, mg.EW);
+  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid);
+  if (tid < W.K) {
+    if (pred_out) pred_out[tid] = sm.pred[tid];
+    sm.pred[16 + tid] = target_w[tid] * scale;  // energy = scale * sum_b T(pred_b), T linear in pred
+  }
+  __syncthreads();
+  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, tid);
+  // clip_coef = min(1, 10 / (||g||_2 + 1e-6)) over all N*(3+F) entries   (en_diffusion.py:905-909)
+  if (tid < 64) {
+    float s = 0.f;
+    for (int e = tid; e < N * D; e += 64) s += sGrad[e] * sGrad[e];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (tid == 0) sMean[4] = fminf(10.0f / (sqrtf(s) + 1e-6f), 1.0f);
+  }
+  __syncthreads();
+  const float coef = sMean[4];
+  for (int e = tid; e < N * D; e += kThreads) sGrad[e] *= coef;
+  __syncthreads();
+  if (tid < 3) {  // masked mean of the x part of the gradient (en_diffusion.py:911-919)
+    float s = 0.f, cnt = 0.f;
+    for (int n = 0; n < N; ++n) { s += sGrad[n * D + tid]; cnt += mg.mask[n]; }
+    sMean[tid] = s / fmaxf(cnt, 1.0f);
+  }
+  __syncthreads();
+  for (int e = tid; e < N * D; e += kThreads) {
+    const int n = e / D, d = e % D;
+    float gv = sGrad[e];
+    if (d < 3) gv = gv - sMean[d] * mg.mask[n];
+    sZ[e] = sZ[e] - sigma * gv;
+  }
+  __syncthreads();
+}
 
 }  // namespace gaudi

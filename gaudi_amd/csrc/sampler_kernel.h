@@ -81,6 +81,8 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
   mg.N = N; mg.D = D; mg.EW = EW;
   mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg;
   mg.npairs = P.npairs[b * kWaves + wave];
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) mg.npairs_all[w] = P.npairs[b * kWaves + w];
 
   const uint64_t gsample = (uint64_t)(P.sample_offset + b);
   // locals (not references into the kernarg struct) so nothing forces P onto the stack

@@ -118,8 +118,8 @@ int gaudi_decode(gaudi_handle* h, int B, int N, const float* z0, const float* no
  * .sample_guidance (:1010-1067).  noise: NULL -> on-device Philox4x32-10 keyed by
  * (seed, sample_offset + b, draw, element) so results do not depend on how samples are sharded;
  * otherwise injected raw N(0,1) draws [T+2,B,N,3+F] (draw 0 -> z_T, 1+k -> k-th step, T+1 -> decode).
- * n_pad_readout: the N the predictor readout divides by (0 -> N); shards of one logical batch pass the
- * global padded N (egnn_predictor/models.py:457). */
+ * Shards of one logical batch must all use the batch-wide padded N (sample_guidance pads to the
+ * batch max, sampling_edm.py:177): pad the masks to that N before calling. */
 int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
                  int64_t sample_offset, const float* noise, float std, const float* target_w /* [K] or NULL */,
                  float scale, float* x_out /* [B,N,3] */, float* onehot_out /* [B,N,F] */,
@@ -134,6 +134,10 @@ int gaudi_philox_normal(gaudi_handle* h, uint64_t seed, int64_t sample_offset, i
  * launches since the reset and their summed duration. */
 int gaudi_profile_reset(gaudi_handle* h, int enable);
 int gaudi_profile_get(gaudi_handle* h, int32_t* n_launches, double* total_ms, int64_t* steps_done);
+
+/* Override the node count the predictor readout divides by (EGNN_predictor.forward takes the mean over
+ * the PADDED N, egnn_predictor/models.py:457).  0 (default) = the N of each call. */
+int gaudi_set_readout_nodes(gaudi_handle* h, int n_pad);
 
 /* Tuning knob: reverse steps fused into one kernel launch (default 25). */
 int gaudi_set_steps_per_launch(gaudi_handle* h, int steps);
