@@ -125,3 +125,58 @@ def test_philox_stream_matches_host_twin():
     assert np.array_equal(part, dev[:, 2:5])
     assert abs(float(dev.mean())) < 0.15 and abs(float(dev.std()) - 1.0) < 0.1
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["cata_tiny_amp", "hetro_tiny_amp", "cata_full", "hetro_full_amp"])
+def test_predictor_forward_and_gradient(golden, O, name):
+    """EGNN_predictor.forward and the hand-written reverse pass vs torch.autograd (reference)."""
+    g = golden("g4_predictor")
+    cfg = cfg_of(g, name)
+    args, sd = pred_from_cfg(cfg)
+    eng = make_engine(pargs=args, psd=sd)
+    z, t, nm, em = g[name + "_z"], g[name + "_t"][:, 0], g[name + "_node_mask"], g[name + "_edge_mask"]
+    pred = eng.predictor_fwd(z, t, nm, em)
+    assert rel_err(pred, g[name + "_pred"]) < TOL
+    for tn, w in (("gap", O.target_max_gap_weights(5)), ("opv", O.target_opv_weights(5, g["prop_std"]))):
+        p2, grad = eng.predictor_grad(z, t, nm, em, w * g["scale"])
+        assert rel_err(p2, g[name + "_pred"]) < TOL
+        assert rel_err(grad, g[f"{name}_grad_{tn}"]) < TOL, tn
+        assert np.abs(grad * (1 - nm)).max() == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_guided_steps_teacher_forced(golden, O, name):
+    """sample_p_zs_given_zt_guidance at several t, clip branch inactive (scale 0.6) and active (400)."""
+    g = golden("g5_steps")
+    cfg = cfg_of(g, name)
+    T = cfg["T"]
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=TINY, wseed=cfg["eseed"], amp=True), diffusion_steps=T)
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["pseed"], amp=True))
+    eng = make_engine(eargs, esd, pargs, psd)
+    z, nm, em = g[name + "_z"], g[name + "_node_mask"], g[name + "_edge_mask"]
+    w = O.target_max_gap_weights(5)
+    for s in (0, 1, 500, 998, 999):
+        for scale in (0.6, 400.0):
+            zs = eng.step(s, z, nm, em, g[f"{name}_s{s}_eps"], target_w=w, scale=scale)
+            assert rel_err(zs, g[f"{name}_s{s}_zs_guided_scale{scale}"]) < TOL, (s, scale)
+    eng.close()
+
+
+@pytest.mark.parametrize("name,tol", [("cata_tiny", 1e-4), ("hetro_tiny", 1e-4), ("cata_tiny_amp", 5e-2)])
+def test_tiny_chains_guided(golden, name, tol):
+    """T=50 guided chains through sample_guidance.  With amplified coordinate heads the chain is
+    ill-conditioned: tolerance = the reference's own fp32-vs-fp64 spread."""
+    g = golden("g7_end_to_end")
+    cfg = cfg_of(g, name)
+    base = dict(dataset=cfg["dataset"], amp=cfg["amp"])
+    eargs, esd = edm_from_cfg(dict(base, over=TINY, wseed=cfg["eseed"]), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(base, over=TINY_P, wseed=cfg["pseed"]))
+    eng = make_engine(eargs, esd, pargs, psd)
+    w = np.zeros(5, np.float32)
+    w[1] = -1
+    x, h, diag = eng.sample(g[name + "_node_mask"], g[name + "_edge_mask"], noise=g[name + "_noise"], std=1.0,
+                            target_w=w, scale=0.6)
+    assert rel_err(x, g[name + "_x_guided"]) < tol
+    assert np.array_equal(h, g[name + "_h_guided"])
+    eng.close()
