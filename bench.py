@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: guided molecules/sec (1000-step) on MI355X.
+
+A "step" (--steps K) is ONE complete pass of the hot path over one batch: a full
+``sample_guidance`` call = 1000 guided reverse-diffusion steps + final decode for B molecules
+(BASELINE.json config C3: cc-PBH 11-ring, batch 256, HOMO-LUMO-gap guidance, default architectures,
+synthetic seeded weights, on-device Philox noise).  With --gpus N the driver launches N ranks
+(torch.distributed.run); each rank samples its own 256 molecules (weak scaling, noise keyed by the
+global sample index) and ONE all_gather over RCCL collects the results at the end of every step.
+
+Prints one JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the fused
+per-molecule sampler kernel, bound = fp32 matrix cores) and `cpu_baseline` (the numpy oracle timed on
+this host, N=1 only).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* = vector fp32 peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed sample_guidance calls (1000 reverse steps each)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3"], help="c2 = unguided, c3 = gap guidance")
+    ap.add_argument("--diffusion-steps", type=int, default=1000)
+    ap.add_argument("--steps-per-launch", type=int, default=25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(eargs, pargs, esd, psd, guided, T):
+    """The numpy oracle (kind "port") on this host's cores over a bounded sample of the same workload:
+    a few guided reverse steps at N=11 on a small batch, extrapolated to T steps + decode."""
+    from oracle import gaudi_oracle as O  # baseline leg only
+    Bc = 32
+    nm, em = O.build_masks([11] * Bc, 11, False)
+    rng = np.random.default_rng(0)
+    z = O._combined_noise(rng.standard_normal((Bc, 11, 4)).astype(np.float32), nm)
+    gamma = O.gamma_table(eargs["diffusion_noise_schedule"], T, eargs["diffusion_noise_precision"])
+    w = O.target_max_gap_weights(5)
+
+    def one(s):
+        eps = rng.standard_normal((Bc, 11, 4)).astype(np.float32)
+        if guided:
+            return O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6)
+        return O.step_unguided(esd, eargs, gamma, s, z, nm, em, eps)
+
+    one(T - 1)  # warm-up
+    n_steps, t0 = 0, time.time()
+    while n_steps < 3 or (time.time() - t0 < 10.0 and n_steps < 40):
+        one(T - 2 - n_steps)
+        n_steps += 1
+    per_step = (time.time() - t0) / n_steps
+    total = per_step * T * (1.0 + (1.0 / T) * (0.3 if guided else 1.0))  # + decode = one EDM evaluation
+    return dict(value=Bc / total, unit="molecules/s", cores=os.cpu_count(), kind="port",
+                sample=f"numpy oracle (BLAS threads = all {os.cpu_count()} cores), B={Bc} x {n_steps} "
+                       f"{'guided' if guided else 'unguided'} reverse steps at N=11, extrapolated x{T} + decode; "
+                       f"{per_step * 1e3:.0f} ms/step")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world == 1:
+        # convenience: relaunch under torch.distributed.run as a CHILD process (never exec after GPU init)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+    from gaudi_amd import dist as gdist
+    from gaudi_amd import flops, synth
+    from gaudi_amd.engine import Engine
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the sampler has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    guided = a.workload == "c3"
+    T, B, N, F, K = a.diffusion_steps, a.batch, 11, 1, 5
+    eargs = synth.edm_args(diffusion_steps=T)
+    pargs = synth.pred_args()
+    esd = synth.synth_edm_state_dict(eargs, F, seed=0)
+    psd = synth.synth_predictor_state_dict(pargs, F, K, seed=1)
+    eng = Engine(local_rank)
+    eng.load_edm(eargs, esd)
+    if guided:
+        eng.load_predictor(pargs, psd)
+    eng.set_steps_per_launch(a.steps_per_launch)
+    nm = np.ones((B, N), np.float32)  # 11-ring cata molecules: every node live (sampling_edm.py:176-186)
+    em = np.broadcast_to(1.0 - np.eye(N, dtype=np.float32), (B, N, N)).copy()
+    tw = None
+    if guided:
+        tw = np.zeros(K, np.float32)
+        tw[1] = -1.0  # target_function_max_gap: -pred[:,1]  (generation_guidance.py:200-203)
+
+    def one_pass(it):
+        x, h, diag = eng.sample(nm, em, seed=1234 + it, sample_offset=rank * B, std=1.0, target_w=tw, scale=0.6)
+        if world > 1:
+            x, h = gdist.gather_to_all(x, h, B * world, N, F, device=dev)
+        return x, h, diag
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(a.warmup):
+        one_pass(-1 - it)
+    eng.profile_reset(True)
+    sync()
+    t0 = time.perf_counter()
+    for it in range(a.steps):
+        x, h, diag = one_pass(it)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    n_launch, kern_ms, steps_done = eng.profile_get()
+    assert x.shape[0] == B * world and np.isfinite(x).all()
+
+    if rank == 0:
+        mols = a.steps * B * world
+        value = mols / dt
+        # ---- roofline of the dominant kernel (sampler_kernel<192,208>: EDM + predictor fwd/bwd + update)
+        f_written = flops.step_flops_as_written(N, F, eargs, pargs if guided else None, K)
+        f_useful = flops.step_flops_useful(N * (N - 1), N, F, eargs, pargs if guided else None, K)
+        evals = steps_done + a.steps * (0.3 if guided else 1.0)  # decode pass = one extra EDM evaluation
+        avg_launch_ms = kern_ms / max(n_launch, 1)
+        per_launch_flops = f_written * B * evals / max(n_launch, 1)
+        achieved = per_launch_flops / (avg_launch_ms * 1e-3) / 1e12
+        wbytes = 4 * (sum(v.size for v in esd.values()) + (2 * sum(v.size for v in psd.values()) if guided else 0))
+        stash = 4 * pargs["n_layers"] * (2 * N * 208 + 4 * N) if guided else 0
+        hbm_bytes_launch = flops.step_bytes_fused(B, N, F, 0, stash) * steps_done / max(n_launch, 1) + wbytes
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"{a.workload}_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "guided molecules/sec (1000-step)" if guided else "unguided molecules/sec (1000-step)",
+            "value": value, "unit": "molecules/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded default-init weights, on-device Philox noise)",
+            "config": {"workload": ("C3: cc-PBH 11-ring, batch=256/GPU, 1000 steps, HOMO-LUMO-gap guidance (scale 0.6)"
+                                    if guided else "C2: cc-PBH 11-ring, batch=256/GPU, 1000 steps, unconditional EDM"),
+                       "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
+                       "edm": "nf=192,n_layers=9", "predictor": "nf=196,n_layers=12" if guided else None,
+                       "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
+                       "steps_per_launch": a.steps_per_launch},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                         "kernel": "sampler_kernel<192,208>" if guided else "sampler_kernel<192,0>",
+                         "avg_launch_ms": avg_launch_ms, "launches": n_launch,
+                         "flops_basis": "as-written reference FLOPs (SURVEY 8d): %.3f GFLOP per molecule-step" % (f_written / 1e9),
+                         "useful_tflops_factorised": f_useful * B * evals / (kern_ms * 1e-3) / 1e12,
+                         "hbm_algorithmic_gbps": hbm_bytes_launch / (avg_launch_ms * 1e-3) / 1e9,
+                         "hbm_frac": hbm_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS},
+            "diag": diag,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(eargs, pargs, esd, psd, guided, T)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

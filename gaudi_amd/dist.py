@@ -1,0 +1,58 @@
+"""Multi-GPU: independent samples are sharded over ranks (one process per GPU); no collective on the
+data path, ONE gather at the end (RCCL over xGMI when the backend is "nccl").  SURVEY.md section 8e.
+
+The noise stream is keyed by the GLOBAL sample index, and every shard pads to the batch-wide N, so the
+gathered result is identical to the unsharded run.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(total: int, rank: int, world: int):
+    """Contiguous block of global sample indices [lo, hi) owned by ``rank``."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def sample_sharded(sample_fn, node_mask: np.ndarray, edge_mask: np.ndarray, rank: int, world: int):
+    """Run ``sample_fn(node_mask_shard, edge_mask_shard, sample_offset) -> (x, h)`` on this rank's block.
+
+    node_mask [B,N(,1)], edge_mask reshapeable to [B,N,N] describe the WHOLE logical batch (already padded
+    to the batch-wide N, as sampling_edm.sample_guidance does, sampling_edm.py:177)."""
+    nm = np.asarray(node_mask, np.float32)
+    B, N = nm.shape[0], nm.shape[1]
+    nm = nm.reshape(B, N)
+    em = np.asarray(edge_mask, np.float32).reshape(B, N, N)
+    lo, hi = shard_bounds(B, rank, world)
+    if hi == lo:
+        return lo, hi, None, None
+    x, h = sample_fn(nm[lo:hi], em[lo:hi], lo)
+    return lo, hi, x, h
+
+
+def gather_to_all(x_local, h_local, total: int, N: int, F: int, device=None):
+    """One all_gather of the per-rank results (padded to the largest shard) -> full [total,N,3], [total,N,F]."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = max(shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world))
+    buf = np.zeros((per, N, 3 + F), np.float32)
+    if x_local is not None:
+        n = x_local.shape[0]
+        buf[:n, :, :3] = x_local
+        buf[:n, :, 3:] = h_local
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    xs, hs = [], []
+    for r in range(world):
+        lo, hi = shard_bounds(total, r, world)
+        a = out[r].cpu().numpy()[: hi - lo]
+        xs.append(a[:, :, :3])
+        hs.append(a[:, :, 3:])
+    return np.concatenate(xs, 0), np.concatenate(hs, 0)
