@@ -24,7 +24,9 @@ constexpr int kPF = 4;  // weight-tile prefetch depth (float4 per lane each)
 __host__ __device__ constexpr int align16(int n) { return (n + 15) & ~15; }
 __host__ __device__ constexpr int pad_hidden(int h) { return (h + 15) & ~15; }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): ~2e-7 relative, well inside the 1e-4 parity budget
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d/dx silu(x) = s * (1 + x * (1 - s))
 __device__ __forceinline__ float dsilu_f(float x) {
@@ -66,50 +68,94 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weight access.  All hot-path weight/bias loads go through ONE buffer descriptor per network
+// (base + size in SGPRs) with a wave-uniform float offset (scalar soffset, folded by the compiler)
+// and a per-lane float4 index (32-bit voffset): `buffer_load_dwordx4 v, voff, s[rsrc], soff offen`.
+// Plain pointer arithmetic made hipcc build a 64-bit per-lane address for every 16x16 tile, hoist
+// them out of the loops and spill them.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+struct WBuf {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ WBuf make_wbuf(const float* p, unsigned bytes) {
+  WBuf w;
+  w.r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+  return w;
+}
+__device__ __forceinline__ f4 ldw4(const WBuf& w, int off_floats, int lane_f4) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(w.r, lane_f4 * 16, off_floats * 4, 0));
+}
+__device__ __forceinline__ float ldw1(const WBuf& w, int off_floats) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w.r, 0, off_floats * 4, 0));
+}
+
+// ---------------------------------------------------------------------------------------------
 // Node-level GEMM:  Y[n][o] = epi( sum_k Wa[o][k] Xa[n][k] (+ sum_k Wb[o][k] Xb[n][k]) + bias[o] )
-// X*, Y live in LDS ([N][LD] row major, LD = HP+4).  W* are tile-packed [HP/16][HP/16][16][16].
-// Wave w produces output-feature tiles t = w, w+4, ... for every node tile, so every weight
-// element is fetched by exactly one wave of the workgroup.
+// X*, Y live in LDS ([N][LD] row major, LD = HP+4).  W* are tile-packed [HP/16][HP/16][16][16]
+// (float offsets into the weight buffer; -1 = absent).  Wave w produces output-feature tiles
+// t = w, w+4, ... for every node tile, so every weight element is fetched by exactly one wave.
 // ---------------------------------------------------------------------------------------------
 enum NodeEpi { EPI_NONE = 0, EPI_SILU = 1, EPI_RESIDUAL_MASK = 2, EPI_MUL_DSILU = 3, EPI_ACCUM = 4 };
 
 template <int HP, int EPI>
-__device__ __forceinline__ void node_gemm(const float* __restrict__ Wa, const float* sXa,
-                                          const float* __restrict__ Wb, const float* sXb,
-                                          const float* __restrict__ bias, float* sY, const float* sRes,
-                                          const float* sMask, int N, int wave, int lane) {
+__device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, int bias,
+                                          float* sY, const float* sRes, const float* sMask, int N, int wave, int lane) {
   constexpr int T = HP / 16;
   constexpr int LD = HP + 4;
   constexpr int UT = (T + kWaves - 1) / kWaves;
   const int c = lane & 15, g = lane >> 4;
+  const int lo = c * 4 + g;  // lane's float4 inside a 16x16 tile
   const int n_tiles = (N + 15) >> 4;
+  // Branch-free inner loops: every wave runs UT output tiles; a wave without a UT-th tile recomputes
+  // tile T-1 and drops the result (wave-uniform test in the epilogue only).
+  int toff[UT];  // float offset of the wave's tiles inside one K chunk of a packed matrix
+#pragma unroll
+  for (int u = 0; u < UT; ++u) {
+    const int t = wave + kWaves * u;
+    toff[u] = (t < T ? t : T - 1) * 256;
+  }
   for (int nt = 0; nt < n_tiles; ++nt) {
     const int node = nt * 16 + c;
     const int nclamp = node < N ? node : N - 1;
     f4 acc[UT];
 #pragma unroll
-    for (int u = 0; u < UT; ++u) {
-      const int t = wave + kWaves * u;
-      acc[u] = (bias != nullptr && t < T) ? *(const f4*)(bias + 16 * t + 4 * g) : splat(0.f);
-    }
+    for (int u = 0; u < UT; ++u) acc[u] = bias >= 0 ? ldw4(wb, bias + (toff[u] >> 4), g) : splat(0.f);
 #pragma unroll
     for (int src = 0; src < 2; ++src) {
-      const float* __restrict__ W = src == 0 ? Wa : Wb;
+      const int W = src == 0 ? Wa : Wb;
       const float* sX = src == 0 ? sXa : sXb;
-      if (W == nullptr) continue;
-      const f4* W4 = (const f4*)W + c * 4 + g;
+      if (W < 0) continue;
       const float* xrow = sX + nclamp * LD + 4 * g;
-#pragma unroll 4
-      for (int cc = 0; cc < T; ++cc) {
-        const f4 b4 = *(const f4*)(xrow + 16 * cc);
+      // two K chunks of weight tiles in flight (registers), refilled as they are consumed
+      f4 q0[UT], q1[UT];
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        q0[u] = ldw4(wb, W + toff[u], lo);
+        q1[u] = ldw4(wb, W + (T > 1 ? T : 0) * 256 + toff[u], lo);
+      }
+#pragma unroll 1
+      for (int cc = 0; cc + 1 < T; cc += 2) {
+        const f4 b0 = *(const f4*)(xrow + 16 * cc);
+        const f4 b1 = *(const f4*)(xrow + 16 * cc + 16);
+        const int n0 = cc + 2 < T ? cc + 2 : T - 1, n1 = cc + 3 < T ? cc + 3 : T - 1;
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
-          const int t = wave + kWaves * u;
-          if (t < T) {
-            const f4 w4 = W4[(cc * T + t) * 64];
-            acc[u] = mfma4(w4, b4, acc[u]);
-          }
+          const f4 w = q0[u];
+          q0[u] = ldw4(wb, W + n0 * (T * 256) + toff[u], lo);
+          acc[u] = mfma4(w, b0, acc[u]);
         }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          const f4 w = q1[u];
+          q1[u] = ldw4(wb, W + n1 * (T * 256) + toff[u], lo);
+          acc[u] = mfma4(w, b1, acc[u]);
+        }
+      }
+      if (T & 1) {
+        const f4 b0 = *(const f4*)(xrow + 16 * (T - 1));
+#pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = mfma4(q0[u], b0, acc[u]);
       }
     }
 #pragma unroll
@@ -135,12 +181,12 @@ __device__ __forceinline__ void node_gemm(const float* __restrict__ Wa, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// Edge-level GEMM core for TWO 16-edge tiles owned by one wave:
+// Edge-level GEMM core for NE 16-edge tiles owned by one wave:
 //   acc[e][t] (features 16t+4g+q of edge column c) = b2 + W2 . silu(u_e)
 //   u_e[f] = P[i_e][f] + Q[j_e][f] + cr[f] * r_e + cd[f] * d0_e        (b1 is folded into P)
 // which is Linear(2H+2 -> H) of [h_i | h_j | r | d0] factorised per node (exact algebra; only the
 // fp32 summation order differs from the reference's concat+Linear: egnn_new.py:42-47,119-129;
-// egnn_predictor/gcl.py:225-231).  U (optional) receives u for the backward pass.
+// egnn_predictor/gcl.py:225-231).
 // ---------------------------------------------------------------------------------------------
 struct EdgeCol {
   int i, j;      // receiving / sending node of the lane's edge column
@@ -148,25 +194,24 @@ struct EdgeCol {
 };
 
 // u[f] for f = 16cc+4g+q of one edge column
-__device__ __forceinline__ f4 edge_u(const float* p, const float* q, const float* crg, const float* cdg, int cc,
+__device__ __forceinline__ f4 edge_u(const float* p, const float* q, const WBuf& wb, int cr, int cd, int g, int cc,
                                      float r, float d0) {
-  const f4 crv = *(const f4*)(crg + 16 * cc);
-  const f4 cdv = *(const f4*)(cdg + 16 * cc);
+  const f4 crv = ldw4(wb, cr + 16 * cc, g);
+  const f4 cdv = ldw4(wb, cd + 16 * cc, g);
   return *(const f4*)(p + 16 * cc) + *(const f4*)(q + 16 * cc) + crv * r + cdv * d0;
 }
 
 template <int HP, int NE>
-__device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const float* __restrict__ W2p,
-                                                  const float* __restrict__ b2, const float* __restrict__ cr,
-                                                  const float* __restrict__ cd, const float* sP, const float* sQ,
-                                                  const EdgeCol (&ec)[NE], int lane) {
+__device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const WBuf& wb, int W2, int b2, int cr, int cd,
+                                                  const float* sP, const float* sQ, const EdgeCol (&ec)[NE], int lane) {
   constexpr int T = HP / 16;
   constexpr int LD = HP + 4;
   constexpr int PF = kPF < T ? kPF : T;
   const int c = lane & 15, g = lane >> 4;
+  const int lo = c * 4 + g;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    const f4 b = *(const f4*)(b2 + 16 * t + 4 * g);
+    const f4 b = ldw4(wb, b2 + 16 * t, g);
 #pragma unroll
     for (int e = 0; e < NE; ++e) acc[e][t] = b;
   }
@@ -177,15 +222,12 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
     pp[e] = sP + ec[e].i * LD + 4 * g;
     qq[e] = sQ + ec[e].j * LD + 4 * g;
   }
-  const float* crg = cr + 4 * g;
-  const float* cdg = cd + 4 * g;
-  const f4* W4 = (const f4*)W2p + c * 4 + g;
   f4 wq[PF];
 #pragma unroll
-  for (int p = 0; p < PF; ++p) wq[p] = W4[p * 64];
+  for (int p = 0; p < PF; ++p) wq[p] = ldw4(wb, W2 + 256 * p, lo);
   f4 bin[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) bin[e] = silu4(edge_u(pp[e], qq[e], crg, cdg, 0, ec[e].r, ec[e].d0));
+  for (int e = 0; e < NE; ++e) bin[e] = silu4(edge_u(pp[e], qq[e], wb, cr, cd, g, 0, ec[e].r, ec[e].d0));
   // K loop stays rolled (one 16-feature chunk per trip): the weight tiles of the next chunk are
   // prefetched by the tail of this one (rotating queue) and the next chunk's activations are
   // generated under this chunk's MFMAs.
@@ -194,7 +236,7 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
     f4 nb[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) nb[e] = bin[e];
-    const f4* Wc = W4 + (size_t)cc * T * 64;
+    const int Wc = W2 + cc * (T * 256);
     f4 r[PF];
 #pragma unroll
     for (int p = 0; p < PF; ++p) r[p] = wq[p];
@@ -203,12 +245,12 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
       const f4 w = r[t % PF];
       // tile index cc*T + t + PF (clamped at the end of the matrix; the surplus loads are unused)
       const int nxt = (cc * T + t + PF < T * T) ? (t + PF) : t;
-      r[t % PF] = Wc[nxt * 64];
+      r[t % PF] = ldw4(wb, Wc + 256 * nxt, lo);
 #pragma unroll
       for (int e = 0; e < NE; ++e) acc[e][t] = mfma4(w, bin[e], acc[e][t]);
       if (t == 0 && cc + 1 < T) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], crg, cdg, cc + 1, ec[e].r, ec[e].d0));
+        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], wb, cr, cd, g, cc + 1, ec[e].r, ec[e].d0));
       }
     }
 #pragma unroll
@@ -220,32 +262,61 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
 
 // Edge-level GEMM whose input already sits in registers in C/B layout (chained MLP layer):
 //   out[e][t] = init + W . in[e]      in[e][cc] = features 16cc+4g+q of edge column c
-// init = bias[16t+4g..] (global, may be null) + per-column LDS rows rowinit[e] (may be null).
+// init = bias (float offset, -1 = none) + per-column LDS rows rowinit[e] (may be null).
+// Output-tile-outer order: only NE*TB accumulator quads are live while the K loop of an output tile
+// runs (NE*TB >= 2 independent MFMA chains), each finished tile is retired once; the inputs stay in
+// VGPRs.  (Input-chunk-outer order made hipcc shuttle every accumulator between AGPRs and VGPRs around
+// each MFMA.)
 template <int HP, int NE>
-__device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[NE][HP / 16], const f4 (&in)[NE][HP / 16],
-                                                    const float* __restrict__ Wp, const float* __restrict__ bias,
-                                                    const float* const (&rowinit)[NE], int lane) {
+__device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[NE][HP / 16], const f4 (&in)[NE][HP / 16], const WBuf& wb,
+                                                    int W, int bias, const float* const (&rowinit)[NE], int lane) {
   constexpr int T = HP / 16;
+  constexpr int TB = NE >= 2 ? 1 : 2;  // output tiles in flight
   constexpr int PF = kPF < T ? kPF : T;
+  constexpr int TT = (T + TB - 1) / TB * TB;  // tile count rounded up to TB (surplus tiles skipped)
   const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const f4 b = bias != nullptr ? *(const f4*)(bias + 16 * t + 4 * g) : splat(0.f);
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-      out[e][t] = rowinit[e] != nullptr ? b + *(const f4*)(rowinit[e] + 16 * t + 4 * g) : b;
-  }
-  const f4* W4 = (const f4*)Wp + c * 4 + g;
+  const int lo = c * 4 + g;
+  // flattened tile sequence: for t0 (step TB) { for cc { for tb } } ; tile (cc, t) sits at (cc*T + t)*256 floats
+  auto tile_off = [](int seq) {
+    const int per = T * TB;
+    const int t0 = seq / per * TB, r = seq % per, cc = r / TB, tb = r % TB;
+    const int t = t0 + tb < T ? t0 + tb : T - 1;
+    return (cc * T + t) * 256;
+  };
+  constexpr int NSEQ = TT * T;
   f4 wq[PF];
 #pragma unroll
-  for (int p = 0; p < PF; ++p) wq[p] = W4[p * 64];
+  for (int p = 0; p < PF; ++p) wq[p] = ldw4(wb, W + tile_off(p), lo);
 #pragma unroll
-  for (int idx = 0; idx < T * T; ++idx) {
-    const int cc = idx / T, t = idx % T;
-    const f4 w = wq[idx % PF];
-    if (idx + PF < T * T) wq[idx % PF] = W4[(idx + PF) * 64];
+  for (int t0 = 0; t0 < T; t0 += TB) {
+    f4 acc[NE][TB];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) out[e][t] = mfma4(w, in[e][cc], out[e][t]);
+    for (int tb = 0; tb < TB; ++tb) {
+      const int t = t0 + tb < T ? t0 + tb : T - 1;
+      const f4 b = bias >= 0 ? ldw4(wb, bias + 16 * t, g) : splat(0.f);
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        acc[e][tb] = rowinit[e] != nullptr ? b + *(const f4*)(rowinit[e] + 16 * t + 4 * g) : b;
+    }
+#pragma unroll
+    for (int cc = 0; cc < T; ++cc) {
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb) {
+        const int seq = (t0 / TB) * (T * TB) + cc * TB + tb;
+        const f4 w = wq[seq % PF];
+        if (seq + PF < NSEQ) wq[seq % PF] = ldw4(wb, W + tile_off(seq + PF), lo);
+        if (t0 + tb < T) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) acc[e][tb] = mfma4(w, in[e][cc], acc[e][tb]);
+        }
+      }
+    }
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+      if (t0 + tb < T) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) out[e][t0 + tb] = acc[e][tb];
+      }
   }
 }
 

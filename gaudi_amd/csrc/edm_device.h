@@ -28,6 +28,7 @@ struct EdmLayout {
 
 struct EdmDev {
   const float* w;
+  unsigned w_bytes;
   int F, L, S, attention, use_tanh;
   float coords_range, norm_constant, normf;
 };
@@ -121,14 +122,15 @@ __device__ __forceinline__ void coord_update(const SM& sm, const MolGraph& mg, f
 
 // eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
 template <int HP>
-__device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP>& sm, const float* sZ, float* sEps,
+__device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP>& sm, const float* sZ, float* sEps,
                             float* sMean /* [4] */, float t_val, int tid) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
-  const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1;
   EdmLayout lay{HP, F1, W.L, W.S};
   const float* __restrict__ w = W.w;
+  const WBuf wb = make_wbuf(W.w, W.w_bytes);
 
   // ---- input split + masking (models.py:88-105): x = z[:, :3]*m ; h = [z[:, 3:]*m , t]
   for (int idx = tid; idx < N * 3; idx += kThreads) {
@@ -157,14 +159,14 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
     compute_geo(sm, mg, W.norm_constant, wave, lane, false);  // egnn_new.py:216
     for (int s = 0; s < W.S; ++s) {
       // ------------------------------------------------------------------ GCL (egnn_new.py:42-89)
-      const float* G = w + lay.gcl(l, s);
+      const int G = lay.gcl(l, s);  // float offsets into the weight buffer
       const int PK = HP * HP;
-      const float* V = G + 6 * PK;
-      const float *cr = V, *cd = V + HP, *b1 = V + 2 * HP, *b2 = V + 3 * HP, *wa = V + 4 * HP, *bn1 = V + 5 * HP,
-                  *bn2 = V + 6 * HP;
-      const float ba = V[7 * HP];
-      node_gemm<HP, EPI_NONE>(G, sm.h, nullptr, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
-      node_gemm<HP, EPI_NONE>(G + PK, sm.h, nullptr, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane);
+      const int V = G + 6 * PK;
+      const int cr = V, cd = V + HP, b1 = V + 2 * HP, b2 = V + 3 * HP, wa = V + 4 * HP, bn1 = V + 5 * HP,
+                bn2 = V + 6 * HP;
+      const float ba = w[V + 7 * HP];
+      node_gemm<HP, EPI_NONE>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_NONE>(wb, G + PK, sm.h, -1, nullptr, -1, sm.q, nullptr, nullptr, N, wave, lane);
       for (int idx = tid; idx < N * LD; idx += kThreads) sm.agg[idx] = 0.f;
       __syncthreads();
       {
@@ -177,7 +179,7 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
           f4 geo2[2];
           load_cols<NetSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
           f4 acc[2][T];
-          edge_gemm_from_pq<HP, 2>(acc, G + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+          edge_gemm_from_pq<HP, 2>(acc, wb, G + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             float sdot = 0.f;
@@ -185,7 +187,7 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
             for (int t = 0; t < T; ++t) {
               const f4 m = silu4(acc[e][t]);
               acc[e][t] = m;
-              const f4 wv = *(const f4*)(wa + 16 * t + 4 * g);
+              const f4 wv = ldw4(wb, wa + 16 * t, g);
               sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
             }
             float a = 1.f;
@@ -201,19 +203,19 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
         ss.flush(sm.agg, W.normf, lane);
       }
       __syncthreads();
-      node_gemm<HP, EPI_SILU>(G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_SILU>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, N, wave, lane);
       __syncthreads();
-      node_gemm<HP, EPI_RESIDUAL_MASK>(G + 5 * PK, sm.p, nullptr, nullptr, bn2, sm.h, sm.h, mg.mask, N, wave, lane);
+      node_gemm<HP, EPI_RESIDUAL_MASK>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, N, wave, lane);
       __syncthreads();
     }
     // -------------------------------------------------------- EquivariantUpdate (egnn_new.py:119-155)
     {
-      const float* E = w + lay.equ(l);
+      const int E = lay.equ(l);
       const int PK = HP * HP;
-      const float* V = E + 3 * PK;
-      const float *cr = V, *cd = V + HP, *b1 = V + 2 * HP, *b2 = V + 3 * HP, *w3 = V + 4 * HP;
-      node_gemm<HP, EPI_NONE>(E, sm.h, nullptr, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
-      node_gemm<HP, EPI_NONE>(E + PK, sm.h, nullptr, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane);
+      const int V = E + 3 * PK;
+      const int cr = V, cd = V + HP, b1 = V + 2 * HP, b2 = V + 3 * HP, w3 = V + 4 * HP;
+      node_gemm<HP, EPI_NONE>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_NONE>(wb, E + PK, sm.h, -1, nullptr, -1, sm.q, nullptr, nullptr, N, wave, lane);
       __syncthreads();
       for (int tp = 0; tp < mg.npairs; ++tp) {
         EdgeCol ec[2];
@@ -221,14 +223,14 @@ __device__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<H
         f4 geo2[2];
         load_cols<NetSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
         f4 acc[2][T];
-        edge_gemm_from_pq<HP, 2>(acc, E + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+        edge_gemm_from_pq<HP, 2>(acc, wb, E + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           float sdot = 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             const f4 m = silu4(acc[e][t]);
-            const f4 wv = *(const f4*)(w3 + 16 * t + 4 * g);
+            const f4 wv = ldw4(wb, w3 + 16 * t, g);
             sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
           }
           const float phi = reduce_groups(sdot);

@@ -48,6 +48,7 @@ struct gaudi_handle {
   gaudi_pred_config pcfg{};
   int HPE = 0, HPP = 0;
   DevBuf edm_w, pred_w, coef_d;
+  size_t edm_w_bytes = 0, pred_w_bytes = 0;
   std::vector<float> gamma, coef;
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
@@ -339,6 +340,7 @@ static void fill_edm(gaudi_handle* h, KParams& P) {
   P.F = c.in_node_nf;
   P.T = c.diffusion_steps;
   P.edm.w = h->edm_w.as<float>();
+  P.edm.w_bytes = (unsigned)h->edm_w_bytes;
   P.edm.F = c.in_node_nf;
   P.edm.L = c.n_layers;
   P.edm.S = c.inv_sublayers;
@@ -479,6 +481,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   if (!T.missing.empty()) return fail(h, GAUDI_E_MISSING, "EDM checkpoint tensor missing or mis-shaped: " + T.missing);
   HIPCHECK(h, h->edm_w.reserve(sizeof(float) * w.size()));
   HIPCHECK(h, hipMemcpy(h->edm_w.p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
+  h->edm_w_bytes = sizeof(float) * w.size();
   h->gamma = make_gamma(cfg->diffusion_steps, cfg->noise_power, cfg->noise_precision);
   make_coef(h->gamma, cfg->diffusion_steps, h->coef);
   HIPCHECK(h, h->coef_d.reserve(sizeof(float) * h->coef.size()));

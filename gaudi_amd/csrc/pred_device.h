@@ -27,6 +27,7 @@ struct PredLayout {
 
 struct PredDev {
   const float* w;
+  unsigned w_bytes;
   int F, K, L, attention, use_tanh;
   float coords_range_layer;  // coords_range / n_layers (egnn_predictor/models.py:515)
 };
@@ -66,19 +67,20 @@ __device__ __forceinline__ f4 dsilu4(f4 u) {
 }
 __device__ __forceinline__ float dot4(f4 a, f4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
+// float offsets of one layer's tensors inside the packed weight buffer
 struct PredLayerW {
-  const float *A, *Bm, *W2, *Wc1, *Wn1h, *Wn1a, *Wn2, *At, *Bmt, *W2t, *Wc1t, *Wn1ht, *Wn1at, *Wn2t;
-  const float *cr, *cd, *b1, *b2, *wa, *bc1, *wc2, *bn1, *bn2;
+  int A, Bm, W2, Wc1, Wn1h, Wn1a, Wn2, At, Bmt, W2t, Wc1t, Wn1ht, Wn1at, Wn2t;
+  int cr, cd, b1, b2, wa, bc1, wc2, bn1, bn2;
   float ba;
-  __device__ PredLayerW(const float* L0, int HP) {
+  __device__ PredLayerW(const float* w, int L0, int HP) {
     const int PK = HP * HP;
     A = L0; Bm = L0 + PK; W2 = L0 + 2 * PK; Wc1 = L0 + 3 * PK; Wn1h = L0 + 4 * PK; Wn1a = L0 + 5 * PK;
     Wn2 = L0 + 6 * PK; At = L0 + 7 * PK; Bmt = L0 + 8 * PK; W2t = L0 + 9 * PK; Wc1t = L0 + 10 * PK;
     Wn1ht = L0 + 11 * PK; Wn1at = L0 + 12 * PK; Wn2t = L0 + 13 * PK;
-    const float* V = L0 + 14 * PK;
+    const int V = L0 + 14 * PK;
     cr = V; cd = V + HP; b1 = V + 2 * HP; b2 = V + 3 * HP; wa = V + 4 * HP; bc1 = V + 5 * HP; wc2 = V + 6 * HP;
     bn1 = V + 7 * HP; bn2 = V + 8 * HP;
-    ba = V[9 * HP];
+    ba = w[V + 9 * HP];
   }
 };
 
@@ -92,14 +94,15 @@ __host__ __device__ inline long long pred_stash_floats(int N, int HP, int L) {
 // buffers: h = b0, P = b1, Q = b2, agg = b3
 // ---------------------------------------------------------------------------------------------
 template <int HP>
-__device__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* sZ, float t_val,
+__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* sZ, float t_val,
                              float* stash, float readout_div, int tid) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
-  const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1, K = W.K;
   PredLayout lay{HP, F1, K, W.L};
   const float* __restrict__ w = W.w;
+  const WBuf wb = make_wbuf(W.w, W.w_bytes);
   float *h = sm.b0, *p = sm.b1, *q = sm.b2, *agg = sm.b3;
 
   for (int idx = tid; idx < N * 3; idx += kThreads) {  // models.py:439
@@ -125,13 +128,13 @@ __device__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSme
 
   for (int l = 0; l < W.L; ++l) {
     const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
-    const PredLayerW Lw(w + lay.layer(l), HP);
+    const PredLayerW Lw(w, lay.layer(l), HP);
     float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
     for (int idx = tid; idx < N * HP; idx += kThreads) st[idx] = h[(idx / HP) * LD + idx % HP];
     for (int idx = tid; idx < N * 4; idx += kThreads) st[2 * N * HP + idx] = sm.x[idx];
     compute_geo(sm, mg, 1.0f, wave, lane, false);  // gcl.py:308-316
-    node_gemm<HP, EPI_NONE>(Lw.A, h, nullptr, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane);
-    node_gemm<HP, EPI_NONE>(Lw.Bm, h, nullptr, nullptr, nullptr, q, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(wb, Lw.Bm, h, -1, nullptr, -1, q, nullptr, nullptr, N, wave, lane);
     for (int idx = tid; idx < N * LD; idx += kThreads) agg[idx] = 0.f;
     __syncthreads();
     {
@@ -144,7 +147,7 @@ __device__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSme
         f4 geo2[2];
         load_cols<PredSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
         f4 acc[2][T];
-        edge_gemm_from_pq<HP, 2>(acc, Lw.W2, Lw.b2, Lw.cr, Lw.cd, p, q, ec, lane);
+        edge_gemm_from_pq<HP, 2>(acc, wb, Lw.W2, Lw.b2, Lw.cr, Lw.cd, p, q, ec, lane);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           float sdot = 0.f;
@@ -152,7 +155,7 @@ __device__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSme
           for (int t = 0; t < T; ++t) {
             const f4 m = silu4(acc[e][t]);
             acc[e][t] = m;
-            sdot += dot4(m, *(const f4*)(Lw.wa + 16 * t + 4 * g));
+            sdot += dot4(m, ldw4(wb, Lw.wa + 16 * t, g));
           }
           float a = 1.f;
           if (W.attention) a = sigmoid_f(reduce_groups(sdot) + Lw.ba);
@@ -168,12 +171,12 @@ __device__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSme
         if (!last) {  // coord_model (gcl.py:252-278): trans = dhat * tanh(wc2 . silu(Wc1 e + bc1)) * R * mask
           f4 cp[2][T];
           const float* const noinit[2] = {nullptr, nullptr};
-          edge_gemm_from_regs<HP, 2>(cp, acc, Lw.Wc1, Lw.bc1, noinit, lane);
+          edge_gemm_from_regs<HP, 2>(cp, acc, wb, Lw.Wc1, Lw.bc1, noinit, lane);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             float sdot = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) sdot += dot4(silu4(cp[e][t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
+            for (int t = 0; t < T; ++t) sdot += dot4(silu4(cp[e][t]), ldw4(wb, Lw.wc2 + 16 * t, g));
             const float phi = reduce_groups(sdot);
             const float tau = W.use_tanh ? tanhf(phi) * W.coords_range_layer : phi;
             if (g == 0) {
@@ -188,9 +191,9 @@ __device__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSme
     }
     __syncthreads();
     for (int idx = tid; idx < N * HP; idx += kThreads) st[N * HP + idx] = agg[(idx / HP) * LD + idx % HP];
-    node_gemm<HP, EPI_SILU>(Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_SILU>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane);
     __syncthreads();
-    node_gemm<HP, EPI_RESIDUAL_MASK>(Lw.Wn2, p, nullptr, nullptr, Lw.bn2, h, h, mg.mask, N, wave, lane);
+    node_gemm<HP, EPI_RESIDUAL_MASK>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, N, wave, lane);
     if (!last) coord_update(sm, mg, 1.0f, tid);
     __syncthreads();
   }
@@ -221,14 +224,15 @@ __device__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSme
 //                          B3 = b3: dh (running)     B4 = b4: npre -> dnpre -> dQ accumulator
 // ---------------------------------------------------------------------------------------------
 template <int HP>
-__device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
+__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
                               float* sGrad, float readout_div, int tid) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
-  const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1, K = W.K, EW = mg.EW;
   PredLayout lay{HP, F1, K, W.L};
   const float* __restrict__ w = W.w;
+  const WBuf wb = make_wbuf(W.w, W.w_bytes);
   float *B0 = sm.b0, *B1 = sm.b1, *B2 = sm.b2, *dh = sm.b3, *B4 = sm.b4;
   const float* dpred = sm.pred + 16;
   int ntmax = 0;
@@ -252,7 +256,7 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
 
   for (int l = W.L - 1; l >= 0; --l) {
     const bool last = l == W.L - 1;
-    const PredLayerW Lw(w + lay.layer(l), HP);
+    const PredLayerW Lw(w, lay.layer(l), HP);
     const float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
     // (a) reload h_l, agg_l, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
     for (int idx = tid; idx < N * HP; idx += kThreads) {
@@ -268,17 +272,17 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
     __syncthreads();
     compute_geo(sm, mg, 1.0f, wave, lane, false);
     // (b1) npre = Wn1h h + Wn1a agg + bn1 -> B4
-    node_gemm<HP, EPI_NONE>(Lw.Wn1h, B0, Lw.Wn1a, B1, Lw.bn1, B4, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(wb, Lw.Wn1h, B0, Lw.Wn1a, B1, Lw.bn1, B4, nullptr, nullptr, N, wave, lane);
     __syncthreads();
     // (b2) P -> B2, Q -> B1 (agg is dead)
-    node_gemm<HP, EPI_NONE>(Lw.A, B0, nullptr, nullptr, Lw.b1, B2, nullptr, nullptr, N, wave, lane);
-    node_gemm<HP, EPI_NONE>(Lw.Bm, B0, nullptr, nullptr, nullptr, B1, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(wb, Lw.A, B0, -1, nullptr, Lw.b1, B2, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(wb, Lw.Bm, B0, -1, nullptr, -1, B1, nullptr, nullptr, N, wave, lane);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
-    node_gemm<HP, EPI_MUL_DSILU>(Lw.Wn2t, dh, nullptr, nullptr, nullptr, B4, B4, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_MUL_DSILU>(wb, Lw.Wn2t, dh, -1, nullptr, -1, B4, B4, nullptr, N, wave, lane);
     __syncthreads();
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
-    node_gemm<HP, EPI_ACCUM>(Lw.Wn1ht, B4, nullptr, nullptr, nullptr, dh, dh, nullptr, N, wave, lane);
-    node_gemm<HP, EPI_NONE>(Lw.Wn1at, B4, nullptr, nullptr, nullptr, B0, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_ACCUM>(wb, Lw.Wn1ht, B4, -1, nullptr, -1, dh, dh, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(wb, Lw.Wn1at, B4, -1, nullptr, -1, B0, nullptr, nullptr, N, wave, lane);
     __syncthreads();
     for (int idx = tid; idx < N * LD; idx += kThreads) B4[idx] = 0.f;  // dQ accumulator
     __syncthreads();
@@ -300,14 +304,14 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
           const float mk = mk1[0];
           const f4 gg = geo1[0];
           f4 v[1][T];
-          edge_gemm_from_pq<HP, 1>(v, Lw.W2, Lw.b2, Lw.cr, Lw.cd, B2, B1, ec, lane);
+          edge_gemm_from_pq<HP, 1>(v, wb, Lw.W2, Lw.b2, Lw.cr, Lw.cd, B2, B1, ec, lane);
           f4 ev[1][T];
           float sdot = 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             const f4 m = silu4(v[0][t]);
             ev[0][t] = m;
-            sdot += dot4(m, *(const f4*)(Lw.wa + 16 * t + 4 * g));
+            sdot += dot4(m, ldw4(wb, Lw.wa + 16 * t, g));
           }
           float a = 1.f;
           if (W.attention) a = sigmoid_f(reduce_groups(sdot) + Lw.ba);
@@ -319,10 +323,10 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
           if (!last) {
             f4 cp[1][T];
             const float* const noinit[1] = {nullptr};
-            edge_gemm_from_regs<HP, 1>(cp, ev, Lw.Wc1, Lw.bc1, noinit, lane);
+            edge_gemm_from_regs<HP, 1>(cp, ev, wb, Lw.Wc1, Lw.bc1, noinit, lane);
             float sd2 = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) sd2 += dot4(silu4(cp[0][t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
+            for (int t = 0; t < T; ++t) sd2 += dot4(silu4(cp[0][t]), ldw4(wb, Lw.wc2 + 16 * t, g));
             const float phi = reduce_groups(sd2);
             const float th = tanhf(phi);
             tau = W.use_tanh ? th * W.coords_range_layer : phi;
@@ -330,11 +334,11 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
             const float dphi = W.use_tanh ? dtau * W.coords_range_layer * (1.0f - th * th) : dtau;
 #pragma unroll
             for (int t = 0; t < T; ++t) {  // dcpre = dphi * wc2 * silu'(cpre)
-              const f4 wv = *(const f4*)(Lw.wc2 + 16 * t + 4 * g);
+              const f4 wv = ldw4(wb, Lw.wc2 + 16 * t, g);
               cp[0][t] = wv * dphi * dsilu4(cp[0][t]);
             }
             const float* const rowinit[1] = {B0 + i * LD};  // + dagg_i (from agg_i = sum_j e_ij)
-            edge_gemm_from_regs<HP, 1>(de, cp, Lw.Wc1t, nullptr, rowinit, lane);
+            edge_gemm_from_regs<HP, 1>(de, cp, wb, Lw.Wc1t, -1, rowinit, lane);
           } else {
 #pragma unroll
             for (int t = 0; t < T; ++t) de[0][t] = *(const f4*)(B0 + i * LD + 16 * t + 4 * g);
@@ -347,13 +351,13 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
           const float ds = W.attention ? da * a * (1.0f - a) : 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) {  // dv = (de*a*mask + ds*wa) * silu'(v)
-            const f4 wv = *(const f4*)(Lw.wa + 16 * t + 4 * g);
+            const f4 wv = ldw4(wb, Lw.wa + 16 * t, g);
             de[0][t] = (de[0][t] * a * mk + wv * ds) * dsilu4(v[0][t]);
           }
           f4 dt1[1][T];
           {
             const float* const noinit[1] = {nullptr};
-            edge_gemm_from_regs<HP, 1>(dt1, de, Lw.W2t, nullptr, noinit, lane);
+            edge_gemm_from_regs<HP, 1>(dt1, de, wb, Lw.W2t, -1, noinit, lane);
           }
           // du = dt1 * silu'(u) -> scratch ; dr = cr . du ; dd0 = cd . du
           const float* pp = B2 + i * LD + 4 * g;
@@ -361,10 +365,10 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
           float drdot = 0.f, dd0dot = 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            const f4 u = edge_u(pp, qq, Lw.cr + 4 * g, Lw.cd + 4 * g, t, ec[0].r, ec[0].d0);
+            const f4 u = edge_u(pp, qq, wb, Lw.cr, Lw.cd, g, t, ec[0].r, ec[0].d0);
             const f4 du = dt1[0][t] * dsilu4(u);
-            drdot += dot4(du, *(const f4*)(Lw.cr + 16 * t + 4 * g));
-            dd0dot += dot4(du, *(const f4*)(Lw.cd + 16 * t + 4 * g));
+            drdot += dot4(du, ldw4(wb, Lw.cr + 16 * t, g));
+            dd0dot += dot4(du, ldw4(wb, Lw.cd + 16 * t, g));
             *(f4*)(scr + c * LD + 16 * t + 4 * g) = du;
           }
           const float dr = reduce_groups(drdot), dd0v = reduce_groups(dd0dot);
@@ -387,7 +391,7 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
         __syncthreads();  // every wave's du tile of this round is in its scratch
         if (active) ss.add_tile(scr, my_i, B2, 1.0f, lane);  // dP_i = sum_j du_ij  (overwrites P_i: dead)
         // dQ_j = sum_i du_ij : the wave owning node j folds the matching rows of all four tiles
-#pragma unroll 1
+#pragma unroll
         for (int w2 = 0; w2 < kWaves; ++w2) {
           if (tile >= 2 * mg.npairs_all[w2]) continue;
           const float* scr2 = sm.scr + w2 * 16 * LD;
@@ -415,6 +419,7 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
     if (tid < N * 3) {
       const int n = tid / 3, d = tid % 3;
       float acc = sm.dx[4 * n + d];
+#pragma unroll
       for (int w2 = 0; w2 < kWaves; ++w2)
         for (int s = 0; s < 32 * mg.npairs_all[w2]; ++s) {
           const uint32_t e = mg.edge[w2 * EW + s];
@@ -426,7 +431,7 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
     }
     __syncthreads();
     // (f) dh += A^T dP + Bm^T dQ
-    node_gemm<HP, EPI_ACCUM>(Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_ACCUM>(wb, Lw.At, B2, Lw.Bmt, B4, -1, dh, dh, nullptr, N, wave, lane);
     __syncthreads();
   }
 
@@ -436,6 +441,7 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
     if (tid < N * 3) {
       const int n = tid / 3, d = tid % 3;
       float acc = sm.dx[4 * n + d];
+#pragma unroll
       for (int w2 = 0; w2 < kWaves; ++w2)
         for (int s = 0; s < 32 * mg.npairs_all[w2]; ++s) {
           const uint32_t e = mg.edge[w2 * EW + s];
@@ -458,7 +464,7 @@ __device__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSm
 
 // unit-test entry: pred (and optionally grad into sGrad) for z in sZ
 template <int HP>
-__device__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
+__device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                 float* sMean, float t_val, const float* dpred, bool want_grad, float* pred_out,
                                 float readout_div, float* stash, int tid) {
   (void)sTmp; (void)sMean;
@@ -475,7 +481,7 @@ __device__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net
 
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 template <int HP>
-__device__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
+__device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                 float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                 float* pred_out, float readout_div, float* stash, int tid) {
   (void)sTmp;

@@ -53,7 +53,7 @@ __host__ __device__ inline int common_floats(int N, int D, int EW) {
 template <int HPE, int HPP>
 __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = P.order[blockIdx.x];
   const int N = P.N, D = 3 + P.F, EW = P.EW;
 
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
       return;
     }
   }
-  if constexpr (HPP > 0) {
+  if constexpr (HPP > 0 && HPE == 0) {  // unit-test modes live in the predictor-only kernels
     if (P.mode == MODE_PRED_FWD || P.mode == MODE_PRED_GRAD) {
       const float* dp = P.dpred_in ? P.dpred_in + (size_t)b * P.pred.K : nullptr;
       predictor_entry<HPP>(P.pred, mg, net, sZ, sEps, sNz, sMean, P.t_in[b], dp, P.mode == MODE_PRED_GRAD,
