@@ -19,7 +19,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 4;
 constexpr int kThreads = 256;
-constexpr int kPF = 4;  // weight-tile prefetch depth (float4 per lane each)
+#ifndef GAUDI_PIN_SCHED
+#define GAUDI_PIN_SCHED 1
+#endif
+constexpr int kPF = 6;  // weight-tile prefetch depth (float4 per lane each)
 
 __host__ __device__ constexpr int align16(int n) { return (n + 15) & ~15; }
 __host__ __device__ constexpr int pad_hidden(int h) { return (h + 15) & ~15; }
@@ -248,10 +251,15 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
       r[t % PF] = ldw4(wb, Wc + 256 * nxt, lo);
 #pragma unroll
       for (int e = 0; e < NE; ++e) acc[e][t] = mfma4(w, bin[e], acc[e][t]);
-      if (t == 0 && cc + 1 < T) {
+      if (t == 0) {  // next chunk's activations (clamped on the last trip: no branch, same basic block)
+        const int ncc = cc + 1 < T ? cc + 1 : T - 1;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], wb, cr, cd, g, cc + 1, ec[e].r, ec[e].d0));
+        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], wb, cr, cd, g, ncc, ec[e].r, ec[e].d0));
       }
+#if GAUDI_PIN_SCHED
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one weight-tile load ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);  // ... per 4*NE MFMAs
+#endif
     }
 #pragma unroll
     for (int p = 0; p < PF; ++p) wq[p] = r[(p + T) % PF];
