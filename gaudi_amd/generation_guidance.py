@@ -1,0 +1,52 @@
+"""Host mirror of generation_guidance.py: predict / get_target_function_values / design (the RDKit stability
+filter and the plots are out of scope: CPU-side chemistry, dependency unavailable -- SURVEY.md section 8f)."""
+from __future__ import annotations
+
+from time import time
+
+import numpy as np
+
+from .models_edm import _like_ref, _to_numpy
+from .sampling_edm import _check, sample_guidance
+
+
+def _normalized_xh(x, h, node_mask, edm_model):
+    x, hh, _ = edm_model.normalize(x, {"categorical": h, "integer": None}, node_mask)
+    return np.concatenate([_to_numpy(x), _to_numpy(hh["categorical"])], axis=-1).astype(np.float32)
+
+
+def predict(model, x, h, node_mask, edge_mask, edm_model):
+    """generation_guidance.py:34-48: predictor at t=0 on the normalised sample."""
+    bs, n_nodes, _ = _to_numpy(x).shape
+    nm = _to_numpy(node_mask).reshape(bs, n_nodes, 1)
+    em = _to_numpy(edge_mask).reshape(bs, n_nodes * n_nodes)
+    return model(_normalized_xh(x, h, nm, edm_model), nm, em, np.zeros((bs, 1), np.float32))
+
+
+def get_target_function_values(x, h, target_function, node_mask, edge_mask, edm_model):
+    """generation_guidance.py:51-66."""
+    bs, n_nodes, _ = _to_numpy(x).shape
+    nm = _to_numpy(node_mask).reshape(bs, n_nodes, 1)
+    em = _to_numpy(edge_mask).reshape(bs, n_nodes * n_nodes)
+    return target_function(_normalized_xh(x, h, nm, edm_model), nm, em, np.zeros((bs, 1), np.float32))
+
+
+def design(args, model, cond_predictor, target_function, nodes_dist, prop_dist, scale, n_nodes):
+    """generation_guidance.py:83-184 up to the RDKit call: sample with guidance, evaluate the target and the
+    predicted properties at t=0, rank by target value.  Returns a dict instead of plotting."""
+    model.eval()
+    cond_predictor.eval()
+    nodesxsample = np.array([n_nodes] * args.batch_size, dtype=np.int64)
+    start_time = time()
+    x, one_hot, node_mask, edge_mask = sample_guidance(args, model, target_function, nodesxsample, scale=scale)
+    seconds = time() - start_time
+    print(f"Generated {x.shape[0]} molecules in {seconds:.2f} seconds")
+    _check(x, node_mask)
+    tvals = _to_numpy(get_target_function_values(x, one_hot, target_function, node_mask, edge_mask, model))
+    pred = _to_numpy(predict(cond_predictor, x, one_hot, node_mask, edge_mask, model))
+    if prop_dist is not None:
+        pred = prop_dist.unnormalize(pred)
+    print(f"Mean target function value: {tvals.mean():.4f}")
+    order = np.argsort(tvals)  # best (lowest energy) first, as the reference's ranking
+    return dict(x=x, one_hot=one_hot, node_mask=node_mask, edge_mask=edge_mask, target_function_values=_like_ref(tvals),
+                pred=_like_ref(pred), best=order, seconds=seconds, molecules_per_second=x.shape[0] / seconds)

@@ -1,0 +1,188 @@
+"""Host mirror of models_edm.get_model / EnVariationalDiffusion's sampling interface
+(models_edm.py:61-104, edm/equivariant_diffusion/en_diffusion.py:958-1067), backed by libgaudi_hip.so."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import checkpoint
+from ._lib import GaudiError
+from .engine import Engine
+
+
+def _to_numpy(a):
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    return np.asarray(a)
+
+
+def _like_ref(a):
+    """The reference returns torch tensors; do the same when torch is importable."""
+    try:
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a))
+    except Exception:  # pragma: no cover
+        return a
+
+
+class PropertyNorm:
+    """DistributionProperty(only_norm=True): mean/std + (un)normalize (models_edm.py:107-113,186-192).
+    mean/std are NOT stored in checkpoints (they come from the dataset) and must be supplied."""
+
+    def __init__(self, mean, std):
+        self.mean = np.asarray(_to_numpy(mean), np.float32)
+        self.std = np.asarray(_to_numpy(std), np.float32)
+
+    def normalize(self, pred):
+        return (pred - self.mean) / self.std
+
+    def unnormalize(self, pred):
+        return pred * self.std + self.mean
+
+
+class LinearTarget:
+    """Declarative target function T(pred) = w . pred + c of the predictor outputs -- the native form of the
+    closures in generation_guidance.py:198-211.  Calling it evaluates T on the GPU (predictor forward)."""
+
+    def __init__(self, cond_predictor, weights, const=0.0, name="linear"):
+        self.cond_predictor = cond_predictor
+        self.weights = np.asarray(weights, np.float32)
+        self.const = float(const)
+        self.name = name
+
+    def __call__(self, _input, _node_mask, _edge_mask, _t):
+        pred = _to_numpy(self.cond_predictor(_input, _node_mask, _edge_mask, _t))
+        return _like_ref((pred @ self.weights + self.const).astype(np.float32))
+
+
+def target_function_max_gap(cond_predictor) -> LinearTarget:
+    """-pred[:,1]  (generation_guidance.py:200-203)."""
+    w = np.zeros(cond_predictor.K, np.float32)
+    w[1] = -1.0
+    return LinearTarget(cond_predictor, w, name="max_gap")
+
+
+def target_function_opv(cond_predictor, prop_dist: PropertyNorm) -> LinearTarget:
+    """ip + ea + 3*gap on the un-normalised prediction (generation_guidance.py:205-211)."""
+    w = np.zeros(cond_predictor.K, np.float32)
+    w[0], w[2], w[3] = 3.0 * prop_dist.std[0], prop_dist.std[2], prop_dist.std[3]
+    c = 3.0 * prop_dist.mean[0] + prop_dist.mean[2] + prop_dist.mean[3]
+    return LinearTarget(cond_predictor, w, c, name="opv")
+
+
+class GaudiModel:
+    """Stands in for EnVariationalDiffusion on the sampling path: .sample / .sample_guidance / .normalize /
+    .unnormalize / .T with the reference's signatures."""
+
+    def __init__(self, args, state_dict, device: int = 0):
+        self.args = checkpoint.args_dict(args)
+        self.engine = Engine(device)
+        self.engine.load_edm(self.args, state_dict)
+        self.T = int(self.args["diffusion_steps"])
+        self.in_node_nf = self.engine.F
+        self.n_dims = 3
+        self.norm_values = list(self.args.get("normalize_factors", [1, 1, 1]))
+        self.norm_biases = (None, 0.0, 0.0)
+        self.seed = 0
+        self.sample_offset = 0
+        self.injected_noise = None  # [T+2,B,N,3+F] raw draws (parity tests); None -> on-device Philox
+        self.last_diag = None
+
+    def eval(self):
+        return self
+
+    # ---- en_diffusion.py:384-415
+    def normalize(self, x, h, node_mask):
+        x = _to_numpy(x) / self.norm_values[0]
+        nm = _to_numpy(node_mask)
+        h_cat = (_to_numpy(h["categorical"]).astype(np.float32) - self.norm_biases[1]) / self.norm_values[1] * nm
+        return _like_ref(x.astype(np.float32)), {"categorical": _like_ref(h_cat.astype(np.float32)),
+                                                  "integer": h.get("integer")}, None
+
+    def unnormalize(self, x, h_cat, h_int, node_mask):
+        nm = _to_numpy(node_mask)
+        x = _to_numpy(x) * self.norm_values[0]
+        h_cat = (_to_numpy(h_cat) * self.norm_values[1] + self.norm_biases[1]) * nm
+        return _like_ref(x), _like_ref(h_cat), h_int
+
+    def _run(self, n_samples, node_mask, edge_mask, std, target, scale, fix_noise):
+        if fix_noise:
+            raise GaudiError("fix_noise=True (visualisation chains) is not supported")
+        nm = _to_numpy(node_mask).astype(np.float32)
+        B, N = nm.shape[0], nm.shape[1]
+        if B != n_samples:
+            raise GaudiError(f"n_samples={n_samples} but node_mask has batch {B}")
+        em = _to_numpy(edge_mask).astype(np.float32).reshape(B, N, N)
+        tw = None
+        if target is not None:
+            if not isinstance(target, LinearTarget):
+                raise GaudiError(
+                    "target_function must be a gaudi_amd.models_edm.LinearTarget (e.g. target_function_max_gap / "
+                    "target_function_opv): arbitrary Python closures cannot run inside the fused HIP kernel and there "
+                    "is no CPU fallback")
+            if target.cond_predictor.engine is not self.engine:
+                raise GaudiError("the target's predictor must be attached to this model (get_cond_predictor_model(..., model=model))")
+            tw = target.weights
+        x, h, diag = self.engine.sample(nm.reshape(B, N), em, seed=self.seed, sample_offset=self.sample_offset,
+                                        noise=self.injected_noise, std=std, target_w=tw, scale=scale)
+        self.last_diag = diag
+        F = h.shape[2]
+        return _like_ref(x), {"categorical": _like_ref(h), "integer": _like_ref(np.zeros((B, N, 0), np.float32))}
+
+    def sample(self, n_samples, n_nodes, node_mask, edge_mask, context=None, fix_noise=False, std=1.0):
+        """EnVariationalDiffusion.sample (en_diffusion.py:958-1008)."""
+        if context is not None:
+            raise GaudiError("context conditioning is not part of the GaUDI sampling path")
+        return self._run(n_samples, node_mask, edge_mask, std, None, 1.0, fix_noise)
+
+    def sample_guidance(self, n_samples, target_function, node_mask, edge_mask, scale=1, fix_noise=False, std=1.0):
+        """EnVariationalDiffusion.sample_guidance (en_diffusion.py:1010-1067)."""
+        return self._run(n_samples, node_mask, edge_mask, std, target_function, scale, fix_noise)
+
+
+class CondPredictor:
+    """Stands in for EGNN_predictor: callable (xh, node_mask, edge_mask, t) -> pred [B,K] (models.py:433-457)."""
+
+    def __init__(self, model: GaudiModel, args, state_dict):
+        self.args = checkpoint.args_dict(args)
+        self.engine = model.engine
+        self.engine.load_predictor(self.args, state_dict)
+        self.K = self.engine.K
+
+    def eval(self):
+        return self
+
+    def __call__(self, xh, node_mask, edge_mask, t=0.0):
+        z = _to_numpy(xh).astype(np.float32)
+        B, N, _ = z.shape
+        tt = np.broadcast_to(_to_numpy(t).astype(np.float32).reshape(-1), (B,)) if np.ndim(_to_numpy(t)) else float(t)
+        return _like_ref(self.engine.predictor_fwd(z, tt, _to_numpy(node_mask).reshape(B, N),
+                                                   _to_numpy(edge_mask).reshape(B, N, N)))
+
+
+def get_model(args, dataloader_train=None, only_norm=True, device: int = 0, state_dict=None):
+    """models_edm.get_model (models_edm.py:61-104) -> (model, nodes_dist, prop_dist).
+
+    ``dataloader_train.dataset`` is only consulted for ``mean``/``std`` (property normalisation); the ring-count
+    histogram sampler (DistributionRings) is out of scope for this round and returned as None."""
+    a = checkpoint.args_dict(args)
+    if state_dict is None:
+        if not a.get("restore"):
+            raise GaudiError("get_model needs a checkpoint (args.restore / exp_dir) or an explicit state_dict")
+        state_dict = checkpoint.load_state_dict(a["exp_dir"])
+    model = GaudiModel(a, state_dict, device=device)
+    prop_dist = None
+    ds = getattr(dataloader_train, "dataset", None)
+    if ds is not None and getattr(ds, "mean", None) is not None:
+        prop_dist = PropertyNorm(ds.mean, ds.std)
+    return model, None, prop_dist
+
+
+def get_cond_predictor_model(args, dataset=None, model: GaudiModel | None = None, state_dict=None) -> CondPredictor:
+    """cond_prediction/train_cond_predictor.py:183-203, attached to ``model``'s GPU handle so that guidance runs
+    inside the same kernel launch as the denoiser."""
+    if model is None:
+        raise GaudiError("pass model=<GaudiModel>: the predictor shares the EDM's device handle")
+    a = checkpoint.args_dict(args)
+    if state_dict is None:
+        state_dict = checkpoint.load_state_dict(a["exp_dir"])
+    return CondPredictor(model, a, state_dict)

@@ -180,3 +180,57 @@ def test_tiny_chains_guided(golden, name, tol):
     assert rel_err(x, g[name + "_x_guided"]) < tol
     assert np.array_equal(h, g[name + "_h_guided"])
     eng.close()
+
+
+def test_reference_entry_points_end_to_end(golden):
+    """sample_pos_edm / sample_guidance with the reference's signatures (gaudi_amd.sampling_edm) against the
+    reference's own outputs for the same injected noise."""
+    import types
+    from gaudi_amd import sampling_edm
+    from gaudi_amd.models_edm import get_cond_predictor_model, get_model, target_function_max_gap
+    g = golden("g7_end_to_end")
+    cfg = cfg_of(g, "c1")
+    eargs = synth.edm_args(diffusion_steps=cfg["T"])
+    model, _, _ = get_model(eargs, state_dict=synth.synth_edm_state_dict(eargs, 1, seed=cfg["eseed"]))
+    model.injected_noise = g["c1_noise"]
+    args = types.SimpleNamespace(device="cuda", dataset="cata", max_nodes=11)
+    x, h, nm, em = sampling_edm.sample_pos_edm(args, model, cfg["nodes"], std=cfg["std"])
+    assert rel_err(x.numpy(), g["c1_x"]) < TOL and np.array_equal(h.numpy(), g["c1_h"])
+    assert np.array_equal(nm.numpy(), g["c1_node_mask"]) and np.array_equal(em.numpy(), g["c1_edge_mask"])
+    model.engine.close()
+
+    name = "hetro_tiny"
+    cfg = cfg_of(g, name)
+    base = dict(dataset=cfg["dataset"], amp=cfg["amp"])
+    eargs, esd = edm_from_cfg(dict(base, over=TINY, wseed=cfg["eseed"]), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(base, over=TINY_P, wseed=cfg["pseed"]))
+    model, _, _ = get_model(eargs, state_dict=esd)
+    pred = get_cond_predictor_model(pargs, model=model, state_dict=psd)
+    model.injected_noise = g[name + "_noise"]
+    args = types.SimpleNamespace(device="cuda", dataset="hetro", max_nodes=10)
+    x, h, nm, em = sampling_edm.sample_guidance(args, model, target_function_max_gap(pred), cfg["nodes"], scale=0.6)
+    assert rel_err(x.numpy(), g[name + "_x_guided"]) < TOL and np.array_equal(h.numpy(), g[name + "_h_guided"])
+    with pytest.raises(Exception, match="LinearTarget"):
+        sampling_edm.sample_guidance(args, model, lambda z, a, b, t: z.sum(), cfg["nodes"])
+    model.engine.close()
+
+
+def test_sharding_invariance_on_device(golden):
+    """Production RNG: sampling samples [2,5) alone (sample_offset=2) equals rows 2..4 of the full batch."""
+    eargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=8)
+    pargs = synth.pred_args(nf=36, n_layers=2)
+    eng = make_engine(eargs, synth.synth_edm_state_dict(eargs, 1, seed=1), pargs,
+                      synth.synth_predictor_state_dict(pargs, 1, 5, seed=2))
+    from oracle import gaudi_oracle as O
+    nm, em = O.build_masks([5, 7, 3, 7, 6], 7, False)
+    w = O.target_max_gap_weights(5)
+    x, h, _ = eng.sample(nm, em, seed=9, target_w=w, scale=0.6)
+    xs, hs, _ = eng.sample(nm[2:5], em.reshape(5, 7, 7)[2:5], seed=9, sample_offset=2, target_w=w, scale=0.6)
+    assert np.array_equal(xs, x[2:5]) and np.array_equal(hs, h[2:5])
+    # and the host Philox twin reproduces the device chain through the oracle
+    from gaudi_amd.philox import philox_normal
+    noise = philox_normal(9, 0, 5, 7 * 4, 0, 10).reshape(10, 5, 7, 4)
+    xo, ho, _ = O.sample(synth.synth_edm_state_dict(eargs, 1, seed=1), eargs, nm, em, noise,
+                         pred_sd=synth.synth_predictor_state_dict(pargs, 1, 5, seed=2), pcfg=pargs, target_w=w, scale=0.6)
+    assert rel_err(x, xo) < TOL
+    eng.close()

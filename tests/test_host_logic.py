@@ -1,0 +1,101 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no compute calls)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+from gaudi_amd import checkpoint, sampling_edm, synth
+from gaudi_amd.models_edm import LinearTarget, PropertyNorm, target_function_max_gap, target_function_opv
+
+
+class RecordingModel:
+    """Captures what the sampling helpers hand to model.sample / model.sample_guidance."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def sample(self, B, n_nodes, node_mask, edge_mask, std=1.0):
+        self.rec = dict(kind="sample", B=B, N=n_nodes, node_mask=node_mask, edge_mask=edge_mask, std=std)
+        return np.zeros((B, n_nodes, 3), np.float32), {"categorical": np.zeros((B, n_nodes, 1), np.float32)}
+
+    def sample_guidance(self, B, tf, node_mask, edge_mask, scale, fix_noise=False, std=1.0):
+        self.rec = dict(kind="guidance", B=B, node_mask=node_mask, edge_mask=edge_mask, std=std, scale=scale, tf=tf)
+        N = node_mask.shape[1]
+        return np.zeros((B, N, 3), np.float32), {"categorical": np.zeros((B, N, 1), np.float32)}
+
+
+@pytest.mark.parametrize("name,n_key,dataset,mx", [("cata", "cata_n", "cata", 11), ("hetro_pos", "hetro_pos_n", "hetro", 10)])
+def test_sample_pos_edm_masks_match_reference(golden, name, n_key, dataset, mx):
+    g = golden("g2_masks")
+    args = types.SimpleNamespace(device="cpu", dataset=dataset, max_nodes=mx)
+    m = RecordingModel()
+    x, h, nm, em = sampling_edm.sample_pos_edm(args, m, g[n_key])
+    assert m.rec["kind"] == "sample" and m.rec["std"] == 0.7  # reference default (sampling_edm.py:128)
+    assert np.array_equal(np.asarray(nm), g[name + "_node_mask"])
+    assert np.array_equal(np.asarray(em), g[name + "_edge_mask"])
+    assert m.rec["N"] == g[name + "_node_mask"].shape[1]
+
+
+@pytest.mark.parametrize("name,n_key,dataset", [("cata_guid", "cata_guid_n", "cata"), ("hetro_guid", "hetro_guid_n", "hetro")])
+def test_sample_guidance_masks_match_reference(golden, name, n_key, dataset):
+    g = golden("g2_masks")
+    args = types.SimpleNamespace(device="cpu", dataset=dataset, max_nodes=11)
+    m = RecordingModel()
+    x, h, nm, em = sampling_edm.sample_guidance(args, m, "TF", g[n_key], scale=0.6)
+    assert m.rec["kind"] == "guidance" and m.rec["std"] == 1.0 and m.rec["scale"] == 0.6 and m.rec["tf"] == "TF"
+    assert np.array_equal(np.asarray(nm), g[name + "_node_mask"])  # padded to the BATCH max (sampling_edm.py:177)
+    assert np.array_equal(np.asarray(em), g[name + "_edge_mask"])
+
+
+def test_sample_pos_edm_rejects_too_many_nodes():
+    args = types.SimpleNamespace(device="cpu", dataset="cata", max_nodes=5)
+    with pytest.raises(AssertionError):
+        sampling_edm.sample_pos_edm(args, RecordingModel(), [6])
+
+
+def test_masking_assert_fires():
+    class Leaky(RecordingModel):
+        def sample(self, B, n_nodes, node_mask, edge_mask, std=1.0):
+            return np.ones((B, n_nodes, 3), np.float32), {"categorical": np.zeros((B, n_nodes, 1), np.float32)}
+    args = types.SimpleNamespace(device="cpu", dataset="cata", max_nodes=5)
+    with pytest.raises(AssertionError, match="not masked"):
+        sampling_edm.sample_pos_edm(args, Leaky(), [3])
+
+
+@pytest.mark.parametrize("dp", [True, False])
+def test_checkpoint_roundtrip(tmp_path, dp):
+    args = synth.edm_args(dp=dp, nf=32, n_layers=2)
+    sd = synth.synth_edm_state_dict(args, 1, seed=5)
+    synth.write_checkpoint(str(tmp_path), args, sd)
+    a = checkpoint.get_edm_args(str(tmp_path))
+    assert a.restore is True and a.exp_dir == str(tmp_path) and a.nf == 32 and a.dp == dp
+    import torch
+    raw = torch.load(os.path.join(str(tmp_path), "model.pt"))
+    assert all(k.startswith("module.") for k in raw) == dp
+    got = checkpoint.load_state_dict(str(tmp_path))
+    assert set(got) == set(sd)
+    for k in sd:
+        assert np.array_equal(got[k], sd[k])
+
+
+def test_linear_targets():
+    pred = types.SimpleNamespace(K=5, engine=None)
+    t = target_function_max_gap(pred)
+    assert t.weights.tolist() == [0, -1, 0, 0, 0]
+    pn = PropertyNorm(mean=[0.3, -1.0, 0.5, 2.0, 0.1], std=[1.5, 0.7, 2.0, 0.9, 1.1])
+    t = target_function_opv(pred, pn)
+    p = np.random.default_rng(0).standard_normal((7, 5)).astype(np.float32)
+    u = pn.unnormalize(p)
+    want = u[:, 3] + u[:, 2] + 3 * u[:, 0]  # generation_guidance.py:205-211
+    np.testing.assert_allclose(p @ t.weights + t.const, want, rtol=1e-5)
+
+
+def test_unsupported_checkpoint_modes_are_refused():
+    from gaudi_amd.engine import _noise_power
+    from gaudi_amd._lib import GaudiError
+    assert _noise_power("polynomial_2") == 2.0
+    for bad in ("learned", "cosine"):
+        with pytest.raises(GaudiError):
+            _noise_power(bad)
