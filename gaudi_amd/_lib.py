@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libgaudi_hip.so")
+LIB_PATH = os.environ.get("GAUDI_LIB", os.path.join(_PKG, "libgaudi_hip.so"))  # GAUDI_LIB: diagnostic builds
 
 
 class GaudiError(RuntimeError):

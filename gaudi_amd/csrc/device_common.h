@@ -22,7 +22,39 @@ constexpr int kThreads = 256;
 #ifndef GAUDI_PIN_SCHED
 #define GAUDI_PIN_SCHED 1
 #endif
-constexpr int kPF = 6;  // weight-tile prefetch depth (float4 per lane each)
+// weight-tile prefetch depth (float4 per lane each) of the rolled edge GEMM: the largest divisor of T up to 13, so that
+// the rotating register queue maps onto itself from one K chunk to the next (no copies, no waits)
+__host__ __device__ constexpr int pick_pf(int T) {
+  int best = 1;
+  for (int d = 1; d <= 13; ++d)
+    if (T % d == 0) best = d;
+  return best;
+}
+constexpr int kPF = 6;  // prefetch depth of the fully unrolled (chained) edge GEMM
+
+// ---- diagnostic build only (-DGAUDI_STAMPS): per-phase cycle accounting by lane 0 of wave 0.
+// Never compiled into the shipped library; numbers from a stamped build are shares, not run times.
+#ifdef GAUDI_STAMPS
+enum { ST_NODE = 0, ST_EDGE = 1, ST_EDGE_EPI = 2, ST_BARRIER = 3, ST_MISC = 4, ST_BWD_NODE = 5, ST_BWD_EDGE = 6,
+       ST_BWD_COL = 7, ST_BWD_BARRIER = 8, ST_STASH = 9, ST_N = 10 };
+struct Stamps {
+  unsigned long long acc[ST_N];
+  unsigned long long last;
+  __device__ void init() { for (int i = 0; i < ST_N; ++i) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void mark(int id) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    acc[id] += t - last;
+    last = t;
+  }
+};
+#define STAMP(id) do { if (stamps_on) g_stamps.mark(id); } while (0)
+#define STAMP_DECL , Stamps& g_stamps, bool stamps_on
+#define STAMP_ARGS , g_stamps, stamps_on
+#else
+#define STAMP(id) do { } while (0)
+#define STAMP_DECL
+#define STAMP_ARGS
+#endif
 
 __host__ __device__ constexpr int align16(int n) { return (n + 15) & ~15; }
 __host__ __device__ constexpr int pad_hidden(int h) { return (h + 15) & ~15; }
@@ -130,35 +162,69 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
       const float* sX = src == 0 ? sXa : sXb;
       if (W < 0) continue;
       const float* xrow = sX + nclamp * LD + 4 * g;
-      // two K chunks of weight tiles in flight (registers), refilled as they are consumed
-      f4 q0[UT], q1[UT];
+      // Weight tiles are double-buffered in registers as two ping-pong sets (A, B) of two K chunks each: while
+      // the MFMAs consume one set, the loads of the other set (4 chunks ahead) are in flight.  Roles are swapped by
+      // unrolling, never by copying registers (a copy of an in-flight load forces vmcnt(0)).
+      f4 a0[UT], a1[UT], b0[UT], b1[UT];
+      auto chunk = [&](int cc) { return W + (cc < T ? cc : T - 1) * (T * 256); };
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
-        q0[u] = ldw4(wb, W + toff[u], lo);
-        q1[u] = ldw4(wb, W + (T > 1 ? T : 0) * 256 + toff[u], lo);
+        a0[u] = ldw4(wb, chunk(0) + toff[u], lo);
+        a1[u] = ldw4(wb, chunk(1) + toff[u], lo);
       }
+      constexpr int MAIN = T / 4 * 4;
 #pragma unroll 1
-      for (int cc = 0; cc + 1 < T; cc += 2) {
-        const f4 b0 = *(const f4*)(xrow + 16 * cc);
-        const f4 b1 = *(const f4*)(xrow + 16 * cc + 16);
-        const int n0 = cc + 2 < T ? cc + 2 : T - 1, n1 = cc + 3 < T ? cc + 3 : T - 1;
+      for (int cc = 0; cc < MAIN; cc += 4) {
+        const f4 x0 = *(const f4*)(xrow + 16 * cc);
+        const f4 x1 = *(const f4*)(xrow + 16 * cc + 16);
+        const f4 x2 = *(const f4*)(xrow + 16 * cc + 32);
+        const f4 x3 = *(const f4*)(xrow + 16 * cc + 48);
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
-          const f4 w = q0[u];
-          q0[u] = ldw4(wb, W + n0 * (T * 256) + toff[u], lo);
-          acc[u] = mfma4(w, b0, acc[u]);
+          b0[u] = ldw4(wb, chunk(cc + 2) + toff[u], lo);
+          b1[u] = ldw4(wb, chunk(cc + 3) + toff[u], lo);
         }
 #pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = mfma4(a0[u], x0, acc[u]);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = mfma4(a1[u], x1, acc[u]);
+#pragma unroll
         for (int u = 0; u < UT; ++u) {
-          const f4 w = q1[u];
-          q1[u] = ldw4(wb, W + n1 * (T * 256) + toff[u], lo);
-          acc[u] = mfma4(w, b1, acc[u]);
+          a0[u] = ldw4(wb, chunk(cc + 4) + toff[u], lo);
+          a1[u] = ldw4(wb, chunk(cc + 5) + toff[u], lo);
         }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = mfma4(b0[u], x2, acc[u]);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = mfma4(b1[u], x3, acc[u]);
+#if GAUDI_PIN_SCHED
+        // keep the issue order written above: hipcc otherwise sinks the loads next to their consumers
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 LDS reads (x0..x3)
+        __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);  // set B loads
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT, 0);  // MFMAs on set A
+        __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);  // set A loads (4 chunks ahead)
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT, 0);  // MFMAs on set B
+#endif
       }
-      if (T & 1) {
-        const f4 b0 = *(const f4*)(xrow + 16 * (T - 1));
+      // tail: T % 4 chunks, already in a0 / a1 (and one more load for the third)
+      if (T - MAIN >= 1) {
+        const f4 x0 = *(const f4*)(xrow + 16 * MAIN);
+        if (T - MAIN >= 3) {
 #pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma4(q0[u], b0, acc[u]);
+          for (int u = 0; u < UT; ++u) b0[u] = ldw4(wb, chunk(MAIN + 2) + toff[u], lo);
+        }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = mfma4(a0[u], x0, acc[u]);
+      }
+      if (T - MAIN >= 2) {
+        const f4 x1 = *(const f4*)(xrow + 16 * (MAIN + 1));
+#pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = mfma4(a1[u], x1, acc[u]);
+      }
+      if (T - MAIN >= 3) {
+        const f4 x2 = *(const f4*)(xrow + 16 * (MAIN + 2));
+#pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = mfma4(b0[u], x2, acc[u]);
       }
     }
 #pragma unroll
@@ -209,7 +275,8 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
                                                   const float* sP, const float* sQ, const EdgeCol (&ec)[NE], int lane) {
   constexpr int T = HP / 16;
   constexpr int LD = HP + 4;
-  constexpr int PF = kPF < T ? kPF : T;
+  constexpr int PF = pick_pf(T);
+  static_assert(T % PF == 0, "queue rotation must be the identity");
   const int c = lane & 15, g = lane >> 4;
   const int lo = c * 4 + g;
 #pragma unroll
@@ -316,6 +383,10 @@ __device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[NE][HP / 16], cons
         if (t0 + tb < T) {
 #pragma unroll
           for (int e = 0; e < NE; ++e) acc[e][tb] = mfma4(w, in[e][cc], acc[e][tb]);
+#if GAUDI_PIN_SCHED
+          if (seq + PF < NSEQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);
+#endif
         }
       }
     }

@@ -123,7 +123,7 @@ __device__ __forceinline__ void coord_update(const SM& sm, const MolGraph& mg, f
 // eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
 template <int HP>
 __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP>& sm, const float* sZ, float* sEps,
-                            float* sMean /* [4] */, float t_val, int tid) {
+                            float* sMean /* [4] */, float t_val, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -168,7 +168,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       node_gemm<HP, EPI_NONE>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
       node_gemm<HP, EPI_NONE>(wb, G + PK, sm.h, -1, nullptr, -1, sm.q, nullptr, nullptr, N, wave, lane);
       for (int idx = tid; idx < N * LD; idx += kThreads) sm.agg[idx] = 0.f;
+      STAMP(ST_NODE);
       __syncthreads();
+      STAMP(ST_BARRIER);
       {
         SegSum<HP> ss;
         ss.init();
@@ -180,6 +182,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           load_cols<NetSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
           f4 acc[2][T];
           edge_gemm_from_pq<HP, 2>(acc, wb, G + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+          STAMP(ST_EDGE);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             float sdot = 0.f;
@@ -202,11 +205,17 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         }
         ss.flush(sm.agg, W.normf, lane);
       }
+      STAMP(ST_EDGE_EPI);
       __syncthreads();
+      STAMP(ST_BARRIER);
       node_gemm<HP, EPI_SILU>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, N, wave, lane);
+      STAMP(ST_NODE);
       __syncthreads();
+      STAMP(ST_BARRIER);
       node_gemm<HP, EPI_RESIDUAL_MASK>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, N, wave, lane);
+      STAMP(ST_NODE);
       __syncthreads();
+      STAMP(ST_BARRIER);
     }
     // -------------------------------------------------------- EquivariantUpdate (egnn_new.py:119-155)
     {
@@ -216,7 +225,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int cr = V, cd = V + HP, b1 = V + 2 * HP, b2 = V + 3 * HP, w3 = V + 4 * HP;
       node_gemm<HP, EPI_NONE>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
       node_gemm<HP, EPI_NONE>(wb, E + PK, sm.h, -1, nullptr, -1, sm.q, nullptr, nullptr, N, wave, lane);
+      STAMP(ST_NODE);
       __syncthreads();
+      STAMP(ST_BARRIER);
       for (int tp = 0; tp < mg.npairs; ++tp) {
         EdgeCol ec[2];
         float mk2[2];
@@ -224,6 +235,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         load_cols<NetSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
         f4 acc[2][T];
         edge_gemm_from_pq<HP, 2>(acc, wb, E + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+        STAMP(ST_EDGE);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           float sdot = 0.f;
@@ -243,9 +255,12 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           }
         }
       }
+      STAMP(ST_EDGE_EPI);
       __syncthreads();
+      STAMP(ST_BARRIER);
       coord_update(sm, mg, W.normf, tid);
       __syncthreads();
+      STAMP(ST_MISC);
     }
   }
 

@@ -59,6 +59,10 @@ struct gaudi_handle {
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   long long prof_steps = 0;
+#ifdef GAUDI_STAMPS
+  DevBuf d_stamps;
+  unsigned long long stamp_acc[16] = {0};
+#endif
 };
 
 #define HIPCHECK(h, call)                                                                         \
@@ -247,9 +251,13 @@ static int build_meta(int B, int N, const float* node_mask, const float* edge_ma
 // -------------------------------------------------------------------------------------------------
 // kernel table: the instantiations live in kern_*.hip (compiled in parallel), each exporting a lookup
 typedef void (*kernel_fn)(const KParams);
+#ifdef GAUDI_STAMP_STUBS  // diagnostic build: only the two production kernels are linked
+#define GAUDI_KERNEL_TUS(X) X(edm_192) X(fused_192_208)
+#else
 #define GAUDI_KERNEL_TUS(X)                                                                            \
   X(edm_small) X(edm_192) X(edm_208) X(edm_256) X(pred_small) X(pred_192) X(pred_208) X(pred_256)      \
   X(fused_tiny) X(fused_128_128) X(fused_192_192) X(fused_192_208) X(fused_208_208) X(fused_256_256)
+#endif
 #define X(name) kernel_fn gaudi_kern_##name(int hpe, int hpp);
 GAUDI_KERNEL_TUS(X)
 #undef X
@@ -293,7 +301,30 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
     HIPCHECK(h, hipEventCreate(&e1));
     HIPCHECK(h, hipEventRecord(e0, h->stream));
   }
+#ifdef GAUDI_STAMPS
+  KParams PS = P;
+  HIPCHECK(h, h->d_stamps.reserve(sizeof(unsigned long long) * 16));
+  HIPCHECK(h, hipMemsetAsync(h->d_stamps.p, 0, sizeof(unsigned long long) * 16, h->stream));
+  PS.stamps = h->d_stamps.as<unsigned long long>();
+  hipLaunchKernelGGL(fn, dim3(P.B), dim3(kThreads), lds, h->stream, PS);
+  {
+    unsigned long long tmp[16];
+    HIPCHECK(h, hipMemcpyAsync(tmp, h->d_stamps.p, sizeof(tmp), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 16; ++i) h->stamp_acc[i] += tmp[i];
+    if (getenv("GAUDI_PRINT_STAMPS")) {
+      static const char* nm[] = {"node_gemm", "edge_gemm", "edge_epilogue", "barrier", "misc", "bwd_node", "bwd_edge",
+                                 "bwd_colsum", "bwd_barrier", "stash"};
+      unsigned long long tot = 0;
+      for (int i = 0; i < 10; ++i) tot += h->stamp_acc[i];
+      fprintf(stderr, "[stamps] cumulative shares (block 0, wave 0):");
+      for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * h->stamp_acc[i] / (tot ? tot : 1));
+      fprintf(stderr, " total=%llu ticks\n", tot);
+    }
+  }
+#else
   hipLaunchKernelGGL(fn, dim3(P.B), dim3(kThreads), lds, h->stream, P);
+#endif
   HIPCHECK(h, hipGetLastError());
   if (h->prof) {
     HIPCHECK(h, hipEventRecord(e1, h->stream));

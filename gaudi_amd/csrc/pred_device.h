@@ -95,7 +95,7 @@ __host__ __device__ inline long long pred_stash_floats(int N, int HP, int L) {
 // ---------------------------------------------------------------------------------------------
 template <int HP>
 __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* sZ, float t_val,
-                             float* stash, float readout_div, int tid) {
+                             float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -134,9 +134,12 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     for (int idx = tid; idx < N * 4; idx += kThreads) st[2 * N * HP + idx] = sm.x[idx];
     compute_geo(sm, mg, 1.0f, wave, lane, false);  // gcl.py:308-316
     node_gemm<HP, EPI_NONE>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane);
+    STAMP(ST_STASH);
     node_gemm<HP, EPI_NONE>(wb, Lw.Bm, h, -1, nullptr, -1, q, nullptr, nullptr, N, wave, lane);
     for (int idx = tid; idx < N * LD; idx += kThreads) agg[idx] = 0.f;
+    STAMP(ST_NODE);
     __syncthreads();
+    STAMP(ST_BARRIER);
     {
       SegSum<HP> ss;
       ss.init();
@@ -148,6 +151,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         load_cols<PredSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
         f4 acc[2][T];
         edge_gemm_from_pq<HP, 2>(acc, wb, Lw.W2, Lw.b2, Lw.cr, Lw.cd, p, q, ec, lane);
+        STAMP(ST_EDGE);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           float sdot = 0.f;
@@ -171,7 +175,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         if (!last) {  // coord_model (gcl.py:252-278): trans = dhat * tanh(wc2 . silu(Wc1 e + bc1)) * R * mask
           f4 cp[2][T];
           const float* const noinit[2] = {nullptr, nullptr};
+          STAMP(ST_EDGE_EPI);
           edge_gemm_from_regs<HP, 2>(cp, acc, wb, Lw.Wc1, Lw.bc1, noinit, lane);
+          STAMP(ST_EDGE);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             float sdot = 0.f;
@@ -189,13 +195,20 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       }
       ss.flush(agg, 1.0f, lane);
     }
+    STAMP(ST_EDGE_EPI);
     __syncthreads();
+    STAMP(ST_BARRIER);
     for (int idx = tid; idx < N * HP; idx += kThreads) st[N * HP + idx] = agg[(idx / HP) * LD + idx % HP];
+    STAMP(ST_STASH);
     node_gemm<HP, EPI_SILU>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane);
+    STAMP(ST_NODE);
     __syncthreads();
+    STAMP(ST_BARRIER);
     node_gemm<HP, EPI_RESIDUAL_MASK>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, N, wave, lane);
     if (!last) coord_update(sm, mg, 1.0f, tid);
+    STAMP(ST_NODE);
     __syncthreads();
+    STAMP(ST_BARRIER);
   }
   // readout: mean over the PADDED node count of (embedding_out(h) * mask)   (models.py:553-557, :457)
   {
@@ -225,7 +238,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 // ---------------------------------------------------------------------------------------------
 template <int HP>
 __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
-                              float* sGrad, float readout_div, int tid) {
+                              float* sGrad, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -270,6 +283,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       sm.dx[idx] *= mg.mask[idx >> 2];
     }
     __syncthreads();
+    STAMP(ST_STASH);
     compute_geo(sm, mg, 1.0f, wave, lane, false);
     // (b1) npre = Wn1h h + Wn1a agg + bn1 -> B4
     node_gemm<HP, EPI_NONE>(wb, Lw.Wn1h, B0, Lw.Wn1a, B1, Lw.bn1, B4, nullptr, nullptr, N, wave, lane);
@@ -286,6 +300,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     __syncthreads();
     for (int idx = tid; idx < N * LD; idx += kThreads) B4[idx] = 0.f;  // dQ accumulator
     __syncthreads();
+    STAMP(ST_BWD_NODE);
     // (e) edge pass, all four waves in lock step (one 16-edge tile per round)
     {
       SegSum<HP> ss;
@@ -388,7 +403,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           }
         }
         wave_lds_fence();
+        STAMP(ST_BWD_EDGE);
         __syncthreads();  // every wave's du tile of this round is in its scratch
+        STAMP(ST_BWD_BARRIER);
         if (active) ss.add_tile(scr, my_i, B2, 1.0f, lane);  // dP_i = sum_j du_ij  (overwrites P_i: dead)
         // dQ_j = sum_i du_ij : the wave owning node j folds the matching rows of all four tiles
 #pragma unroll
@@ -405,7 +422,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           }
         }
         wave_lds_fence();
+        STAMP(ST_BWD_COL);
         __syncthreads();  // scratch may be overwritten
+        STAMP(ST_BWD_BARRIER);
       }
       if (nt_me > 0) ss.flush(B2, 1.0f, lane);
     }
@@ -431,8 +450,10 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     }
     __syncthreads();
     // (f) dh += A^T dP + Bm^T dQ
+    STAMP(ST_MISC);
     node_gemm<HP, EPI_ACCUM>(wb, Lw.At, B2, Lw.Bmt, B4, -1, dh, dh, nullptr, N, wave, lane);
     __syncthreads();
+    STAMP(ST_BWD_NODE);
   }
 
   // embedding backward (time column dropped), d0 backward, input masking
@@ -466,35 +487,35 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 template <int HP>
 __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                 float* sMean, float t_val, const float* dpred, bool want_grad, float* pred_out,
-                                float readout_div, float* stash, int tid) {
+                                float readout_div, float* stash, int tid STAMP_DECL) {
   (void)sTmp; (void)sMean;
   PredSmem<HP> sm;
   sm.carve(net, mg.N, mg.EW);
-  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid);
+  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
     if (pred_out) pred_out[tid] = sm.pred[tid];
     sm.pred[16 + tid] = dpred ? dpred[tid] : 0.f;
   }
   __syncthreads();
-  if (want_grad) pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, tid);
+  if (want_grad) pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, tid STAMP_ARGS);
 }
 
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 template <int HP>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                 float* sMean, float t_val, float sigma, const float* target_w, float scale,
-                                float* pred_out, float readout_div, float* stash, int tid) {
+                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
   (void)sTmp;
   const int N = mg.N, D = mg.D;
   PredSmem<HP> sm;
   sm.carve(net, N, mg.EW);
-  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid);
+  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
     if (pred_out) pred_out[tid] = sm.pred[tid];
     sm.pred[16 + tid] = target_w[tid] * scale;  // energy = scale * sum_b T(pred_b), T linear in pred
   }
   __syncthreads();
-  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, tid);
+  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, tid STAMP_ARGS);
   // clip_coef = min(1, 10 / (||g||_2 + 1e-6)) over all N*(3+F) entries   (en_diffusion.py:905-909)
   if (tid < 64) {
     float s = 0.f;

@@ -44,6 +44,7 @@ struct KParams {
   float* stash;             // predictor activation stash, [B] x stash_stride floats
   long long stash_stride;
   float readout_div;        // padded N the predictor readout divides by
+  unsigned long long* stamps;  // diagnostic builds only (-DGAUDI_STAMPS): [ST_N] cycle sums of block 0
 };
 
 __host__ __device__ inline int common_floats(int N, int D, int EW) {
@@ -117,6 +118,11 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
   };
 
   const int mode = P.mode;
+#ifdef GAUDI_STAMPS
+  Stamps g_stamps;
+  g_stamps.init();
+  const bool stamps_on = P.stamps != nullptr && blockIdx.x == 0 && tid == 0;
+#endif
   if (mode == MODE_SAMPLE && P.do_init) {
     __syncthreads();
     combined_noise(0, P.std0);
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
         const float t_val = mode == MODE_PHI ? P.t_in[b] : cf[3];  // decode: t = 0
         if (is_step == false && mode == MODE_SAMPLE)               // z_0 is final: publish it
           for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
-        edm_forward<HPE>(edm, mg, sm, sZ, sEps, sMean, t_val, tid);
+        edm_forward<HPE>(edm, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
         if (mode == MODE_PHI) {
           for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
         } else if (is_step) {
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
               // guidance (en_diffusion.py:899-920): predictor at (z_s, t), clip, project, apply
               guidance_update<HPP>(P.pred, mg, net, sZ, sEps /* grad */, sNz /* scratch */, sMean, cf[3], cf[2],
                                    P.target_w, P.scale, nullptr, P.readout_div,
-                                   P.stash + (size_t)b * P.stash_stride, tid);
+                                   P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS);
             }
           }
           col_means(sZ);
@@ -207,6 +213,9 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
       }
       if (mode == MODE_SAMPLE && !P.do_decode)
         for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
+#ifdef GAUDI_STAMPS
+      if (stamps_on) for (int i = 0; i < ST_N; ++i) P.stamps[i] = g_stamps.acc[i];
+#endif
       if (nan_local) atomicAdd(P.nan_count, nan_local);
       return;
     }
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
     if (P.mode == MODE_PRED_FWD || P.mode == MODE_PRED_GRAD) {
       const float* dp = P.dpred_in ? P.dpred_in + (size_t)b * P.pred.K : nullptr;
       predictor_entry<HPP>(P.pred, mg, net, sZ, sEps, sNz, sMean, P.t_in[b], dp, P.mode == MODE_PRED_GRAD,
-                           P.pred_out + (size_t)b * P.pred.K, P.readout_div, P.stash + (size_t)b * P.stash_stride, tid);
+                           P.pred_out + (size_t)b * P.pred.K, P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS);
       if (P.mode == MODE_PRED_GRAD)
         for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
     }
