@@ -22,6 +22,9 @@ constexpr int kThreads = 256;
 #ifndef GAUDI_PIN_SCHED
 #define GAUDI_PIN_SCHED 1
 #endif
+#ifndef GAUDI_PIN_SCHED_UNROLLED
+#define GAUDI_PIN_SCHED_UNROLLED 1
+#endif
 // weight-tile prefetch depth (float4 per lane each) of the rolled edge GEMM: the largest divisor of T up to 13, so that
 // the rotating register queue maps onto itself from one K chunk to the next (no copies, no waits)
 __host__ __device__ constexpr int pick_pf(int T) {
@@ -383,9 +386,13 @@ __device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[NE][HP / 16], cons
         if (t0 + tb < T) {
 #pragma unroll
           for (int e = 0; e < NE; ++e) acc[e][tb] = mfma4(w, in[e][cc], acc[e][tb]);
-#if GAUDI_PIN_SCHED
-          if (seq + PF < NSEQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);
+#if GAUDI_PIN_SCHED_UNROLLED
+          // +5 % on the reverse pass, but the group solver's compile time explodes with the block size:
+          // only for single-tile calls at the production sizes (T = 12, 13)
+          if constexpr (NE == 1 && T >= 12 && T <= 13) {
+            if (seq + PF < NSEQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);
+          }
 #endif
         }
       }

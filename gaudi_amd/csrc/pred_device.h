@@ -6,6 +6,10 @@
 #include "device_common.h"
 #include "edm_device.h"
 
+#ifndef GAUDI_BWD_TILES
+#define GAUDI_BWD_TILES 1  // 16-edge tiles per wave per round of the reverse edge pass
+#endif
+
 namespace gaudi {
 
 // Packed predictor weights (floats), HP = padded hidden, PK = HP*HP:
@@ -301,130 +305,159 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     for (int idx = tid; idx < N * LD; idx += kThreads) B4[idx] = 0.f;  // dQ accumulator
     __syncthreads();
     STAMP(ST_BWD_NODE);
-    // (e) edge pass, all four waves in lock step (one 16-edge tile per round)
+    // (e) edge pass, all four waves in lock step.  Each wave runs the MLP chain forward and backward for NB
+    //     16-edge tiles at a time (registers), then publishes the NB du tiles one after the other through its
+    //     single scratch tile (two workgroup barriers per published tile).
     {
+      constexpr int NB = GAUDI_BWD_TILES;
       SegSum<HP> ss;
       ss.init();
       float* scr = sm.scr + wave * 16 * LD;
-      for (int tile = 0; tile < ntmax; ++tile) {
-        const bool active = tile < nt_me;
-        int my_i = 0;
+      const int rounds = (ntmax + NB - 1) / NB;
+      for (int rd = 0; rd < rounds; ++rd) {
+        const int tile0 = rd * NB;
+        const bool active = tile0 < nt_me;  // npairs*2 tiles: with NB <= 2 a round is all-active or all-idle
+        f4 du[NB][T];
+        int my_i[NB];
+#pragma unroll
+        for (int e = 0; e < NB; ++e) my_i[e] = 0;
         if (active) {
-          EdgeCol ec[1];
-          float mk1[1];
-          f4 geo1[1];
-          load_cols<PredSmem<HP>, 1>(sm, mg, wave, tile * 16, c, ec, mk1, geo1);
-          const int i = ec[0].i, j = ec[0].j;
-          my_i = i;
-          const float mk = mk1[0];
-          const f4 gg = geo1[0];
-          f4 v[1][T];
-          edge_gemm_from_pq<HP, 1>(v, wb, Lw.W2, Lw.b2, Lw.cr, Lw.cd, B2, B1, ec, lane);
-          f4 ev[1][T];
-          float sdot = 0.f;
+          EdgeCol ec[NB];
+          float mk[NB];
+          f4 gg[NB];
+          load_cols<PredSmem<HP>, NB>(sm, mg, wave, tile0 * 16, c, ec, mk, gg);
+          f4 v[NB][T];
+          edge_gemm_from_pq<HP, NB>(v, wb, Lw.W2, Lw.b2, Lw.cr, Lw.cd, B2, B1, ec, lane);
+          f4 ev[NB][T];
+          float a[NB], tau[NB], dtx[NB], dty[NB], dtz[NB];
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            const f4 m = silu4(v[0][t]);
-            ev[0][t] = m;
-            sdot += dot4(m, ldw4(wb, Lw.wa + 16 * t, g));
-          }
-          float a = 1.f;
-          if (W.attention) a = sigmoid_f(reduce_groups(sdot) + Lw.ba);
+          for (int e = 0; e < NB; ++e) {
+            my_i[e] = ec[e].i;
+            float sdot = 0.f;
 #pragma unroll
-          for (int t = 0; t < T; ++t) ev[0][t] = ev[0][t] * a * mk;
-          f4 de[1][T];
-          float tau = 0.f;
-          const float dtx = sm.dx[4 * i + 0], dty = sm.dx[4 * i + 1], dtz = sm.dx[4 * i + 2];  // dtrans = dx'_i
-          if (!last) {
-            f4 cp[1][T];
-            const float* const noinit[1] = {nullptr};
-            edge_gemm_from_regs<HP, 1>(cp, ev, wb, Lw.Wc1, Lw.bc1, noinit, lane);
-            float sd2 = 0.f;
-#pragma unroll
-            for (int t = 0; t < T; ++t) sd2 += dot4(silu4(cp[0][t]), ldw4(wb, Lw.wc2 + 16 * t, g));
-            const float phi = reduce_groups(sd2);
-            const float th = tanhf(phi);
-            tau = W.use_tanh ? th * W.coords_range_layer : phi;
-            const float dtau = (dtx * gg[1] + dty * gg[2] + dtz * gg[3]) * mk;
-            const float dphi = W.use_tanh ? dtau * W.coords_range_layer * (1.0f - th * th) : dtau;
-#pragma unroll
-            for (int t = 0; t < T; ++t) {  // dcpre = dphi * wc2 * silu'(cpre)
-              const f4 wv = ldw4(wb, Lw.wc2 + 16 * t, g);
-              cp[0][t] = wv * dphi * dsilu4(cp[0][t]);
+            for (int t = 0; t < T; ++t) {
+              const f4 m = silu4(v[e][t]);
+              ev[e][t] = m;
+              sdot += dot4(m, ldw4(wb, Lw.wa + 16 * t, g));
             }
-            const float* const rowinit[1] = {B0 + i * LD};  // + dagg_i (from agg_i = sum_j e_ij)
-            edge_gemm_from_regs<HP, 1>(de, cp, wb, Lw.Wc1t, -1, rowinit, lane);
+            a[e] = 1.f;
+            if (W.attention) a[e] = sigmoid_f(reduce_groups(sdot) + Lw.ba);
+#pragma unroll
+            for (int t = 0; t < T; ++t) ev[e][t] = ev[e][t] * a[e] * mk[e];
+            tau[e] = 0.f;
+            dtx[e] = sm.dx[4 * ec[e].i + 0];  // dtrans = dx'_i
+            dty[e] = sm.dx[4 * ec[e].i + 1];
+            dtz[e] = sm.dx[4 * ec[e].i + 2];
+          }
+          f4 de[NB][T];
+          if (!last) {
+            f4 cp[NB][T];
+            const float* noinit[NB];
+            const float* rowinit[NB];
+#pragma unroll
+            for (int e = 0; e < NB; ++e) { noinit[e] = nullptr; rowinit[e] = B0 + ec[e].i * LD; }
+            edge_gemm_from_regs<HP, NB>(cp, ev, wb, Lw.Wc1, Lw.bc1, noinit, lane);
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+              float sd2 = 0.f;
+#pragma unroll
+              for (int t = 0; t < T; ++t) sd2 += dot4(silu4(cp[e][t]), ldw4(wb, Lw.wc2 + 16 * t, g));
+              const float phi = reduce_groups(sd2);
+              const float th = tanhf(phi);
+              tau[e] = W.use_tanh ? th * W.coords_range_layer : phi;
+              const float dtau = (dtx[e] * gg[e][1] + dty[e] * gg[e][2] + dtz[e] * gg[e][3]) * mk[e];
+              const float dphi = W.use_tanh ? dtau * W.coords_range_layer * (1.0f - th * th) : dtau;
+#pragma unroll
+              for (int t = 0; t < T; ++t)  // dcpre = dphi * wc2 * silu'(cpre)
+                cp[e][t] = ldw4(wb, Lw.wc2 + 16 * t, g) * dphi * dsilu4(cp[e][t]);
+            }
+            edge_gemm_from_regs<HP, NB>(de, cp, wb, Lw.Wc1t, -1, rowinit, lane);  // + dagg_i (agg_i = sum_j e_ij)
           } else {
 #pragma unroll
-            for (int t = 0; t < T; ++t) de[0][t] = *(const f4*)(B0 + i * LD + 16 * t + 4 * g);
-          }
-          // e = m * a * mask ; a = sigmoid(wa . m + ba)
-          float dadot = 0.f;
+            for (int e = 0; e < NB; ++e)
 #pragma unroll
-          for (int t = 0; t < T; ++t) dadot += dot4(de[0][t], silu4(v[0][t]));
-          const float da = reduce_groups(dadot) * mk;
-          const float ds = W.attention ? da * a * (1.0f - a) : 0.f;
-#pragma unroll
-          for (int t = 0; t < T; ++t) {  // dv = (de*a*mask + ds*wa) * silu'(v)
-            const f4 wv = ldw4(wb, Lw.wa + 16 * t, g);
-            de[0][t] = (de[0][t] * a * mk + wv * ds) * dsilu4(v[0][t]);
+              for (int t = 0; t < T; ++t) de[e][t] = *(const f4*)(B0 + ec[e].i * LD + 16 * t + 4 * g);
           }
-          f4 dt1[1][T];
+#pragma unroll
+          for (int e = 0; e < NB; ++e) {
+            // e = m * a * mask ; a = sigmoid(wa . m + ba)
+            float dadot = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) dadot += dot4(de[e][t], silu4(v[e][t]));
+            const float da = reduce_groups(dadot) * mk[e];
+            const float ds = W.attention ? da * a[e] * (1.0f - a[e]) : 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t)  // dv = (de*a*mask + ds*wa) * silu'(v)
+              de[e][t] = (de[e][t] * a[e] * mk[e] + ldw4(wb, Lw.wa + 16 * t, g) * ds) * dsilu4(v[e][t]);
+          }
           {
-            const float* const noinit[1] = {nullptr};
-            edge_gemm_from_regs<HP, 1>(dt1, de, wb, Lw.W2t, -1, noinit, lane);
-          }
-          // du = dt1 * silu'(u) -> scratch ; dr = cr . du ; dd0 = cd . du
-          const float* pp = B2 + i * LD + 4 * g;
-          const float* qq = B1 + j * LD + 4 * g;
-          float drdot = 0.f, dd0dot = 0.f;
+            const float* noinit[NB];
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            const f4 u = edge_u(pp, qq, wb, Lw.cr, Lw.cd, g, t, ec[0].r, ec[0].d0);
-            const f4 du = dt1[0][t] * dsilu4(u);
-            drdot += dot4(du, ldw4(wb, Lw.cr + 16 * t, g));
-            dd0dot += dot4(du, ldw4(wb, Lw.cd + 16 * t, g));
-            *(f4*)(scr + c * LD + 16 * t + 4 * g) = du;
+            for (int e = 0; e < NB; ++e) noinit[e] = nullptr;
+            edge_gemm_from_regs<HP, NB>(du, de, wb, Lw.W2t, -1, noinit, lane);  // dt1
           }
-          const float dr = reduce_groups(drdot), dd0v = reduce_groups(dd0dot);
-          if (g == 0) {
-            // d/d(diff) of r = |diff|^2 and dhat = diff / (sqrt(r + 1e-8) + 1)   (gcl.py:308-316)
-            const float fx = sm.x[4 * i + 0] - sm.x[4 * j + 0];
-            const float fy = sm.x[4 * i + 1] - sm.x[4 * j + 1];
-            const float fz = sm.x[4 * i + 2] - sm.x[4 * j + 2];
-            const float nrm = sqrtf(gg[0] + 1e-8f), den = nrm + 1.0f;
-            const float cx = dtx * tau * mk, cy = dty * tau * mk, cz = dtz * tau * mk;  // d(dhat)
-            const float k1 = (cx * fx + cy * fy + cz * fz) / (den * den * nrm);
-            const int slot = wave * EW + tile * 16 + c;
-            sm.trans[4 * slot + 0] = cx / den - fx * k1 + 2.0f * fx * dr;
-            sm.trans[4 * slot + 1] = cy / den - fy * k1 + 2.0f * fy * dr;
-            sm.trans[4 * slot + 2] = cz / den - fz * k1 + 2.0f * fz * dr;
-            sm.dd0[slot] += dd0v;
-          }
-        }
-        wave_lds_fence();
-        STAMP(ST_BWD_EDGE);
-        __syncthreads();  // every wave's du tile of this round is in its scratch
-        STAMP(ST_BWD_BARRIER);
-        if (active) ss.add_tile(scr, my_i, B2, 1.0f, lane);  // dP_i = sum_j du_ij  (overwrites P_i: dead)
-        // dQ_j = sum_i du_ij : the wave owning node j folds the matching rows of all four tiles
 #pragma unroll
-        for (int w2 = 0; w2 < kWaves; ++w2) {
-          if (tile >= 2 * mg.npairs_all[w2]) continue;
-          const float* scr2 = sm.scr + w2 * 16 * LD;
-          for (int k = 0; k < 16; ++k) {
-            const int jj = __builtin_amdgcn_readfirstlane((int)((mg.edge[w2 * EW + tile * 16 + k] >> 8) & 255));
-            const int owner = __builtin_amdgcn_readfirstlane((int)(mg.seg[jj] >> 30));
-            if (owner == wave && lane < HP / 4) {
-              f4* dst = (f4*)(B4 + jj * LD + 4 * lane);
-              *dst = *dst + *(const f4*)(scr2 + k * LD + 4 * lane);
+          for (int e = 0; e < NB; ++e) {
+            // du = dt1 * silu'(u) ; dr = cr . du ; dd0 = cd . du
+            const float* pp = B2 + ec[e].i * LD + 4 * g;
+            const float* qq = B1 + ec[e].j * LD + 4 * g;
+            float drdot = 0.f, dd0dot = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const f4 u = edge_u(pp, qq, wb, Lw.cr, Lw.cd, g, t, ec[e].r, ec[e].d0);
+              du[e][t] = du[e][t] * dsilu4(u);
+              drdot += dot4(du[e][t], ldw4(wb, Lw.cr + 16 * t, g));
+              dd0dot += dot4(du[e][t], ldw4(wb, Lw.cd + 16 * t, g));
+            }
+            const float dr = reduce_groups(drdot), dd0v = reduce_groups(dd0dot);
+            if (g == 0) {
+              // d/d(diff) of r = |diff|^2 and dhat = diff / (sqrt(r + 1e-8) + 1)   (gcl.py:308-316)
+              const int i = ec[e].i, j = ec[e].j;
+              const float fx = sm.x[4 * i + 0] - sm.x[4 * j + 0];
+              const float fy = sm.x[4 * i + 1] - sm.x[4 * j + 1];
+              const float fz = sm.x[4 * i + 2] - sm.x[4 * j + 2];
+              const float nrm = sqrtf(gg[e][0] + 1e-8f), den = nrm + 1.0f;
+              const float cx = dtx[e] * tau[e] * mk[e], cy = dty[e] * tau[e] * mk[e], cz = dtz[e] * tau[e] * mk[e];
+              const float k1 = (cx * fx + cy * fy + cz * fz) / (den * den * nrm);
+              const int slot = wave * EW + (tile0 + e) * 16 + c;
+              sm.trans[4 * slot + 0] = cx / den - fx * k1 + 2.0f * fx * dr;
+              sm.trans[4 * slot + 1] = cy / den - fy * k1 + 2.0f * fy * dr;
+              sm.trans[4 * slot + 2] = cz / den - fz * k1 + 2.0f * fz * dr;
+              sm.dd0[slot] += dd0v;
             }
           }
         }
-        wave_lds_fence();
-        STAMP(ST_BWD_COL);
-        __syncthreads();  // scratch may be overwritten
-        STAMP(ST_BWD_BARRIER);
+        STAMP(ST_BWD_EDGE);
+        // publish the NB du tiles one by one: dP_i = sum_j du_ij (own rows), dQ_j = sum_i du_ij (owner of j)
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+          const int tile = tile0 + e;
+          if (active) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) *(f4*)(scr + c * LD + 16 * t + 4 * g) = du[e][t];
+          }
+          wave_lds_fence();
+          __syncthreads();  // every wave's du tile of this round is in its scratch
+          STAMP(ST_BWD_BARRIER);
+          if (active) ss.add_tile(scr, my_i[e], B2, 1.0f, lane);  // overwrites P_i: dead by now
+#pragma unroll
+          for (int w2 = 0; w2 < kWaves; ++w2) {
+            if (tile >= 2 * mg.npairs_all[w2]) continue;
+            const float* scr2 = sm.scr + w2 * 16 * LD;
+            for (int k = 0; k < 16; ++k) {
+              const int jj = __builtin_amdgcn_readfirstlane((int)((mg.edge[w2 * EW + tile * 16 + k] >> 8) & 255));
+              const int owner = __builtin_amdgcn_readfirstlane((int)(mg.seg[jj] >> 30));
+              if (owner == wave && lane < HP / 4) {
+                f4* dst = (f4*)(B4 + jj * LD + 4 * lane);
+                *dst = *dst + *(const f4*)(scr2 + k * LD + 4 * lane);
+              }
+            }
+          }
+          wave_lds_fence();
+          STAMP(ST_BWD_COL);
+          __syncthreads();  // scratch may be overwritten
+          STAMP(ST_BWD_BARRIER);
+        }
       }
       if (nt_me > 0) ss.flush(B2, 1.0f, lane);
     }
