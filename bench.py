@@ -33,8 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2, help="timed sample_guidance calls (1000 reverse steps each)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3"], help="c2 = unguided, c3 = gap guidance")
+    ap.add_argument("--batch", type=int, default=None, help="molecules per GPU (default 256; 1024 for c4)")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"],
+                    help="c2 = unguided cata, c3 = gap-guided cata (headline), c4 = hetero mixed 3-10 rings, multi-objective")
     ap.add_argument("--diffusion-steps", type=int, default=1000)
     ap.add_argument("--steps-per-launch", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -96,10 +97,13 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    guided = a.workload == "c3"
-    T, B, N, F, K = a.diffusion_steps, a.batch, 11, 1, 5
-    eargs = synth.edm_args(diffusion_steps=T)
-    pargs = synth.pred_args()
+    guided = a.workload in ("c3", "c4")
+    hetero = a.workload == "c4"
+    T, K = a.diffusion_steps, 5
+    B = a.batch or (1024 if hetero else 256)
+    N, F = (20, 12) if hetero else (11, 1)
+    eargs = synth.edm_args(diffusion_steps=T, dataset="hetro" if hetero else "cata")
+    pargs = synth.pred_args(dataset="hetro" if hetero else "cata")
     esd = synth.synth_edm_state_dict(eargs, F, seed=0)
     psd = synth.synth_predictor_state_dict(pargs, F, K, seed=1)
     eng = Engine(local_rank)
@@ -107,12 +111,24 @@ def main():
     if guided:
         eng.load_predictor(pargs, psd)
     eng.set_steps_per_launch(a.steps_per_launch)
-    nm = np.ones((B, N), np.float32)  # 11-ring cata molecules: every node live (sampling_edm.py:176-186)
-    em = np.broadcast_to(1.0 - np.eye(N, dtype=np.float32), (B, N, N)).copy()
+    if hetero:
+        # PASs-like batch: 3..10 rings drawn uniformly (seed 1), orientation nodes -> 6..20 graph nodes, N = 20
+        from gaudi_amd.sampling_edm import build_masks
+        rings = np.random.default_rng(1 + rank).integers(3, 11, size=B)
+        nm3, em_flat, _ = build_masks(rings, 10, True)
+        nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+        live_edges, live_nodes = float(em.sum() / B), float(nm.sum() / B)
+    else:
+        nm = np.ones((B, N), np.float32)  # 11-ring cata molecules: every node live (sampling_edm.py:176-186)
+        em = np.broadcast_to(1.0 - np.eye(N, dtype=np.float32), (B, N, N)).copy()
+        live_edges, live_nodes = float(N * (N - 1)), float(N)
     tw = None
     if guided:
         tw = np.zeros(K, np.float32)
-        tw[1] = -1.0  # target_function_max_gap: -pred[:,1]  (generation_guidance.py:200-203)
+        if hetero:
+            tw[0], tw[2], tw[3] = 3.0, 1.0, 1.0  # target_function_opv with mean=0, std=1 (generation_guidance.py:205-211)
+        else:
+            tw[1] = -1.0  # target_function_max_gap: -pred[:,1]  (generation_guidance.py:200-203)
 
     def one_pass(it):
         x, h, diag = eng.sample(nm, em, seed=1234 + it, sample_offset=rank * B, std=1.0, target_w=tw, scale=0.6)
@@ -147,7 +163,7 @@ def main():
         value = mols / dt
         # ---- roofline of the dominant kernel (sampler_kernel<192,208>: EDM + predictor fwd/bwd + update)
         f_written = flops.step_flops_as_written(N, F, eargs, pargs if guided else None, K)
-        f_useful = flops.step_flops_useful(N * (N - 1), N, F, eargs, pargs if guided else None, K)
+        f_useful = flops.step_flops_useful(live_edges, live_nodes, F, eargs, pargs if guided else None, K)
         evals = steps_done + a.steps * (0.3 if guided else 1.0)  # decode pass = one extra EDM evaluation
         avg_launch_ms = kern_ms / max(n_launch, 1)
         per_launch_flops = f_written * B * evals / max(n_launch, 1)
@@ -157,7 +173,7 @@ def main():
         hbm_bytes_launch = flops.step_bytes_fused(B, N, F, 0, stash) * steps_done / max(n_launch, 1) + wbytes
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and B == 256 and a.steps_per_launch == 25:  # counters were collected on this shape
             try:
                 traffic = json.load(open(pmc)).get(f"{a.workload}_bytes_per_launch")
             except Exception:
@@ -167,8 +183,10 @@ def main():
             "value": value, "unit": "molecules/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded default-init weights, on-device Philox noise)",
-            "config": {"workload": ("C3: cc-PBH 11-ring, batch=256/GPU, 1000 steps, HOMO-LUMO-gap guidance (scale 0.6)"
-                                    if guided else "C2: cc-PBH 11-ring, batch=256/GPU, 1000 steps, unconditional EDM"),
+            "config": {"workload": {"c3": f"C3: cc-PBH 11-ring, batch={B}/GPU, {T} steps, HOMO-LUMO-gap guidance (scale 0.6)",
+                                    "c2": f"C2: cc-PBH 11-ring, batch={B}/GPU, {T} steps, unconditional EDM",
+                                    "c4": f"C4: PASs-like hetero, 3-10 rings (6-20 graph nodes, N=20), batch={B}/GPU, {T} steps, "
+                                          "multi-objective (OPV) guidance"}[a.workload],
                        "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
                        "edm": "nf=192,n_layers=9", "predictor": "nf=196,n_layers=12" if guided else None,
                        "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
@@ -176,6 +194,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                          "kernel": "sampler_kernel<192,208>" if guided else "sampler_kernel<192,0>",
+                         "live_edges_per_molecule": live_edges,
                          "avg_launch_ms": avg_launch_ms, "launches": n_launch,
                          "flops_basis": "as-written reference FLOPs (SURVEY 8d): %.3f GFLOP per molecule-step" % (f_written / 1e9),
                          "useful_tflops_factorised": f_useful * B * evals / (kern_ms * 1e-3) / 1e12,

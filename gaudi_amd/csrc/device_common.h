@@ -22,6 +22,9 @@ constexpr int kThreads = 256;
 #ifndef GAUDI_PIN_SCHED
 #define GAUDI_PIN_SCHED 1
 #endif
+#ifndef GAUDI_PF_REGS_NE1
+#define GAUDI_PF_REGS_NE1 12
+#endif
 #ifndef GAUDI_PIN_SCHED_UNROLLED
 #define GAUDI_PIN_SCHED_UNROLLED 1
 #endif
@@ -39,7 +42,8 @@ constexpr int kPF = 6;  // prefetch depth of the fully unrolled (chained) edge G
 // Never compiled into the shipped library; numbers from a stamped build are shares, not run times.
 #ifdef GAUDI_STAMPS
 enum { ST_NODE = 0, ST_EDGE = 1, ST_EDGE_EPI = 2, ST_BARRIER = 3, ST_MISC = 4, ST_BWD_NODE = 5, ST_BWD_EDGE = 6,
-       ST_BWD_COL = 7, ST_BWD_BARRIER = 8, ST_STASH = 9, ST_N = 10 };
+       ST_BWD_COL = 7, ST_BWD_BARRIER = 8, ST_STASH = 9, ST_B_V = 10, ST_B_EV = 11, ST_B_CP = 12, ST_B_DCP = 13,
+       ST_B_DE = 14, ST_B_DV = 15, ST_B_DT1 = 16, ST_B_DU = 17, ST_N = 18 };
 struct Stamps {
   unsigned long long acc[ST_N];
   unsigned long long last;
@@ -89,6 +93,12 @@ __device__ __forceinline__ f4 mfma4(f4 w, f4 b, f4 acc) {
   return acc;
 }
 
+__device__ __forceinline__ f4 mfma1(float w, float b, f4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, acc, 0, 0, 0);
+}
+// NOTE on issue order: v_mfma_f32_16x16x4_f32 issues every 32 cycles but a dependent accumulate needs 40, so
+// the k-step loop (q) is always the OUTER loop over >= 2 independent accumulators.
+
 // sum over the 4 lane groups g = lane>>4 (same column), result in every lane
 __device__ __forceinline__ float reduce_groups(float v) {
   v += __shfl_xor(v, 16);
@@ -137,7 +147,8 @@ __device__ __forceinline__ float ldw1(const WBuf& w, int off_floats) {
 enum NodeEpi { EPI_NONE = 0, EPI_SILU = 1, EPI_RESIDUAL_MASK = 2, EPI_MUL_DSILU = 3, EPI_ACCUM = 4 };
 
 template <int HP, int EPI>
-__device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, int bias,
+__device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
+                                          const float* sBias /* LDS [HP] or null */,
                                           float* sY, const float* sRes, const float* sMask, int N, int wave, int lane) {
   constexpr int T = HP / 16;
   constexpr int LD = HP + 4;
@@ -158,7 +169,7 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
     const int nclamp = node < N ? node : N - 1;
     f4 acc[UT];
 #pragma unroll
-    for (int u = 0; u < UT; ++u) acc[u] = bias >= 0 ? ldw4(wb, bias + (toff[u] >> 4), g) : splat(0.f);
+    for (int u = 0; u < UT; ++u) acc[u] = sBias != nullptr ? *(const f4*)(sBias + (toff[u] >> 4) + 4 * g) : splat(0.f);
 #pragma unroll
     for (int src = 0; src < 2; ++src) {
       const int W = src == 0 ? Wa : Wb;
@@ -188,18 +199,26 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
           b1[u] = ldw4(wb, chunk(cc + 3) + toff[u], lo);
         }
 #pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma4(a0[u], x0, acc[u]);
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma4(a1[u], x1, acc[u]);
+          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a0[u][q], x0[q], acc[u]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a1[u][q], x1[q], acc[u]);
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
           a0[u] = ldw4(wb, chunk(cc + 4) + toff[u], lo);
           a1[u] = ldw4(wb, chunk(cc + 5) + toff[u], lo);
         }
 #pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma4(b0[u], x2, acc[u]);
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma4(b1[u], x3, acc[u]);
+          for (int u = 0; u < UT; ++u) acc[u] = mfma1(b0[u][q], x2[q], acc[u]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < UT; ++u) acc[u] = mfma1(b1[u][q], x3[q], acc[u]);
 #if GAUDI_PIN_SCHED
         // keep the issue order written above: hipcc otherwise sinks the loads next to their consumers
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 LDS reads (x0..x3)
@@ -217,17 +236,23 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
           for (int u = 0; u < UT; ++u) b0[u] = ldw4(wb, chunk(MAIN + 2) + toff[u], lo);
         }
 #pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma4(a0[u], x0, acc[u]);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a0[u][q], x0[q], acc[u]);
       }
       if (T - MAIN >= 2) {
         const f4 x1 = *(const f4*)(xrow + 16 * (MAIN + 1));
 #pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma4(a1[u], x1, acc[u]);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a1[u][q], x1[q], acc[u]);
       }
       if (T - MAIN >= 3) {
         const f4 x2 = *(const f4*)(xrow + 16 * (MAIN + 2));
 #pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma4(b0[u], x2, acc[u]);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < UT; ++u) acc[u] = mfma1(b0[u][q], x2[q], acc[u]);
       }
     }
 #pragma unroll
@@ -266,15 +291,18 @@ struct EdgeCol {
 };
 
 // u[f] for f = 16cc+4g+q of one edge column
-__device__ __forceinline__ f4 edge_u(const float* p, const float* q, const WBuf& wb, int cr, int cd, int g, int cc,
+// cr / cd (and every other per-layer vector) are staged in LDS once per layer: a VMEM load consumed inside a
+// pipelined GEMM loop would force vmcnt(0) (in-order counter) and drain the weight prefetch queue.
+__device__ __forceinline__ f4 edge_u(const float* p, const float* q, const float* sCr, const float* sCd, int g, int cc,
                                      float r, float d0) {
-  const f4 crv = ldw4(wb, cr + 16 * cc, g);
-  const f4 cdv = ldw4(wb, cd + 16 * cc, g);
+  const f4 crv = *(const f4*)(sCr + 16 * cc + 4 * g);
+  const f4 cdv = *(const f4*)(sCd + 16 * cc + 4 * g);
   return *(const f4*)(p + 16 * cc) + *(const f4*)(q + 16 * cc) + crv * r + cdv * d0;
 }
 
 template <int HP, int NE>
-__device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const WBuf& wb, int W2, int b2, int cr, int cd,
+__device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const WBuf& wb, int W2, const float* sB2,
+                                                  const float* sCr, const float* sCd,
                                                   const float* sP, const float* sQ, const EdgeCol (&ec)[NE], int lane) {
   constexpr int T = HP / 16;
   constexpr int LD = HP + 4;
@@ -284,7 +312,7 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
   const int lo = c * 4 + g;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    const f4 b = ldw4(wb, b2 + 16 * t, g);
+    const f4 b = *(const f4*)(sB2 + 16 * t + 4 * g);
 #pragma unroll
     for (int e = 0; e < NE; ++e) acc[e][t] = b;
   }
@@ -300,7 +328,7 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
   for (int p = 0; p < PF; ++p) wq[p] = ldw4(wb, W2 + 256 * p, lo);
   f4 bin[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) bin[e] = silu4(edge_u(pp[e], qq[e], wb, cr, cd, g, 0, ec[e].r, ec[e].d0));
+  for (int e = 0; e < NE; ++e) bin[e] = silu4(edge_u(pp[e], qq[e], sCr, sCd, g, 0, ec[e].r, ec[e].d0));
   // K loop stays rolled (one 16-feature chunk per trip): the weight tiles of the next chunk are
   // prefetched by the tail of this one (rotating queue) and the next chunk's activations are
   // generated under this chunk's MFMAs.
@@ -310,29 +338,44 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
 #pragma unroll
     for (int e = 0; e < NE; ++e) nb[e] = bin[e];
     const int Wc = W2 + cc * (T * 256);
-    f4 r[PF];
+    constexpr int TG = NE >= 2 ? 1 : 2;  // output tiles issued together: NE*TG >= 2 independent chains
 #pragma unroll
-    for (int p = 0; p < PF; ++p) r[p] = wq[p];
+    for (int t0 = 0; t0 < T; t0 += TG) {
+      // T % PF == 0: tile (cc, t) always lives in queue slot t % PF.  The MFMAs read the slot, THEN the slot is
+      // refilled in place with tile t + PF (issuing the refill first would need a second register and a copy at
+      // the loop back-edge, i.e. a full vmcnt(0) drain per K chunk).
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const f4 w = r[t % PF];
-      // tile index cc*T + t + PF (clamped at the end of the matrix; the surplus loads are unused)
-      const int nxt = (cc * T + t + PF < T * T) ? (t + PF) : t;
-      r[t % PF] = ldw4(wb, Wc + 256 * nxt, lo);
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int e = 0; e < NE; ++e) acc[e][t] = mfma4(w, bin[e], acc[e][t]);
-      if (t == 0) {  // next chunk's activations (clamped on the last trip: no branch, same basic block)
+        for (int k = 0; k < TG; ++k)
+          if (t0 + k < T) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) acc[e][t0 + k] = mfma1(wq[(t0 + k) % PF][q], bin[e][q], acc[e][t0 + k]);
+          }
+#pragma unroll
+      for (int k = 0; k < TG; ++k) {
+        const int t = t0 + k;
+        if (t < T) {
+          // tile index cc*T + t + PF (clamped at the end of the matrix; the surplus loads are unused)
+          const int nxt = (cc * T + t + PF < T * T) ? (t + PF) : t;
+          wq[t % PF] = ldw4(wb, Wc + 256 * nxt, lo);
+        }
+      }
+      if (t0 == 0) {  // next chunk's activations (clamped on the last trip: no branch, same basic block)
         const int ncc = cc + 1 < T ? cc + 1 : T - 1;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], wb, cr, cd, g, ncc, ec[e].r, ec[e].d0));
+        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], sCr, sCd, g, ncc, ec[e].r, ec[e].d0));
       }
 #if GAUDI_PIN_SCHED
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one weight-tile load ...
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);  // ... per 4*NE MFMAs
+      if (t0 + TG <= T) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE * TG, 0);  // MFMA group on the queue slots ...
+        __builtin_amdgcn_sched_group_barrier(0x020, TG, 0);           // ... then their refills
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
 #endif
     }
-#pragma unroll
-    for (int p = 0; p < PF; ++p) wq[p] = r[(p + T) % PF];
 #pragma unroll
     for (int e = 0; e < NE; ++e) bin[e] = nb[e];
   }
@@ -340,17 +383,20 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
 
 // Edge-level GEMM whose input already sits in registers in C/B layout (chained MLP layer):
 //   out[e][t] = init + W . in[e]      in[e][cc] = features 16cc+4g+q of edge column c
-// init = bias (float offset, -1 = none) + per-column LDS rows rowinit[e] (may be null).
+// init = bias (LDS vector or null) + per-column LDS rows rowinit[e] (may be null).
 // Output-tile-outer order: only NE*TB accumulator quads are live while the K loop of an output tile
 // runs (NE*TB >= 2 independent MFMA chains), each finished tile is retired once; the inputs stay in
 // VGPRs.  (Input-chunk-outer order made hipcc shuttle every accumulator between AGPRs and VGPRs around
 // each MFMA.)
 template <int HP, int NE>
 __device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[NE][HP / 16], const f4 (&in)[NE][HP / 16], const WBuf& wb,
-                                                    int W, int bias, const float* const (&rowinit)[NE], int lane) {
+                                                    int W, const float* sBias, const float* const (&rowinit)[NE], int lane) {
   constexpr int T = HP / 16;
   constexpr int TB = NE >= 2 ? 1 : 2;  // output tiles in flight
-  constexpr int PF = kPF < T ? kPF : T;
+  // queue depth in tiles: a tile feeds 4*NE MFMAs (128*NE cycles), so single-tile calls need a deeper queue to
+  // look the same ~1.5k cycles ahead
+  constexpr int PFW = GAUDI_PF_REGS_NE1 > 0 && NE == 1 ? GAUDI_PF_REGS_NE1 : kPF;
+  constexpr int PF = PFW < T ? PFW : T;
   constexpr int TT = (T + TB - 1) / TB * TB;  // tile count rounded up to TB (surplus tiles skipped)
   const int c = lane & 15, g = lane >> 4;
   const int lo = c * 4 + g;
@@ -371,31 +417,39 @@ __device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[NE][HP / 16], cons
 #pragma unroll
     for (int tb = 0; tb < TB; ++tb) {
       const int t = t0 + tb < T ? t0 + tb : T - 1;
-      const f4 b = bias >= 0 ? ldw4(wb, bias + 16 * t, g) : splat(0.f);
+      const f4 b = sBias != nullptr ? *(const f4*)(sBias + 16 * t + 4 * g) : splat(0.f);
 #pragma unroll
       for (int e = 0; e < NE; ++e)
         acc[e][tb] = rowinit[e] != nullptr ? b + *(const f4*)(rowinit[e] + 16 * t + 4 * g) : b;
     }
 #pragma unroll
     for (int cc = 0; cc < T; ++cc) {
+      f4 w[TB];
 #pragma unroll
       for (int tb = 0; tb < TB; ++tb) {
         const int seq = (t0 / TB) * (T * TB) + cc * TB + tb;
-        const f4 w = wq[seq % PF];
+        w[tb] = wq[seq % PF];
         if (seq + PF < NSEQ) wq[seq % PF] = ldw4(wb, W + tile_off(seq + PF), lo);
-        if (t0 + tb < T) {
-#pragma unroll
-          for (int e = 0; e < NE; ++e) acc[e][tb] = mfma4(w, in[e][cc], acc[e][tb]);
-#if GAUDI_PIN_SCHED_UNROLLED
-          // +5 % on the reverse pass, but the group solver's compile time explodes with the block size:
-          // only for single-tile calls at the production sizes (T = 12, 13)
-          if constexpr (NE == 1 && T >= 12 && T <= 13) {
-            if (seq + PF < NSEQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);
-          }
-#endif
-        }
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+          if (t0 + tb < T) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) acc[e][tb] = mfma1(w[tb][q], in[e][cc][q], acc[e][tb]);
+          }
+#if GAUDI_PIN_SCHED_UNROLLED
+      // +5 % on the reverse pass, but the group solver's compile time explodes with the block size:
+      // only for single-tile calls at the production sizes (T = 12, 13)
+      if constexpr (NE == 1 && T >= 12 && T <= 13) {
+        if ((t0 / TB) * (T * TB) + cc * TB + PF < NSEQ) __builtin_amdgcn_sched_group_barrier(0x020, TB, 0);
+        if (t0 + TB <= T)
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE * TB, 0);
+        else
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);
+      }
+#endif
     }
 #pragma unroll
     for (int tb = 0; tb < TB; ++tb)

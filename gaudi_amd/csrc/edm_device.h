@@ -53,8 +53,9 @@ struct NetSmem {
   f4* geo;                 // [4][EW] (r, dhat)
   float* d0;               // [4][EW]
   float* trans;            // [4][EW][4]
+  float* vec;              // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
   __device__ static int floats(int N, int EW) {
-    return 4 * N * (HP + 4) + kWaves * 16 * (HP + 4) + 8 * N + kWaves * EW * 9;
+    return 4 * N * (HP + 4) + kWaves * 16 * (HP + 4) + 8 * N + kWaves * EW * 9 + 8 * HP;
   }
   __device__ void carve(float* base, int N, int EW) {
     constexpr int LD = HP + 4;
@@ -67,7 +68,8 @@ struct NetSmem {
     x0 = base; base += 4 * N;
     geo = (f4*)base; base += kWaves * EW * 4;
     d0 = base; base += kWaves * EW;
-    trans = base;
+    trans = base; base += kWaves * EW * 4;
+    vec = base;
   }
 };
 
@@ -162,11 +164,14 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int G = lay.gcl(l, s);  // float offsets into the weight buffer
       const int PK = HP * HP;
       const int V = G + 6 * PK;
-      const int cr = V, cd = V + HP, b1 = V + 2 * HP, b2 = V + 3 * HP, wa = V + 4 * HP, bn1 = V + 5 * HP,
-                bn2 = V + 6 * HP;
-      const float ba = w[V + 7 * HP];
+      // stage the layer's vectors in LDS (previous readers are behind the barrier that ended the last layer)
+      for (int idx = tid; idx < 7 * HP + 16; idx += kThreads) sm.vec[idx] = w[V + idx];
+      __syncthreads();
+      const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
+                  *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
+      const float ba = sm.vec[7 * HP];
       node_gemm<HP, EPI_NONE>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
-      node_gemm<HP, EPI_NONE>(wb, G + PK, sm.h, -1, nullptr, -1, sm.q, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_NONE>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane);
       for (int idx = tid; idx < N * LD; idx += kThreads) sm.agg[idx] = 0.f;
       STAMP(ST_NODE);
       __syncthreads();
@@ -190,7 +195,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
             for (int t = 0; t < T; ++t) {
               const f4 m = silu4(acc[e][t]);
               acc[e][t] = m;
-              const f4 wv = ldw4(wb, wa + 16 * t, g);
+              const f4 wv = *(const f4*)(wa + 16 * t + 4 * g);
               sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
             }
             float a = 1.f;
@@ -222,9 +227,11 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int E = lay.equ(l);
       const int PK = HP * HP;
       const int V = E + 3 * PK;
-      const int cr = V, cd = V + HP, b1 = V + 2 * HP, b2 = V + 3 * HP, w3 = V + 4 * HP;
+      for (int idx = tid; idx < 5 * HP; idx += kThreads) sm.vec[idx] = w[V + idx];
+      __syncthreads();
+      const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
       node_gemm<HP, EPI_NONE>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
-      node_gemm<HP, EPI_NONE>(wb, E + PK, sm.h, -1, nullptr, -1, sm.q, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_NONE>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
@@ -242,7 +249,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             const f4 m = silu4(acc[e][t]);
-            const f4 wv = ldw4(wb, w3 + 16 * t, g);
+            const f4 wv = *(const f4*)(w3 + 16 * t + 4 * g);
             sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
           }
           const float phi = reduce_groups(sdot);

@@ -61,7 +61,7 @@ struct gaudi_handle {
   long long prof_steps = 0;
 #ifdef GAUDI_STAMPS
   DevBuf d_stamps;
-  unsigned long long stamp_acc[16] = {0};
+  unsigned long long stamp_acc[32] = {0};
 #endif
 };
 
@@ -281,8 +281,8 @@ static int round_hidden(int H) {
 
 static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW) {
   size_t net = 0;
-  if (hpe) net = std::max(net, (size_t)(4 * N * (hpe + 4) + kWaves * 16 * (hpe + 4) + 8 * N + kWaves * EW * 9));
-  if (hpp) net = std::max(net, (size_t)(5 * N * (hpp + 4) + kWaves * 16 * (hpp + 4) + 12 * N + kWaves * EW * 10 + 32));
+  if (hpe) net = std::max(net, (size_t)(4 * N * (hpe + 4) + kWaves * 16 * (hpe + 4) + 8 * N + kWaves * EW * 9 + 8 * hpe));
+  if (hpp) net = std::max(net, (size_t)(5 * N * (hpp + 4) + kWaves * 16 * (hpp + 4) + 12 * N + kWaves * EW * 10 + 32 + 10 * hpp));
   return sizeof(float) * (common_floats(N, D, EW) + net);
 }
 
@@ -303,22 +303,23 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
   }
 #ifdef GAUDI_STAMPS
   KParams PS = P;
-  HIPCHECK(h, h->d_stamps.reserve(sizeof(unsigned long long) * 16));
-  HIPCHECK(h, hipMemsetAsync(h->d_stamps.p, 0, sizeof(unsigned long long) * 16, h->stream));
+  HIPCHECK(h, h->d_stamps.reserve(sizeof(unsigned long long) * 32));
+  HIPCHECK(h, hipMemsetAsync(h->d_stamps.p, 0, sizeof(unsigned long long) * 32, h->stream));
   PS.stamps = h->d_stamps.as<unsigned long long>();
   hipLaunchKernelGGL(fn, dim3(P.B), dim3(kThreads), lds, h->stream, PS);
   {
-    unsigned long long tmp[16];
+    unsigned long long tmp[32];
     HIPCHECK(h, hipMemcpyAsync(tmp, h->d_stamps.p, sizeof(tmp), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < 16; ++i) h->stamp_acc[i] += tmp[i];
+    for (int i = 0; i < 32; ++i) h->stamp_acc[i] += tmp[i];
     if (getenv("GAUDI_PRINT_STAMPS")) {
       static const char* nm[] = {"node_gemm", "edge_gemm", "edge_epilogue", "barrier", "misc", "bwd_node", "bwd_edge",
-                                 "bwd_colsum", "bwd_barrier", "stash"};
+                                 "bwd_colsum", "bwd_barrier", "stash", "b_gemm_v", "b_ev", "b_gemm_cp", "b_dcp",
+                                 "b_gemm_de", "b_dv", "b_gemm_dt1", "b_du"};
       unsigned long long tot = 0;
-      for (int i = 0; i < 10; ++i) tot += h->stamp_acc[i];
+      for (int i = 0; i < 18; ++i) tot += h->stamp_acc[i];
       fprintf(stderr, "[stamps] cumulative shares (block 0, wave 0):");
-      for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * h->stamp_acc[i] / (tot ? tot : 1));
+      for (int i = 0; i < 18; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * h->stamp_acc[i] / (tot ? tot : 1));
       fprintf(stderr, " total=%llu ticks\n", tot);
     }
   }

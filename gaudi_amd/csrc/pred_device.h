@@ -44,8 +44,9 @@ struct PredSmem {
   f4* geo;                        // [4][EW]
   float *d0, *trans, *dd0;        // [4][EW], [4][EW][4], [4][EW]
   float* pred;                    // [16] pred | [16] dpred
+  float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
   __host__ __device__ static int floats(int N, int EW) {
-    return 5 * N * (HP + 4) + kWaves * 16 * (HP + 4) + 12 * N + kWaves * EW * 10 + 32;
+    return 5 * N * (HP + 4) + kWaves * 16 * (HP + 4) + 12 * N + kWaves * EW * 10 + 32 + 10 * HP;
   }
   __device__ void carve(float* base, int N, int EW) {
     constexpr int LD = HP + 4;
@@ -62,7 +63,8 @@ struct PredSmem {
     d0 = base; base += kWaves * EW;
     trans = base; base += kWaves * EW * 4;
     dd0 = base; base += kWaves * EW;
-    pred = base;
+    pred = base; base += 32;
+    vec = base;
   }
 };
 
@@ -74,16 +76,21 @@ __device__ __forceinline__ float dot4(f4 a, f4 b) { return a[0] * b[0] + a[1] * 
 // float offsets of one layer's tensors inside the packed weight buffer
 struct PredLayerW {
   int A, Bm, W2, Wc1, Wn1h, Wn1a, Wn2, At, Bmt, W2t, Wc1t, Wn1ht, Wn1at, Wn2t;
-  int cr, cd, b1, b2, wa, bc1, wc2, bn1, bn2;
+  int V;  // start of the vector block (9 HP + 16) in the weight buffer
+  const float *cr, *cd, *b1, *b2, *wa, *bc1, *wc2, *bn1, *bn2;  // LDS copies (stage() first)
   float ba;
-  __device__ PredLayerW(const float* w, int L0, int HP) {
+  // copy the vector block to LDS; the caller places a barrier before the first use
+  __device__ void stage(const float* w, float* sVec, int HP, int tid) const {
+    for (int idx = tid; idx < 9 * HP + 16; idx += kThreads) sVec[idx] = w[V + idx];
+  }
+  __device__ PredLayerW(const float* w, int L0, int HP, const float* sVec) {
     const int PK = HP * HP;
     A = L0; Bm = L0 + PK; W2 = L0 + 2 * PK; Wc1 = L0 + 3 * PK; Wn1h = L0 + 4 * PK; Wn1a = L0 + 5 * PK;
     Wn2 = L0 + 6 * PK; At = L0 + 7 * PK; Bmt = L0 + 8 * PK; W2t = L0 + 9 * PK; Wc1t = L0 + 10 * PK;
     Wn1ht = L0 + 11 * PK; Wn1at = L0 + 12 * PK; Wn2t = L0 + 13 * PK;
-    const int V = L0 + 14 * PK;
-    cr = V; cd = V + HP; b1 = V + 2 * HP; b2 = V + 3 * HP; wa = V + 4 * HP; bc1 = V + 5 * HP; wc2 = V + 6 * HP;
-    bn1 = V + 7 * HP; bn2 = V + 8 * HP;
+    V = L0 + 14 * PK;
+    cr = sVec; cd = sVec + HP; b1 = sVec + 2 * HP; b2 = sVec + 3 * HP; wa = sVec + 4 * HP; bc1 = sVec + 5 * HP;
+    wc2 = sVec + 6 * HP; bn1 = sVec + 7 * HP; bn2 = sVec + 8 * HP;
     ba = w[V + 9 * HP];
   }
 };
@@ -132,14 +139,16 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 
   for (int l = 0; l < W.L; ++l) {
     const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
-    const PredLayerW Lw(w, lay.layer(l), HP);
+    const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
+    Lw.stage(w, sm.vec, HP, tid);
+    __syncthreads();
     float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
     for (int idx = tid; idx < N * HP; idx += kThreads) st[idx] = h[(idx / HP) * LD + idx % HP];
     for (int idx = tid; idx < N * 4; idx += kThreads) st[2 * N * HP + idx] = sm.x[idx];
     compute_geo(sm, mg, 1.0f, wave, lane, false);  // gcl.py:308-316
     node_gemm<HP, EPI_NONE>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane);
     STAMP(ST_STASH);
-    node_gemm<HP, EPI_NONE>(wb, Lw.Bm, h, -1, nullptr, -1, q, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, N, wave, lane);
     for (int idx = tid; idx < N * LD; idx += kThreads) agg[idx] = 0.f;
     STAMP(ST_NODE);
     __syncthreads();
@@ -163,7 +172,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           for (int t = 0; t < T; ++t) {
             const f4 m = silu4(acc[e][t]);
             acc[e][t] = m;
-            sdot += dot4(m, ldw4(wb, Lw.wa + 16 * t, g));
+            sdot += dot4(m, *(const f4*)(Lw.wa + 16 * t + 4 * g));
           }
           float a = 1.f;
           if (W.attention) a = sigmoid_f(reduce_groups(sdot) + Lw.ba);
@@ -186,7 +195,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           for (int e = 0; e < 2; ++e) {
             float sdot = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) sdot += dot4(silu4(cp[e][t]), ldw4(wb, Lw.wc2 + 16 * t, g));
+            for (int t = 0; t < T; ++t) sdot += dot4(silu4(cp[e][t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
             const float phi = reduce_groups(sdot);
             const float tau = W.use_tanh ? tanhf(phi) * W.coords_range_layer : phi;
             if (g == 0) {
@@ -273,7 +282,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 
   for (int l = W.L - 1; l >= 0; --l) {
     const bool last = l == W.L - 1;
-    const PredLayerW Lw(w, lay.layer(l), HP);
+    const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
+    Lw.stage(w, sm.vec, HP, tid);
+    __syncthreads();
     const float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
     // (a) reload h_l, agg_l, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
     for (int idx = tid; idx < N * HP; idx += kThreads) {
@@ -294,13 +305,13 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     __syncthreads();
     // (b2) P -> B2, Q -> B1 (agg is dead)
     node_gemm<HP, EPI_NONE>(wb, Lw.A, B0, -1, nullptr, Lw.b1, B2, nullptr, nullptr, N, wave, lane);
-    node_gemm<HP, EPI_NONE>(wb, Lw.Bm, B0, -1, nullptr, -1, B1, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(wb, Lw.Bm, B0, -1, nullptr, nullptr, B1, nullptr, nullptr, N, wave, lane);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
-    node_gemm<HP, EPI_MUL_DSILU>(wb, Lw.Wn2t, dh, -1, nullptr, -1, B4, B4, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_MUL_DSILU>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, N, wave, lane);
     __syncthreads();
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
-    node_gemm<HP, EPI_ACCUM>(wb, Lw.Wn1ht, B4, -1, nullptr, -1, dh, dh, nullptr, N, wave, lane);
-    node_gemm<HP, EPI_NONE>(wb, Lw.Wn1at, B4, -1, nullptr, -1, B0, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_ACCUM>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, N, wave, lane);
     __syncthreads();
     for (int idx = tid; idx < N * LD; idx += kThreads) B4[idx] = 0.f;  // dQ accumulator
     __syncthreads();
@@ -327,7 +338,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           f4 gg[NB];
           load_cols<PredSmem<HP>, NB>(sm, mg, wave, tile0 * 16, c, ec, mk, gg);
           f4 v[NB][T];
+          STAMP(ST_BWD_EDGE);
           edge_gemm_from_pq<HP, NB>(v, wb, Lw.W2, Lw.b2, Lw.cr, Lw.cd, B2, B1, ec, lane);
+          STAMP(ST_B_V);
           f4 ev[NB][T];
           float a[NB], tau[NB], dtx[NB], dty[NB], dtz[NB];
 #pragma unroll
@@ -338,7 +351,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             for (int t = 0; t < T; ++t) {
               const f4 m = silu4(v[e][t]);
               ev[e][t] = m;
-              sdot += dot4(m, ldw4(wb, Lw.wa + 16 * t, g));
+              sdot += dot4(m, *(const f4*)(Lw.wa + 16 * t + 4 * g));
             }
             a[e] = 1.f;
             if (W.attention) a[e] = sigmoid_f(reduce_groups(sdot) + Lw.ba);
@@ -349,6 +362,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             dty[e] = sm.dx[4 * ec[e].i + 1];
             dtz[e] = sm.dx[4 * ec[e].i + 2];
           }
+          STAMP(ST_B_EV);
           f4 de[NB][T];
           if (!last) {
             f4 cp[NB][T];
@@ -357,11 +371,12 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 #pragma unroll
             for (int e = 0; e < NB; ++e) { noinit[e] = nullptr; rowinit[e] = B0 + ec[e].i * LD; }
             edge_gemm_from_regs<HP, NB>(cp, ev, wb, Lw.Wc1, Lw.bc1, noinit, lane);
+            STAMP(ST_B_CP);
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
               float sd2 = 0.f;
 #pragma unroll
-              for (int t = 0; t < T; ++t) sd2 += dot4(silu4(cp[e][t]), ldw4(wb, Lw.wc2 + 16 * t, g));
+              for (int t = 0; t < T; ++t) sd2 += dot4(silu4(cp[e][t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
               const float phi = reduce_groups(sd2);
               const float th = tanhf(phi);
               tau[e] = W.use_tanh ? th * W.coords_range_layer : phi;
@@ -369,9 +384,11 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
               const float dphi = W.use_tanh ? dtau * W.coords_range_layer * (1.0f - th * th) : dtau;
 #pragma unroll
               for (int t = 0; t < T; ++t)  // dcpre = dphi * wc2 * silu'(cpre)
-                cp[e][t] = ldw4(wb, Lw.wc2 + 16 * t, g) * dphi * dsilu4(cp[e][t]);
+                cp[e][t] = *(const f4*)(Lw.wc2 + 16 * t + 4 * g) * dphi * dsilu4(cp[e][t]);
             }
-            edge_gemm_from_regs<HP, NB>(de, cp, wb, Lw.Wc1t, -1, rowinit, lane);  // + dagg_i (agg_i = sum_j e_ij)
+            STAMP(ST_B_DCP);
+            edge_gemm_from_regs<HP, NB>(de, cp, wb, Lw.Wc1t, nullptr, rowinit, lane);  // + dagg_i (agg_i = sum_j e_ij)
+            STAMP(ST_B_DE);
           } else {
 #pragma unroll
             for (int e = 0; e < NB; ++e)
@@ -388,13 +405,15 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             const float ds = W.attention ? da * a[e] * (1.0f - a[e]) : 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t)  // dv = (de*a*mask + ds*wa) * silu'(v)
-              de[e][t] = (de[e][t] * a[e] * mk[e] + ldw4(wb, Lw.wa + 16 * t, g) * ds) * dsilu4(v[e][t]);
+              de[e][t] = (de[e][t] * a[e] * mk[e] + *(const f4*)(Lw.wa + 16 * t + 4 * g) * ds) * dsilu4(v[e][t]);
           }
           {
             const float* noinit[NB];
 #pragma unroll
             for (int e = 0; e < NB; ++e) noinit[e] = nullptr;
-            edge_gemm_from_regs<HP, NB>(du, de, wb, Lw.W2t, -1, noinit, lane);  // dt1
+            STAMP(ST_B_DV);
+            edge_gemm_from_regs<HP, NB>(du, de, wb, Lw.W2t, nullptr, noinit, lane);  // dt1
+            STAMP(ST_B_DT1);
           }
 #pragma unroll
           for (int e = 0; e < NB; ++e) {
@@ -404,10 +423,10 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             float drdot = 0.f, dd0dot = 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-              const f4 u = edge_u(pp, qq, wb, Lw.cr, Lw.cd, g, t, ec[e].r, ec[e].d0);
+              const f4 u = edge_u(pp, qq, Lw.cr, Lw.cd, g, t, ec[e].r, ec[e].d0);
               du[e][t] = du[e][t] * dsilu4(u);
-              drdot += dot4(du[e][t], ldw4(wb, Lw.cr + 16 * t, g));
-              dd0dot += dot4(du[e][t], ldw4(wb, Lw.cd + 16 * t, g));
+              drdot += dot4(du[e][t], *(const f4*)(Lw.cr + 16 * t + 4 * g));
+              dd0dot += dot4(du[e][t], *(const f4*)(Lw.cd + 16 * t + 4 * g));
             }
             const float dr = reduce_groups(drdot), dd0v = reduce_groups(dd0dot);
             if (g == 0) {
@@ -427,7 +446,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             }
           }
         }
-        STAMP(ST_BWD_EDGE);
+        STAMP(ST_B_DU);
         // publish the NB du tiles one by one: dP_i = sum_j du_ij (own rows), dQ_j = sum_i du_ij (owner of j)
 #pragma unroll
         for (int e = 0; e < NB; ++e) {
@@ -484,7 +503,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     __syncthreads();
     // (f) dh += A^T dP + Bm^T dQ
     STAMP(ST_MISC);
-    node_gemm<HP, EPI_ACCUM>(wb, Lw.At, B2, Lw.Bmt, B4, -1, dh, dh, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_ACCUM>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, N, wave, lane);
     __syncthreads();
     STAMP(ST_BWD_NODE);
   }
