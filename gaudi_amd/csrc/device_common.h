@@ -440,15 +440,9 @@ __device__ __forceinline__ void edge_gemm_from_regs(f4 (&out)[NE][HP / 16], cons
             for (int e = 0; e < NE; ++e) acc[e][tb] = mfma1(w[tb][q], in[e][cc][q], acc[e][tb]);
           }
 #if GAUDI_PIN_SCHED_UNROLLED
-      // +5 % on the reverse pass, but the group solver's compile time explodes with the block size:
-      // only for single-tile calls at the production sizes (T = 12, 13)
-      if constexpr (NE == 1 && T >= 12 && T <= 13) {
-        if ((t0 / TB) * (T * TB) + cc * TB + PF < NSEQ) __builtin_amdgcn_sched_group_barrier(0x020, TB, 0);
-        if (t0 + TB <= T)
-          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE * TB, 0);
-        else
-          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);
-      }
+      // Hard fence per tile group: nothing may cross, so the refill loads stay PF tiles ahead of their use exactly
+      // as written (left alone, hipcc sinks them next to their consumers: vmcnt(1) waits, ~45 % MFMA efficiency).
+      __builtin_amdgcn_sched_barrier(0);
 #endif
     }
 #pragma unroll
