@@ -42,6 +42,10 @@ struct MolGraph {
   const uint32_t* seg;    // LDS [N]      wave<<30 | start<<15 | len  (edge run of node n)
   int npairs;             // 32-edge passes of THIS wave
   int npairs_all[kWaves]; // ... of every wave of the workgroup (lock-step loops of the reverse pass)
+  // npairs_all[w] for a per-lane (non-uniform) w without dynamically indexing the array (which would spill it)
+  __device__ __forceinline__ int npairs_all_lane(int w) const {
+    return w == 0 ? npairs_all[0] : w == 1 ? npairs_all[1] : w == 2 ? npairs_all[2] : npairs_all[3];
+  }
 };
 
 // LDS working set of one network evaluation

@@ -143,8 +143,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     Lw.stage(w, sm.vec, HP, tid);
     __syncthreads();
     float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
-    for (int idx = tid; idx < N * HP; idx += kThreads) st[idx] = h[(idx / HP) * LD + idx % HP];
-    for (int idx = tid; idx < N * 4; idx += kThreads) st[2 * N * HP + idx] = sm.x[idx];
+    for (int idx = tid; idx < N * (HP / 4); idx += kThreads)
+      ((f4*)st)[idx] = *(const f4*)(h + (idx / (HP / 4)) * LD + 4 * (idx % (HP / 4)));
+    for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 2 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
     compute_geo(sm, mg, 1.0f, wave, lane, false);  // gcl.py:308-316
     node_gemm<HP, EPI_NONE>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane);
     STAMP(ST_STASH);
@@ -211,7 +212,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     STAMP(ST_EDGE_EPI);
     __syncthreads();
     STAMP(ST_BARRIER);
-    for (int idx = tid; idx < N * HP; idx += kThreads) st[N * HP + idx] = agg[(idx / HP) * LD + idx % HP];
+    for (int idx = tid; idx < N * (HP / 4); idx += kThreads)
+      ((f4*)(st + N * HP))[idx] = *(const f4*)(agg + (idx / (HP / 4)) * LD + 4 * (idx % (HP / 4)));
     STAMP(ST_STASH);
     node_gemm<HP, EPI_SILU>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane);
     STAMP(ST_NODE);
@@ -287,15 +289,16 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     __syncthreads();
     const float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
     // (a) reload h_l, agg_l, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
-    for (int idx = tid; idx < N * HP; idx += kThreads) {
-      const int n = idx / HP, f = idx % HP;
-      B0[n * LD + f] = st[idx];
-      B1[n * LD + f] = st[N * HP + idx];
-      dh[n * LD + f] *= mg.mask[n];
+    for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
+      const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
+      const f4 hv = ((const f4*)st)[idx], av = ((const f4*)(st + N * HP))[idx];
+      *(f4*)(B0 + n * LD + f) = hv;
+      *(f4*)(B1 + n * LD + f) = av;
+      *(f4*)(dh + n * LD + f) = *(const f4*)(dh + n * LD + f) * mg.mask[n];
     }
-    for (int idx = tid; idx < N * 4; idx += kThreads) {
-      sm.x[idx] = st[2 * N * HP + idx];
-      sm.dx[idx] *= mg.mask[idx >> 2];
+    for (int idx = tid; idx < N; idx += kThreads) {
+      *(f4*)(sm.x + 4 * idx) = ((const f4*)(st + 2 * N * HP))[idx];
+      *(f4*)(sm.dx + 4 * idx) = *(const f4*)(sm.dx + 4 * idx) * mg.mask[idx];
     }
     __syncthreads();
     STAMP(ST_STASH);
@@ -459,16 +462,24 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           __syncthreads();  // every wave's du tile of this round is in its scratch
           STAMP(ST_BWD_BARRIER);
           if (active) ss.add_tile(scr, my_i[e], B2, 1.0f, lane);  // overwrites P_i: dead by now
+          {
+            // lane l holds the sending node j and its owner wave for slot (wave l>>4, column l&15) of this round;
+            // the 64 slots are then walked with v_readlane (no LDS traffic on the serial path)
+            const int w2l = lane >> 4;
+            const bool live = tile < 2 * mg.npairs_all_lane(w2l);
+            const uint32_t ew = live ? mg.edge[w2l * EW + tile * 16 + (lane & 15)] : 0u;
+            const int jl = (int)((ew >> 8) & 255);
+            const int ownl = live ? (int)(mg.seg[jl] >> 30) : -1;
 #pragma unroll
-          for (int w2 = 0; w2 < kWaves; ++w2) {
-            if (tile >= 2 * mg.npairs_all[w2]) continue;
-            const float* scr2 = sm.scr + w2 * 16 * LD;
-            for (int k = 0; k < 16; ++k) {
-              const int jj = __builtin_amdgcn_readfirstlane((int)((mg.edge[w2 * EW + tile * 16 + k] >> 8) & 255));
-              const int owner = __builtin_amdgcn_readfirstlane((int)(mg.seg[jj] >> 30));
-              if (owner == wave && lane < HP / 4) {
-                f4* dst = (f4*)(B4 + jj * LD + 4 * lane);
-                *dst = *dst + *(const f4*)(scr2 + k * LD + 4 * lane);
+            for (int sl = 0; sl < 64; ++sl) {
+              const int owner = __builtin_amdgcn_readlane(ownl, sl);
+              if (owner == wave) {
+                const int jj = __builtin_amdgcn_readlane(jl, sl);
+                if (lane < HP / 4) {
+                  const float* scr2 = sm.scr + (sl >> 4) * 16 * LD + (sl & 15) * LD;
+                  f4* dst = (f4*)(B4 + jj * LD + 4 * lane);
+                  *dst = *dst + *(const f4*)(scr2 + 4 * lane);
+                }
               }
             }
           }
