@@ -22,6 +22,9 @@ constexpr int kThreads = 256;
 #ifndef GAUDI_PIN_SCHED
 #define GAUDI_PIN_SCHED 1
 #endif
+#ifndef GAUDI_ROTATE_K
+#define GAUDI_ROTATE_K 0
+#endif
 #ifndef GAUDI_PF_REGS_NE1
 #define GAUDI_PF_REGS_NE1 12
 #endif
@@ -146,10 +149,36 @@ __device__ __forceinline__ float ldw1(const WBuf& w, int off_floats) {
 // ---------------------------------------------------------------------------------------------
 enum NodeEpi { EPI_NONE = 0, EPI_SILU = 1, EPI_RESIDUAL_MASK = 2, EPI_MUL_DSILU = 3, EPI_ACCUM = 4 };
 
-template <int HP, int EPI>
+// First two K chunks of a node GEMM's weight tiles, loaded ahead of the call (typically before the previous
+// GEMM's epilogue and the barrier in between) so the call does not start with an exposed L2 round trip.
+template <int HP>
+struct NodePF {
+  static constexpr int UT = (HP / 16 + kWaves - 1) / kWaves;
+  f4 a0[UT], a1[UT];
+  int rot = 0;  // per-molecule rotation of the K order (experiment, GAUDI_ROTATE_K)
+};
+
+template <int HP>
+__device__ __forceinline__ void node_prefetch(NodePF<HP>& pf, const WBuf& wb, int W, int wave, int lane) {
+  constexpr int T = HP / 16;
+  constexpr int UT = NodePF<HP>::UT;
+  const int lo = (lane & 15) * 4 + (lane >> 4);
+#pragma unroll
+  for (int u = 0; u < UT; ++u) {
+    const int t = wave + kWaves * u;
+    const int toff = (t < T ? t : T - 1) * 256;
+    pf.a0[u] = ldw4(wb, W + toff, lo);
+    pf.a1[u] = ldw4(wb, W + (T > 1 ? T : 0) * 256 + toff, lo);
+  }
+}
+
+// PRE: the first two chunks of Wa are already in `pf`.  nextW >= 0: before the epilogue, load the first two chunks
+// of the NEXT node GEMM (weight offset nextW) into `pf`.
+template <int HP, int EPI, bool PRE = false>
 __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
-                                          const float* sBias /* LDS [HP] or null */,
-                                          float* sY, const float* sRes, const float* sMask, int N, int wave, int lane) {
+                                          const float* sBias /* LDS [HP] or null */, float* sY, const float* sRes,
+                                          const float* sMask, int N, int wave, int lane, NodePF<HP>* pf = nullptr,
+                                          int nextW = -1) {
   constexpr int T = HP / 16;
   constexpr int LD = HP + 4;
   constexpr int UT = (T + kWaves - 1) / kWaves;
@@ -164,96 +193,128 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
     const int t = wave + kWaves * u;
     toff[u] = (t < T ? t : T - 1) * 256;
   }
+  // Two sources (Y = Wa Xa + Wb Xb) run as ONE K loop of 2T chunks so the load pipeline never restarts.
+  const int KT = Wb >= 0 ? 2 * T : T;
+  const int rot = (GAUDI_ROTATE_K && pf != nullptr) ? pf->rot % KT : 0;
+  // `rot` rotates the K order per molecule: all 256 CUs run the same GEMM at the same time, and without it they
+  // all hit the same L2 lines (channels) in lock step.  (PRE-loaded chunks assume rot = 0 for chunks 0, 1.)
+  auto kmap = [&](int cc) {
+    int k = cc < KT ? cc : KT - 1;
+    if (GAUDI_ROTATE_K) { k += rot; k = k >= KT ? k - KT : k; }
+    return k;
+  };
+  auto chunk = [&](int cc) {  // float offset of K chunk cc (clamped past the end: surplus loads are unused)
+    const int k = kmap(cc);
+    return k < T ? Wa + k * (T * 256) : Wb + (k - T) * (T * 256);
+  };
   for (int nt = 0; nt < n_tiles; ++nt) {
     const int node = nt * 16 + c;
     const int nclamp = node < N ? node : N - 1;
+    const float* xa = sXa + nclamp * LD + 4 * g;
+    const float* xb = Wb >= 0 ? sXb + nclamp * LD + 4 * g - 16 * T : xa;  // indexed by the global chunk number
+    auto xin = [&](int cc) { const int k = kmap(cc); return *(const f4*)((k < T ? xa : xb) + 16 * k); };
     f4 acc[UT];
 #pragma unroll
-    for (int u = 0; u < UT; ++u) acc[u] = sBias != nullptr ? *(const f4*)(sBias + (toff[u] >> 4) + 4 * g) : splat(0.f);
+    for (int u = 0; u < UT; ++u)
+      acc[u] = sBias != nullptr ? *(const f4*)(sBias + (toff[u] >> 4) + 4 * g) : splat(0.f);
+    // Weight tiles are double-buffered in registers as two ping-pong sets (A, B) of two K chunks each: while
+    // the MFMAs consume one set, the loads of the other set (4 chunks ahead) are in flight.  Roles are swapped by
+    // unrolling, never by copying registers (a copy of an in-flight load forces vmcnt(0)).
+    f4 a0[UT], a1[UT], b0[UT], b1[UT];
+    if (PRE && nt == 0 && !GAUDI_ROTATE_K) {
 #pragma unroll
-    for (int src = 0; src < 2; ++src) {
-      const int W = src == 0 ? Wa : Wb;
-      const float* sX = src == 0 ? sXa : sXb;
-      if (W < 0) continue;
-      const float* xrow = sX + nclamp * LD + 4 * g;
-      // Weight tiles are double-buffered in registers as two ping-pong sets (A, B) of two K chunks each: while
-      // the MFMAs consume one set, the loads of the other set (4 chunks ahead) are in flight.  Roles are swapped by
-      // unrolling, never by copying registers (a copy of an in-flight load forces vmcnt(0)).
-      f4 a0[UT], a1[UT], b0[UT], b1[UT];
-      auto chunk = [&](int cc) { return W + (cc < T ? cc : T - 1) * (T * 256); };
+      for (int u = 0; u < UT; ++u) { a0[u] = pf->a0[u]; a1[u] = pf->a1[u]; }
+    } else {
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
         a0[u] = ldw4(wb, chunk(0) + toff[u], lo);
         a1[u] = ldw4(wb, chunk(1) + toff[u], lo);
       }
-      constexpr int MAIN = T / 4 * 4;
+    }
+    const int main_end = KT / 4 * 4;
 #pragma unroll 1
-      for (int cc = 0; cc < MAIN; cc += 4) {
-        const f4 x0 = *(const f4*)(xrow + 16 * cc);
-        const f4 x1 = *(const f4*)(xrow + 16 * cc + 16);
-        const f4 x2 = *(const f4*)(xrow + 16 * cc + 32);
-        const f4 x3 = *(const f4*)(xrow + 16 * cc + 48);
+    for (int cc = 0; cc < main_end; cc += 4) {
+      const f4 x0 = xin(cc), x1 = xin(cc + 1), x2 = xin(cc + 2), x3 = xin(cc + 3);
 #pragma unroll
-        for (int u = 0; u < UT; ++u) {
-          b0[u] = ldw4(wb, chunk(cc + 2) + toff[u], lo);
-          b1[u] = ldw4(wb, chunk(cc + 3) + toff[u], lo);
-        }
+      for (int u = 0; u < UT; ++u) {
+        b0[u] = ldw4(wb, chunk(cc + 2) + toff[u], lo);
+        b1[u] = ldw4(wb, chunk(cc + 3) + toff[u], lo);
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a0[u][q], x0[q], acc[u]);
+        for (int u = 0; u < UT; ++u) acc[u] = mfma1(a0[u][q], x0[q], acc[u]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a1[u][q], x1[q], acc[u]);
+        for (int u = 0; u < UT; ++u) acc[u] = mfma1(a1[u][q], x1[q], acc[u]);
 #pragma unroll
-        for (int u = 0; u < UT; ++u) {
-          a0[u] = ldw4(wb, chunk(cc + 4) + toff[u], lo);
-          a1[u] = ldw4(wb, chunk(cc + 5) + toff[u], lo);
-        }
+      for (int u = 0; u < UT; ++u) {
+        a0[u] = ldw4(wb, chunk(cc + 4) + toff[u], lo);
+        a1[u] = ldw4(wb, chunk(cc + 5) + toff[u], lo);
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int u = 0; u < UT; ++u) acc[u] = mfma1(b0[u][q], x2[q], acc[u]);
+        for (int u = 0; u < UT; ++u) acc[u] = mfma1(b0[u][q], x2[q], acc[u]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int u = 0; u < UT; ++u) acc[u] = mfma1(b1[u][q], x3[q], acc[u]);
+        for (int u = 0; u < UT; ++u) acc[u] = mfma1(b1[u][q], x3[q], acc[u]);
 #if GAUDI_PIN_SCHED
-        // keep the issue order written above: hipcc otherwise sinks the loads next to their consumers
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 LDS reads (x0..x3)
-        __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);  // set B loads
-        __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT, 0);  // MFMAs on set A
-        __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);  // set A loads (4 chunks ahead)
-        __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT, 0);  // MFMAs on set B
+      // keep the issue order written above: hipcc otherwise sinks the loads next to their consumers
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 LDS reads (x0..x3)
+      __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);  // set B loads
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT, 0);  // MFMAs on set A
+      __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);  // set A loads (4 chunks ahead)
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT, 0);  // MFMAs on set B
 #endif
-      }
-      // tail: T % 4 chunks, already in a0 / a1 (and one more load for the third)
-      if (T - MAIN >= 1) {
-        const f4 x0 = *(const f4*)(xrow + 16 * MAIN);
-        if (T - MAIN >= 3) {
+    }
+    // tail: KT % 4 chunks (0..3), the first two already in a0 / a1
+    const int rem = KT - main_end;
+    if (rem >= 3) {
 #pragma unroll
-          for (int u = 0; u < UT; ++u) b0[u] = ldw4(wb, chunk(MAIN + 2) + toff[u], lo);
-        }
+      for (int u = 0; u < UT; ++u) b0[u] = ldw4(wb, chunk(main_end + 2) + toff[u], lo);
+    }
+    if (nextW >= 0 && nt == n_tiles - 1 && !GAUDI_ROTATE_K) {
+      // software pipelining ACROSS calls: the next node GEMM's first tiles travel while this one drains
+      if (rem >= 1) {
+        const f4 x0 = xin(main_end);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int u = 0; u < UT; ++u) acc[u] = mfma1(a0[u][q], x0[q], acc[u]);
       }
-      if (T - MAIN >= 2) {
-        const f4 x1 = *(const f4*)(xrow + 16 * (MAIN + 1));
+      if (rem >= 2) {
+        const f4 x1 = xin(main_end + 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int u = 0; u < UT; ++u) acc[u] = mfma1(a1[u][q], x1[q], acc[u]);
       }
-      if (T - MAIN >= 3) {
-        const f4 x2 = *(const f4*)(xrow + 16 * (MAIN + 2));
+      node_prefetch<HP>(*pf, wb, nextW, wave, lane);
+    } else {
+      if (rem >= 1) {
+        const f4 x0 = xin(main_end);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int u = 0; u < UT; ++u) acc[u] = mfma1(b0[u][q], x2[q], acc[u]);
+          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a0[u][q], x0[q], acc[u]);
       }
+      if (rem >= 2) {
+        const f4 x1 = xin(main_end + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a1[u][q], x1[q], acc[u]);
+      }
+    }
+    if (rem >= 3) {
+      const f4 x2 = xin(main_end + 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = mfma1(b0[u][q], x2[q], acc[u]);
     }
 #pragma unroll
     for (int u = 0; u < UT; ++u) {

@@ -41,6 +41,7 @@ struct MolGraph {
   const float* em;        // LDS [4][EW]  edge_mask value (0 for padding slots)
   const uint32_t* seg;    // LDS [N]      wave<<30 | start<<15 | len  (edge run of node n)
   int npairs;             // 32-edge passes of THIS wave
+  int rot;                // per-molecule K-order rotation (global sample index based)
   int npairs_all[kWaves]; // ... of every wave of the workgroup (lock-step loops of the reverse pass)
   // npairs_all[w] for a per-lane (non-uniform) w without dynamically indexing the array (which would spill it)
   __device__ __forceinline__ int npairs_all_lane(int w) const {
@@ -160,6 +161,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   }
   __syncthreads();
   compute_geo(sm, mg, 0.f, wave, lane, true);  // d0 of the input coordinates (egnn_new.py:301)
+  NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it (device_common.h)
+  pf.rot = mg.rot;
+  node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);
 
   for (int l = 0; l < W.L; ++l) {
     compute_geo(sm, mg, W.norm_constant, wave, lane, false);  // egnn_new.py:216
@@ -174,8 +178,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
                   *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
       const float ba = sm.vec[7 * HP];
-      node_gemm<HP, EPI_NONE>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
-      node_gemm<HP, EPI_NONE>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane, &pf, G + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane, &pf);
       for (int idx = tid; idx < N * LD; idx += kThreads) sm.agg[idx] = 0.f;
       STAMP(ST_NODE);
       __syncthreads();
@@ -212,16 +216,19 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
             wave_lds_fence();
           }
         }
+        node_prefetch<HP>(pf, wb, G + 3 * PK, wave, lane);  // node MLP weights travel across the barrier
         ss.flush(sm.agg, W.normf, lane);
       }
       STAMP(ST_EDGE_EPI);
       __syncthreads();
       STAMP(ST_BARRIER);
-      node_gemm<HP, EPI_SILU>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, N, wave, lane,
+                                    &pf, G + 5 * PK);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
-      node_gemm<HP, EPI_RESIDUAL_MASK>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, N, wave, lane);
+      node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, N, wave, lane,
+                                             &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
@@ -234,8 +241,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       for (int idx = tid; idx < 5 * HP; idx += kThreads) sm.vec[idx] = w[V + idx];
       __syncthreads();
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
-      node_gemm<HP, EPI_NONE>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane);
-      node_gemm<HP, EPI_NONE>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane);
+      node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane, &pf, E + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane, &pf);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
@@ -266,6 +273,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           }
         }
       }
+      if (l + 1 < W.L) node_prefetch<HP>(pf, wb, lay.gcl(l + 1, 0), wave, lane);
       STAMP(ST_EDGE_EPI);
       __syncthreads();
       STAMP(ST_BARRIER);

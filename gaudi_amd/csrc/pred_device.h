@@ -95,9 +95,18 @@ struct PredLayerW {
   }
 };
 
-// stash per layer: h [N][HP] | agg [N][HP] | x [N][4]
-__host__ __device__ inline long long pred_stash_floats(int N, int HP, int L) {
+// stash per molecule: node part  L x { h [N][HP] | agg [N][HP] | x [N][4] }
+//                     edge part  L x 4 waves x (EW/16) tiles x { v | cpre } x [HP/16][64 lanes] float4
+// (the two edge pre-activations, in the accumulator layout they are produced in: 1 KiB per store instruction).
+__host__ __device__ inline long long pred_stash_node_floats(int N, int HP, int L) {
   return (long long)L * (2LL * N * HP + 4LL * N);
+}
+__host__ __device__ inline long long pred_stash_floats(int N, int HP, int L, int EW) {
+  return pred_stash_node_floats(N, HP, L) + (long long)L * kWaves * EW * HP * 2;
+}
+// float offset of tile `tile` of wave `wave` in layer l, array arr (0 = v, 1 = cpre), inside the edge part
+__device__ __forceinline__ size_t edge_stash_off(int l, int wave, int tile, int arr, int EW, int HP) {
+  return ((((size_t)l * kWaves + wave) * (EW / 16) + tile) * 2 + arr) * (size_t)(16 * HP);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -115,6 +124,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   const float* __restrict__ w = W.w;
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
   float *h = sm.b0, *p = sm.b1, *q = sm.b2, *agg = sm.b3;
+  float* estash = stash + pred_stash_node_floats(N, HP, W.L);
 
   for (int idx = tid; idx < N * 3; idx += kThreads) {  // models.py:439
     const int n = idx / 3, d = idx % 3;
@@ -136,6 +146,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   }
   __syncthreads();
   compute_geo(sm, mg, 0.f, wave, lane, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
+  NodePF<HP> pf;
+  pf.rot = mg.rot;
+  node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane);
 
   for (int l = 0; l < W.L; ++l) {
     const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
@@ -147,9 +160,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       ((f4*)st)[idx] = *(const f4*)(h + (idx / (HP / 4)) * LD + 4 * (idx % (HP / 4)));
     for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 2 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
     compute_geo(sm, mg, 1.0f, wave, lane, false);  // gcl.py:308-316
-    node_gemm<HP, EPI_NONE>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane, &pf, Lw.Bm);
     STAMP(ST_STASH);
-    node_gemm<HP, EPI_NONE>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, N, wave, lane, &pf);
     for (int idx = tid; idx < N * LD; idx += kThreads) agg[idx] = 0.f;
     STAMP(ST_NODE);
     __syncthreads();
@@ -166,6 +179,12 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         f4 acc[2][T];
         edge_gemm_from_pq<HP, 2>(acc, wb, Lw.W2, Lw.b2, Lw.cr, Lw.cd, p, q, ec, lane);
         STAMP(ST_EDGE);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {  // v (pre-activation of m) -> edge stash for the reverse pass
+          f4* sv = (f4*)(estash + edge_stash_off(l, wave, tp * 2 + e, 0, mg.EW, HP)) + lane;
+#pragma unroll
+          for (int t = 0; t < T; ++t) sv[t * 64] = acc[e][t];
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           float sdot = 0.f;
@@ -193,6 +212,12 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           edge_gemm_from_regs<HP, 2>(cp, acc, wb, Lw.Wc1, Lw.bc1, noinit, lane);
           STAMP(ST_EDGE);
 #pragma unroll
+          for (int e = 0; e < 2; ++e) {  // cpre -> edge stash
+            f4* sc = (f4*)(estash + edge_stash_off(l, wave, tp * 2 + e, 1, mg.EW, HP)) + lane;
+#pragma unroll
+            for (int t = 0; t < T; ++t) sc[t * 64] = cp[e][t];
+          }
+#pragma unroll
           for (int e = 0; e < 2; ++e) {
             float sdot = 0.f;
 #pragma unroll
@@ -207,6 +232,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           }
         }
       }
+      node_prefetch<HP>(pf, wb, Lw.Wn1h, wave, lane);
       ss.flush(agg, 1.0f, lane);
     }
     STAMP(ST_EDGE_EPI);
@@ -215,11 +241,12 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads)
       ((f4*)(st + N * HP))[idx] = *(const f4*)(agg + (idx / (HP / 4)) * LD + 4 * (idx % (HP / 4)));
     STAMP(ST_STASH);
-    node_gemm<HP, EPI_SILU>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane, &pf, Lw.Wn2);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
-    node_gemm<HP, EPI_RESIDUAL_MASK>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, N, wave, lane);
+    node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, N, wave, lane, &pf,
+                                           l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
     STAMP(ST_NODE);
     __syncthreads();
@@ -262,6 +289,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   const float* __restrict__ w = W.w;
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
   float *B0 = sm.b0, *B1 = sm.b1, *B2 = sm.b2, *dh = sm.b3, *B4 = sm.b4;
+  const float* estash = stash + pred_stash_node_floats(N, HP, W.L);
   const float* dpred = sm.pred + 16;
   int ntmax = 0;
 #pragma unroll
@@ -282,6 +310,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   }
   __syncthreads();
 
+  NodePF<HP> pf;
+  pf.rot = mg.rot;
+  node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 4 * HP * HP /* Wn1h of the last layer */, wave, lane);
   for (int l = W.L - 1; l >= 0; --l) {
     const bool last = l == W.L - 1;
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
@@ -304,17 +335,17 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     STAMP(ST_STASH);
     compute_geo(sm, mg, 1.0f, wave, lane, false);
     // (b1) npre = Wn1h h + Wn1a agg + bn1 -> B4
-    node_gemm<HP, EPI_NONE>(wb, Lw.Wn1h, B0, Lw.Wn1a, B1, Lw.bn1, B4, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1h, B0, Lw.Wn1a, B1, Lw.bn1, B4, nullptr, nullptr, N, wave, lane, &pf, Lw.A);
     __syncthreads();
     // (b2) P -> B2, Q -> B1 (agg is dead)
-    node_gemm<HP, EPI_NONE>(wb, Lw.A, B0, -1, nullptr, Lw.b1, B2, nullptr, nullptr, N, wave, lane);
-    node_gemm<HP, EPI_NONE>(wb, Lw.Bm, B0, -1, nullptr, nullptr, B1, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, B0, -1, nullptr, Lw.b1, B2, nullptr, nullptr, N, wave, lane, &pf, Lw.Bm);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, B0, -1, nullptr, nullptr, B1, nullptr, nullptr, N, wave, lane, &pf, Lw.Wn2t);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
-    node_gemm<HP, EPI_MUL_DSILU>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, N, wave, lane, &pf, Lw.Wn1ht);
     __syncthreads();
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
-    node_gemm<HP, EPI_ACCUM>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, N, wave, lane);
-    node_gemm<HP, EPI_NONE>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, N, wave, lane, &pf, Lw.Wn1at);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, N, wave, lane, &pf);
     __syncthreads();
     for (int idx = tid; idx < N * LD; idx += kThreads) B4[idx] = 0.f;  // dQ accumulator
     __syncthreads();
@@ -340,26 +371,30 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           float mk[NB];
           f4 gg[NB];
           load_cols<PredSmem<HP>, NB>(sm, mg, wave, tile0 * 16, c, ec, mk, gg);
-          f4 v[NB][T];
+          // v and cpre come back from the forward's edge stash (no recompute of W2 / Wc1)
+          f4 v[NB][T], cp[NB][T];
           STAMP(ST_BWD_EDGE);
-          edge_gemm_from_pq<HP, NB>(v, wb, Lw.W2, Lw.b2, Lw.cr, Lw.cd, B2, B1, ec, lane);
+#pragma unroll
+          for (int e = 0; e < NB; ++e) {
+            const f4* sv = (const f4*)(estash + edge_stash_off(l, wave, tile0 + e, 0, EW, HP)) + lane;
+            const f4* sc = (const f4*)(estash + edge_stash_off(l, wave, tile0 + e, 1, EW, HP)) + lane;
+#pragma unroll
+            for (int t = 0; t < T; ++t) v[e][t] = sv[t * 64];
+            if (!last) {
+#pragma unroll
+              for (int t = 0; t < T; ++t) cp[e][t] = sc[t * 64];
+            }
+          }
           STAMP(ST_B_V);
-          f4 ev[NB][T];
           float a[NB], tau[NB], dtx[NB], dty[NB], dtz[NB];
 #pragma unroll
           for (int e = 0; e < NB; ++e) {
             my_i[e] = ec[e].i;
             float sdot = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-              const f4 m = silu4(v[e][t]);
-              ev[e][t] = m;
-              sdot += dot4(m, *(const f4*)(Lw.wa + 16 * t + 4 * g));
-            }
+            for (int t = 0; t < T; ++t) sdot += dot4(silu4(v[e][t]), *(const f4*)(Lw.wa + 16 * t + 4 * g));
             a[e] = 1.f;
             if (W.attention) a[e] = sigmoid_f(reduce_groups(sdot) + Lw.ba);
-#pragma unroll
-            for (int t = 0; t < T; ++t) ev[e][t] = ev[e][t] * a[e] * mk[e];
             tau[e] = 0.f;
             dtx[e] = sm.dx[4 * ec[e].i + 0];  // dtrans = dx'_i
             dty[e] = sm.dx[4 * ec[e].i + 1];
@@ -368,12 +403,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           STAMP(ST_B_EV);
           f4 de[NB][T];
           if (!last) {
-            f4 cp[NB][T];
-            const float* noinit[NB];
             const float* rowinit[NB];
 #pragma unroll
-            for (int e = 0; e < NB; ++e) { noinit[e] = nullptr; rowinit[e] = B0 + ec[e].i * LD; }
-            edge_gemm_from_regs<HP, NB>(cp, ev, wb, Lw.Wc1, Lw.bc1, noinit, lane);
+            for (int e = 0; e < NB; ++e) rowinit[e] = B0 + ec[e].i * LD;
             STAMP(ST_B_CP);
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
@@ -489,6 +521,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           STAMP(ST_BWD_BARRIER);
         }
       }
+      node_prefetch<HP>(pf, wb, Lw.At, wave, lane);  // (f)'s first tiles travel across the barriers below
       if (nt_me > 0) ss.flush(B2, 1.0f, lane);
     }
     __syncthreads();
@@ -514,7 +547,8 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     __syncthreads();
     // (f) dh += A^T dP + Bm^T dQ
     STAMP(ST_MISC);
-    node_gemm<HP, EPI_ACCUM>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, N, wave, lane);
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, N, wave, lane, &pf,
+                                   l > 0 ? lay.layer(l - 1) + 4 * HP * HP : -1);
     __syncthreads();
     STAMP(ST_BWD_NODE);
   }
