@@ -178,7 +178,7 @@ template <int HP, int EPI, bool PRE = false>
 __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
                                           const float* sBias /* LDS [HP] or null */, float* sY, const float* sRes,
                                           const float* sMask, int N, int wave, int lane, NodePF<HP>* pf = nullptr,
-                                          int nextW = -1) {
+                                          int nextW = -1, float* gPre = nullptr /* global [N][HP]: pre-epilogue value */) {
   constexpr int T = HP / 16;
   constexpr int LD = HP + 4;
   constexpr int UT = (T + kWaves - 1) / kWaves;
@@ -322,6 +322,7 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
       if (t < T && node < N) {
         f4 y = acc[u];
         float* dst = sY + node * LD + 16 * t + 4 * g;
+        if (gPre != nullptr) *(f4*)(gPre + node * HP + 16 * t + 4 * g) = y;
         if (EPI == EPI_SILU) y = silu4(y);
         if (EPI == EPI_RESIDUAL_MASK) {
           const f4 r = *(const f4*)(sRes + node * LD + 16 * t + 4 * g);

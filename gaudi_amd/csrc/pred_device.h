@@ -95,11 +95,12 @@ struct PredLayerW {
   }
 };
 
-// stash per molecule: node part  L x { h [N][HP] | agg [N][HP] | x [N][4] }
+// stash per molecule: node part  L x { P [N][HP] | Q [N][HP] | npre [N][HP] | x [N][4] }   (P = A h + b1, Q = B h,
+//                                npre = pre-activation of the node MLP: the reverse pass reloads instead of recomputing)
 //                     edge part  L x 4 waves x (EW/16) tiles x { v | cpre } x [HP/16][64 lanes] float4
 // (the two edge pre-activations, in the accumulator layout they are produced in: 1 KiB per store instruction).
 __host__ __device__ inline long long pred_stash_node_floats(int N, int HP, int L) {
-  return (long long)L * (2LL * N * HP + 4LL * N);
+  return (long long)L * (3LL * N * HP + 4LL * N);
 }
 __host__ __device__ inline long long pred_stash_floats(int N, int HP, int L, int EW) {
   return pred_stash_node_floats(N, HP, L) + (long long)L * kWaves * EW * HP * 2;
@@ -155,10 +156,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
     Lw.stage(w, sm.vec, HP, tid);
     __syncthreads();
-    float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
-    for (int idx = tid; idx < N * (HP / 4); idx += kThreads)
-      ((f4*)st)[idx] = *(const f4*)(h + (idx / (HP / 4)) * LD + 4 * (idx % (HP / 4)));
-    for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 2 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
+    float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
+    for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 3 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
     compute_geo(sm, mg, 1.0f, wave, lane, false);  // gcl.py:308-316
     node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane, &pf, Lw.Bm);
     STAMP(ST_STASH);
@@ -167,6 +166,11 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
+    for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // P, Q -> stash
+      const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
+      ((f4*)st)[idx] = *(const f4*)(p + n * LD + f);
+      ((f4*)(st + N * HP))[idx] = *(const f4*)(q + n * LD + f);
+    }
     {
       SegSum<HP> ss;
       ss.init();
@@ -238,10 +242,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     STAMP(ST_EDGE_EPI);
     __syncthreads();
     STAMP(ST_BARRIER);
-    for (int idx = tid; idx < N * (HP / 4); idx += kThreads)
-      ((f4*)(st + N * HP))[idx] = *(const f4*)(agg + (idx / (HP / 4)) * LD + 4 * (idx % (HP / 4)));
     STAMP(ST_STASH);
-    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane, &pf, Lw.Wn2);
+    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane, &pf, Lw.Wn2,
+                                  st + 2 * N * HP /* npre -> stash */);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
@@ -274,9 +277,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 
 // ---------------------------------------------------------------------------------------------
 // reverse pass: sGrad[N][D] = d( sum_k dpred[k] * pred[k] ) / dz      (dpred in sm.pred[16..16+K))
-// buffer roles per layer:  B0 = b0: h_l -> dagg      B1 = b1: agg_l -> Q
-//                          B2 = b2: P -> dP (in place, rows owned by the wave that reduces them)
-//                          B3 = b3: dh (running)     B4 = b4: npre -> dnpre -> dQ accumulator
+// buffer roles per layer:  B0 = b0: dagg             B1 = b1: Q (from the stash)
+//                          B2 = b2: P (stash) -> dP (in place, rows owned by the wave that reduces them)
+//                          B3 = b3: dh (running)     B4 = b4: npre (stash) -> dnpre -> dQ accumulator
 // ---------------------------------------------------------------------------------------------
 template <int HP>
 __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
@@ -312,34 +315,29 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 
   NodePF<HP> pf;
   pf.rot = mg.rot;
-  node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 4 * HP * HP /* Wn1h of the last layer */, wave, lane);
+  node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane);
   for (int l = W.L - 1; l >= 0; --l) {
     const bool last = l == W.L - 1;
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
     Lw.stage(w, sm.vec, HP, tid);
     __syncthreads();
-    const float* st = stash + (size_t)l * (2 * N * HP + 4 * N);
-    // (a) reload h_l, agg_l, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
+    const float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
+    // (a) reload P -> B2, Q -> B1, npre -> B4, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
       const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
-      const f4 hv = ((const f4*)st)[idx], av = ((const f4*)(st + N * HP))[idx];
-      *(f4*)(B0 + n * LD + f) = hv;
-      *(f4*)(B1 + n * LD + f) = av;
+      const f4 pv = ((const f4*)st)[idx], qv = ((const f4*)(st + N * HP))[idx], nv = ((const f4*)(st + 2 * N * HP))[idx];
+      *(f4*)(B2 + n * LD + f) = pv;
+      *(f4*)(B1 + n * LD + f) = qv;
+      *(f4*)(B4 + n * LD + f) = nv;
       *(f4*)(dh + n * LD + f) = *(const f4*)(dh + n * LD + f) * mg.mask[n];
     }
     for (int idx = tid; idx < N; idx += kThreads) {
-      *(f4*)(sm.x + 4 * idx) = ((const f4*)(st + 2 * N * HP))[idx];
+      *(f4*)(sm.x + 4 * idx) = ((const f4*)(st + 3 * N * HP))[idx];
       *(f4*)(sm.dx + 4 * idx) = *(const f4*)(sm.dx + 4 * idx) * mg.mask[idx];
     }
     __syncthreads();
     STAMP(ST_STASH);
     compute_geo(sm, mg, 1.0f, wave, lane, false);
-    // (b1) npre = Wn1h h + Wn1a agg + bn1 -> B4
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1h, B0, Lw.Wn1a, B1, Lw.bn1, B4, nullptr, nullptr, N, wave, lane, &pf, Lw.A);
-    __syncthreads();
-    // (b2) P -> B2, Q -> B1 (agg is dead)
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, B0, -1, nullptr, Lw.b1, B2, nullptr, nullptr, N, wave, lane, &pf, Lw.Bm);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, B0, -1, nullptr, nullptr, B1, nullptr, nullptr, N, wave, lane, &pf, Lw.Wn2t);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
     node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, N, wave, lane, &pf, Lw.Wn1ht);
     __syncthreads();
@@ -548,7 +546,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     // (f) dh += A^T dP + Bm^T dQ
     STAMP(ST_MISC);
     node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, N, wave, lane, &pf,
-                                   l > 0 ? lay.layer(l - 1) + 4 * HP * HP : -1);
+                                   l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
     STAMP(ST_BWD_NODE);
   }
