@@ -234,3 +234,51 @@ def test_sharding_invariance_on_device(golden):
                          pred_sd=synth.synth_predictor_state_dict(pargs, 1, 5, seed=2), pcfg=pargs, target_w=w, scale=0.6)
     assert rel_err(x, xo) < TOL
     eng.close()
+
+
+def test_degenerate_molecules(O):
+    """Ragged batch with 1- and 2-node molecules (no / two live edges) and a fully padded row."""
+    eargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=6)
+    pargs = synth.pred_args(nf=36, n_layers=2)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=21, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=22, amplify_coord=True)
+    eng = make_engine(eargs, esd, pargs, psd)
+    nm, em = O.build_masks([1, 2, 5, 0, 3], 5, False)
+    B, N = nm.shape[0], nm.shape[1]
+    z = (np.random.default_rng(0).standard_normal((B, N, 4)).astype(np.float32)) * nm
+    t = np.full(B, 0.4, np.float32)
+    assert rel_err(eng.phi(z, t, nm, em), O.edm_phi(esd, eargs, z, t, nm, em)) < TOL
+    w = O.target_max_gap_weights(5)
+    pred, grad = eng.predictor_grad(z, t, nm, em, w)
+    po, go = O.predictor_grad(psd, pargs, z, nm, em, t, np.broadcast_to(w, (B, 5)))
+    assert rel_err(pred, po) < TOL and rel_err(grad, go) < TOL
+    noise = np.random.default_rng(1).standard_normal((8, B, N, 4)).astype(np.float32)
+    x, h, d = eng.sample(nm, em, noise=noise, target_w=w, scale=0.6)
+    xo, ho, _ = O.sample(esd, eargs, nm, em, noise, pred_sd=psd, pcfg=pargs, target_w=w, scale=0.6)
+    assert rel_err(x, xo) < TOL and np.array_equal(h, ho)
+    assert np.abs(x[3]).max() == 0 and np.abs(h[3]).max() == 0  # the empty molecule stays empty
+    eng.close()
+
+
+def test_error_paths():
+    """Loud failures instead of fallbacks: capacity, missing tensors, guidance without a predictor, bad sizes."""
+    from gaudi_amd._lib import GaudiError
+    from gaudi_amd.engine import Engine
+    eargs = synth.edm_args(diffusion_steps=5)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=0)
+    eng = Engine(0)
+    with pytest.raises(GaudiError, match="not loaded"):
+        eng.phi(np.zeros((1, 3, 4), np.float32), 0.5, np.ones((1, 3)), np.ones((1, 3, 3)))
+    broken = dict(esd)
+    broken.pop("dynamics.egnn.e_block_3.gcl_0.edge_mlp.2.weight")
+    with pytest.raises(GaudiError, match="edge_mlp.2.weight"):
+        eng.load_edm(eargs, broken)
+    eng.load_edm(eargs, esd)
+    N = 40  # 40 nodes of a 192-wide net do not fit 160 KiB of LDS
+    with pytest.raises(GaudiError, match="LDS"):
+        eng.phi(np.zeros((1, N, 4), np.float32), 0.5, np.ones((1, N)), np.ones((1, N, N)) - np.eye(N))
+    with pytest.raises(GaudiError, match="predictor"):
+        eng.sample(np.ones((2, 4), np.float32), np.ones((2, 4, 4), np.float32), target_w=np.zeros(5, np.float32))
+    with pytest.raises(GaudiError, match="hidden"):
+        eng.load_edm(synth.edm_args(nf=300), synth.synth_edm_state_dict(synth.edm_args(nf=300, n_layers=1), 1))
+    eng.close()
