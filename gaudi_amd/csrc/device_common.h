@@ -22,9 +22,6 @@ constexpr int kThreads = 256;
 #ifndef GAUDI_PIN_SCHED
 #define GAUDI_PIN_SCHED 1
 #endif
-#ifndef GAUDI_ROTATE_K
-#define GAUDI_ROTATE_K 0
-#endif
 #ifndef GAUDI_PF_REGS_NE1
 #define GAUDI_PF_REGS_NE1 12
 #endif
@@ -155,7 +152,6 @@ template <int HP>
 struct NodePF {
   static constexpr int UT = (HP / 16 + kWaves - 1) / kWaves;
   f4 a0[UT], a1[UT];
-  int rot = 0;  // per-molecule rotation of the K order (experiment, GAUDI_ROTATE_K)
 };
 
 template <int HP>
@@ -173,12 +169,12 @@ __device__ __forceinline__ void node_prefetch(NodePF<HP>& pf, const WBuf& wb, in
 }
 
 // PRE: the first two chunks of Wa are already in `pf`.  nextW >= 0: before the epilogue, load the first two chunks
-// of the NEXT node GEMM (weight offset nextW) into `pf`.
-template <int HP, int EPI, bool PRE = false>
-__device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
-                                          const float* sBias /* LDS [HP] or null */, float* sY, const float* sRes,
-                                          const float* sMask, int N, int wave, int lane, NodePF<HP>* pf = nullptr,
-                                          int nextW = -1, float* gPre = nullptr /* global [N][HP]: pre-epilogue value */) {
+// of the NEXT node GEMM (weight offset nextW) into `pf`.  NT = 16-node column tiles served per weight load (the GEMM
+// is bound by the per-CU L2 stream of its weights, so N > 16 must not stream them once per column tile).
+template <int HP, int EPI, bool PRE, int NT>
+__device__ __forceinline__ void node_gemm_impl(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
+                                               const float* sBias, float* sY, const float* sRes, const float* sMask,
+                                               int N, int wave, int lane, NodePF<HP>* pf, int nextW, float* gPre) {
   constexpr int T = HP / 16;
   constexpr int LD = HP + 4;
   constexpr int UT = (T + kWaves - 1) / kWaves;
@@ -195,33 +191,34 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
   }
   // Two sources (Y = Wa Xa + Wb Xb) run as ONE K loop of 2T chunks so the load pipeline never restarts.
   const int KT = Wb >= 0 ? 2 * T : T;
-  const int rot = (GAUDI_ROTATE_K && pf != nullptr) ? pf->rot % KT : 0;
-  // `rot` rotates the K order per molecule: all 256 CUs run the same GEMM at the same time, and without it they
-  // all hit the same L2 lines (channels) in lock step.  (PRE-loaded chunks assume rot = 0 for chunks 0, 1.)
-  auto kmap = [&](int cc) {
-    int k = cc < KT ? cc : KT - 1;
-    if (GAUDI_ROTATE_K) { k += rot; k = k >= KT ? k - KT : k; }
-    return k;
-  };
   auto chunk = [&](int cc) {  // float offset of K chunk cc (clamped past the end: surplus loads are unused)
-    const int k = kmap(cc);
+    const int k = cc < KT ? cc : KT - 1;
     return k < T ? Wa + k * (T * 256) : Wb + (k - T) * (T * 256);
   };
-  for (int nt = 0; nt < n_tiles; ++nt) {
-    const int node = nt * 16 + c;
-    const int nclamp = node < N ? node : N - 1;
-    const float* xa = sXa + nclamp * LD + 4 * g;
-    const float* xb = Wb >= 0 ? sXb + nclamp * LD + 4 * g - 16 * T : xa;  // indexed by the global chunk number
-    auto xin = [&](int cc) { const int k = kmap(cc); return *(const f4*)((k < T ? xa : xb) + 16 * k); };
-    f4 acc[UT];
+  for (int nt0 = 0; nt0 < n_tiles; nt0 += NT) {
+    const float* xa[NT];
+    const float* xb[NT];
+    int node[NT];
 #pragma unroll
-    for (int u = 0; u < UT; ++u)
-      acc[u] = sBias != nullptr ? *(const f4*)(sBias + (toff[u] >> 4) + 4 * g) : splat(0.f);
+    for (int j = 0; j < NT; ++j) {
+      node[j] = (nt0 + j) * 16 + c;
+      const int nclamp = node[j] < N ? node[j] : N - 1;
+      xa[j] = sXa + nclamp * LD + 4 * g;
+      xb[j] = Wb >= 0 ? sXb + nclamp * LD + 4 * g - 16 * T : xa[j];  // indexed by the global chunk number
+    }
+    auto xin = [&](int j, int cc) { return *(const f4*)((cc < T ? xa[j] : xb[j]) + 16 * cc); };
+    f4 acc[NT][UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const f4 b = sBias != nullptr ? *(const f4*)(sBias + (toff[u] >> 4) + 4 * g) : splat(0.f);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j][u] = b;
+    }
     // Weight tiles are double-buffered in registers as two ping-pong sets (A, B) of two K chunks each: while
     // the MFMAs consume one set, the loads of the other set (4 chunks ahead) are in flight.  Roles are swapped by
     // unrolling, never by copying registers (a copy of an in-flight load forces vmcnt(0)).
     f4 a0[UT], a1[UT], b0[UT], b1[UT];
-    if (PRE && nt == 0 && !GAUDI_ROTATE_K) {
+    if (PRE && nt0 == 0) {
 #pragma unroll
       for (int u = 0; u < UT; ++u) { a0[u] = pf->a0[u]; a1[u] = pf->a1[u]; }
     } else {
@@ -231,43 +228,55 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
         a1[u] = ldw4(wb, chunk(1) + toff[u], lo);
       }
     }
+    // k-step (q) outermost over NT*UT independent accumulators
+    auto mmx = [&](const f4 (&w)[UT], const f4 (&x)[NT]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int u = 0; u < UT; ++u) acc[j][u] = mfma1(w[u][q], x[j][q], acc[j][u]);
+    };
+    auto mm = [&](const f4 (&w)[UT], int cc) {
+      f4 x[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) x[j] = xin(j, cc);
+      mmx(w, x);
+    };
     const int main_end = KT / 4 * 4;
 #pragma unroll 1
     for (int cc = 0; cc < main_end; cc += 4) {
-      const f4 x0 = xin(cc), x1 = xin(cc + 1), x2 = xin(cc + 2), x3 = xin(cc + 3);
+      f4 x0[NT], x1[NT], x2[NT], x3[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        x0[j] = xin(j, cc);
+        x1[j] = xin(j, cc + 1);
+        x2[j] = xin(j, cc + 2);
+        x3[j] = xin(j, cc + 3);
+      }
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
         b0[u] = ldw4(wb, chunk(cc + 2) + toff[u], lo);
         b1[u] = ldw4(wb, chunk(cc + 3) + toff[u], lo);
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma1(a0[u][q], x0[q], acc[u]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma1(a1[u][q], x1[q], acc[u]);
+      mmx(a0, x0);
+      mmx(a1, x1);
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
         a0[u] = ldw4(wb, chunk(cc + 4) + toff[u], lo);
         a1[u] = ldw4(wb, chunk(cc + 5) + toff[u], lo);
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma1(b0[u][q], x2[q], acc[u]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma1(b1[u][q], x3[q], acc[u]);
+      mmx(b0, x2);
+      mmx(b1, x3);
 #if GAUDI_PIN_SCHED
-      // keep the issue order written above: hipcc otherwise sinks the loads next to their consumers
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 LDS reads (x0..x3)
-      __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);  // set B loads
-      __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT, 0);  // MFMAs on set A
-      __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);  // set A loads (4 chunks ahead)
-      __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT, 0);  // MFMAs on set B
+      // keep the issue order written above: hipcc otherwise sinks the loads next to their consumers.
+      // (This exact group layout is the validated one; a variant with the LDS reads split per half
+      // produced wrong results at T = 13 and is not used.)
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * NT, 0);       // LDS reads (x0..x3)
+      __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);       // set B loads
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT * NT, 0);  // MFMAs on set A
+      __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);       // set A loads (4 chunks ahead)
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT * NT, 0);  // MFMAs on set B
 #endif
     }
     // tail: KT % 4 chunks (0..3), the first two already in a0 / a1
@@ -276,67 +285,46 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
 #pragma unroll
       for (int u = 0; u < UT; ++u) b0[u] = ldw4(wb, chunk(main_end + 2) + toff[u], lo);
     }
-    if (nextW >= 0 && nt == n_tiles - 1 && !GAUDI_ROTATE_K) {
-      // software pipelining ACROSS calls: the next node GEMM's first tiles travel while this one drains
-      if (rem >= 1) {
-        const f4 x0 = xin(main_end);
+    if (rem >= 1) mm(a0, main_end);
+    if (rem >= 2) mm(a1, main_end + 1);
+    // software pipelining ACROSS calls: the next node GEMM's first tiles travel while this one drains
+    if (nextW >= 0 && nt0 + NT >= n_tiles) node_prefetch<HP>(*pf, wb, nextW, wave, lane);
+    if (rem >= 3) mm(b0, main_end + 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a0[u][q], x0[q], acc[u]);
-      }
-      if (rem >= 2) {
-        const f4 x1 = xin(main_end + 1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a1[u][q], x1[q], acc[u]);
-      }
-      node_prefetch<HP>(*pf, wb, nextW, wave, lane);
-    } else {
-      if (rem >= 1) {
-        const f4 x0 = xin(main_end);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a0[u][q], x0[q], acc[u]);
-      }
-      if (rem >= 2) {
-        const f4 x1 = xin(main_end + 1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int u = 0; u < UT; ++u) acc[u] = mfma1(a1[u][q], x1[q], acc[u]);
-      }
-    }
-    if (rem >= 3) {
-      const f4 x2 = xin(main_end + 2);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int u = 0; u < UT; ++u) acc[u] = mfma1(b0[u][q], x2[q], acc[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < UT; ++u) {
-      const int t = wave + kWaves * u;
-      if (t < T && node < N) {
-        f4 y = acc[u];
-        float* dst = sY + node * LD + 16 * t + 4 * g;
-        if (gPre != nullptr) *(f4*)(gPre + node * HP + 16 * t + 4 * g) = y;
-        if (EPI == EPI_SILU) y = silu4(y);
-        if (EPI == EPI_RESIDUAL_MASK) {
-          const f4 r = *(const f4*)(sRes + node * LD + 16 * t + 4 * g);
-          y = (r + y) * sMask[node];
+      for (int u = 0; u < UT; ++u) {
+        const int t = wave + kWaves * u;
+        const int nd = node[j];
+        if (t < T && nd < N) {
+          f4 y = acc[j][u];
+          float* dst = sY + nd * LD + 16 * t + 4 * g;
+          if (gPre != nullptr) *(f4*)(gPre + nd * HP + 16 * t + 4 * g) = y;
+          if (EPI == EPI_SILU) y = silu4(y);
+          if (EPI == EPI_RESIDUAL_MASK) {
+            const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
+            y = (r + y) * sMask[nd];
+          }
+          if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
+            const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
+            y = (f4){y[0] * dsilu_f(r[0]), y[1] * dsilu_f(r[1]), y[2] * dsilu_f(r[2]), y[3] * dsilu_f(r[3])};
+          }
+          if (EPI == EPI_ACCUM) y = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g) + y;
+          *(f4*)dst = y;
         }
-        if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
-          const f4 r = *(const f4*)(sRes + node * LD + 16 * t + 4 * g);
-          y = (f4){y[0] * dsilu_f(r[0]), y[1] * dsilu_f(r[1]), y[2] * dsilu_f(r[2]), y[3] * dsilu_f(r[3])};
-        }
-        if (EPI == EPI_ACCUM) y = *(const f4*)(sRes + node * LD + 16 * t + 4 * g) + y;
-        *(f4*)dst = y;
       }
-    }
   }
+}
+
+template <int HP, int EPI, bool PRE = false>
+__device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
+                                          const float* sBias /* LDS [HP] or null */, float* sY, const float* sRes,
+                                          const float* sMask, int N, int wave, int lane, NodePF<HP>* pf = nullptr,
+                                          int nextW = -1, float* gPre = nullptr /* global [N][HP]: pre-epilogue value */) {
+  if (N <= 16)
+    node_gemm_impl<HP, EPI, PRE, 1>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
+  else
+    node_gemm_impl<HP, EPI, PRE, 2>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
 }
 
 // ---------------------------------------------------------------------------------------------

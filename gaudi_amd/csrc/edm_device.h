@@ -41,7 +41,6 @@ struct MolGraph {
   const float* em;        // LDS [4][EW]  edge_mask value (0 for padding slots)
   const uint32_t* seg;    // LDS [N]      wave<<30 | start<<15 | len  (edge run of node n)
   int npairs;             // 32-edge passes of THIS wave
-  int rot;                // per-molecule K-order rotation (global sample index based)
   int npairs_all[kWaves]; // ... of every wave of the workgroup (lock-step loops of the reverse pass)
   // npairs_all[w] for a per-lane (non-uniform) w without dynamically indexing the array (which would spill it)
   __device__ __forceinline__ int npairs_all_lane(int w) const {
@@ -162,7 +161,6 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   __syncthreads();
   compute_geo(sm, mg, 0.f, wave, lane, true);  // d0 of the input coordinates (egnn_new.py:301)
   NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it (device_common.h)
-  pf.rot = mg.rot;
   node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);
 
   for (int l = 0; l < W.L; ++l) {

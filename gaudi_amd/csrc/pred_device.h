@@ -148,7 +148,6 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   __syncthreads();
   compute_geo(sm, mg, 0.f, wave, lane, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
   NodePF<HP> pf;
-  pf.rot = mg.rot;
   node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane);
 
   for (int l = 0; l < W.L; ++l) {
@@ -314,7 +313,6 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   __syncthreads();
 
   NodePF<HP> pf;
-  pf.rot = mg.rot;
   node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane);
   for (int l = W.L - 1; l >= 0; --l) {
     const bool last = l == W.L - 1;

@@ -86,7 +86,6 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
   for (int w = 0; w < kWaves; ++w) mg.npairs_all[w] = P.npairs[b * kWaves + w];
 
   const uint64_t gsample = (uint64_t)(P.sample_offset + b);
-  mg.rot = (int)(gsample % 1009u);
   // locals (not references into the kernarg struct) so nothing forces P onto the stack
   const float* const noise_p = P.noise ? P.noise + (size_t)b * N * D : nullptr;
   const long long draw_stride = P.draw_stride;
