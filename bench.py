@@ -92,10 +92,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sampler has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GAUDI_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing test on a 1-GPU box); the real
+    # multi-GPU run uses RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("GAUDI_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     guided = a.workload in ("c3", "c4")
     hetero = a.workload == "c4"
@@ -106,7 +113,7 @@ def main():
     pargs = synth.pred_args(dataset="hetro" if hetero else "cata")
     esd = synth.synth_edm_state_dict(eargs, F, seed=0)
     psd = synth.synth_predictor_state_dict(pargs, F, K, seed=1)
-    eng = Engine(local_rank)
+    eng = Engine(gpu)
     eng.load_edm(eargs, esd)
     if guided:
         eng.load_predictor(pargs, psd)
@@ -133,7 +140,7 @@ def main():
     def one_pass(it):
         x, h, diag = eng.sample(nm, em, seed=1234 + it, sample_offset=rank * B, std=1.0, target_w=tw, scale=0.6)
         if world > 1:
-            x, h = gdist.gather_to_all(x, h, B * world, N, F, device=dev)
+            x, h = gdist.gather_to_all(x, h, B * world, N, F, device=dev if backend == "nccl" else None)
         return x, h, diag
 
     def sync():
@@ -152,7 +159,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n_launch, kern_ms, steps_done = eng.profile_get()
