@@ -186,7 +186,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "guided molecules/sec (1000-step)" if guided else "unguided molecules/sec (1000-step)",
+            "metric": ("guided" if guided else "unguided") + f" molecules/sec ({T}-step)",
             "value": value, "unit": "molecules/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded default-init weights, on-device Philox noise)",

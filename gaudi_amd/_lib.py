@@ -51,6 +51,7 @@ EXPORTS = {
     "gaudi_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, FP, FP, FP, FP]),
     "gaudi_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, FP,
                                C.c_float, FP, FP, FP, C.POINTER(Diag)]),
+    "gaudi_sample_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, C.c_int, FP]),
     "gaudi_philox_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, FP]),
     "gaudi_profile_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "gaudi_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -82,17 +82,9 @@ __device__ __forceinline__ f4 silu4(f4 u) {
 }
 __device__ __forceinline__ f4 splat(float v) { return (f4){v, v, v, v}; }
 
-__device__ __forceinline__ f4 mfma4(f4 w, f4 b, f4 acc) {
-  // 4 k-steps: the A fragment holds W[row = lane&15][k = 4*(lane>>4) + q], the B fragment the
-  // activation of column lane&15 at the same k (k order inside a 16-chunk is permuted
-  // consistently on both operands, which only changes the summation order).
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], b[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], b[3], acc, 0, 0, 0);
-  return acc;
-}
-
+// One MFMA k-step: the A fragment holds W[row = lane&15][k = 4*(lane>>4) + q], the B fragment the activation of
+// column lane&15 at the same k (the k order inside a 16-chunk is permuted consistently on both operands, which only
+// changes the summation order).
 __device__ __forceinline__ f4 mfma1(float w, float b, f4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, acc, 0, 0, 0);
 }

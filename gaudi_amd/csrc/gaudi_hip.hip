@@ -52,7 +52,7 @@ struct gaudi_handle {
   std::vector<float> gamma, coef;
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
-      d_pred, d_tw, d_stash;
+      d_pred, d_tw, d_stash, d_chain;
   int steps_per_launch = 25;
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
   // profiling
@@ -418,7 +418,7 @@ void gaudi_destroy(gaudi_handle* h) {
   }
   DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
                     &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
-                    &h->d_pred, &h->d_tw, &h->d_stash};
+                    &h->d_pred, &h->d_tw, &h->d_stash, &h->d_chain};
   for (DevBuf* b : bufs) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -570,7 +570,8 @@ static int fill_pred(gaudi_handle* h, KParams& P, const float* target_w, int B, 
 static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, const float* z_in,
                      bool do_init, int s_hi, int s_lo, bool do_decode, const float* noise, int draw_base, int n_draws,
                      uint64_t seed, int64_t sample_offset, float std0, const float* target_w, float scale,
-                     float* z_out, float* x_out, float* onehot_out, int* nan_count) {
+                     float* z_out, float* x_out, float* onehot_out, int* nan_count, float* chain_out = nullptr,
+                     int keep_frames = 0) {
   if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
   if (target_w && !h->has_pred) return fail(h, GAUDI_E_STATE, "guided sampling needs predictor weights");
   HIPCHECK(h, hipSetDevice(h->device));
@@ -604,6 +605,12 @@ static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, cons
   P.nan_count = h->d_nan.as<int>();
   P.guided = target_w != nullptr;
   P.scale = scale;
+  if (chain_out) {
+    HIPCHECK(h, h->d_chain.reserve(zb * (size_t)keep_frames));
+    HIPCHECK(h, hipMemsetAsync(h->d_chain.p, 0, zb * (size_t)keep_frames, h->stream));
+    P.chain_out = h->d_chain.as<float>();
+    P.keep_frames = keep_frames;
+  }
   int hpp = 0;
   if (target_w) {
     rc = fill_pred(h, P, target_w, B, N);
@@ -636,6 +643,8 @@ static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, cons
     HIPCHECK(h, hipMemcpyAsync(x_out, h->d_x.p, sizeof(float) * B * N * 3, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipMemcpyAsync(onehot_out, h->d_h.p, sizeof(float) * B * N * P.F, hipMemcpyDeviceToHost, h->stream));
   }
+  if (chain_out)
+    HIPCHECK(h, hipMemcpyAsync(chain_out, h->d_chain.p, zb * (size_t)keep_frames, hipMemcpyDeviceToHost, h->stream));
   int nanc = 0;
   HIPCHECK(h, hipMemcpyAsync(&nanc, h->d_nan.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -708,6 +717,26 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
     diag->nan_count = nanc;
     diag->reprojected = reproj;
   }
+  return GAUDI_OK;
+}
+
+int gaudi_sample_chain(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                       int64_t sample_offset, const float* noise, float std, int keep_frames, float* chain_out) {
+  if (!h || !node_mask || !edge_mask || !chain_out) return GAUDI_E_INVALID;
+  if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
+  const int T = h->ecfg.diffusion_steps, F = h->ecfg.in_node_nf, D = 3 + F;
+  if (keep_frames < 1 || keep_frames > T) return fail(h, GAUDI_E_INVALID, "keep_frames must be in 1..T");
+  std::vector<float> x((size_t)B * N * 3), oh((size_t)B * N * F);
+  int rc = run_chain(h, B, N, node_mask, edge_mask, nullptr, true, T - 1, 0, true, noise, 0, T + 2, seed, sample_offset,
+                     std, nullptr, 0.f, nullptr, x.data(), oh.data(), nullptr, chain_out, keep_frames);
+  if (rc) return rc;
+  // chain[0] = cat[x, h_categorical] (en_diffusion.py:1168-1169)
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n) {
+      float* dst = chain_out + ((size_t)b * N + n) * D;
+      for (int d = 0; d < 3; ++d) dst[d] = x[((size_t)b * N + n) * 3 + d];
+      for (int k = 0; k < F; ++k) dst[3 + k] = oh[((size_t)b * N + n) * F + k];
+    }
   return GAUDI_OK;
 }
 

@@ -44,6 +44,8 @@ struct KParams {
   float* stash;             // predictor activation stash, [B] x stash_stride floats
   long long stash_stride;
   float readout_div;        // padded N the predictor readout divides by
+  float* chain_out;         // sample_chain: [keep_frames][B][N][D] un-normalised frames, or nullptr
+  int keep_frames;
   unsigned long long* stamps;  // diagnostic builds only (-DGAUDI_STAMPS): [ST_N] cycle sums of block 0
 };
 
@@ -188,6 +190,19 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
               sZ[e] = v;
             }
             __syncthreads();
+          }
+          if (P.chain_out != nullptr) {
+            // sample_chain (en_diffusion.py:1145-1161): frame (s*K)//T receives unnormalize_z(z_s); a later (smaller) s
+            // mapping to the same frame overwrites it, so only the last writer of each frame stores.
+            const int K = P.keep_frames;
+            const int idx = (int)(((long long)s * K) / T);
+            if (s == 0 || (int)(((long long)(s - 1) * K) / T) != idx) {
+              float* dst = P.chain_out + ((size_t)idx * P.B + b) * N * D;
+              for (int e = tid; e < N * D; e += kThreads) {
+                const int n = e / D, d = e % D;
+                dst[e] = d < 3 ? sZ[e] * P.nv0 : (sZ[e] * P.nv1 + 0.0f) * sMask[n];
+              }
+            }
           }
         } else {
           // ---- decode: sample_p_xh_given_z0 (en_diffusion.py:533-560) + unnormalize (:406-415)

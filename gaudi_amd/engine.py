@@ -194,6 +194,18 @@ class Engine:
                  nan_count=diag.nan_count, reprojected=diag.reprojected)
         return (x, h, d, z0) if return_z0 else (x, h, d)
 
+    def sample_chain(self, node_mask, edge_mask, keep_frames, *, seed=0, sample_offset=0, noise=None, std=1.0):
+        """-> chain [keep_frames, B, N, 3+F] (frame 0 = final [x | one_hot])."""
+        nm = f32(node_mask)
+        B, N = nm.shape[0], nm.shape[1]
+        nm, em = self._masks(nm, edge_mask, B, N)
+        D = 3 + self.F
+        nz = None if noise is None else f32(noise)
+        chain = np.empty((int(keep_frames), B, N, D), np.float32)
+        self._check(self.lib.gaudi_sample_chain(self.h, B, N, fptr(nm), fptr(em), int(seed), int(sample_offset), fptr(nz),
+                                                float(std), int(keep_frames), fptr(chain)), "gaudi_sample_chain")
+        return chain
+
     def philox_normal(self, seed, sample_offset, B, n_elem, draw0, n_draws) -> np.ndarray:
         out = np.empty((n_draws, B, n_elem), np.float32)
         self._check(self.lib.gaudi_philox_normal(self.h, int(seed), int(sample_offset), B, n_elem, draw0, n_draws,

@@ -134,6 +134,19 @@ class GaudiModel:
             raise GaudiError("context conditioning is not part of the GaUDI sampling path")
         return self._run(n_samples, node_mask, edge_mask, std, None, 1.0, fix_noise)
 
+    def sample_chain(self, n_samples, n_nodes, node_mask, edge_mask, context, keep_frames=None, std=1.0):
+        """EnVariationalDiffusion.sample_chain (en_diffusion.py:1118-1174) -> chain_flat [keep_frames*n_samples, N, 3+F]."""
+        if context is not None:
+            raise GaudiError("context conditioning is not part of the GaUDI sampling path")
+        nm = _to_numpy(node_mask).astype(np.float32)
+        B, N = nm.shape[0], nm.shape[1]
+        K = self.T if keep_frames is None else int(keep_frames)
+        assert K <= self.T
+        chain = self.engine.sample_chain(nm.reshape(B, N), _to_numpy(edge_mask).astype(np.float32).reshape(B, N, N), K,
+                                         seed=self.seed, sample_offset=self.sample_offset, noise=self.injected_noise,
+                                         std=std)
+        return _like_ref(chain.reshape(K * B, N, chain.shape[-1]))
+
     def sample_guidance(self, n_samples, target_function, node_mask, edge_mask, scale=1, fix_noise=False, std=1.0):
         """EnVariationalDiffusion.sample_guidance (en_diffusion.py:1010-1067)."""
         return self._run(n_samples, node_mask, edge_mask, std, target_function, scale, fix_noise)

@@ -125,6 +125,13 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
                  float scale, float* x_out /* [B,N,3] */, float* onehot_out /* [B,N,F] */,
                  float* z0_out /* [B,N,3+F] or NULL */, gaudi_diag* diag /* or NULL */);
 
+/* EnVariationalDiffusion.sample_chain (en_diffusion.py:1118-1174): the unguided chain with `keep_frames`
+ * intermediate states: chain_out [keep_frames,B,N,3+F], frame (s*keep_frames)//T = unnormalize_z(z_s) of the last
+ * step s mapping to it, frame 0 = the final [x | one_hot].  (The reference returns the same data viewed as
+ * [keep_frames*B, N, 3+F].) */
+int gaudi_sample_chain(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                       int64_t sample_offset, const float* noise, float std, int keep_frames, float* chain_out);
+
 /* Device Philox stream used when noise == NULL, exposed for tests: out[draw][b][e], e < n_elem. */
 int gaudi_philox_normal(gaudi_handle* h, uint64_t seed, int64_t sample_offset, int B, int n_elem, int draw0,
                         int n_draws, float* out);

@@ -504,3 +504,22 @@ def sample(edm_sd, cfg, node_mask, edge_mask, noise, std=1.0, pred_sd=None, pcfg
     if max_cog > 5e-2:  # en_diffusion.py:1000-1006
         x = remove_mean_with_mask(x, nm)
     return x, h, z
+
+
+def sample_chain(edm_sd, cfg, node_mask, edge_mask, noise, keep_frames, std=1.0, dtype=F32):
+    """EnVariationalDiffusion.sample_chain (en_diffusion.py:1118-1174) -> chain [keep_frames,B,N,3+F]
+    (the reference returns it viewed as [keep_frames*B, N, 3+F])."""
+    T = cfg["diffusion_steps"]
+    gamma = gamma_table(cfg["diffusion_noise_schedule"], T, cfg["diffusion_noise_precision"])
+    B, N, _ = node_mask.shape
+    nm = np.asarray(node_mask, dtype=dtype).reshape(B, N, 1)
+    nv = cfg["normalize_factors"]
+    z = _combined_noise(np.asarray(noise[0], dtype=dtype), nm, std)
+    chain = np.zeros((keep_frames,) + z.shape, dtype=dtype)
+    for k, s in enumerate(reversed(range(T))):
+        z = step_unguided(edm_sd, cfg, gamma, s, z, nm, edge_mask, noise[1 + k], dtype)
+        frame = np.concatenate([z[:, :, :3] * dtype(nv[0]), (z[:, :, 3:] * dtype(nv[1]) + dtype(0.0)) * nm], axis=2)
+        chain[(s * keep_frames) // T] = frame  # unnormalize_z (en_diffusion.py:417-431)
+    x, h = decode_z0(edm_sd, cfg, gamma, z, nm, edge_mask, noise[T + 1], dtype)
+    chain[0] = np.concatenate([x, h], axis=2)
+    return chain

@@ -282,3 +282,20 @@ def test_error_paths():
     with pytest.raises(GaudiError, match="hidden"):
         eng.load_edm(synth.edm_args(nf=300), synth.synth_edm_state_dict(synth.edm_args(nf=300, n_layers=1), 1))
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_sample_chain(golden, name):
+    """EnVariationalDiffusion.sample_chain through the model mirror vs the reference's chain tensor."""
+    from gaudi_amd.models_edm import get_model
+    g = golden("g9_sample_chain")
+    cfg = cfg_of(g, name)
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=TINY, wseed=cfg["eseed"], amp=False), diffusion_steps=cfg["T"])
+    model, _, _ = get_model(eargs, state_dict=esd)
+    model.injected_noise = g[name + "_noise"]
+    nm, em = g[name + "_node_mask"], g[name + "_edge_mask"]
+    model.engine.set_steps_per_launch(7)  # frame writes must survive launch chunking
+    chain = model.sample_chain(nm.shape[0], nm.shape[1], nm, em, None, keep_frames=cfg["K"], std=cfg["std"]).numpy()
+    assert chain.shape == g[name + "_chain"].shape
+    assert rel_err(chain, g[name + "_chain"]) < TOL
+    model.engine.close()

@@ -130,3 +130,15 @@ def test_g7_tiny_chains(golden, name, tol_u, tol_g):
     x, h, _ = O.sample(esd, eargs, nm, em, noise, std=1.0, pred_sd=psd, pcfg=pargs,
                        target_w=O.target_max_gap_weights(5), scale=0.6)
     assert rel_err(x, g[name + "_x_guided"]) < tol_g
+
+
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_g9_sample_chain(golden, name):
+    """sample_chain: frame index (s*K)//T, later steps overwrite, frame 0 = final [x | one_hot]."""
+    g = golden("g9_sample_chain")
+    cfg = cfg_of(g, name)
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=TINY, wseed=cfg["eseed"], amp=False), diffusion_steps=cfg["T"])
+    chain = O.sample_chain(esd, eargs, g[name + "_node_mask"], g[name + "_edge_mask"], g[name + "_noise"], cfg["K"], std=cfg["std"])
+    ref = g[name + "_chain"].reshape(chain.shape)  # reference returns [K*B, N, D]
+    assert rel_err(chain, ref) < 1e-4
+    assert np.array_equal(chain[0][:, :, 3:], ref[0][:, :, 3:])  # the one-hot part of the final frame

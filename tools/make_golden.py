@@ -383,6 +383,26 @@ def g7_end_to_end():
     save("g7_end_to_end", **out)
 
 
+def g9_sample_chain():
+    """EnVariationalDiffusion.sample_chain (keep_frames trajectory capture), tiny config, injected noise."""
+    out = {}
+    T, K = 50, 10
+    for ci, (name, ds, nodes) in enumerate([("cata", "cata", [6, 8]), ("hetro", "hetro", [3, 5])]):
+        F = synth.num_node_features(ds)
+        over = dict(diffusion_steps=T, **TINY)
+        esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=900 + ci)
+        a, model = build_ref_edm(ds, esd, **over)
+        nm, em = masks(ds, nodes, None)
+        B, N, _ = nm.shape
+        noise = rng_noise(920 + ci, (T + 2, B, N, 3 + F))
+        with InjectNoise(list(noise)):
+            chain = model.sample_chain(B, N, torch.from_numpy(nm), torch.from_numpy(em), None, keep_frames=K, std=0.7)
+        out[f"{name}_noise"], out[f"{name}_node_mask"], out[f"{name}_edge_mask"] = noise, nm, em
+        out[f"{name}_chain"] = chain.numpy()
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, T=T, K=K, eseed=900 + ci, nodes=nodes, amp=False, std=0.7)))
+    save("g9_sample_chain", **out)
+
+
 def g8_checkpoint_roundtrip():
     """The reference's own loader must accept checkpoints written by gaudi_amd.synth.write_checkpoint
     (args.txt + model.pt, with and without the ``module.`` prefix).  Stores nothing but a marker."""
@@ -407,8 +427,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain)
     for w in which:
         fns[w]()
