@@ -251,24 +251,27 @@ __device__ __forceinline__ void node_gemm_impl(const WBuf& wb, int Wa, const flo
         b0[u] = ldw4(wb, chunk(cc + 2) + toff[u], lo);
         b1[u] = ldw4(wb, chunk(cc + 3) + toff[u], lo);
       }
+#if GAUDI_PIN_SCHED
+      // plain fences in source order: LDS reads + set B loads | MFMAs on set A | set A loads | MFMAs on set B
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       mmx(a0, x0);
       mmx(a1, x1);
+#if GAUDI_PIN_SCHED
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
         a0[u] = ldw4(wb, chunk(cc + 4) + toff[u], lo);
         a1[u] = ldw4(wb, chunk(cc + 5) + toff[u], lo);
       }
+#if GAUDI_PIN_SCHED
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       mmx(b0, x2);
       mmx(b1, x3);
 #if GAUDI_PIN_SCHED
-      // keep the issue order written above: hipcc otherwise sinks the loads next to their consumers.
-      // (This exact group layout is the validated one; a variant with the LDS reads split per half
-      // produced wrong results at T = 13 and is not used.)
-      __builtin_amdgcn_sched_group_barrier(0x100, 4 * NT, 0);       // LDS reads (x0..x3)
-      __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);       // set B loads
-      __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT * NT, 0);  // MFMAs on set A
-      __builtin_amdgcn_sched_group_barrier(0x020, 2 * UT, 0);       // set A loads (4 chunks ahead)
-      __builtin_amdgcn_sched_group_barrier(0x008, 8 * UT * NT, 0);  // MFMAs on set B
+      __builtin_amdgcn_sched_barrier(0);
 #endif
     }
     // tail: KT % 4 chunks (0..3), the first two already in a0 / a1
@@ -394,6 +397,17 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
 #pragma unroll
             for (int e = 0; e < NE; ++e) acc[e][t0 + k] = mfma1(wq[(t0 + k) % PF][q], bin[e][q], acc[e][t0 + k]);
           }
+      if (t0 == 0) {  // next chunk's activations (clamped on the last trip: no branch), interleaved with group 0
+        const int ncc = cc + 1 < T ? cc + 1 : T - 1;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], sCr, sCd, g, ncc, ec[e].r, ec[e].d0));
+      }
+#if GAUDI_PIN_SCHED
+      // Plain scheduling fences in source order: MFMA group | refills of the slots it read | next group ...
+      // Left alone, hipcc sinks the refill loads next to their consumers.  (The group-solver pins used earlier were
+      // a few percent faster but miscompiled some instantiations -- DESIGN.md section 7.)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int k = 0; k < TG; ++k) {
         const int t = t0 + k;
@@ -403,19 +417,8 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
           wq[t % PF] = ldw4(wb, Wc + 256 * nxt, lo);
         }
       }
-      if (t0 == 0) {  // next chunk's activations (clamped on the last trip: no branch, same basic block)
-        const int ncc = cc + 1 < T ? cc + 1 : T - 1;
-#pragma unroll
-        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], sCr, sCd, g, ncc, ec[e].r, ec[e].d0));
-      }
 #if GAUDI_PIN_SCHED
-      if (t0 + TG <= T) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE * TG, 0);  // MFMA group on the queue slots ...
-        __builtin_amdgcn_sched_group_barrier(0x020, TG, 0);           // ... then their refills
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NE, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
 #endif
     }
 #pragma unroll
