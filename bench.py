@@ -176,7 +176,8 @@ def main():
         per_launch_flops = f_written * B * evals / max(n_launch, 1)
         achieved = per_launch_flops / (avg_launch_ms * 1e-3) / 1e12
         wbytes = 4 * (sum(v.size for v in esd.values()) + (2 * sum(v.size for v in psd.values()) if guided else 0))
-        stash = 4 * pargs["n_layers"] * (2 * N * 208 + 4 * N) if guided else 0
+        # predictor stash per molecule-step: node part (P, Q, npre, x) + edge part (v, cpre of every 16-edge tile)
+        stash = 4 * pargs["n_layers"] * ((3 * N * 208 + 4 * N) + 4 * 32 * 208 * 2) if guided else 0
         hbm_bytes_launch = flops.step_bytes_fused(B, N, F, 0, stash) * steps_done / max(n_launch, 1) + wbytes
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
