@@ -126,6 +126,13 @@ __device__ __forceinline__ WBuf make_wbuf(const float* p, unsigned bytes) {
 __device__ __forceinline__ f4 ldw4(const WBuf& w, int off_floats, int lane_f4) {
   return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(w.r, lane_f4 * 16, off_floats * 4, 0));
 }
+// node-GEMM weight tiles are read once per CU (no reuse in L1): cache-policy bits for those loads (experiment knob)
+#ifndef GAUDI_NODE_LOAD_AUX
+#define GAUDI_NODE_LOAD_AUX 0
+#endif
+__device__ __forceinline__ f4 ldw4n(const WBuf& w, int off_floats, int lane_f4) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(w.r, lane_f4 * 16, off_floats * 4, GAUDI_NODE_LOAD_AUX));
+}
 __device__ __forceinline__ float ldw1(const WBuf& w, int off_floats) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w.r, 0, off_floats * 4, 0));
 }
@@ -155,8 +162,8 @@ __device__ __forceinline__ void node_prefetch(NodePF<HP>& pf, const WBuf& wb, in
   for (int u = 0; u < UT; ++u) {
     const int t = wave + kWaves * u;
     const int toff = (t < T ? t : T - 1) * 256;
-    pf.a0[u] = ldw4(wb, W + toff, lo);
-    pf.a1[u] = ldw4(wb, W + (T > 1 ? T : 0) * 256 + toff, lo);
+    pf.a0[u] = ldw4n(wb, W + toff, lo);
+    pf.a1[u] = ldw4n(wb, W + (T > 1 ? T : 0) * 256 + toff, lo);
   }
 }
 
@@ -216,8 +223,8 @@ __device__ __forceinline__ void node_gemm_impl(const WBuf& wb, int Wa, const flo
     } else {
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
-        a0[u] = ldw4(wb, chunk(0) + toff[u], lo);
-        a1[u] = ldw4(wb, chunk(1) + toff[u], lo);
+        a0[u] = ldw4n(wb, chunk(0) + toff[u], lo);
+        a1[u] = ldw4n(wb, chunk(1) + toff[u], lo);
       }
     }
     // k-step (q) outermost over NT*UT independent accumulators
@@ -248,8 +255,8 @@ __device__ __forceinline__ void node_gemm_impl(const WBuf& wb, int Wa, const flo
       }
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
-        b0[u] = ldw4(wb, chunk(cc + 2) + toff[u], lo);
-        b1[u] = ldw4(wb, chunk(cc + 3) + toff[u], lo);
+        b0[u] = ldw4n(wb, chunk(cc + 2) + toff[u], lo);
+        b1[u] = ldw4n(wb, chunk(cc + 3) + toff[u], lo);
       }
 #if GAUDI_PIN_SCHED
       // plain fences in source order: LDS reads + set B loads | MFMAs on set A | set A loads | MFMAs on set B
@@ -262,8 +269,8 @@ __device__ __forceinline__ void node_gemm_impl(const WBuf& wb, int Wa, const flo
 #endif
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
-        a0[u] = ldw4(wb, chunk(cc + 4) + toff[u], lo);
-        a1[u] = ldw4(wb, chunk(cc + 5) + toff[u], lo);
+        a0[u] = ldw4n(wb, chunk(cc + 4) + toff[u], lo);
+        a1[u] = ldw4n(wb, chunk(cc + 5) + toff[u], lo);
       }
 #if GAUDI_PIN_SCHED
       __builtin_amdgcn_sched_barrier(0);
@@ -278,7 +285,7 @@ __device__ __forceinline__ void node_gemm_impl(const WBuf& wb, int Wa, const flo
     const int rem = KT - main_end;
     if (rem >= 3) {
 #pragma unroll
-      for (int u = 0; u < UT; ++u) b0[u] = ldw4(wb, chunk(main_end + 2) + toff[u], lo);
+      for (int u = 0; u < UT; ++u) b0[u] = ldw4n(wb, chunk(main_end + 2) + toff[u], lo);
     }
     if (rem >= 1) mm(a0, main_end);
     if (rem >= 2) mm(a1, main_end + 1);

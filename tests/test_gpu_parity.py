@@ -299,3 +299,41 @@ def test_sample_chain(golden, name):
     assert chain.shape == g[name + "_chain"].shape
     assert rel_err(chain, g[name + "_chain"]) < TOL
     model.engine.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_general_edge_masks(O, seed):
+    """The ABI takes an arbitrary edge_mask[B,N,N]: asymmetric, sparse, with self loops and non-binary weights.
+    (The reference only ever builds symmetric 0/1 masks; its arithmetic is defined for any mask, and the oracle
+    restates that arithmetic.)  Exercises the live-edge lists, uneven wave loads, idle waves in the lock-step reverse
+    pass and the transposed (column) scatter with an asymmetric pattern."""
+    rng = np.random.default_rng(seed)
+    F, N, B = 3, 9, 6
+    eargs = synth.edm_args(nf=48, n_layers=2, inv_sublayers=2, diffusion_steps=8, normalization_factor=2.0)
+    pargs = synth.pred_args(nf=40, n_layers=3)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=31 + seed, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 4, seed=41 + seed, amplify_coord=True)
+    eng = make_engine(eargs, esd, pargs, psd)
+    n_live = rng.integers(2, N + 1, size=B)
+    nm = (np.arange(N)[None, :] < n_live[:, None]).astype(np.float32)[:, :, None]
+    em = (rng.random((B, N, N)) < 0.45).astype(np.float32) * rng.choice([1.0, 1.0, 0.5, 2.0], size=(B, N, N)).astype(np.float32)
+    em *= nm * nm.transpose(0, 2, 1)          # no edges to padded nodes
+    em[0] = 0                                  # a molecule with no edges at all
+    em[1, 3:, :] = 0                           # some waves / nodes idle
+    z = rng.standard_normal((B, N, 3 + F)).astype(np.float32) * nm
+    z[:, :, :3] -= z[:, :, :3].sum(1, keepdims=True) / nm.sum(1, keepdims=True) * nm
+    t = rng.random(B).astype(np.float32)
+    assert rel_err(eng.phi(z, t, nm, em), O.edm_phi(esd, eargs, z, t, nm, em)) < TOL
+    dp = rng.standard_normal((B, 4)).astype(np.float32)
+    pred, grad = eng.predictor_grad(z, t, nm, em, dp)
+    po, go = O.predictor_grad(psd, pargs, z, nm, em, t, dp)
+    assert rel_err(pred, po) < TOL
+    assert rel_err(grad, go) < TOL
+    gamma = O.gamma_table("polynomial_2", 8, 1e-5)
+    eps = rng.standard_normal(z.shape).astype(np.float32)
+    w = np.array([0.5, -1.0, 0.25, 0.0], np.float32)
+    for s in (7, 3, 0):
+        got = eng.step(s, z, nm, em, eps, target_w=w, scale=0.8)
+        want = O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.8)
+        assert rel_err(got, want) < TOL, s
+    eng.close()
