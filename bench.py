@@ -42,32 +42,31 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(eargs, pargs, esd, psd, guided, T):
-    """The numpy oracle (kind "port") on this host's cores over a bounded sample of the same workload:
-    a few guided reverse steps at N=11 on a small batch, extrapolated to T steps + decode."""
+def cpu_baseline(eargs, pargs, esd, psd, guided, T, B):
+    """The numpy oracle (kind "port") on this host's cores over a bounded sample of the SAME workload shape:
+    a few reverse steps of the full batch (B molecules, N=11), extrapolated to T steps + decode."""
     from oracle import gaudi_oracle as O  # baseline leg only
-    Bc = 32
-    nm, em = O.build_masks([11] * Bc, 11, False)
+    nm, em = O.build_masks([11] * B, 11, False)
     rng = np.random.default_rng(0)
-    z = O._combined_noise(rng.standard_normal((Bc, 11, 4)).astype(np.float32), nm)
+    z = O._combined_noise(rng.standard_normal((B, 11, 4)).astype(np.float32), nm)
     gamma = O.gamma_table(eargs["diffusion_noise_schedule"], T, eargs["diffusion_noise_precision"])
     w = O.target_max_gap_weights(5)
 
     def one(s):
-        eps = rng.standard_normal((Bc, 11, 4)).astype(np.float32)
+        eps = rng.standard_normal((B, 11, 4)).astype(np.float32)
         if guided:
             return O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6)
         return O.step_unguided(esd, eargs, gamma, s, z, nm, em, eps)
 
     one(T - 1)  # warm-up
     n_steps, t0 = 0, time.time()
-    while n_steps < 3 or (time.time() - t0 < 10.0 and n_steps < 40):
+    while n_steps < 2 or (time.time() - t0 < 12.0 and n_steps < 20):
         one(T - 2 - n_steps)
         n_steps += 1
     per_step = (time.time() - t0) / n_steps
     total = per_step * T * (1.0 + (1.0 / T) * (0.3 if guided else 1.0))  # + decode = one EDM evaluation
-    return dict(value=Bc / total, unit="molecules/s", cores=os.cpu_count(), kind="port",
-                sample=f"numpy oracle (BLAS threads = all {os.cpu_count()} cores), B={Bc} x {n_steps} "
+    return dict(value=B / total, unit="molecules/s", cores=os.cpu_count(), kind="port",
+                sample=f"numpy oracle (BLAS threads = all {os.cpu_count()} cores), B={B} x {n_steps} "
                        f"{'guided' if guided else 'unguided'} reverse steps at N=11, extrapolated x{T} + decode; "
                        f"{per_step * 1e3:.0f} ms/step")
 
@@ -211,7 +210,10 @@ def main():
             "diag": diag,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(eargs, pargs, esd, psd, guided, T)
+            out["cpu_baseline"] = cpu_baseline(synth.edm_args(diffusion_steps=T), synth.pred_args(),
+                                                synth.synth_edm_state_dict(synth.edm_args(diffusion_steps=T), 1, seed=0),
+                                                synth.synth_predictor_state_dict(synth.pred_args(), 1, K, seed=1), guided, T,
+                                                256)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     eng.close()

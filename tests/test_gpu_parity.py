@@ -337,3 +337,34 @@ def test_general_edge_masks(O, seed):
         want = O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.8)
         assert rel_err(got, want) < TOL, s
     eng.close()
+
+
+def test_design_entry_point():
+    """generation_guidance.design with the reference's argument list: guided sampling, target values and predictions
+    at t=0, ranking.  Checks the pieces against the oracle."""
+    import types
+    from gaudi_amd import generation_guidance as gg
+    from gaudi_amd.models_edm import PropertyNorm, get_cond_predictor_model, get_model, target_function_opv
+    from oracle import gaudi_oracle as O
+    eargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=10)
+    pargs = synth.pred_args(nf=36, n_layers=2)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=51)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=52)
+    model, _, _ = get_model(eargs, state_dict=esd)
+    pred = get_cond_predictor_model(pargs, model=model, state_dict=psd)
+    prop = PropertyNorm(mean=[0.3, -1.0, 0.5, 2.0, 0.1], std=[1.5, 0.7, 2.0, 0.9, 1.1])
+    target = target_function_opv(pred, prop)
+    args = types.SimpleNamespace(device="cuda", dataset="cata", batch_size=6)
+    model.seed = 11
+    out = gg.design(args, model, pred, target, None, prop, scale=0.6, n_nodes=7)
+    x, h = out["x"].numpy(), out["one_hot"].numpy()
+    assert x.shape == (6, 7, 3) and np.isfinite(x).all()
+    # predictions / target values at t = 0 on the normalised sample (generation_guidance.py:34-66)
+    nm, em = out["node_mask"].numpy(), out["edge_mask"].numpy()
+    xh = np.concatenate([x / 3.0, h / 4.0 * nm], axis=-1).astype(np.float32)
+    po = O.predictor_forward(psd, pargs, xh, nm, em, np.zeros(6, np.float32))
+    assert rel_err(out["pred"].numpy(), prop.unnormalize(po)) < TOL
+    u = prop.unnormalize(po)
+    assert rel_err(out["target_function_values"].numpy(), u[:, 3] + u[:, 2] + 3 * u[:, 0]) < TOL
+    assert sorted(out["best"].tolist()) == list(range(6))
+    model.engine.close()
