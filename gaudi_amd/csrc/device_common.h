@@ -161,7 +161,7 @@ __device__ __forceinline__ void node_prefetch(NodePF<HP>& pf, const WBuf& wb, in
 #pragma unroll
   for (int u = 0; u < UT; ++u) {
     const int t = wave + kWaves * u;
-    const int toff = (t < T ? t : T - 1) * 256;
+    const int toff = (t < T ? t : wave) * 256;  // same dummy-tile rule as node_gemm_impl
     pf.a0[u] = ldw4n(wb, W + toff, lo);
     pf.a1[u] = ldw4n(wb, W + (T > 1 ? T : 0) * 256 + toff, lo);
   }
@@ -180,13 +180,14 @@ __device__ __forceinline__ void node_gemm_impl(const WBuf& wb, int Wa, const flo
   const int c = lane & 15, g = lane >> 4;
   const int lo = c * 4 + g;  // lane's float4 inside a 16x16 tile
   const int n_tiles = (N + 15) >> 4;
-  // Branch-free inner loops: every wave runs UT output tiles; a wave without a UT-th tile recomputes
-  // tile T-1 and drops the result (wave-uniform test in the epilogue only).
+  // Branch-free inner loops: every wave runs UT output tiles; a wave without a UT-th tile recomputes its OWN first
+  // tile and drops the result (wave-uniform test in the epilogue only).  Re-reading a tile this wave has just
+  // requested hits L1; streaming some other tile would add L2 traffic to a loop that is bound by exactly that.
   int toff[UT];  // float offset of the wave's tiles inside one K chunk of a packed matrix
 #pragma unroll
   for (int u = 0; u < UT; ++u) {
     const int t = wave + kWaves * u;
-    toff[u] = (t < T ? t : T - 1) * 256;
+    toff[u] = (t < T ? t : wave) * 256;
   }
   // Two sources (Y = Wa Xa + Wb Xb) run as ONE K loop of 2T chunks so the load pipeline never restarts.
   const int KT = Wb >= 0 ? 2 * T : T;
