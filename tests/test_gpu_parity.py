@@ -368,3 +368,39 @@ def test_design_entry_point():
     assert rel_err(out["target_function_values"].numpy(), u[:, 3] + u[:, 2] + 3 * u[:, 0]) < TOL
     assert sorted(out["best"].tolist()) == list(range(6))
     model.engine.close()
+
+
+@pytest.mark.parametrize("he,hp,N,F", [(64, 64, 5, 1), (128, 128, 17, 12), (256, 256, 11, 1), (200, 200, 20, 12),
+                                       (192, 192, 16, 1), (60, 33, 7, 2)])
+def test_every_kernel_instantiation(O, he, hp, N, F):
+    """One shallow network per instantiated (padded) hidden size -- 64, 128, 256, 208, 192, 64/48 -- with N below,
+    at and above one 16-node column tile: phi, predictor gradient and a guided step against the oracle."""
+    rng = np.random.default_rng(he + hp + N)
+    B = 5
+    eargs = synth.edm_args(nf=he, n_layers=2, diffusion_steps=20)
+    pargs = synth.pred_args(nf=hp, n_layers=2)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=61, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=62, amplify_coord=True)
+    try:
+        eng = make_engine(eargs, esd, pargs, psd)
+    except Exception as e:  # a size without a fused instantiation must fail loudly, not silently
+        pytest.fail(f"load failed: {e}")
+    n_live = rng.integers(2, N + 1, size=B)
+    n_live[0] = N
+    nm = (np.arange(N)[None, :] < n_live[:, None]).astype(np.float32)[:, :, None]
+    em = (nm * nm.transpose(0, 2, 1) * (1 - np.eye(N, dtype=np.float32))[None]).astype(np.float32)
+    z = rng.standard_normal((B, N, 3 + F)).astype(np.float32) * nm
+    z[:, :, :3] -= z[:, :, :3].sum(1, keepdims=True) / nm.sum(1, keepdims=True) * nm
+    t = rng.random(B).astype(np.float32)
+    assert rel_err(eng.phi(z, t, nm, em), O.edm_phi(esd, eargs, z, t, nm, em)) < TOL
+    dp = rng.standard_normal((B, 5)).astype(np.float32)
+    pred, grad = eng.predictor_grad(z, t, nm, em, dp)
+    po, go = O.predictor_grad(psd, pargs, z, nm, em, t, dp)
+    assert rel_err(pred, po) < TOL and rel_err(grad, go) < TOL
+    if (he, hp) in ((64, 64), (128, 128), (256, 256), (200, 200), (192, 192)):  # sizes with a fused instantiation
+        gamma = O.gamma_table("polynomial_2", 20, 1e-5)
+        eps = rng.standard_normal(z.shape).astype(np.float32)
+        w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
+        got = eng.step(11, z, nm, em, eps, target_w=w, scale=0.7)
+        assert rel_err(got, O.step_guided(esd, eargs, psd, pargs, gamma, 11, z, nm, em, eps, w, 0.7)) < TOL
+    eng.close()
