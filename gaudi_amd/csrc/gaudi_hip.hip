@@ -766,6 +766,46 @@ int gaudi_philox_normal(gaudi_handle* h, uint64_t seed, int64_t sample_offset, i
   return GAUDI_OK;
 }
 
+// ---- device-free entry points: the host logic of the library, callable (and tested) without a GPU
+int gaudi_host_schedule(int T, float noise_power, float noise_precision, float* gamma_out, float* coef_out) {
+  if (T < 1 || !gamma_out) return GAUDI_E_INVALID;
+  const std::vector<float> g = make_gamma(T, noise_power, noise_precision);
+  std::memcpy(gamma_out, g.data(), sizeof(float) * g.size());
+  if (coef_out) {
+    std::vector<float> c;
+    make_coef(g, T, c);
+    std::memcpy(coef_out, c.data(), sizeof(float) * c.size());
+  }
+  return GAUDI_OK;
+}
+
+int gaudi_host_graph_meta(int B, int N, const float* node_mask, const float* edge_mask, int32_t* ew_out,
+                          int32_t* order_out, int32_t* npairs_out, uint32_t* seg_out, uint32_t* edges_out,
+                          float* emask_out, int32_t edges_capacity) {
+  if (B <= 0 || N <= 0 || !edge_mask || !ew_out) return GAUDI_E_INVALID;
+  Meta M;
+  std::string err;
+  const int rc = build_meta(B, N, node_mask, edge_mask, M, err);
+  if (rc) return rc;
+  *ew_out = M.EW;
+  if (order_out) std::memcpy(order_out, M.order.data(), sizeof(int) * B);
+  if (npairs_out) std::memcpy(npairs_out, M.npairs.data(), sizeof(int) * B * kWaves);
+  if (seg_out) std::memcpy(seg_out, M.seg.data(), sizeof(uint32_t) * B * N);
+  if (edges_out || emask_out) {
+    if ((size_t)edges_capacity < M.edges.size()) return GAUDI_E_CAPACITY;
+    if (edges_out) std::memcpy(edges_out, M.edges.data(), sizeof(uint32_t) * M.edges.size());
+    if (emask_out) std::memcpy(emask_out, M.emask.data(), sizeof(float) * M.emask.size());
+  }
+  return GAUDI_OK;
+}
+
+int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, const float* W, float* packed_out) {
+  if (H < 1 || HP < H || HP % 16 || !W || !packed_out) return GAUDI_E_INVALID;
+  std::memset(packed_out, 0, sizeof(float) * (size_t)HP * HP);
+  pack_matrix(packed_out, W, H, ldw, col0, HP, transpose != 0);
+  return GAUDI_OK;
+}
+
 int gaudi_profile_reset(gaudi_handle* h, int enable) {
   if (!h) return GAUDI_E_INVALID;
   for (auto& p : h->prof_events) {

@@ -28,3 +28,114 @@ def test_no_cpu_fallback_without_gpu():
     from gaudi_amd.engine import Engine
     with pytest.raises(GaudiError):
         Engine(0)
+
+
+# ---- device-free host logic of the library (C++), checked on CPU -------------------------------------------------
+import ctypes as C  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+
+def _lib():
+    from gaudi_amd import _lib, build
+    build.build()
+    return _lib.load_library(), _lib
+
+
+def test_host_schedule_matches_reference(golden):
+    """gamma table and per-step scalars built by the C++ host code vs the reference's PredefinedNoiseSchedule /
+    sigma_and_alpha_t_given_s outputs (golden g1)."""
+    lib, L = _lib()
+    g = golden("g1_schedule")
+    for T in (50, 1000):
+        gamma = np.empty(T + 1, np.float32)
+        coef = np.empty((T, 4), np.float32)
+        assert lib.gaudi_host_schedule(T, 2.0, 1e-5, L.fptr(gamma), L.fptr(coef)) == 0
+        np.testing.assert_allclose(gamma, g[f"gamma_T{T}"], rtol=2e-7, atol=0)
+        for row in g[f"coef_T{T}"]:
+            s = int(row[0])
+            np.testing.assert_allclose(coef[s], [row[1], row[3], row[4], row[7]], rtol=1e-5)
+    assert lib.gaudi_host_schedule(0, 2.0, 1e-5, L.fptr(gamma), None) != 0
+
+
+def _meta(lib, L, nm, em):
+    B, N = nm.shape[0], nm.shape[1]
+    nm = np.ascontiguousarray(nm.reshape(B, N), np.float32)
+    em = np.ascontiguousarray(em.reshape(B, N, N), np.float32)
+    ew = C.c_int32()
+    order = np.empty(B, np.int32)
+    npairs = np.empty((B, 4), np.int32)
+    seg = np.empty((B, N), np.uint32)
+    cap = B * 4 * 4096
+    edges = np.empty(cap, np.uint32)
+    emask = np.empty(cap, np.float32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    rc = lib.gaudi_host_graph_meta(B, N, L.fptr(nm), L.fptr(em), C.byref(ew), ip(order), ip(npairs), up(seg), up(edges),
+                                   L.fptr(emask), cap)
+    assert rc == 0
+    EW = ew.value
+    return EW, order, npairs, seg, edges[: B * 4 * EW].reshape(B, 4, EW), emask[: B * 4 * EW].reshape(B, 4, EW)
+
+
+@pytest.mark.parametrize("kind", ["cata", "hetro", "random"])
+def test_host_graph_meta_invariants(kind):
+    """Every live edge appears exactly once, in the list of the wave that owns its receiving node, lists are sorted by
+    receiving node, padded to 32 with mask-0 slots, and the launch order is heaviest-first."""
+    from oracle import gaudi_oracle as O
+    lib, L = _lib()
+    rng = np.random.default_rng(3)
+    if kind == "cata":
+        nm, em = O.build_masks([4, 11, 7, 1, 11, 0], 11, False)
+    elif kind == "hetro":
+        nm, em = O.build_masks([3, 5, 10, 7], 10, True)
+    else:
+        B, N = 5, 13
+        nm = np.ones((B, N, 1), np.float32)
+        em = (rng.random((B, N, N)) < 0.3).astype(np.float32) * rng.choice([1.0, 0.5], size=(B, N, N))
+        em[2] = 0
+    B, N = nm.shape[0], nm.shape[1]
+    em3 = np.asarray(em, np.float32).reshape(B, N, N)
+    EW, order, npairs, seg, edges, emask = _meta(lib, L, nm, em3)
+    assert EW % 32 == 0 and EW >= 32
+    totals = (em3 != 0).reshape(B, -1).sum(1)
+    assert sorted(order.tolist()) == list(range(B))
+    assert all(totals[order[k]] >= totals[order[k + 1]] for k in range(B - 1))
+    for b in range(B):
+        seen = {}
+        for w in range(4):
+            n_slots = npairs[b, w] * 32
+            assert n_slots <= EW
+            ii = (edges[b, w, :n_slots] & 255).astype(int)
+            jj = ((edges[b, w, :n_slots] >> 8) & 255).astype(int)
+            mk = emask[b, w, :n_slots]
+            live = mk != 0
+            assert np.all(np.diff(ii[live]) >= 0)  # sorted by receiving node
+            assert n_slots - live.sum() < 32 or live.sum() == 0  # padding only up to the next multiple of 32
+            for i, j, m in zip(ii[live], jj[live], mk[live]):
+                assert (i, j) not in seen
+                seen[(i, j)] = m
+                assert seg[b, i] >> 30 == w  # owned by this wave
+        want = {(i, j): em3[b, i, j] for i in range(N) for j in range(N) if em3[b, i, j] != 0}
+        assert seen == want
+        for n in range(N):  # segment word: start/len of node n's run inside its wave's list
+            w, st, ln = seg[b, n] >> 30, (seg[b, n] >> 15) & 0x7FFF, seg[b, n] & 0x7FFF
+            assert ln == int((em3[b, n] != 0).sum())
+            if ln:
+                assert np.all((edges[b, w, st:st + ln] & 255) == n)
+
+
+def test_host_pack_matrix_layout():
+    lib, L = _lib()
+    H, HP = 36, 48
+    W = np.random.default_rng(0).standard_normal((H, 2 * H + 2)).astype(np.float32)
+    for tr in (0, 1):
+        out = np.empty(HP * HP, np.float32)
+        assert lib.gaudi_host_pack_matrix(H, 2 * H + 2, H, HP, tr, L.fptr(W), L.fptr(out)) == 0
+        blk = W[:, H:2 * H].T if tr else W[:, H:2 * H]  # logical [o][k]
+        T = HP // 16
+        p = out.reshape(T, T, 16, 16)  # [k/16][o/16][o%16][k%16]
+        full = np.zeros((HP, HP), np.float32)
+        full[:H, :H] = blk
+        got = p.transpose(1, 2, 0, 3).reshape(HP, HP)
+        assert np.array_equal(got, full)
