@@ -527,6 +527,13 @@ struct SegSum {
   // scr: [16][LD] tile written as scr[col][feature]; node_of_col: value held by lane k = node of column k
   __device__ __forceinline__ void add_tile(const float* scr, int node_of_col, float* sOut, float div, int lane) {
     constexpr int LD = HP + 4;
+    // all 16 rows are fetched first (independent LDS reads, one latency), then folded in slot order; reading them one
+    // by one behind the wave-uniform "node changed" branches serialised 16 LDS round trips per tile
+    f4 row[16];
+    if (lane < HP / 4) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) row[k] = *(const f4*)(scr + k * LD + 4 * lane);
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int nk = __builtin_amdgcn_readlane(node_of_col, k);
@@ -535,7 +542,7 @@ struct SegSum {
         run = splat(0.f);
         cur = nk;
       }
-      if (lane < HP / 4) run += *(const f4*)(scr + k * LD + 4 * lane);
+      if (lane < HP / 4) run += row[k];
     }
   }
 };

@@ -50,3 +50,30 @@ def design(args, model, cond_predictor, target_function, nodes_dist, prop_dist, 
     order = np.argsort(tvals)  # best (lowest energy) first, as the reference's ranking
     return dict(x=x, one_hot=one_hot, node_mask=node_mask, edge_mask=edge_mask, target_function_values=_like_ref(tvals),
                 pred=_like_ref(pred), best=order, seconds=seconds, molecules_per_second=x.shape[0] / seconds)
+
+
+def main(args, cond_predictor_args, prop_mean=None, prop_std=None, target="max_gap", batch_size=512, scale=0.6,
+         n_nodes=10, device=0):
+    """generation_guidance.main (reference lines 187-222) for checkpoint directories in the reference's format.
+
+    ``args`` / ``cond_predictor_args`` come from ``gaudi_amd.checkpoint.get_edm_args / get_cond_predictor_args``
+    (``args.txt`` + ``model.pt``).  The reference builds a dataloader only to obtain the property normalisation
+    (``mean`` / ``std``, models_edm.py:111-112), which is not stored in checkpoints: pass it explicitly.  ``target`` is
+    "max_gap" or "opv" (the two targets shipped with the reference) or a LinearTarget factory taking the predictor."""
+    from .models_edm import (PropertyNorm, get_cond_predictor_model, get_model, target_function_max_gap,
+                             target_function_opv)
+    args.batch_size = batch_size  # the reference hard-codes these three knobs in main()
+    model, nodes_dist, _ = get_model(args, device=device)
+    cond_predictor = get_cond_predictor_model(cond_predictor_args, model=model)
+    prop_dist = None
+    if prop_mean is not None:
+        prop_dist = PropertyNorm(prop_mean, prop_std)
+    if target == "max_gap":
+        target_function = target_function_max_gap(cond_predictor)
+    elif target == "opv":
+        if prop_dist is None:
+            raise ValueError("the OPV target needs the property mean/std (prop_dist.unnormalize)")
+        target_function = target_function_opv(cond_predictor, prop_dist)
+    else:
+        target_function = target(cond_predictor)
+    return design(args, model, cond_predictor, target_function, nodes_dist, prop_dist, scale, n_nodes)

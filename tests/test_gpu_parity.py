@@ -417,3 +417,29 @@ def test_every_kernel_instantiation(O, he, hp, N, F):
         got = eng.step(11, z, nm, em, eps, target_w=w, scale=0.7)
         assert rel_err(got, O.step_guided(esd, eargs, psd, pargs, gamma, 11, z, nm, em, eps, w, 0.7)) < TOL
     eng.close()
+
+
+@pytest.mark.parametrize("dp", [True, False])
+def test_main_from_checkpoint_directories(tmp_path, dp):
+    """args.txt + model.pt on disk (reference format, with / without the DataParallel `module.` prefix) ->
+    get_edm_args / get_cond_predictor_args -> main() -> guided molecules; equals the in-memory path bit for bit."""
+    from gaudi_amd import checkpoint, generation_guidance as gg
+    eargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=8, dp=dp)
+    pargs = synth.pred_args(nf=36, n_layers=2, dp=dp)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=71)
+    esd["gamma.gamma"] = np.zeros(9, np.float32)  # present in real checkpoints; rebuilt from args by the loader
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=72)
+    synth.write_checkpoint(str(tmp_path / "edm"), eargs, esd)
+    synth.write_checkpoint(str(tmp_path / "pred"), pargs, psd)
+    a = checkpoint.get_edm_args(str(tmp_path / "edm"))
+    pa = checkpoint.get_cond_predictor_args(str(tmp_path / "pred"))
+    out = gg.main(a, pa, target="max_gap", batch_size=4, scale=0.6, n_nodes=6)
+    x = out["x"].numpy()
+    assert x.shape == (4, 6, 3) and np.isfinite(x).all()
+    eng = make_engine(eargs, esd, pargs, psd)
+    nm = np.ones((4, 6), np.float32)
+    em = np.broadcast_to(1 - np.eye(6, dtype=np.float32), (4, 6, 6)).copy()
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    x2, h2, _ = eng.sample(nm, em, seed=0, target_w=w, scale=0.6)
+    assert np.array_equal(x, x2) and np.array_equal(out["one_hot"].numpy(), h2)
+    eng.close()
