@@ -34,6 +34,9 @@ class Diag(C.Structure):
 
 
 FP = C.POINTER(C.c_float)
+# gaudi_target_cb(user, B, K, pred, t, dT_dpred_out)
+TARGET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, FP, C.c_float, FP)
+
 EXPORTS = {
     "gaudi_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "gaudi_destroy": (None, [C.c_void_p]),
@@ -51,6 +54,8 @@ EXPORTS = {
     "gaudi_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, FP, FP, FP, FP]),
     "gaudi_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, FP,
                                C.c_float, FP, FP, FP, C.POINTER(Diag)]),
+    "gaudi_sample_cb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, TARGET_CB,
+                                  C.c_void_p, C.c_float, FP, FP, FP, C.POINTER(Diag)]),
     "gaudi_sample_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, C.c_int, FP]),
     "gaudi_philox_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, FP]),
     "gaudi_host_schedule": (C.c_int, [C.c_int, C.c_float, C.c_float, FP, FP]),

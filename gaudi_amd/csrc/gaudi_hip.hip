@@ -566,6 +566,45 @@ int gaudi_phi(gaudi_handle* h, int B, int N, const float* z, const float* t, con
 
 static int fill_pred(gaudi_handle* h, KParams& P, const float* target_w, int B, int N);  // pred_host.inc
 
+// diagnostics replacing assert_correctly_masked / assert_mean_zero_with_mask (utils.py:52-65) and the
+// CoG re-projection of en_diffusion.py:1000-1006 (batch-wide condition -> host side)
+static void finish_sample(int B, int N, const float* node_mask, float* x_out, int nanc, gaudi_diag* diag) {
+  float leak = 0.f, cog = 0.f, big = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float s[3] = {0, 0, 0};
+    for (int n = 0; n < N; ++n)
+      for (int d = 0; d < 3; ++d) {
+        const float v = x_out[((size_t)b * N + n) * 3 + d];
+        s[d] += v;
+        big = std::max(big, std::fabs(v));
+        leak = std::max(leak, std::fabs(v * (1.f - node_mask[b * N + n])));
+      }
+    for (int d = 0; d < 3; ++d) cog = std::max(cog, std::fabs(s[d]));
+  }
+  int reproj = 0;
+  if (cog > 5e-2f) {
+    reproj = 1;
+    for (int b = 0; b < B; ++b) {
+      float cnt = 0.f;
+      for (int n = 0; n < N; ++n) cnt += node_mask[b * N + n];
+      cnt = std::max(cnt, 1.f);
+      for (int d = 0; d < 3; ++d) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += x_out[((size_t)b * N + n) * 3 + d];
+        const float mean = s / cnt;
+        for (int n = 0; n < N; ++n) x_out[((size_t)b * N + n) * 3 + d] -= mean * node_mask[b * N + n];
+      }
+    }
+  }
+  if (diag) {
+    diag->max_masked_leak = leak;
+    diag->max_cog_abs = cog;
+    diag->max_cog_rel = cog / (big + 1e-10f);
+    diag->nan_count = nanc;
+    diag->reprojected = reproj;
+  }
+}
+
 // shared by gaudi_step / gaudi_decode / gaudi_sample
 static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, const float* z_in,
                      bool do_init, int s_hi, int s_lo, bool do_decode, const float* noise, int draw_base, int n_draws,
@@ -681,42 +720,95 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
                      std, target_w, scale, z0_out, x_out, onehot_out, &nanc);
   if (rc) return rc;
   (void)F;
-  // diagnostics replacing assert_correctly_masked / assert_mean_zero_with_mask (utils.py:52-65) and the
-  // CoG re-projection of en_diffusion.py:1000-1006 (batch-wide condition -> host side)
-  float leak = 0.f, cog = 0.f, big = 0.f;
-  for (int b = 0; b < B; ++b) {
-    float s[3] = {0, 0, 0};
-    for (int n = 0; n < N; ++n)
-      for (int d = 0; d < 3; ++d) {
-        const float v = x_out[((size_t)b * N + n) * 3 + d];
-        s[d] += v;
-        big = std::max(big, std::fabs(v));
-        leak = std::max(leak, std::fabs(v * (1.f - node_mask[b * N + n])));
-      }
-    for (int d = 0; d < 3; ++d) cog = std::max(cog, std::fabs(s[d]));
+  finish_sample(B, N, node_mask, x_out, nanc, diag);
+  return GAUDI_OK;
+}
+
+int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                    int64_t sample_offset, const float* noise, float std, gaudi_target_cb target_grad, void* user,
+                    float scale, float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag) {
+  if (!h || !node_mask || !edge_mask || !x_out || !onehot_out || !target_grad) return GAUDI_E_INVALID;
+  if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
+  if (!h->has_pred) return fail(h, GAUDI_E_STATE, "guided sampling needs predictor weights");
+  HIPCHECK(h, hipSetDevice(h->device));
+  KParams P{};
+  int rc = stage_graph(h, B, N, node_mask, edge_mask, P);
+  if (rc) return rc;
+  fill_edm(h, P);
+  const int D = 3 + P.F, T = P.T, K = h->pcfg.out_nf;
+  const size_t zb = sizeof(float) * B * N * D, pb = sizeof(float) * B * K;
+  HIPCHECK(h, h->d_zin.reserve(zb));
+  HIPCHECK(h, h->d_zout.reserve(zb));
+  HIPCHECK(h, h->d_x.reserve(sizeof(float) * B * N * 3));
+  HIPCHECK(h, h->d_h.reserve(sizeof(float) * B * N * P.F));
+  HIPCHECK(h, h->d_nan.reserve(sizeof(int)));
+  HIPCHECK(h, h->d_pred.reserve(pb));
+  HIPCHECK(h, h->d_dpred.reserve(pb));
+  HIPCHECK(h, hipMemsetAsync(h->d_nan.p, 0, sizeof(int), h->stream));
+  if (noise) {
+    HIPCHECK(h, h->d_noise.reserve(zb * (size_t)(T + 2)));
+    HIPCHECK(h, hipMemcpyAsync(h->d_noise.p, noise, zb * (size_t)(T + 2), hipMemcpyHostToDevice, h->stream));
+    P.noise = h->d_noise.as<float>();
   }
-  int reproj = 0;
-  if (cog > 5e-2f) {
-    reproj = 1;
-    for (int b = 0; b < B; ++b) {
-      float cnt = 0.f;
-      for (int n = 0; n < N; ++n) cnt += node_mask[b * N + n];
-      cnt = std::max(cnt, 1.f);
-      for (int d = 0; d < 3; ++d) {
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += x_out[((size_t)b * N + n) * 3 + d];
-        const float mean = s / cnt;
-        for (int n = 0; n < N; ++n) x_out[((size_t)b * N + n) * 3 + d] -= mean * node_mask[b * N + n];
-      }
-    }
+  P.draw_base = 0;
+  P.draw_stride = (long long)B * N * D;
+  P.seed = seed;
+  P.sample_offset = sample_offset;
+  P.std0 = std;
+  P.mode = MODE_SAMPLE;
+  P.x_out = h->d_x.as<float>();
+  P.h_out = h->d_h.as<float>();
+  P.nan_count = h->d_nan.as<int>();
+  P.guided = 1;
+  P.scale = scale;
+  std::vector<float> zero_w(16, 0.f);
+  rc = fill_pred(h, P, zero_w.data(), B, N);
+  if (rc) return rc;
+  P.pred_out = h->d_pred.as<float>();
+  P.dpred_in = h->d_dpred.as<float>();
+  std::vector<float> pred((size_t)B * K), dT((size_t)B * K);
+  float* zin = h->d_zin.as<float>();
+  float* zout = h->d_zout.as<float>();
+  for (int s = T - 1; s >= 0; --s) {
+    // phase A: z_t -> z_s (before guidance) and pred = predictor(z_s, t); the activation stash stays on the device
+    P.s_hi = P.s_lo = s;
+    P.do_init = s == T - 1;
+    P.do_decode = 0;
+    P.split = 1;
+    P.z_in = zin;
+    P.z_out = zout;
+    rc = launch(h, P, h->HPE, h->HPP, 1);
+    if (rc) return rc;
+    HIPCHECK(h, hipMemcpyAsync(pred.data(), h->d_pred.p, pb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    std::fill(dT.begin(), dT.end(), 0.f);
+    target_grad(user, B, K, pred.data(), (float)(s + 1) / (float)T, dT.data());
+    HIPCHECK(h, hipMemcpyAsync(h->d_dpred.p, dT.data(), pb, hipMemcpyHostToDevice, h->stream));
+    // phase B: reverse pass with the caller's dT/dpred, clip / project / apply, CoG removal
+    P.do_init = 0;
+    P.split = 2;
+    P.z_in = zout;
+    P.z_out = zin;
+    rc = launch(h, P, h->HPE, h->HPP, 0);
+    if (rc) return rc;
   }
-  if (diag) {
-    diag->max_masked_leak = leak;
-    diag->max_cog_abs = cog;
-    diag->max_cog_rel = cog / (big + 1e-10f);
-    diag->nan_count = nanc;
-    diag->reprojected = reproj;
-  }
+  // decode pass
+  P.split = 0;
+  P.s_hi = -1;
+  P.s_lo = 0;
+  P.do_init = 0;
+  P.do_decode = 1;
+  P.z_in = zin;
+  P.z_out = zout;
+  rc = launch(h, P, h->HPE, h->HPP, 0);
+  if (rc) return rc;
+  if (z0_out) HIPCHECK(h, hipMemcpyAsync(z0_out, zout, zb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(x_out, h->d_x.p, sizeof(float) * B * N * 3, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipMemcpyAsync(onehot_out, h->d_h.p, sizeof(float) * B * N * P.F, hipMemcpyDeviceToHost, h->stream));
+  int nanc = 0;
+  HIPCHECK(h, hipMemcpyAsync(&nanc, h->d_nan.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  finish_sample(B, N, node_mask, x_out, nanc, diag);
   return GAUDI_OK;
 }
 

@@ -282,7 +282,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 // ---------------------------------------------------------------------------------------------
 template <int HP>
 __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
-                              float* sGrad, float readout_div, int tid STAMP_DECL) {
+                              float* sGrad, float readout_div, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -298,6 +298,18 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   for (int k = 0; k < kWaves; ++k) ntmax = max(ntmax, 2 * mg.npairs_all[k]);
   const int nt_me = 2 * mg.npairs;
 
+  if (sZin != nullptr) {
+    // split-step mode: the forward ran in an earlier launch; rebuild the two input-geometry tensors it left in LDS
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
+      const float v = sZin[n * D + d] * mg.mask[n];
+      sm.x[4 * n + d] = v;
+      sm.x0[4 * n + d] = v;
+    }
+    __syncthreads();
+    compute_geo(sm, mg, 0.f, wave, lane, true);
+    __syncthreads();
+  }
   // readout backward: dh = mask * (dpred / N_pad) . W_out
   {
     const float* ow = w + lay.out_w();
@@ -594,21 +606,26 @@ __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph
 }
 
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
+// phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
+// (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
 template <int HP>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                 float* sMean, float t_val, float sigma, const float* target_w, float scale,
-                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
+                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase = 0,
+                                const float* dpred_ext = nullptr) {
   (void)sTmp;
   const int N = mg.N, D = mg.D;
   PredSmem<HP> sm;
   sm.carve(net, N, mg.EW);
-  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
+  if (phase != 2) pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
-    if (pred_out) pred_out[tid] = sm.pred[tid];
-    sm.pred[16 + tid] = target_w[tid] * scale;  // energy = scale * sum_b T(pred_b), T linear in pred
+    if (pred_out && phase != 2) pred_out[tid] = sm.pred[tid];
+    // energy = scale * sum_b T(pred_b)  ->  d(energy)/dpred = scale * dT/dpred
+    sm.pred[16 + tid] = (phase == 2 ? dpred_ext[tid] : target_w[tid]) * scale;
   }
   __syncthreads();
-  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, tid STAMP_ARGS);
+  if (phase == 1) return;
+  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
   // clip_coef = min(1, 10 / (||g||_2 + 1e-6)) over all N*(3+F) entries   (en_diffusion.py:905-909)
   if (tid < 64) {
     float s = 0.f;

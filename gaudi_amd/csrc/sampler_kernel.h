@@ -44,6 +44,7 @@ struct KParams {
   float* stash;             // predictor activation stash, [B] x stash_stride floats
   long long stash_stride;
   float readout_div;        // padded N the predictor readout divides by
+  int split;                // 0 fused step; 1 = phase A (denoise + predictor forward); 2 = phase B (reverse pass + update)
   float* chain_out;         // sample_chain: [keep_frames][B][N][D] un-normalised frames, or nullptr
   int keep_frames;
   unsigned long long* stamps;  // diagnostic builds only (-DGAUDI_STAMPS): [ST_N] cycle sums of block 0
@@ -152,30 +153,35 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
         const float t_val = mode == MODE_PHI ? P.t_in[b] : cf[3];  // decode: t = 0
         if (is_step == false && mode == MODE_SAMPLE)               // z_0 is final: publish it
           for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
-        edm_forward<HPE>(edm, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
+        const int split = P.split;
+        if (split != 2) edm_forward<HPE>(edm, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
         if (mode == MODE_PHI) {
           for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
         } else if (is_step) {
-          // ---- z_s = z_t/alpha_ts - c*eps + sigma*noise ; x part mean-removed (en_diffusion.py:831-852)
-          combined_noise(T - s, 1.0f);
-          for (int e = tid; e < N * D; e += kThreads) {
-            float ep = sEps[e];
-            if (guided) {  // eps_t.nan_to_num(0.)  (en_diffusion.py:881)
-              if (ep != ep) { ep = 0.f; ++nan_local; }
-              ep = fminf(fmaxf(ep, -3.4028234663852886e38f), 3.4028234663852886e38f);
+          if (split != 2) {
+            // ---- z_s = z_t/alpha_ts - c*eps + sigma*noise ; x part mean-removed (en_diffusion.py:831-852)
+            combined_noise(T - s, 1.0f);
+            for (int e = tid; e < N * D; e += kThreads) {
+              float ep = sEps[e];
+              if (guided) {  // eps_t.nan_to_num(0.)  (en_diffusion.py:881)
+                if (ep != ep) { ep = 0.f; ++nan_local; }
+                ep = fminf(fmaxf(ep, -3.4028234663852886e38f), 3.4028234663852886e38f);
+              }
+              const float mu = sZ[e] / cf[0] - cf[1] * ep;
+              sZ[e] = mu + cf[2] * sNz[e];
             }
-            const float mu = sZ[e] / cf[0] - cf[1] * ep;
-            sZ[e] = mu + cf[2] * sNz[e];
+            __syncthreads();
           }
-          __syncthreads();
           if constexpr (HPP > 0) {
             if (guided) {
               // guidance (en_diffusion.py:899-920): predictor at (z_s, t), clip, project, apply
               guidance_update<HPP>(P.pred, mg, net, sZ, sEps /* grad */, sNz /* scratch */, sMean, cf[3], cf[2],
-                                   P.target_w, P.scale, nullptr, P.readout_div,
-                                   P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS);
+                                   P.target_w, P.scale, split == 1 ? P.pred_out + (size_t)b * P.pred.K : nullptr,
+                                   P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS, split,
+                                   split == 2 ? P.dpred_in + (size_t)b * P.pred.K : nullptr);
             }
           }
+          if (split == 1) break;  // phase A ends before the projection: phase B resumes from this z_s
           col_means(sZ);
           __syncthreads();
           for (int e = tid; e < N * 3; e += kThreads) {

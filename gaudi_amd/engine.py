@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Diag, EdmConfig, GaudiError, PredConfig, f32, fptr
+from ._lib import TARGET_CB, Diag, EdmConfig, GaudiError, PredConfig, f32, fptr
 
 
 def _strip(sd: dict) -> dict:
@@ -190,6 +190,46 @@ class Engine:
         self._check(self.lib.gaudi_sample(self.h, B, N, fptr(nm), fptr(em), int(seed), int(sample_offset), fptr(nz),
                                           float(std), fptr(tw), float(scale), fptr(x), fptr(h), fptr(z0),
                                           C.byref(diag)), "gaudi_sample")
+        d = dict(max_masked_leak=diag.max_masked_leak, max_cog_rel=diag.max_cog_rel, max_cog_abs=diag.max_cog_abs,
+                 nan_count=diag.nan_count, reprojected=diag.reprojected)
+        return (x, h, d, z0) if return_z0 else (x, h, d)
+
+    def sample_callback(self, node_mask, edge_mask, target_grad, *, seed=0, sample_offset=0, noise=None, std=1.0,
+                        scale=1.0, return_z0=False):
+        """Guided chain for an arbitrary target: ``target_grad(pred [B,K], t) -> dT/dpred [B,K]`` is called once per
+        reverse step between the two device phases (include/gaudi_hip.h: gaudi_sample_cb)."""
+        nm = f32(node_mask)
+        B, N = nm.shape[0], nm.shape[1]
+        nm, em = self._masks(nm, edge_mask, B, N)
+        D = 3 + self.F
+        nz = None
+        if noise is not None:
+            nz = f32(noise)
+            if nz.shape != (self.T + 2, B, N, D):
+                raise GaudiError(f"noise must be [T+2,B,N,3+F] = {(self.T + 2, B, N, D)}, got {nz.shape}")
+        x = np.empty((B, N, 3), np.float32)
+        h = np.empty((B, N, self.F), np.float32)
+        z0 = np.empty((B, N, D), np.float32) if return_z0 else None
+        diag = Diag()
+        failure = []
+
+        def _cb(_user, b, k, pred_p, t, out_p):
+            try:
+                pred = np.ctypeslib.as_array(pred_p, shape=(b, k)).copy()
+                g = np.ascontiguousarray(target_grad(pred, float(t)), dtype=np.float32)
+                if g.shape != (b, k):
+                    raise GaudiError(f"target_grad must return [B,K] = {(b, k)}, got {g.shape}")
+                np.ctypeslib.as_array(out_p, shape=(b, k))[...] = g
+            except BaseException as exc:  # never unwind through the C frames; report after the call returns
+                if not failure:
+                    failure.append(exc)
+
+        cb = TARGET_CB(_cb)
+        rc = self.lib.gaudi_sample_cb(self.h, B, N, fptr(nm), fptr(em), int(seed), int(sample_offset), fptr(nz),
+                                      float(std), cb, None, float(scale), fptr(x), fptr(h), fptr(z0), C.byref(diag))
+        if failure:
+            raise failure[0]
+        self._check(rc, "gaudi_sample_cb")
         d = dict(max_masked_leak=diag.max_masked_leak, max_cog_rel=diag.max_cog_rel, max_cog_abs=diag.max_cog_abs,
                  nan_count=diag.nan_count, reprojected=diag.reprojected)
         return (x, h, d, z0) if return_z0 else (x, h, d)

@@ -54,6 +54,35 @@ class LinearTarget:
         return _like_ref((pred @ self.weights + self.const).astype(np.float32))
 
 
+class PredTarget:
+    """Arbitrary differentiable target T = fn(pred, t) of the predictor outputs (any closure the reference's
+    sample_guidance accepts has this form, generation_guidance.py:187-211).  ``fn`` takes a torch tensor pred [B,K]
+    (requires_grad) and the step time t and returns one value per molecule [B]; only its K-vector gradient is taken on
+    the host (torch.autograd on a [B,K] leaf) -- the predictor forward and reverse passes stay on the GPU
+    (gaudi_sample_cb)."""
+
+    def __init__(self, cond_predictor, fn, name="custom"):
+        self.cond_predictor = cond_predictor
+        self.fn = fn
+        self.name = name
+
+    def grad(self, pred: np.ndarray, t: float) -> np.ndarray:
+        import torch
+
+        p = torch.from_numpy(np.ascontiguousarray(pred, dtype=np.float32)).requires_grad_(True)
+        with torch.enable_grad():
+            val = self.fn(p, t)
+            (g,) = torch.autograd.grad(val.sum(), p, allow_unused=True)
+        return np.zeros_like(pred) if g is None else g.detach().numpy().astype(np.float32)
+
+    def __call__(self, _input, _node_mask, _edge_mask, _t):
+        import torch
+
+        pred = torch.from_numpy(_to_numpy(self.cond_predictor(_input, _node_mask, _edge_mask, _t)))
+        t = float(np.asarray(_to_numpy(_t)).reshape(-1)[0]) if np.ndim(_to_numpy(_t)) else float(_t)
+        return self.fn(pred, t)
+
+
 def target_function_max_gap(cond_predictor) -> LinearTarget:
     """-pred[:,1]  (generation_guidance.py:200-203)."""
     w = np.zeros(cond_predictor.K, np.float32)
@@ -114,16 +143,22 @@ class GaudiModel:
         em = _to_numpy(edge_mask).astype(np.float32).reshape(B, N, N)
         tw = None
         if target is not None:
-            if not isinstance(target, LinearTarget):
+            if not isinstance(target, (LinearTarget, PredTarget)):
                 raise GaudiError(
-                    "target_function must be a gaudi_amd.models_edm.LinearTarget (e.g. target_function_max_gap / "
-                    "target_function_opv): arbitrary Python closures cannot run inside the fused HIP kernel and there "
-                    "is no CPU fallback")
+                    "target_function must be a gaudi_amd.models_edm.LinearTarget (target_function_max_gap / "
+                    "target_function_opv: fused in-kernel guidance) or a PredTarget(cond_predictor, fn(pred, t)) for any "
+                    "other differentiable function of the predictor outputs; an opaque closure over (z, masks, t) "
+                    "cannot be differentiated on the GPU and there is no CPU fallback")
             if target.cond_predictor.engine is not self.engine:
                 raise GaudiError("the target's predictor must be attached to this model (get_cond_predictor_model(..., model=model))")
-            tw = target.weights
-        x, h, diag = self.engine.sample(nm.reshape(B, N), em, seed=self.seed, sample_offset=self.sample_offset,
-                                        noise=self.injected_noise, std=std, target_w=tw, scale=scale)
+        if isinstance(target, PredTarget):
+            x, h, diag = self.engine.sample_callback(nm.reshape(B, N), em, target.grad, seed=self.seed,
+                                                     sample_offset=self.sample_offset, noise=self.injected_noise,
+                                                     std=std, scale=scale)
+        else:
+            tw = None if target is None else target.weights
+            x, h, diag = self.engine.sample(nm.reshape(B, N), em, seed=self.seed, sample_offset=self.sample_offset,
+                                            noise=self.injected_noise, std=std, target_w=tw, scale=scale)
         self.last_diag = diag
         F = h.shape[2]
         return _like_ref(x), {"categorical": _like_ref(h), "integer": _like_ref(np.zeros((B, N, 0), np.float32))}

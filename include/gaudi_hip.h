@@ -125,6 +125,17 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
                  float scale, float* x_out /* [B,N,3] */, float* onehot_out /* [B,N,F] */,
                  float* z0_out /* [B,N,3+F] or NULL */, gaudi_diag* diag /* or NULL */);
 
+/* sample_guidance for an ARBITRARY differentiable target T(pred, t) (the reference accepts any closure over the
+ * predictor, generation_guidance.py:187-205).  Each reverse step runs in two launches: (A) denoise + predictor forward,
+ * (B) predictor reverse pass + guidance update; in between, target_grad receives pred [B,K] and t and must write
+ * dT/dpred [B,K] (the energy is scale * sum_b T(pred_b), en_diffusion.py:899).  Both networks stay on the device;
+ * only the K-vector per molecule crosses the boundary.  With target_grad returning a constant w this equals
+ * gaudi_sample(target_w = w) bit for bit. */
+typedef void (*gaudi_target_cb)(void* user, int B, int K, const float* pred, float t, float* dT_dpred_out);
+int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                    int64_t sample_offset, const float* noise, float std, gaudi_target_cb target_grad, void* user,
+                    float scale, float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag);
+
 /* EnVariationalDiffusion.sample_chain (en_diffusion.py:1118-1174): the unguided chain with `keep_frames`
  * intermediate states: chain_out [keep_frames,B,N,3+F], frame (s*keep_frames)//T = unnormalize_z(z_s) of the last
  * step s mapping to it, frame 0 = the final [x | one_hot].  (The reference returns the same data viewed as

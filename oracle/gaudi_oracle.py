@@ -428,9 +428,11 @@ def step_unguided(edm_sd, cfg, gamma, s_idx, z_t, node_mask, edge_mask, eps_raw,
 
 def step_guided(edm_sd, cfg, pred_sd, pcfg, gamma, s_idx, z_t, node_mask, edge_mask, eps_raw,
                 target_w, scale, dtype=F32, return_aux=False):
-    """sample_p_zs_given_zt_guidance (en_diffusion.py:854-935) for a target that is linear in the
-    predictor outputs: T(pred) = target_w . pred (+const).  The predictor is evaluated at
-    (z_s, t) -- t, not s (en_diffusion.py:902)."""
+    """sample_p_zs_given_zt_guidance (en_diffusion.py:854-935).  target_w is either the weight vector of a target
+    linear in the predictor outputs, T(pred) = target_w . pred (+const), or a callable
+    target_grad(pred [B,K], t) -> dT/dpred [B,K] for an arbitrary target (the chain rule through the closure that
+    torch.autograd applies at en_diffusion.py:899-903).  The predictor is evaluated at (z_s, t) -- t, not s
+    (en_diffusion.py:902)."""
     T = cfg["diffusion_steps"]
     B, N, D = z_t.shape
     nm = np.asarray(node_mask, dtype=dtype).reshape(B, N, 1)
@@ -441,7 +443,11 @@ def step_guided(edm_sd, cfg, pred_sd, pcfg, gamma, s_idx, z_t, node_mask, edge_m
     eps_hat = np.nan_to_num(eps_hat, nan=0.0, posinf=np.finfo(dtype).max, neginf=np.finfo(dtype).min)
     mu = z_t / c["alpha_ts"] - c["eps_coef"] * eps_hat
     zs = mu + c["sigma"] * _combined_noise(np.asarray(eps_raw, dtype=dtype), nm)
-    dpred = np.broadcast_to(np.asarray(target_w, dtype=dtype) * dtype(scale), (B, len(target_w)))
+    if callable(target_w):
+        pred0 = predictor_forward(pred_sd, pcfg, zs, nm, edge_mask, t_val, dtype)
+        dpred = np.asarray(target_w(pred0, float(t_val)), dtype=dtype).reshape(B, -1) * dtype(scale)
+    else:
+        dpred = np.broadcast_to(np.asarray(target_w, dtype=dtype) * dtype(scale), (B, len(target_w)))
     pred, grad = predictor_grad(pred_sd, pcfg, zs, nm, edge_mask, t_val, dpred, dtype)
     gnorm = np.sqrt((grad.reshape(B, -1) ** 2).sum(-1))
     clip = np.minimum(dtype(10.0) / (gnorm + dtype(1e-6)), dtype(1.0))

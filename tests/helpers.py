@@ -35,3 +35,22 @@ def pred_from_cfg(cfg, K=5, **extra):
     F = synth.num_node_features(cfg["dataset"])
     sd = synth.synth_predictor_state_dict(args, F, K, seed=cfg.get("wseed", cfg.get("pseed")), amplify_coord=cfg.get("amp", False))
     return args, sd
+
+
+def nonlinear_target(pred, t):
+    """numpy twin of tools/make_golden.py:nonlinear_target_torch -> (T [B], dT/dpred [B,K]):
+    T = 0.5*log(1+p1^2) + 0.1*tanh(p0)*p3 + t*p2  (smooth for the large |pred| of synthetic-weight chains)."""
+    pred = np.asarray(pred)
+    t = pred.dtype.type(t)
+    th = np.tanh(pred[:, 0])
+    val = 0.5 * np.log1p(pred[:, 1] ** 2) + 0.1 * th * pred[:, 3] + t * pred[:, 2]
+    g = np.zeros_like(pred)
+    g[:, 0] = 0.1 * (1.0 - th * th) * pred[:, 3]
+    g[:, 1] = pred[:, 1] / (1.0 + pred[:, 1] ** 2)
+    g[:, 2] = t
+    g[:, 3] = 0.1 * th
+    return val, g
+
+
+def nonlinear_target_grad(pred, t):
+    return nonlinear_target(pred, t)[1]

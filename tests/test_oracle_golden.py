@@ -1,5 +1,7 @@
 """Pin the numpy oracle against golden vectors produced by the reference itself
 (tools/make_golden.py, torch 2.10.0 CPU fp32).  CPU-only."""
+import json
+
 import numpy as np
 import pytest
 
@@ -142,3 +144,27 @@ def test_g9_sample_chain(golden, name):
     ref = g[name + "_chain"].reshape(chain.shape)  # reference returns [K*B, N, D]
     assert rel_err(chain, ref) < 1e-4
     assert np.array_equal(chain[0][:, :, 3:], ref[0][:, :, 3:])  # the one-hot part of the final frame
+
+
+def test_g10_nonlinear_target(golden):
+    """Guidance through a target that is not linear in pred (and depends on t): the oracle's chain rule
+    (dT/dpred from the numpy twin -> hand-written reverse pass) against the reference's autograd."""
+    from tests.helpers import nonlinear_target_grad
+
+    g = golden("g10_nonlinear_target")
+    cfg = json.loads(str(g["cfg"]))
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=TINY, wseed=cfg["eseed"], amp=True), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["pseed"], amp=True))
+    gamma = O.gamma_table("polynomial_2", cfg["T"], 1e-5)
+    z, nm, em = g["z"], g["node_mask"], g["edge_mask"]
+    for s in (0, 500, 999):
+        for scale in (0.6, 400.0):
+            zg = O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, g[f"s{s}_eps"], nonlinear_target_grad, scale)
+            assert rel_err(zg, g[f"s{s}_zs_scale{scale}"]) < 2e-5, (s, scale)
+    cfg = json.loads(str(g["chain_cfg"]))
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=TINY, wseed=cfg["eseed"], amp=False), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["pseed"], amp=False))
+    x, h, _ = O.sample(esd, eargs, g["chain_node_mask"], g["chain_edge_mask"], g["chain_noise"], std=1.0, pred_sd=psd,
+                       pcfg=pargs, target_w=nonlinear_target_grad, scale=0.6)
+    assert rel_err(x, g["chain_x"]) < 1e-4
+    assert np.array_equal(h, g["chain_h"])

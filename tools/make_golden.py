@@ -403,6 +403,56 @@ def g9_sample_chain():
     save("g9_sample_chain", **out)
 
 
+def nonlinear_target_torch(pred, t):
+    """Golden nonlinear, time-dependent target (numpy twin with its analytic gradient: tests/helpers.py)."""
+    return 0.5 * torch.log1p(pred[:, 1] ** 2) + 0.1 * torch.tanh(pred[:, 0]) * pred[:, 3] + t * pred[:, 2]
+
+
+def g10_nonlinear_target():
+    """Guidance with a target that is NOT linear in the predictor outputs: teacher-forced steps and a T=50 chain
+    through the reference's sample_guidance (autograd through the closure, en_diffusion.py:899-903)."""
+    out = {}
+    ds, nodes = "hetro", [3, 5, 4]
+    F = synth.num_node_features(ds)
+    T = 1000
+    esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **TINY), F, seed=900, amplify_coord=True)
+    a, model = build_ref_edm(ds, esd, **TINY)
+    psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **TINY_P), F, 5, seed=910, amplify_coord=True)
+    pa, pred = build_ref_pred(ds, psd, **TINY_P)
+
+    def tf(_in, _nm, _em, _t):
+        return nonlinear_target_torch(pred(_in, _nm, _em, _t), _t.reshape(-1))
+
+    nm, em, z = case_inputs(ds, nodes, None, seed=920, guidance_pad=True)
+    B, N, D = z.shape
+    tnm, tem = torch.from_numpy(nm), torch.from_numpy(em)
+    out["z"], out["node_mask"], out["edge_mask"] = z, nm, em
+    for s in (0, 500, 999):
+        eps = rng_noise(930 + s % 7, (B, N, D))
+        st = torch.full((B, 1), s) / T
+        tt = (torch.full((B, 1), s) + 1) / T
+        out[f"s{s}_eps"] = eps
+        for scale in (0.6, 400.0):
+            with InjectNoise([eps]), torch.no_grad():
+                zg = model.sample_p_zs_given_zt_guidance(st, tt, torch.from_numpy(z), tnm, tem, tf, scale).numpy()
+            out[f"s{s}_zs_scale{scale}"] = zg
+    out["cfg"] = np.array(json.dumps(dict(dataset=ds, eseed=900, pseed=910, T=T, nodes=nodes)))
+    # chain, T=50
+    Tc = 50
+    over = dict(diffusion_steps=Tc, **TINY)
+    esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=940, amplify_coord=False)
+    a, model = build_ref_edm(ds, esd, **over)
+    psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **TINY_P), F, 5, seed=950, amplify_coord=False)
+    pa, pred = build_ref_pred(ds, psd, **TINY_P)
+    noise = rng_noise(960, (Tc + 2, len(nodes), 2 * max(nodes), 3 + F))
+    with InjectNoise(list(noise)):
+        x, h, nm, em = ref_sampling.sample_guidance(a, model, tf, torch.tensor(nodes), scale=0.6, std=1.0)
+    out["chain_noise"], out["chain_x"], out["chain_h"] = noise, x.numpy(), h.numpy().astype(np.float32)
+    out["chain_node_mask"], out["chain_edge_mask"] = nm.numpy(), em.numpy()
+    out["chain_cfg"] = np.array(json.dumps(dict(dataset=ds, T=Tc, eseed=940, pseed=950, nodes=nodes)))
+    save("g10_nonlinear_target", **out)
+
+
 def g8_checkpoint_roundtrip():
     """The reference's own loader must accept checkpoints written by gaudi_amd.synth.write_checkpoint
     (args.txt + model.pt, with and without the ``module.`` prefix).  Stores nothing but a marker."""
@@ -427,8 +477,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target)
     for w in which:
         fns[w]()
