@@ -33,7 +33,20 @@ class Diag(C.Structure):
                 ("nan_count", C.c_int32), ("reprojected", C.c_int32)]
 
 
+class RingTables(C.Structure):
+    _fields_ = [("n_types", C.c_int32), ("orientation", C.c_int32), ("check_dihedrals", C.c_int32), ("tol", C.c_double),
+                ("min_dist", C.c_double), ("dist_lo", (C.c_double * 16) * 16), ("dist_hi", (C.c_double * 16) * 16),
+                ("a3_count", C.c_int32 * 16), ("a3_lo", (C.c_double * 4) * 16), ("a3_hi", (C.c_double * 4) * 16),
+                ("a4_0", C.c_double), ("a4_180", C.c_double)]
+
+
+class StabilityAux(C.Structure):
+    _fields_ = [("n_rings", C.c_int32), ("n_edges", C.c_int32), ("n_triplets", C.c_int32), ("n_nan_angles", C.c_int32),
+                ("a3_min", C.c_float), ("a3_max", C.c_float), ("a4_min", C.c_float), ("a4_max", C.c_float)]
+
+
 FP = C.POINTER(C.c_float)
+IP = C.POINTER(C.c_int32)
 # gaudi_target_cb(user, B, K, pred, t, dT_dpred_out)
 TARGET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, FP, C.c_float, FP)
 
@@ -57,6 +70,9 @@ EXPORTS = {
     "gaudi_sample_cb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, TARGET_CB,
                                   C.c_void_p, C.c_float, FP, FP, FP, C.POINTER(Diag)]),
     "gaudi_sample_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, C.c_int, FP]),
+    "gaudi_check_stability": (C.c_int, [C.c_void_p, C.POINTER(RingTables), C.c_int, C.c_int, FP, IP, IP,
+                                        C.POINTER(C.c_uint8), FP, FP, C.POINTER(StabilityAux)]),
+    "gaudi_stability_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "gaudi_philox_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, FP]),
     "gaudi_host_schedule": (C.c_int, [C.c_int, C.c_float, C.c_float, FP, FP]),
     "gaudi_host_graph_meta": (C.c_int, [C.c_int, C.c_int, FP, FP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

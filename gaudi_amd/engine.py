@@ -40,6 +40,15 @@ class Engine:
         self.F = None
         self.K = None
 
+    _default = None
+
+    @classmethod
+    def default(cls, device: int = 0) -> "Engine":
+        """Process-wide handle for calls that need no weights (stability check); created on first use."""
+        if cls._default is None or not cls._default.h:
+            cls._default = cls(device)
+        return cls._default
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             self.lib.gaudi_destroy(self.h)
@@ -262,6 +271,12 @@ class Engine:
         steps = C.c_int64()
         self._check(self.lib.gaudi_profile_get(self.h, C.byref(n), C.byref(ms), C.byref(steps)), "gaudi_profile_get")
         return n.value, ms.value, steps.value
+
+    def stability_profile_get(self):
+        n = C.c_int32()
+        ms = C.c_double()
+        self._check(self.lib.gaudi_stability_profile_get(self.h, C.byref(n), C.byref(ms)), "gaudi_stability_profile_get")
+        return n.value, ms.value
 
     def set_steps_per_launch(self, k: int):
         self._check(self.lib.gaudi_set_steps_per_launch(self.h, int(k)), "gaudi_set_steps_per_launch")

@@ -1,11 +1,14 @@
-"""Host mirror of generation_guidance.py: predict / get_target_function_values / design (the RDKit stability
-filter and the plots are out of scope: CPU-side chemistry, dependency unavailable -- SURVEY.md section 8f)."""
+"""Host mirror of generation_guidance.py: predict / get_target_function_values / design.  The reference filters the
+designed molecules with RDKit validity (eval_stability, generation_guidance.py:69-80; dependency unavailable, SURVEY.md
+section 8f "not planned"); here the filter is the graph-of-rings stability check of eval_validity.py on the GPU
+(gaudi_amd.analyze), and plots are replaced by the returned dict."""
 from __future__ import annotations
 
 from time import time
 
 import numpy as np
 
+from .analyze import analyze_validity_for_molecules
 from .models_edm import _like_ref, _to_numpy
 from .sampling_edm import _check, sample_guidance
 
@@ -31,9 +34,22 @@ def get_target_function_values(x, h, target_function, node_mask, edge_mask, edm_
     return target_function(_normalized_xh(x, h, nm, edm_model), nm, em, np.zeros((bs, 1), np.float32))
 
 
+def eval_stability(x, one_hot, node_mask, edge_mask, dataset="cata", engine=None):
+    """generation_guidance.py:69-80 with the graph-of-rings check in place of RDKit validity:
+    -> (stability_dict, x, one_hot, node_mask, edge_mask) of the stable molecules."""
+    import torch
+    bs, n, _ = x.shape
+    atom_type = one_hot.argmax(2)
+    keep = [node_mask[i, :, 0].bool() for i in range(bs)]
+    molecule_list = [(x[i][keep[i]], atom_type[i][keep[i]]) for i in range(bs)]
+    stability_dict, _ = analyze_validity_for_molecules(molecule_list, dataset=dataset, engine=engine)
+    ok = torch.tensor(stability_dict["molecule_stable_bool"], dtype=torch.bool)
+    return stability_dict, x[ok], one_hot[ok], node_mask[ok], edge_mask.view(bs, n, n)[ok].view(-1, 1)
+
+
 def design(args, model, cond_predictor, target_function, nodes_dist, prop_dist, scale, n_nodes):
-    """generation_guidance.py:83-184 up to the RDKit call: sample with guidance, evaluate the target and the
-    predicted properties at t=0, rank by target value.  Returns a dict instead of plotting."""
+    """generation_guidance.py:83-184: sample with guidance, check stability, evaluate the target and the predicted
+    properties at t=0, rank all / stable molecules by target value.  Returns a dict instead of plotting."""
     model.eval()
     cond_predictor.eval()
     nodesxsample = np.array([n_nodes] * args.batch_size, dtype=np.int64)
@@ -42,13 +58,20 @@ def design(args, model, cond_predictor, target_function, nodes_dist, prop_dist, 
     seconds = time() - start_time
     print(f"Generated {x.shape[0]} molecules in {seconds:.2f} seconds")
     _check(x, node_mask)
+    stability_dict, _, _, _, _ = eval_stability(x, one_hot, node_mask, edge_mask, dataset=args.dataset,
+                                                engine=model.engine)
+    print(f"{scale=}")
+    print(f"{stability_dict['mol_stable']=:.2%} out of {x.shape[0]}")
     tvals = _to_numpy(get_target_function_values(x, one_hot, target_function, node_mask, edge_mask, model))
     pred = _to_numpy(predict(cond_predictor, x, one_hot, node_mask, edge_mask, model))
     if prop_dist is not None:
         pred = prop_dist.unnormalize(pred)
     print(f"Mean target function value: {tvals.mean():.4f}")
     order = np.argsort(tvals)  # best (lowest energy) first, as the reference's ranking
-    return dict(x=x, one_hot=one_hot, node_mask=node_mask, edge_mask=edge_mask, target_function_values=_like_ref(tvals),
+    stable = np.array(stability_dict["molecule_stable_bool"], dtype=bool)
+    if stable.any():
+        print(f"Mean target function value (from stable): {tvals[stable].mean():.4f}")
+    return dict(stability=stability_dict, best_stable=order[stable[order]], x=x, one_hot=one_hot, node_mask=node_mask, edge_mask=edge_mask, target_function_values=_like_ref(tvals),
                 pred=_like_ref(pred), best=order, seconds=seconds, molecules_per_second=x.shape[0] / seconds)
 
 

@@ -24,6 +24,35 @@ def _like_ref(a):
         return a
 
 
+class DistributionRings:
+    """models_edm.DistributionRings (models_edm.py:21-58): ring-count sampler over the dataset histogram
+    (utils/helpers.py:64-95; shipped as data in gaudi_amd/data/ring_tables.json, histogram order preserved).
+    sample() draws through torch.distributions.Categorical exactly as the reference does, so a run seeded with
+    torch.manual_seed reproduces the reference's ring counts."""
+
+    def __init__(self, dataset="cata"):
+        import torch
+        from torch.distributions.categorical import Categorical
+
+        from .analyze import ring_tables
+        hist = ring_tables()["n_nodes"]["cata" if dataset == "peri" else dataset]
+        self.n_nodes = torch.tensor([int(k) for k in hist])
+        self.keys = {int(k): i for i, k in enumerate(hist)}
+        prob = np.array([hist[k] for k in hist])
+        prob = prob / np.sum(prob)
+        self.prob = torch.from_numpy(prob).float()
+        self.m = Categorical(torch.tensor(prob))
+
+    def sample(self, n_samples=1):
+        return self.n_nodes[self.m.sample((n_samples,))]
+
+    def log_prob(self, batch_n_nodes):
+        import torch
+        assert len(batch_n_nodes.size()) == 1
+        idcs = torch.tensor([self.keys[i.item()] for i in batch_n_nodes])
+        return torch.log(self.prob + 1e-30)[idcs]
+
+
 class PropertyNorm:
     """DistributionProperty(only_norm=True): mean/std + (un)normalize (models_edm.py:107-113,186-192).
     mean/std are NOT stored in checkpoints (they come from the dataset) and must be supplied."""
@@ -210,8 +239,7 @@ class CondPredictor:
 def get_model(args, dataloader_train=None, only_norm=True, device: int = 0, state_dict=None):
     """models_edm.get_model (models_edm.py:61-104) -> (model, nodes_dist, prop_dist).
 
-    ``dataloader_train.dataset`` is only consulted for ``mean``/``std`` (property normalisation); the ring-count
-    histogram sampler (DistributionRings) is out of scope for this round and returned as None."""
+    ``dataloader_train.dataset`` is only consulted for ``mean``/``std`` (property normalisation)."""
     a = checkpoint.args_dict(args)
     if state_dict is None:
         if not a.get("restore"):
@@ -222,7 +250,7 @@ def get_model(args, dataloader_train=None, only_norm=True, device: int = 0, stat
     ds = getattr(dataloader_train, "dataset", None)
     if ds is not None and getattr(ds, "mean", None) is not None:
         prop_dist = PropertyNorm(ds.mean, ds.std)
-    return model, None, prop_dist
+    return model, DistributionRings(a.get("dataset", "cata")), prop_dist
 
 
 def get_cond_predictor_model(args, dataset=None, model: GaudiModel | None = None, state_dict=None) -> CondPredictor:

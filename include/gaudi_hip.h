@@ -143,6 +143,43 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
 int gaudi_sample_chain(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
                        int64_t sample_offset, const float* noise, float std, int keep_frames, float* chain_out);
 
+/* ---- Graph-of-rings stability check: the step that follows sampling (eval_validity.py:49, sampling_edm.py:96). ----
+ * Geometry tables of one dataset, indexed by ring-type index (= class index of the one-hot node features,
+ * data/aromatic_dataloader.py:31-35).  Raw values of utils/helpers.py:11-157 in double; the library applies `tol`
+ * as the reference does ((1 - tol) on lower, (1 + tol) on upper bounds, then fp32). */
+typedef struct {
+  int32_t n_types;          /* len(RINGS_LIST[dataset]) <= 16                                               */
+  int32_t orientation;      /* 1 if dataset != "cata": nodes [n/2, n) are orientation nodes of type n_types-1 */
+  int32_t check_dihedrals;  /* 0 for "hetro" (check_angels4 returns True, analyze/analyze.py:40)              */
+  double tol;               /* 0.1 in every reference call                                                    */
+  double min_dist;          /* min over ring_distances[dataset] of the lower bound                            */
+  double dist_lo[16][16], dist_hi[16][16]; /* ring_distances window of the type pair; hi == 0: never bonded   */
+  int32_t a3_count[16];     /* number of 3-ring angle windows of the centre type (<= 4)                       */
+  double a3_lo[16][4], a3_hi[16][4];       /* angels3_dict[dataset][type]                                     */
+  double a4_0, a4_180;      /* angels4_dict[dataset]                                                          */
+} gaudi_ring_tables;
+
+typedef struct {
+  int32_t n_rings;       /* rings tested (orientation nodes excluded)              */
+  int32_t n_edges;       /* bonded ring pairs                                      */
+  int32_t n_triplets;    /* de-duplicated 3-ring paths the reference enumerates    */
+  int32_t n_nan_angles;  /* 3-ring angles that came out NaN (acos of 1 + 1 ulp)    */
+  float a3_min, a3_max;  /* range of the 3-ring angles (degrees; +-inf when none)  */
+  float a4_min, a4_max;  /* range of the 4-ring dihedrals tested                   */
+} gaudi_stability_aux;
+
+/* check_stability (analyze/analyze.py:50-100) for B molecules at once: x [B,N,3] and ring_type [B,N] hold each
+ * molecule's n_nodes[b] valid nodes first (the reference compacts with node_mask before the call).
+ * flags_out [B,5] = {orientation_nodes, dist_stable, connected, angels3, angels4}; a molecule is stable when all
+ * five are 1.  Optional outputs: dist_out / adj_out [B,N,N] = positions2adj (utils/helpers.py:167-190) of the ring
+ * block, zero elsewhere; aux_out [B]. */
+int gaudi_check_stability(gaudi_handle* h, const gaudi_ring_tables* tables, int B, int N, const float* x,
+                          const int32_t* ring_type, const int32_t* n_nodes, uint8_t* flags_out,
+                          float* dist_out /* or NULL */, float* adj_out /* or NULL */,
+                          gaudi_stability_aux* aux_out /* or NULL */);
+/* Number of stability-kernel launches since gaudi_profile_reset(h, 1) and their summed duration (HIP events). */
+int gaudi_stability_profile_get(gaudi_handle* h, int32_t* n_launches, double* total_ms);
+
 /* Device Philox stream used when noise == NULL, exposed for tests: out[draw][b][e], e < n_elem. */
 int gaudi_philox_normal(gaudi_handle* h, uint64_t seed, int64_t sample_offset, int B, int n_elem, int draw0,
                         int n_draws, float* out);

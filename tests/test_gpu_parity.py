@@ -367,6 +367,11 @@ def test_design_entry_point():
     u = prop.unnormalize(po)
     assert rel_err(out["target_function_values"].numpy(), u[:, 3] + u[:, 2] + 3 * u[:, 0]) < TOL
     assert sorted(out["best"].tolist()) == list(range(6))
+    # stability filter (graph-of-rings check on the GPU) against the stability oracle on the same molecules
+    from oracle import stability_oracle as S
+    want = [all(S.check_stability(x[i], h[i].argmax(1), dataset="cata").values()) for i in range(6)]
+    assert out["stability"]["molecule_stable_bool"] == want
+    assert out["best_stable"].tolist() == [i for i in out["best"].tolist() if want[i]]
     model.engine.close()
 
 

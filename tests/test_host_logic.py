@@ -99,3 +99,18 @@ def test_unsupported_checkpoint_modes_are_refused():
     for bad in ("learned", "cosine"):
         with pytest.raises(GaudiError):
             _noise_power(bad)
+
+
+def test_ring_count_sampler_matches_reference(golden):
+    """DistributionRings: same histogram order, probabilities, seeded Categorical draws and log-probs as the reference."""
+    import torch
+    from gaudi_amd.models_edm import DistributionRings
+    g = golden("g12_ring_count_sampler")
+    for ds in ("cata", "hetro"):
+        d = DistributionRings(ds)
+        assert np.array_equal(d.n_nodes.numpy(), g[f"{ds}_n_nodes"])
+        assert np.array_equal(d.prob.numpy(), g[f"{ds}_prob"])
+        torch.manual_seed(1234)
+        s = d.sample(2000)
+        assert np.array_equal(s.numpy(), g[f"{ds}_sample"])
+        assert np.array_equal(d.log_prob(s[:64]).numpy(), g[f"{ds}_log_prob"])

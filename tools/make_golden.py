@@ -453,6 +453,158 @@ def g10_nonlinear_target():
     save("g10_nonlinear_target", **out)
 
 
+def _rand_rot(rng):
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    return q
+
+
+def synth_cata_molecule(rng, n, tree_prob, jitter, zjit):
+    """Ring centres on a triangular lattice (spacing ~2.45): tree-like growth gives cata-condensed shapes, allowing
+    lattice neighbours gives cycles (peri shapes, 60-degree triplets) -- a mix of stable / unstable molecules."""
+    dirs = [(1, 0), (0, 1), (-1, 1), (-1, 0), (0, -1), (1, -1)]
+    occ = [(0, 0)]
+    tries = 0
+    while len(occ) < n and tries < 1000:
+        tries += 1
+        a = occ[rng.integers(len(occ))]
+        d = dirs[rng.integers(6)]
+        c = (a[0] + d[0], a[1] + d[1])
+        if c in occ:
+            continue
+        nb = sum(((c[0] + e[0], c[1] + e[1]) in occ) for e in dirs)
+        if nb > 1 and rng.random() < tree_prob:
+            continue
+        occ.append(c)
+    occ = np.array(occ, np.float64)
+    d = rng.uniform(2.40, 2.50)
+    xy = np.stack([occ[:, 0] + 0.5 * occ[:, 1], occ[:, 1] * np.sqrt(3) / 2], 1) * d
+    x = np.concatenate([xy, np.zeros((len(occ), 1))], 1)
+    x += rng.standard_normal(x.shape) * jitter
+    x[:, 2] += rng.standard_normal(len(occ)) * zjit
+    x = (x - x.mean(0)) @ _rand_rot(rng)
+    return x.astype(np.float32)
+
+
+def synth_hetro_molecule(rng, n, tables, jitter, corrupt):
+    """Tree growth in the plane: bonded-distance windows and 3-ring angle windows of the reference's tables pick the
+    bond length / direction, then jitter.  Orientation nodes (type '.') are appended; `corrupt` breaks them."""
+    R = len(tables["rings"]["hetro"]) - 1
+    lo, hi, a3 = tables["dist_lo"]["hetro"], tables["dist_hi"]["hetro"], tables["a3"]["hetro"]
+    w = np.array([6, 1, 1, 1, 1, 1, 1, 1, 0.3, 1, 0.5])
+    types = [int(rng.choice(R, p=w / w.sum()))]
+    pos = [np.zeros(2)]
+    heading = [rng.uniform(0, 2 * np.pi)]  # direction towards the parent (or arbitrary for the root)
+    tries = 0
+    while len(pos) < n and tries < 2000:
+        tries += 1
+        p = int(rng.integers(len(pos)))
+        t = int(rng.choice(R, p=w / w.sum()))
+        if hi[types[p]][t] <= 0:
+            continue
+        d = rng.uniform(lo[types[p]][t], hi[types[p]][t])
+        wins = a3[types[p]] or [[120.0, 120.0]]
+        win = wins[rng.integers(len(wins))]
+        ang = np.deg2rad(rng.uniform(win[0], win[1])) * rng.choice([-1, 1])
+        th = heading[p] + ang
+        c = pos[p] + d * np.array([np.cos(th), np.sin(th)])
+        if min(np.linalg.norm(c - q) for q in pos) < 1.3 and rng.random() < 0.9:
+            continue
+        pos.append(c)
+        types.append(t)
+        heading.append(th + np.pi)
+    k = len(pos)
+    x = np.concatenate([np.array(pos), np.zeros((k, 1))], 1)
+    x += rng.standard_normal(x.shape) * jitter
+    orient = x + rng.standard_normal(x.shape) * 0.5
+    x = np.concatenate([x, orient], 0)
+    x = (x - x.mean(0)) @ _rand_rot(rng)
+    ty = np.array(types + [R] * k, np.int64)
+    if corrupt == 1:
+        ty[k + rng.integers(k)] = 0          # an orientation slot holds a real ring type
+    elif corrupt == 2:
+        ty[rng.integers(k)] = R              # a ring slot holds the orientation type
+    return x.astype(np.float32), ty
+
+
+def g11_stability():
+    """Graph-of-rings stability check (analyze/analyze.py:50-100) on seeded synthetic molecules + a few degenerate
+    ones; stores the reference's flags, distance matrix, adjacency and the sorted 3-ring / 4-ring angle lists."""
+    from analyze import analyze as ref_an
+    from utils import helpers as ref_h
+    tables = json.load(open(os.path.join(ROOT, "gaudi_amd", "data", "ring_tables.json")))
+    rng = np.random.default_rng(1100)
+    out = {}
+    for ds in ("cata", "hetro"):
+        mols = []
+        if ds == "cata":
+            for i in range(260):
+                n = int(rng.integers(1, 12))
+                jit = [0.0, 0.01, 0.03, 0.08, 0.2][i % 5]
+                zj = [0.0, 0.02, 0.3, 0.8][(i // 5) % 4]
+                x = synth_cata_molecule(rng, n, tree_prob=[1.0, 0.9, 0.5][i % 3], jitter=jit, zjit=zj)
+                mols.append((x, np.zeros(len(x), np.int64)))
+            # degenerate: two far-apart fragments, two coincident rings, an exactly straight chain
+            mols.append((np.array([[0, 0, 0], [2.45, 0, 0], [9, 0, 0], [11.45, 0, 0]], np.float32), np.zeros(4, np.int64)))
+            mols.append((np.array([[0, 0, 0], [2.45, 0, 0], [2.45, 0.1, 0]], np.float32), np.zeros(3, np.int64)))
+            mols.append((np.array([[2.45 * i, 0, 0] for i in range(5)], np.float32), np.zeros(5, np.int64)))
+        else:
+            for i in range(260):
+                n = int(rng.integers(2, 11))
+                x, ty = synth_hetro_molecule(rng, n, tables, jitter=[0.0, 0.01, 0.03, 0.1][i % 4],
+                                             corrupt=[0, 0, 0, 0, 0, 0, 1, 2][i % 8])
+                mols.append((x, ty))
+        M = len(mols)
+        NM = max(len(x) for x, _ in mols)
+        X = np.zeros((M, NM, 3), np.float32)
+        TY = -np.ones((M, NM), np.int64)
+        NN = np.zeros(M, np.int64)
+        FL = np.zeros((M, 5), np.uint8)
+        DIST = np.zeros((M, NM, NM), np.float32)
+        ADJ = np.zeros((M, NM, NM), np.float32)
+        A3 = np.full((M, 128), np.nan, np.float32)
+        A3T = -np.ones((M, 128), np.int64)
+        A4 = np.full((M, 256), np.nan, np.float32)
+        CNT = np.zeros((M, 2), np.int64)
+        for m, (x, ty) in enumerate(mols):
+            k = len(x)
+            X[m, :k], TY[m, :k], NN[m] = x, ty, k
+            res = ref_an.check_stability(torch.from_numpy(x.copy()), torch.from_numpy(ty.copy()), dataset=ds)
+            FL[m] = [res[key] for key in ("orientation_nodes", "dist_stable", "connected", "angels3", "angels4")]
+            nr = k if ds == "cata" else k // 2
+            if res["orientation_nodes"]:
+                dist, adj = ref_h.positions2adj(torch.from_numpy(x[None, :nr].copy()), torch.from_numpy(ty[None, :nr].copy()),
+                                                0.1, dataset=ds)
+                DIST[m, :nr, :nr], ADJ[m, :nr, :nr] = dist[0].numpy(), adj[0].numpy()
+                if res["connected"]:
+                    a3, a4 = ref_an.get_angels(torch.from_numpy(x[None, :nr].copy()), torch.from_numpy(ty[None, :nr].copy()),
+                                               adj, dataset=ds)
+                    rl = tables["rings"][ds]
+                    pairs = [(rl.index(sym), float(a)) for sym, a in a3]
+                    for i, (t, a) in enumerate(pairs):
+                        A3T[m, i], A3[m, i] = t, a
+                    for i, a in enumerate(float(a) for _, a in a4):
+                        A4[m, i] = a
+                    CNT[m] = len(a3), len(a4)
+        out.update({f"{ds}_x": X, f"{ds}_types": TY, f"{ds}_n": NN, f"{ds}_flags": FL, f"{ds}_dist": DIST,
+                    f"{ds}_adj": ADJ, f"{ds}_a3": A3, f"{ds}_a3_type": A3T, f"{ds}_a4": A4, f"{ds}_counts": CNT})
+        print(ds, "flag rates", FL.mean(0), "all-stable", FL.all(1).mean())
+    save("g11_stability", **out)
+
+
+def g12_ring_count_sampler():
+    """DistributionRings (models_edm.py:21-58): seeded draws and log-probabilities of the reference."""
+    out = {}
+    for ds in ("cata", "hetro"):
+        d = models_edm.DistributionRings(ds)
+        torch.manual_seed(1234)
+        s = d.sample(2000)
+        out[f"{ds}_sample"] = s.numpy()
+        out[f"{ds}_log_prob"] = d.log_prob(s[:64]).numpy()
+        out[f"{ds}_n_nodes"] = d.n_nodes.numpy()
+        out[f"{ds}_prob"] = d.prob.numpy()
+    save("g12_ring_count_sampler", **out)
+
+
 def g8_checkpoint_roundtrip():
     """The reference's own loader must accept checkpoints written by gaudi_amd.synth.write_checkpoint
     (args.txt + model.pt, with and without the ``module.`` prefix).  Stores nothing but a marker."""
@@ -477,8 +629,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler)
     for w in which:
         fns[w]()
