@@ -70,6 +70,7 @@ EXPORTS = {
     "gaudi_sample_cb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, TARGET_CB,
                                   C.c_void_p, C.c_float, FP, FP, FP, C.POINTER(Diag)]),
     "gaudi_sample_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, C.c_int, FP]),
+    "gaudi_predict_noised": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, IP, FP, FP, C.c_uint64, C.c_int64, FP, FP, FP]),
     "gaudi_check_stability": (C.c_int, [C.c_void_p, C.POINTER(RingTables), C.c_int, C.c_int, FP, IP, IP,
                                         C.POINTER(C.c_uint8), FP, FP, C.POINTER(StabilityAux)]),
     "gaudi_stability_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),

@@ -52,7 +52,7 @@ struct gaudi_handle {
   std::vector<float> gamma, coef;
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
-      d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab;
+      d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as;
   int steps_per_launch = 25;
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
   // profiling
@@ -419,7 +419,7 @@ void gaudi_destroy(gaudi_handle* h) {
   DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
                     &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
                     &h->d_pred, &h->d_tw, &h->d_stash, &h->d_chain, &h->d_sx, &h->d_stype, &h->d_sn,
-                    &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab};
+                    &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as};
   for (DevBuf* b : bufs) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

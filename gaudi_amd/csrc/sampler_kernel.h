@@ -44,6 +44,8 @@ struct KParams {
   float* stash;             // predictor activation stash, [B] x stash_stride floats
   long long stash_stride;
   float readout_div;        // padded N the predictor readout divides by
+  const float* alpha_sigma; // [B][2] or nullptr: forward-noising prologue z_t = alpha*normalize(xh) + sigma*eps (sample_edm_t)
+  float* zt_out;            // [B][N][D] noised input (only with alpha_sigma) or nullptr
   int split;                // 0 fused step; 1 = phase A (denoise + predictor forward); 2 = phase B (reverse pass + update)
   float* chain_out;         // sample_chain: [keep_frames][B][N][D] un-normalised frames, or nullptr
   int keep_frames;
@@ -130,6 +132,22 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
     __syncthreads();
     combined_noise(0, P.std0);
     for (int e = tid; e < N * D; e += kThreads) sZ[e] = sNz[e];
+  } else if (P.alpha_sigma != nullptr) {
+    // sample_edm_t (cond_prediction/train_cond_predictor.py:47-61): z_t = alpha_t * normalize([x | h]) + sigma_t * eps
+    __syncthreads();
+    combined_noise(draw_base, 1.0f);
+    const float a_t = P.alpha_sigma[2 * b], s_t = P.alpha_sigma[2 * b + 1];
+    const float nv0 = P.nv0, nv1 = P.nv1;
+    for (int e = tid; e < N * D; e += kThreads) {
+      const int n = e / D, d = e % D;
+      const float raw = P.z_in[(size_t)b * N * D + e];
+      const float xh = d < 3 ? raw / nv0 : (raw - 0.0f) / nv1 * sMask[n];  // en_diffusion.py:384-392
+      sZ[e] = a_t * xh + s_t * sNz[e];
+    }
+    if (P.zt_out != nullptr) {
+      __syncthreads();
+      for (int e = tid; e < N * D; e += kThreads) P.zt_out[(size_t)b * N * D + e] = sZ[e];
+    }
   } else {
     for (int e = tid; e < N * D; e += kThreads) sZ[e] = P.z_in[(size_t)b * N * D + e];
   }

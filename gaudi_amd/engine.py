@@ -203,6 +203,25 @@ class Engine:
                  nan_count=diag.nan_count, reprojected=diag.reprojected)
         return (x, h, d, z0) if return_z0 else (x, h, d)
 
+    def predict_noised(self, x, onehot, t_int, node_mask, edge_mask, *, seed=0, sample_offset=0, noise=None):
+        """sample_edm_t + predictor forward in one launch -> (z_t [B,N,3+F], pred [B,K])."""
+        x = f32(x)
+        B, N = x.shape[0], x.shape[1]
+        oh = f32(onehot).reshape(B, N, self.F)
+        nm, em = self._masks(f32(node_mask).reshape(B, N), edge_mask, B, N)
+        ti = np.ascontiguousarray(np.broadcast_to(np.asarray(t_int).reshape(-1), (B,)), dtype=np.int32)
+        nz = None
+        if noise is not None:
+            nz = f32(noise)
+            if nz.shape != (B, N, 3 + self.F):
+                raise GaudiError(f"noise must be [B,N,3+F] = {(B, N, 3 + self.F)}, got {nz.shape}")
+        zt = np.empty((B, N, 3 + self.F), np.float32)
+        pred = np.empty((B, self.K), np.float32)
+        self._check(self.lib.gaudi_predict_noised(self.h, B, N, fptr(x), fptr(oh), ti.ctypes.data_as(_lib.IP), fptr(nm),
+                                                  fptr(em), int(seed), int(sample_offset), fptr(nz), fptr(zt),
+                                                  fptr(pred)), "gaudi_predict_noised")
+        return zt, pred
+
     def sample_callback(self, node_mask, edge_mask, target_grad, *, seed=0, sample_offset=0, noise=None, std=1.0,
                         scale=1.0, return_z0=False):
         """Guided chain for an arbitrary target: ``target_grad(pred [B,K], t) -> dT/dpred [B,K]`` is called once per

@@ -261,4 +261,5 @@ def get_cond_predictor_model(args, dataset=None, model: GaudiModel | None = None
     a = checkpoint.args_dict(args)
     if state_dict is None:
         state_dict = checkpoint.load_state_dict(a["exp_dir"])
-    return CondPredictor(model, a, state_dict)
+    model.cond_predictor = CondPredictor(model, a, state_dict)
+    return model.cond_predictor

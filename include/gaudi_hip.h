@@ -102,6 +102,16 @@ int gaudi_predictor_grad(gaudi_handle* h, int B, int N, const float* z, const fl
                          const float* edge_mask, const float* dpred /* [B,K] */, float* pred_out /* [B,K] or NULL */,
                          float* grad_out /* [B,N,3+F] */);
 
+/* Forward noising + predictor evaluation at noise level t: sample_edm_t (cond_prediction/train_cond_predictor.py:47-61)
+ * followed by the predictor forward of compute_loss (:64-81) / eval_cond_predictor.val_epoch (eval_cond_predictor.py:34-60).
+ * x [B,N,3] (un-normalised, masked, mean-free) and onehot [B,N,F] are normalised as EnVariationalDiffusion.normalize does,
+ * z_t = alpha_t * xh + sigma_t * eps with gamma looked up at t_int[b] in 0..T and eps = the combined position/feature noise
+ * (injected raw draws `noise` [B,N,3+F], or Philox draw 0 of (seed, sample_offset + b) when NULL);
+ * pred = predictor(z_t, t_int/T).  Either output may be NULL. */
+int gaudi_predict_noised(gaudi_handle* h, int B, int N, const float* x, const float* onehot, const int32_t* t_int,
+                         const float* node_mask, const float* edge_mask, uint64_t seed, int64_t sample_offset,
+                         const float* noise, float* zt_out /* [B,N,3+F] or NULL */, float* pred_out /* [B,K] or NULL */);
+
 /* One teacher-forced reverse step z_t -> z_s with s = s_idx/T, t = (s_idx+1)/T:
  * sample_p_zs_given_zt (en_diffusion.py:807-852) when target_w == NULL, else
  * sample_p_zs_given_zt_guidance (:854-935) for the target  T(pred) = target_w . pred  scaled by `scale`.

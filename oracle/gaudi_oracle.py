@@ -411,6 +411,20 @@ def _combined_noise(eps_raw, nm, std=1.0):
     return np.concatenate([ex, eh], axis=2)
 
 
+def sample_edm_t(cfg, gamma, x, onehot, t_int, node_mask, eps_raw, dtype=F32):
+    """cond_prediction/train_cond_predictor.py:47-61: z_t = alpha_t * normalize([x | h]) + sigma_t * eps with
+    gamma looked up at t_int (en_diffusion.py:220-223), normalize = en_diffusion.py:384-392."""
+    B, N, _ = x.shape
+    nm = np.asarray(node_mask, dtype=dtype).reshape(B, N, 1)
+    nv = cfg["normalize_factors"]
+    xh = np.concatenate([np.asarray(x, dtype) / dtype(nv[0]),
+                         (np.asarray(onehot, dtype) - dtype(0.0)) / dtype(nv[1]) * nm], axis=2)
+    g = gamma[np.asarray(t_int).astype(np.int64)].astype(dtype).reshape(B, 1, 1)
+    alpha = np.sqrt(_sigmoid(-g))
+    sigma = np.sqrt(_sigmoid(g))
+    return alpha * xh + sigma * _combined_noise(np.asarray(eps_raw, dtype=dtype), nm)
+
+
 def step_unguided(edm_sd, cfg, gamma, s_idx, z_t, node_mask, edge_mask, eps_raw, dtype=F32):
     """sample_p_zs_given_zt (en_diffusion.py:807-852). s = s_idx/T, t = (s_idx+1)/T."""
     T = cfg["diffusion_steps"]

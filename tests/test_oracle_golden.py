@@ -168,3 +168,22 @@ def test_g10_nonlinear_target(golden):
                        pcfg=pargs, target_w=nonlinear_target_grad, scale=0.6)
     assert rel_err(x, g["chain_x"]) < 1e-4
     assert np.array_equal(h, g["chain_h"])
+
+
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_g13_forward_noising_and_predictor(golden, name):
+    """sample_edm_t + predictor at the noise level (rank-4 row): the oracle against the reference."""
+    g = golden("g13_noised_predictor")
+    cfg = json.loads(str(g[name + "_cfg"]))
+    eargs, _ = edm_from_cfg(dict(dataset=cfg["dataset"], over=TINY, wseed=cfg["eseed"], amp=False))
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["pseed"], amp=True))
+    gamma = O.gamma_table("polynomial_2", cfg["T"], 1e-5)
+    x, h, nm, em = g[name + "_x"], g[name + "_h"], g[name + "_node_mask"], g[name + "_edge_mask"]
+    for tag in ("t0", "t500", "tT", "tmix"):
+        ti = g[f"{name}_{tag}_t_int"]
+        zt = O.sample_edm_t(eargs, gamma, x, h, ti, nm, g[f"{name}_{tag}_eps"])
+        assert rel_err(zt, g[f"{name}_{tag}_zt"]) < 1e-6, tag
+        pred = O.predictor_forward(psd, pargs, zt, nm, em, (ti / np.float32(cfg["T"])).astype(np.float32))
+        assert rel_err(pred, g[f"{name}_{tag}_pred"]) < 1e-5, tag
+    err = np.abs(O.predictor_forward(psd, pargs, g[f"{name}_t500_zt"], nm, em, np.float32(0.5)) - g[name + "_y"])
+    assert rel_err(err, g[f"{name}_t500_err"]) < 1e-5 and abs(err.mean() - g[f"{name}_t500_loss"]) < 1e-5

@@ -605,6 +605,46 @@ def g12_ring_count_sampler():
     save("g12_ring_count_sampler", **out)
 
 
+def g13_noised_predictor():
+    """sample_edm_t + compute_loss (cond_prediction/train_cond_predictor.py:47-81): forward-noised inputs, predictor
+    outputs at the noise level and the per-target absolute errors, for fixed and per-sample t."""
+    from cond_prediction import train_cond_predictor as tcp
+    out = {}
+    for ci, (name, ds, nodes) in enumerate([("cata", "cata", [4, 11, 7, 1, 11]), ("hetro", "hetro", [3, 9, 6, 10])]):
+        F = synth.num_node_features(ds)
+        eargs = synth.edm_args(dataset=ds, **TINY)
+        esd = synth.synth_edm_state_dict(eargs, F, seed=1300 + ci)
+        a, model = build_ref_edm(ds, esd, **TINY)
+        psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **TINY_P), F, 5, seed=1310 + ci, amplify_coord=True)
+        pa, pred = build_ref_pred(ds, psd, **TINY_P)
+        nm, em, z = case_inputs(ds, nodes, None, seed=1320 + ci, guidance_pad=(ds != "cata"))
+        B, N, D = z.shape
+        rng = np.random.default_rng(1330 + ci)
+        x = (z[:, :, :3] * 3.0).astype(np.float32)                      # un-normalised, masked, mean-free positions
+        cls = rng.integers(0, F, (B, N))
+        h = (np.eye(F, dtype=np.float32)[cls] * nm).astype(np.float32)   # one-hot ring types
+        y = rng.standard_normal((B, 5)).astype(np.float32)
+        out[f"{name}_x"], out[f"{name}_h"], out[f"{name}_y"] = x, h, y
+        out[f"{name}_node_mask"], out[f"{name}_edge_mask"] = nm, em
+        tx, th, tnm, tem = (torch.from_numpy(v) for v in (x, h, nm, em))
+        T = a.diffusion_steps
+        for tag, t_int in (("t0", np.zeros(B)), ("t500", np.full(B, 500.0)), ("tT", np.full(B, float(T))),
+                           ("tmix", rng.integers(0, T + 1, B).astype(np.float64))):
+            eps = rng_noise(1340 + ci + len(tag), (B, N, D))
+            t = torch.from_numpy((t_int / T).astype(np.float32)).view(B, 1)
+            with InjectNoise([eps]), torch.no_grad():
+                zt = tcp.sample_edm_t(tx, th, model, t, tnm)
+                p = pred(zt, tnm, tem.view(B, N * N), t)
+            out[f"{name}_{tag}_t_int"] = t_int.astype(np.int32)
+            out[f"{name}_{tag}_eps"], out[f"{name}_{tag}_zt"], out[f"{name}_{tag}_pred"] = eps, zt.numpy(), p.numpy()
+            if tag == "t500":   # the whole compute_loss with t_fix (same noise -> same z_t)
+                with InjectNoise([eps]), torch.no_grad():
+                    loss, err = tcp.compute_loss(pred, tx, th, tnm, tem, torch.from_numpy(y), model, a, t_fix=500)
+                out[f"{name}_t500_loss"], out[f"{name}_t500_err"] = np.float32(loss.item()), err.numpy()
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, eseed=1300 + ci, pseed=1310 + ci, T=T)))
+    save("g13_noised_predictor", **out)
+
+
 def g8_checkpoint_roundtrip():
     """The reference's own loader must accept checkpoints written by gaudi_amd.synth.write_checkpoint
     (args.txt + model.pt, with and without the ``module.`` prefix).  Stores nothing but a marker."""
@@ -629,8 +669,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor)
     for w in which:
         fns[w]()
