@@ -36,7 +36,10 @@ __host__ __device__ constexpr int pick_pf(int T) {
     if (T % d == 0) best = d;
   return best;
 }
-constexpr int kPF = 6;  // prefetch depth of the fully unrolled (chained) edge GEMM
+#ifndef GAUDI_KPF
+#define GAUDI_KPF 6
+#endif
+constexpr int kPF = GAUDI_KPF;  // prefetch depth of the fully unrolled (chained) edge GEMM
 
 // ---- diagnostic build only (-DGAUDI_STAMPS): per-phase cycle accounting by lane 0 of wave 0.
 // Never compiled into the shipped library; numbers from a stamped build are shares, not run times.

@@ -379,28 +379,28 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           float mk[NB];
           f4 gg[NB];
           load_cols<PredSmem<HP>, NB>(sm, mg, wave, tile0 * 16, c, ec, mk, gg);
-          // v and cpre come back from the forward's edge stash (no recompute of W2 / Wc1)
-          f4 v[NB][T], cp[NB][T];
+          // v and cpre come back from the forward's edge stash (no recompute of W2 / Wc1).  v is needed twice (attention
+          // gate before the first GEMM, gate / SiLU derivatives after it): with NB = 2 it is loaded again rather than
+          // kept, so that only one NB x T quad array (the GEMM input) is live in VGPRs across each GEMM.
+          constexpr bool kKeepV = NB == 1;
+          f4 v[kKeepV ? NB : 1][T], cp[NB][T];
           STAMP(ST_BWD_EDGE);
+          float a[NB], tau[NB], dtx[NB], dty[NB], dtz[NB];
 #pragma unroll
           for (int e = 0; e < NB; ++e) {
             const f4* sv = (const f4*)(estash + edge_stash_off(l, wave, tile0 + e, 0, EW, HP)) + lane;
             const f4* sc = (const f4*)(estash + edge_stash_off(l, wave, tile0 + e, 1, EW, HP)) + lane;
+            f4(&ve)[T] = v[kKeepV ? e : 0];
 #pragma unroll
-            for (int t = 0; t < T; ++t) v[e][t] = sv[t * 64];
+            for (int t = 0; t < T; ++t) ve[t] = sv[t * 64];
             if (!last) {
 #pragma unroll
               for (int t = 0; t < T; ++t) cp[e][t] = sc[t * 64];
             }
-          }
-          STAMP(ST_B_V);
-          float a[NB], tau[NB], dtx[NB], dty[NB], dtz[NB];
-#pragma unroll
-          for (int e = 0; e < NB; ++e) {
             my_i[e] = ec[e].i;
             float sdot = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) sdot += dot4(silu4(v[e][t]), *(const f4*)(Lw.wa + 16 * t + 4 * g));
+            for (int t = 0; t < T; ++t) sdot += dot4(silu4(ve[t]), *(const f4*)(Lw.wa + 16 * t + 4 * g));
             a[e] = 1.f;
             if (W.attention) a[e] = sigmoid_f(reduce_groups(sdot) + Lw.ba);
             tau[e] = 0.f;
@@ -408,6 +408,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             dty[e] = sm.dx[4 * ec[e].i + 1];
             dtz[e] = sm.dx[4 * ec[e].i + 2];
           }
+          STAMP(ST_B_V);
           STAMP(ST_B_EV);
           f4 de[NB][T];
           if (!last) {
@@ -441,14 +442,20 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 #pragma unroll
           for (int e = 0; e < NB; ++e) {
             // e = m * a * mask ; a = sigmoid(wa . m + ba)
+            f4(&ve)[T] = v[kKeepV ? e : 0];
+            if (!kKeepV) {
+              const f4* sv = (const f4*)(estash + edge_stash_off(l, wave, tile0 + e, 0, EW, HP)) + lane;
+#pragma unroll
+              for (int t = 0; t < T; ++t) ve[t] = sv[t * 64];
+            }
             float dadot = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) dadot += dot4(de[e][t], silu4(v[e][t]));
+            for (int t = 0; t < T; ++t) dadot += dot4(de[e][t], silu4(ve[t]));
             const float da = reduce_groups(dadot) * mk[e];
             const float ds = W.attention ? da * a[e] * (1.0f - a[e]) : 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t)  // dv = (de*a*mask + ds*wa) * silu'(v)
-              de[e][t] = (de[e][t] * a[e] * mk[e] + *(const f4*)(Lw.wa + 16 * t + 4 * g) * ds) * dsilu4(v[e][t]);
+              de[e][t] = (de[e][t] * a[e] * mk[e] + *(const f4*)(Lw.wa + 16 * t + 4 * g) * ds) * dsilu4(ve[t]);
           }
           {
             const float* noinit[NB];
