@@ -46,7 +46,7 @@ constexpr int kPF = GAUDI_KPF;  // prefetch depth of the fully unrolled (chained
 #ifdef GAUDI_STAMPS
 enum { ST_NODE = 0, ST_EDGE = 1, ST_EDGE_EPI = 2, ST_BARRIER = 3, ST_MISC = 4, ST_BWD_NODE = 5, ST_BWD_EDGE = 6,
        ST_BWD_COL = 7, ST_BWD_BARRIER = 8, ST_STASH = 9, ST_B_V = 10, ST_B_EV = 11, ST_B_CP = 12, ST_B_DCP = 13,
-       ST_B_DE = 14, ST_B_DV = 15, ST_B_DT1 = 16, ST_B_DU = 17, ST_N = 18 };
+       ST_B_DE = 14, ST_B_DV = 15, ST_B_DT1 = 16, ST_B_DU = 17, ST_STAGE = 18, ST_GEO = 19, ST_N = 20 };
 struct Stamps {
   unsigned long long acc[ST_N];
   unsigned long long last;
@@ -138,6 +138,24 @@ __device__ __forceinline__ f4 ldw4n(const WBuf& w, int off_floats, int lane_f4) 
 }
 __device__ __forceinline__ float ldw1(const WBuf& w, int off_floats) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w.r, 0, off_floats * 4, 0));
+}
+
+// Copy `count` floats of the weight buffer (float offset `off`) into LDS.  All loads are issued before the first
+// store: the obvious `for (idx...) s[idx] = w[idx]` loop compiled into 8 dependent load->store round trips (4.5 us per
+// call, 6 % of a guided step).  Dword loads / stores on purpose: a float4 version of this helper made the fused
+// sampler_kernel<48,48> produce wrong, run-to-run varying results (either network alone was fine with it; hipcc also
+// aborted with "Operand has incorrect register class" on a close variant), so the shape that is verified stays.
+template <int MAXLOADS>
+__device__ __forceinline__ void stage_vectors(const WBuf& wb, int off, float* sVec, int count, int tid) {
+  float tmp[MAXLOADS];
+#pragma unroll
+  for (int k = 0; k < MAXLOADS; ++k)
+    tmp[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wb.r, (tid + k * kThreads) * 4, off * 4, 0));
+#pragma unroll
+  for (int k = 0; k < MAXLOADS; ++k) {
+    const int idx = tid + k * kThreads;
+    if (idx < count) sVec[idx] = tmp[k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -171,8 +171,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int PK = HP * HP;
       const int V = G + 6 * PK;
       // stage the layer's vectors in LDS (previous readers are behind the barrier that ended the last layer)
-      for (int idx = tid; idx < 7 * HP + 16; idx += kThreads) sm.vec[idx] = w[V + idx];
+      stage_vectors<8>(wb, V, sm.vec, 7 * HP + 16, tid);  // <= 7 * 256 + 16 floats <= 8 * 256
       __syncthreads();
+      STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
                   *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
       const float ba = sm.vec[7 * HP];
@@ -236,8 +237,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int E = lay.equ(l);
       const int PK = HP * HP;
       const int V = E + 3 * PK;
-      for (int idx = tid; idx < 5 * HP; idx += kThreads) sm.vec[idx] = w[V + idx];
+      stage_vectors<5>(wb, V, sm.vec, 5 * HP, tid);
       __syncthreads();
+      STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
       node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane, &pf, E + PK);
       node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane, &pf);

@@ -80,8 +80,8 @@ struct PredLayerW {
   const float *cr, *cd, *b1, *b2, *wa, *bc1, *wc2, *bn1, *bn2;  // LDS copies (stage() first)
   float ba;
   // copy the vector block to LDS; the caller places a barrier before the first use
-  __device__ void stage(const float* w, float* sVec, int HP, int tid) const {
-    for (int idx = tid; idx < 9 * HP + 16; idx += kThreads) sVec[idx] = w[V + idx];
+  __device__ __forceinline__ void stage(const WBuf& wb, float* sVec, int HP, int tid) const {
+    stage_vectors<10>(wb, V, sVec, 9 * HP + 16, tid);  // 9 * 256 + 16 floats at most <= 10 * 256
   }
   __device__ PredLayerW(const float* w, int L0, int HP, const float* sVec) {
     const int PK = HP * HP;
@@ -153,13 +153,14 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   for (int l = 0; l < W.L; ++l) {
     const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
-    Lw.stage(w, sm.vec, HP, tid);
+    Lw.stage(wb, sm.vec, HP, tid);
     __syncthreads();
+    STAMP(ST_STAGE);
     float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
     for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 3 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
     compute_geo(sm, mg, 1.0f, wave, lane, false);  // gcl.py:308-316
+    STAMP(ST_GEO);
     node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane, &pf, Lw.Bm);
-    STAMP(ST_STASH);
     node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, N, wave, lane, &pf);
     for (int idx = tid; idx < N * LD; idx += kThreads) agg[idx] = 0.f;
     STAMP(ST_NODE);
@@ -241,7 +242,6 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     STAMP(ST_EDGE_EPI);
     __syncthreads();
     STAMP(ST_BARRIER);
-    STAMP(ST_STASH);
     node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane, &pf, Lw.Wn2,
                                   st + 2 * N * HP /* npre -> stash */);
     STAMP(ST_NODE);
@@ -329,8 +329,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   for (int l = W.L - 1; l >= 0; --l) {
     const bool last = l == W.L - 1;
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
-    Lw.stage(w, sm.vec, HP, tid);
+    Lw.stage(wb, sm.vec, HP, tid);
     __syncthreads();
+    STAMP(ST_STAGE);
     const float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
     // (a) reload P -> B2, Q -> B1, npre -> B4, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
@@ -348,6 +349,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     __syncthreads();
     STAMP(ST_STASH);
     compute_geo(sm, mg, 1.0f, wave, lane, false);
+    STAMP(ST_GEO);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
     node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, N, wave, lane, &pf, Lw.Wn1ht);
     __syncthreads();
