@@ -140,21 +140,29 @@ __device__ __forceinline__ float ldw1(const WBuf& w, int off_floats) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w.r, 0, off_floats * 4, 0));
 }
 
-// Copy `count` floats of the weight buffer (float offset `off`) into LDS.  All loads are issued before the first
-// store: the obvious `for (idx...) s[idx] = w[idx]` loop compiled into 8 dependent load->store round trips (4.5 us per
-// call, 6 % of a guided step).  Dword loads / stores on purpose: a float4 version of this helper made the fused
-// sampler_kernel<48,48> produce wrong, run-to-run varying results (either network alone was fine with it; hipcc also
-// aborted with "Operand has incorrect register class" on a close variant), so the shape that is verified stays.
+// Per-layer vectors (biases, attention / radial columns): weight buffer -> registers -> LDS in two halves.
+// vec_prefetch issues all loads at once, one phase early (before the last node GEMM of the previous layer), so that
+// the layer starts with LDS stores only; vec_commit writes them.  History: the obvious `for (idx...) s[idx] = w[idx]`
+// loop compiled into 8 dependent load->store round trips (4.5 us per layer, 6 % of a guided step).  Dword loads / stores
+// on purpose: a float4 version made the fused sampler_kernel<48,48> produce wrong, run-to-run varying results (either
+// network alone was fine with it; hipcc also aborted with "Operand has incorrect register class" on a close variant),
+// so the shape that is verified stays (tests/test_gpu_parity.py::test_guided_steps_are_reproducible).
 template <int MAXLOADS>
-__device__ __forceinline__ void stage_vectors(const WBuf& wb, int off, float* sVec, int count, int tid) {
-  float tmp[MAXLOADS];
+struct VecPF {
+  float r[MAXLOADS];
+};
+template <int MAXLOADS>
+__device__ __forceinline__ void vec_prefetch(VecPF<MAXLOADS>& pf, const WBuf& wb, int off, int tid) {
 #pragma unroll
   for (int k = 0; k < MAXLOADS; ++k)
-    tmp[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wb.r, (tid + k * kThreads) * 4, off * 4, 0));
+    pf.r[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wb.r, (tid + k * kThreads) * 4, off * 4, 0));
+}
+template <int MAXLOADS>
+__device__ __forceinline__ void vec_commit(const VecPF<MAXLOADS>& pf, float* sVec, int count, int tid) {
 #pragma unroll
   for (int k = 0; k < MAXLOADS; ++k) {
     const int idx = tid + k * kThreads;
-    if (idx < count) sVec[idx] = tmp[k];
+    if (idx < count) sVec[idx] = pf.r[k];
   }
 }
 

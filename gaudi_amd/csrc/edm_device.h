@@ -162,6 +162,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   compute_geo(sm, mg, 0.f, wave, lane, true);  // d0 of the input coordinates (egnn_new.py:301)
   NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it (device_common.h)
   node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);
+  constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
+  VecPF<NV> vpf;  // the next sub-layer's vectors (GCL: 7 HP + 16 floats, EquivariantUpdate: 5 HP), loaded a phase ahead
+  vec_prefetch(vpf, wb, lay.gcl(0, 0) + 6 * HP * HP, tid);
 
   for (int l = 0; l < W.L; ++l) {
     compute_geo(sm, mg, W.norm_constant, wave, lane, false);  // egnn_new.py:216
@@ -171,7 +174,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int PK = HP * HP;
       const int V = G + 6 * PK;
       // stage the layer's vectors in LDS (previous readers are behind the barrier that ended the last layer)
-      stage_vectors<8>(wb, V, sm.vec, 7 * HP + 16, tid);  // <= 7 * 256 + 16 floats <= 8 * 256
+      (void)V;
+      vec_commit(vpf, sm.vec, 7 * HP + 16, tid);
       __syncthreads();
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
@@ -226,6 +230,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
+      vec_prefetch(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK, tid);
       node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, N, wave, lane,
                                              &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
@@ -237,7 +242,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int E = lay.equ(l);
       const int PK = HP * HP;
       const int V = E + 3 * PK;
-      stage_vectors<5>(wb, V, sm.vec, 5 * HP, tid);
+      (void)V;
+      vec_commit(vpf, sm.vec, 5 * HP, tid);
       __syncthreads();
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
@@ -273,7 +279,10 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           }
         }
       }
-      if (l + 1 < W.L) node_prefetch<HP>(pf, wb, lay.gcl(l + 1, 0), wave, lane);
+      if (l + 1 < W.L) {
+        node_prefetch<HP>(pf, wb, lay.gcl(l + 1, 0), wave, lane);
+        vec_prefetch(vpf, wb, lay.gcl(l + 1, 0) + 6 * HP * HP, tid);  // travels across the barrier and coord_update
+      }
       STAMP(ST_EDGE_EPI);
       __syncthreads();
       STAMP(ST_BARRIER);

@@ -80,9 +80,8 @@ struct PredLayerW {
   const float *cr, *cd, *b1, *b2, *wa, *bc1, *wc2, *bn1, *bn2;  // LDS copies (stage() first)
   float ba;
   // copy the vector block to LDS; the caller places a barrier before the first use
-  __device__ __forceinline__ void stage(const WBuf& wb, float* sVec, int HP, int tid) const {
-    stage_vectors<10>(wb, V, sVec, 9 * HP + 16, tid);  // 9 * 256 + 16 floats at most <= 10 * 256
-  }
+  __host__ __device__ static constexpr int vec_off(int L0, int HP) { return L0 + 14 * HP * HP; }
+  __host__ __device__ static constexpr int vec_count(int HP) { return 9 * HP + 16; }
   __device__ PredLayerW(const float* w, int L0, int HP, const float* sVec) {
     const int PK = HP * HP;
     A = L0; Bm = L0 + PK; W2 = L0 + 2 * PK; Wc1 = L0 + 3 * PK; Wn1h = L0 + 4 * PK; Wn1a = L0 + 5 * PK;
@@ -149,11 +148,14 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   compute_geo(sm, mg, 0.f, wave, lane, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
   NodePF<HP> pf;
   node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane);
+  constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
+  VecPF<NV> vpf;  // the next layer's vectors, loaded one node GEMM ahead
+  vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(0), HP), tid);
 
   for (int l = 0; l < W.L; ++l) {
     const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
-    Lw.stage(wb, sm.vec, HP, tid);
+    vec_commit(vpf, sm.vec, PredLayerW::vec_count(HP), tid);  // previous readers are behind the barrier that ended layer l-1
     __syncthreads();
     STAMP(ST_STAGE);
     float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
@@ -247,6 +249,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
+    vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), tid);
     node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, N, wave, lane, &pf,
                                            l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
@@ -326,10 +329,13 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 
   NodePF<HP> pf;
   node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane);
+  constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
+  VecPF<NV> vpf;
+  vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(W.L - 1), HP), tid);
   for (int l = W.L - 1; l >= 0; --l) {
     const bool last = l == W.L - 1;
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
-    Lw.stage(wb, sm.vec, HP, tid);
+    vec_commit(vpf, sm.vec, PredLayerW::vec_count(HP), tid);
     __syncthreads();
     STAMP(ST_STAGE);
     const float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
@@ -547,23 +553,34 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       const int n = idx / LD;
       if ((mg.seg[n] & 0x7fff) == 0) B2[idx] = 0.f;
     }
-    // dx <- dx*mask + sum_{e: i=n} ddiff_e - sum_{e: j=n} ddiff_e   (fixed slot order)
+    // dx <- dx*mask + sum_{e: i=n} ddiff_e - sum_{e: j=n} ddiff_e : one thread per (wave list, node, axis) walks that
+    // wave's slots in order, the four partial sums are then added in wave order (fixed order, no atomics; a single
+    // thread per (node, axis) walking all 4 lists cost 4 % of the guided step)
+    float* part = sm.scr;  // [kWaves][N*3]; the transposition scratch is idle between edge passes
+    for (int t = tid; t < kWaves * N * 3; t += kThreads) {
+      const int w2 = t / (N * 3), nd = t % (N * 3), n = nd / 3, d = nd % 3;
+      float acc = 0.f;
+      const int ns = 32 * mg.npairs_all_lane(w2);
+      for (int s = 0; s < ns; ++s) {
+        const uint32_t e = mg.edge[w2 * EW + s];
+        const float v = sm.trans[4 * (w2 * EW + s) + d];
+        if ((int)(e & 255) == n) acc += v;
+        if ((int)((e >> 8) & 255) == n) acc -= v;
+      }
+      part[t] = acc;
+    }
+    __syncthreads();
     if (tid < N * 3) {
       const int n = tid / 3, d = tid % 3;
       float acc = sm.dx[4 * n + d];
 #pragma unroll
-      for (int w2 = 0; w2 < kWaves; ++w2)
-        for (int s = 0; s < 32 * mg.npairs_all[w2]; ++s) {
-          const uint32_t e = mg.edge[w2 * EW + s];
-          const float v = sm.trans[4 * (w2 * EW + s) + d];
-          if ((int)(e & 255) == n) acc += v;
-          if ((int)((e >> 8) & 255) == n) acc -= v;
-        }
+      for (int w2 = 0; w2 < kWaves; ++w2) acc += part[w2 * N * 3 + tid];
       sm.dx[4 * n + d] = acc;
     }
     __syncthreads();
     // (f) dh += A^T dP + Bm^T dQ
     STAMP(ST_MISC);
+    vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(l > 0 ? l - 1 : 0), HP), tid);
     node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, N, wave, lane, &pf,
                                    l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
