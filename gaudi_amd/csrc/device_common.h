@@ -46,7 +46,8 @@ constexpr int kPF = GAUDI_KPF;  // prefetch depth of the fully unrolled (chained
 #ifdef GAUDI_STAMPS
 enum { ST_NODE = 0, ST_EDGE = 1, ST_EDGE_EPI = 2, ST_BARRIER = 3, ST_MISC = 4, ST_BWD_NODE = 5, ST_BWD_EDGE = 6,
        ST_BWD_COL = 7, ST_BWD_BARRIER = 8, ST_STASH = 9, ST_B_V = 10, ST_B_EV = 11, ST_B_CP = 12, ST_B_DCP = 13,
-       ST_B_DE = 14, ST_B_DV = 15, ST_B_DT1 = 16, ST_B_DU = 17, ST_STAGE = 18, ST_GEO = 19, ST_N = 20 };
+       ST_B_DE = 14, ST_B_DV = 15, ST_B_DT1 = 16, ST_B_DU = 17, ST_STAGE = 18, ST_GEO = 19,
+       ST_EDM_IO = 20, ST_UPDATE = 21, ST_PRED_IO = 22, ST_GUIDE = 23, ST_N = 24 };
 struct Stamps {
   unsigned long long acc[ST_N];
   unsigned long long last;
@@ -140,6 +141,34 @@ __device__ __forceinline__ float ldw1(const WBuf& w, int off_floats) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w.r, 0, off_floats * 4, 0));
 }
 
+// Small dense dot products  out(p) = sum_{k < K} a(p, k) * b(p, k)  for p < P  (embedding heads, readout, their reverse):
+// with few pairs (cata: N*F = 11) one thread per pair walks K = 192..256 elements alone, 11 busy lanes and K dependent
+// steps; then 16 lanes share a pair and fold with 4 shuffles.  With many pairs (hetero: N*F = 240) a thread per pair is the
+// better shape.  Summation order differs between the two shapes, both are fixed (no atomics).
+template <class FA, class FB, class ST>
+__device__ __forceinline__ void small_dots(int P, int K, int tid, FA a, FB b, ST store) {
+  if (P * 16 > 2 * kThreads) {
+    for (int p = tid; p < P; p += kThreads) {
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc += a(p, k) * b(p, k);
+      store(p, acc);
+    }
+  } else {
+    const int sub = tid & 15;
+    for (int p0 = 0; p0 < P; p0 += kThreads / 16) {
+      const int p = p0 + (tid >> 4);
+      float acc = 0.f;
+      if (p < P)
+        for (int k = sub; k < K; k += 16) acc += a(p, k) * b(p, k);
+      acc += __shfl_xor(acc, 8);
+      acc += __shfl_xor(acc, 4);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 1);
+      if (p < P && sub == 0) store(p, acc);
+    }
+  }
+}
+
 // Per-layer vectors (biases, attention / radial columns): weight buffer -> registers -> LDS in two halves.
 // vec_prefetch issues all loads at once, one phase early (before the last node GEMM of the previous layer), so that
 // the layer starts with LDS stores only; vec_commit writes them.  History: the obvious `for (idx...) s[idx] = w[idx]`
@@ -151,11 +180,17 @@ template <int MAXLOADS>
 struct VecPF {
   float r[MAXLOADS];
 };
+// count: floats of the vector block.  Lanes past it do not load: the descriptor's range check looks at the lane offset
+// only (not at the scalar base), so an unguarded tail would read past the end of the weight allocation.
 template <int MAXLOADS>
-__device__ __forceinline__ void vec_prefetch(VecPF<MAXLOADS>& pf, const WBuf& wb, int off, int tid) {
+__device__ __forceinline__ void vec_prefetch(VecPF<MAXLOADS>& pf, const WBuf& wb, int off, int count, int tid) {
 #pragma unroll
-  for (int k = 0; k < MAXLOADS; ++k)
-    pf.r[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wb.r, (tid + k * kThreads) * 4, off * 4, 0));
+  for (int k = 0; k < MAXLOADS; ++k) {
+    const int idx = tid + k * kThreads;
+    pf.r[k] = idx < count
+                  ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wb.r, idx * 4, off * 4, 0))
+                  : 0.f;
+  }
 }
 template <int MAXLOADS>
 __device__ __forceinline__ void vec_commit(const VecPF<MAXLOADS>& pf, float* sVec, int count, int tid) {

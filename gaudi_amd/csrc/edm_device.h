@@ -164,7 +164,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);
   constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next sub-layer's vectors (GCL: 7 HP + 16 floats, EquivariantUpdate: 5 HP), loaded a phase ahead
-  vec_prefetch(vpf, wb, lay.gcl(0, 0) + 6 * HP * HP, tid);
+  vec_prefetch(vpf, wb, lay.gcl(0, 0) + 6 * HP * HP, 7 * HP + 16, tid);
+  STAMP(ST_EDM_IO);
 
   for (int l = 0; l < W.L; ++l) {
     compute_geo(sm, mg, W.norm_constant, wave, lane, false);  // egnn_new.py:216
@@ -230,7 +231,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
-      vec_prefetch(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK, tid);
+      vec_prefetch(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK, s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
       node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, N, wave, lane,
                                              &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
@@ -281,7 +282,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       }
       if (l + 1 < W.L) {
         node_prefetch<HP>(pf, wb, lay.gcl(l + 1, 0), wave, lane);
-        vec_prefetch(vpf, wb, lay.gcl(l + 1, 0) + 6 * HP * HP, tid);  // travels across the barrier and coord_update
+        vec_prefetch(vpf, wb, lay.gcl(l + 1, 0) + 6 * HP * HP, 7 * HP + 16, tid);  // travels across the barrier and coord_update
       }
       STAMP(ST_EDGE_EPI);
       __syncthreads();
@@ -297,21 +298,18 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   {
     const float* ow = w + lay.out_w();
     const float* ob = w + lay.out_b();
-    for (int idx = tid; idx < N * D; idx += kThreads) {
-      const int n = idx / D, d = idx % D;
-      const float m = mg.mask[n];
-      float v;
-      if (d < 3) {
-        v = (sm.x[4 * n + d] - sm.x0[4 * n + d]) * m;
-        if (v != v) v = 0.f;
-      } else {
-        const int o = d - 3;
-        float acc = 0.f;
-        for (int k = 0; k < HP; ++k) acc += ow[o * HP + k] * sm.h[n * LD + k];
-        v = (acc + ob[o]) * m;
-      }
-      sEps[idx] = v;
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
+      float v = (sm.x[4 * n + d] - sm.x0[4 * n + d]) * mg.mask[n];
+      if (v != v) v = 0.f;
+      sEps[n * D + d] = v;
     }
+    const float* hh = sm.h;
+    const float* msk = mg.mask;
+    small_dots(
+        N * F, HP, tid, [=](int p, int k) { return ow[(p % F) * HP + k]; },
+        [=](int p, int k) { return hh[(p / F) * LD + k]; },
+        [=](int p, float acc) { sEps[(p / F) * D + 3 + p % F] = (acc + ob[p % F]) * msk[p / F]; });
     __syncthreads();
     if (tid < 3) {
       float s = 0.f, cnt = 0.f;
@@ -328,6 +326,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
     }
     __syncthreads();
   }
+  STAMP(ST_EDM_IO);
 }
 
 }  // namespace gaudi

@@ -315,7 +315,8 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
     if (getenv("GAUDI_PRINT_STAMPS")) {
       static const char* nm[] = {"node_gemm", "edge_gemm", "edge_epilogue", "barrier", "misc", "bwd_node", "bwd_edge",
                                  "bwd_colsum", "bwd_barrier", "stash", "b_gemm_v", "b_ev", "b_gemm_cp", "b_dcp",
-                                 "b_gemm_de", "b_dv", "b_gemm_dt1", "b_du", "stage_vectors", "geo"};
+                                 "b_gemm_de", "b_dv", "b_gemm_dt1", "b_du", "stage_vectors", "geo", "edm_embed_head", "noise_update",
+                                 "pred_embed_readout", "guide_clip"};
       unsigned long long tot = 0;
       for (int i = 0; i < ST_N; ++i) tot += h->stamp_acc[i];
       fprintf(stderr, "[stamps] cumulative shares (block 0, wave 0):");

@@ -150,7 +150,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane);
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next layer's vectors, loaded one node GEMM ahead
-  vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(0), HP), tid);
+  vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(0), HP), PredLayerW::vec_count(HP), tid);
+  STAMP(ST_PRED_IO);
 
   for (int l = 0; l < W.L; ++l) {
     const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
@@ -249,7 +250,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
-    vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), tid);
+    vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), PredLayerW::vec_count(HP), tid);
     node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, N, wave, lane, &pf,
                                            l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
@@ -261,12 +262,11 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   {
     const float* ow = w + lay.out_w();
     const float* ob = w + lay.out_b();
-    for (int idx = tid; idx < N * K; idx += kThreads) {
-      const int n = idx / K, k = idx % K;
-      float acc = 0.f;
-      for (int f = 0; f < HP; ++f) acc += ow[k * HP + f] * h[n * LD + f];
-      p[idx] = (acc + ob[k]) * mg.mask[n];
-    }
+    const float* msk = mg.mask;
+    small_dots(
+        N * K, HP, tid, [=](int q, int f) { return ow[(q % K) * HP + f]; },
+        [=](int q, int f) { return h[(q / K) * LD + f]; },
+        [=](int q, float acc) { p[q] = (acc + ob[q % K]) * msk[q / K]; });
     __syncthreads();
     if (tid < K) {
       float s = 0.f;
@@ -275,6 +275,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     }
     __syncthreads();
   }
+  STAMP(ST_PRED_IO);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,7 +332,8 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane);
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;
-  vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(W.L - 1), HP), tid);
+  vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(W.L - 1), HP), PredLayerW::vec_count(HP), tid);
+  STAMP(ST_PRED_IO);
   for (int l = W.L - 1; l >= 0; --l) {
     const bool last = l == W.L - 1;
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
@@ -580,7 +582,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     __syncthreads();
     // (f) dh += A^T dP + Bm^T dQ
     STAMP(ST_MISC);
-    vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(l > 0 ? l - 1 : 0), HP), tid);
+    vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(l > 0 ? l - 1 : 0), HP), PredLayerW::vec_count(HP), tid);
     node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, N, wave, lane, &pf,
                                    l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
@@ -604,14 +606,14 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         }
       sGrad[n * D + d] = acc * mg.mask[n];
     }
-    for (int idx = tid; idx < N * F; idx += kThreads) {
-      const int n = idx / F, k = idx % F;
-      float acc = 0.f;
-      for (int f = 0; f < HP; ++f) acc += dh[n * LD + f] * ew[f * F1 + k];
-      sGrad[n * D + 3 + k] = acc * mg.mask[n];
-    }
+    const float* msk = mg.mask;
+    small_dots(
+        N * F, HP, tid, [=](int q, int f) { return ew[f * F1 + q % F]; },
+        [=](int q, int f) { return dh[(q / F) * LD + f]; },
+        [=](int q, float acc) { sGrad[(q / F) * D + 3 + q % F] = acc * msk[q / F]; });
   }
   __syncthreads();
+  STAMP(ST_PRED_IO);
 }
 
 // unit-test entry: pred (and optionally grad into sGrad) for z in sZ
@@ -676,6 +678,7 @@ __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph
     sZ[e] = sZ[e] - sigma * gv;
   }
   __syncthreads();
+  STAMP(ST_GUIDE);
 }
 
 }  // namespace gaudi

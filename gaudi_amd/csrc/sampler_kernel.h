@@ -189,6 +189,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
               sZ[e] = mu + cf[2] * sNz[e];
             }
             __syncthreads();
+            STAMP(ST_UPDATE);
           }
           if constexpr (HPP > 0) {
             if (guided) {
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
             }
             __syncthreads();
           }
+          STAMP(ST_UPDATE);
           if (P.chain_out != nullptr) {
             // sample_chain (en_diffusion.py:1145-1161): frame (s*K)//T receives unnormalize_z(z_s); a later (smaller) s
             // mapping to the same frame overwrites it, so only the last writer of each frame stores.
