@@ -34,8 +34,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=2, help="timed sample_guidance calls (1000 reverse steps each)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=None, help="molecules per GPU (default 256; 1024 for c4)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"],
-                    help="c2 = unguided cata, c3 = gap-guided cata (headline), c4 = hetero mixed 3-10 rings, multi-objective")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "stability"],
+                    help="c2 = unguided cata, c3 = gap-guided cata (headline), c4 = hetero mixed 3-10 rings, multi-objective; "
+                         "stability = the graph-of-rings stability kernel that follows sampling (SURVEY 8f rank 1)")
+    ap.add_argument("--molecules", type=int, default=262144, help="stability workload: molecules per call")
+    ap.add_argument("--dataset", default="cata", choices=["cata", "hetro"], help="stability workload: geometry tables")
     ap.add_argument("--diffusion-steps", type=int, default=1000)
     ap.add_argument("--steps-per-launch", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -71,8 +74,53 @@ def cpu_baseline(eargs, pargs, esd, psd, guided, T, B):
                        f"{per_step * 1e3:.0f} ms/step")
 
 
+def bench_stability(a):
+    """Side workload: gaudi_check_stability on replicated golden molecules (one step = one call over `--molecules`).
+    Same JSON contract; the kernel is HBM-side by its algorithmic bytes but bound by its serial sections."""
+    from gaudi_amd import analyze
+    from gaudi_amd.engine import Engine
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g11_stability.npz"))
+    ds, M = a.dataset, a.molecules
+    idx = np.arange(M) % len(g[f"{ds}_n"])
+    X = np.ascontiguousarray(g[f"{ds}_x"][idx])
+    T = np.ascontiguousarray(np.maximum(g[f"{ds}_types"][idx], 0).astype(np.int32))
+    nn = np.ascontiguousarray(g[f"{ds}_n"][idx].astype(np.int32))
+    eng = Engine(0)
+    want = g[f"{ds}_flags"].astype(bool)[idx]
+    for _ in range(max(a.warmup, 1)):
+        flags = analyze.check_stability_batch(X, T, nn, 0.1, ds, engine=eng)
+    assert np.array_equal(flags, want), "stability flags differ from the reference's (g11 fixture)"
+    eng.profile_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        analyze.check_stability_batch(X, T, nn, 0.1, ds, engine=eng)
+    wall = (time.perf_counter() - t0) / a.steps
+    n_launch, kernel_ms = eng.stability_profile_get()
+    kernel_s = kernel_ms / 1e3 / max(n_launch, 1)
+    bytes_per_mol = X.shape[1] * 3 * 4 + X.shape[1] * 4 + 4 + 5
+    out = dict(metric="stability-checked molecules/sec", value=M / wall, unit="molecules/s", n_gpus=1, steps=a.steps,
+               warmup=max(a.warmup, 1), ms_per_step=wall * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32", data="synthetic (g11 fixture molecules replicated)",
+               config=dict(workload=f"graph-of-rings stability check, {ds}, {M} molecules per call, N={X.shape[1]}"),
+               roofline=dict(bound="hbm", achieved=M * bytes_per_mol / kernel_s / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
+                             frac=M * bytes_per_mol / kernel_s / 1e9 / PEAK_HBM_GBPS, traffic=None,
+                             kernel="stability_kernel", avg_launch_ms=kernel_s * 1e3, launches=n_launch,
+                             algorithmic_bytes_per_molecule=bytes_per_mol, kernel_molecules_per_s=M / kernel_s))
+    if not a.no_cpu_baseline:
+        from oracle import stability_oracle as S  # baseline leg only
+        m, t0 = 0, time.perf_counter()
+        while m < M and (m < 64 or time.perf_counter() - t0 < 10.0):
+            S.check_stability(X[m, : nn[m]], T[m, : nn[m]], dataset=ds)
+            m += 1
+        out["cpu_baseline"] = dict(value=m / (time.perf_counter() - t0), unit="molecules/s", cores=1, kind="port",
+                                   sample=f"numpy/Python stability oracle on the first {m} molecules of the same batch")
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
+    if a.workload == "stability":
+        return bench_stability(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world == 1:
         # convenience: relaunch under torch.distributed.run as a CHILD process (never exec after GPU init)

@@ -10,7 +10,7 @@ cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 R="rocprofv3 --kernel-trace --stats --output-format csv"
 $R -d $out/c3 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/c3_bench.json 2> $out/c3.log
 $R -d $out/c2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --workload c2 > $out/c2_bench.json 2> $out/c2.log
-$R -d $out/stab -- python3 tools/bench_stability.py --molecules 262144 --reps 20 --cpu-sample 8 > $out/stab_bench.json 2> $out/stab.log
+$R -d $out/stab -- python3 bench.py --workload stability --steps 20 --warmup 1 --no-cpu-baseline > $out/stab_bench.json 2> $out/stab.log
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 1 --warmup 0 \
     --no-cpu-baseline --diffusion-steps 100 > $out/pmc_$c.json 2> $out/pmc_$c.log
