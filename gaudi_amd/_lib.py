@@ -77,7 +77,8 @@ EXPORTS = {
     "gaudi_philox_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, FP]),
     "gaudi_host_schedule": (C.c_int, [C.c_int, C.c_float, C.c_float, FP, FP]),
     "gaudi_host_graph_meta": (C.c_int, [C.c_int, C.c_int, FP, FP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), FP, C.c_int32]),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), FP, C.c_int32,
+                                        C.POINTER(C.c_int32)]),
     "gaudi_host_pack_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, FP, FP]),
     "gaudi_profile_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "gaudi_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -36,6 +36,7 @@ struct EdmDev {
 // Per-molecule graph metadata prepared on the host (gaudi_hip.hip: build_meta) and staged in LDS.
 struct MolGraph {
   int N, D, EW;           // nodes (padded), 3+F, per-wave edge-slot capacity (multiple of 32)
+  int NC;                 // node columns that matter: 1 + last node that is live or touches a live edge (<= N)
   const float* mask;      // LDS [N]
   const uint32_t* edge;   // LDS [4][EW]  i | j<<8
   const float* em;        // LDS [4][EW]  edge_mask value (0 for padding slots)
@@ -182,8 +183,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
                   *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
       const float ba = sm.vec[7 * HP];
-      node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane, &pf, G + PK);
-      node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane, &pf);
+      node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, G + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf);
       for (int idx = tid; idx < N * LD; idx += kThreads) sm.agg[idx] = 0.f;
       STAMP(ST_NODE);
       __syncthreads();
@@ -226,13 +227,13 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       STAMP(ST_EDGE_EPI);
       __syncthreads();
       STAMP(ST_BARRIER);
-      node_gemm<HP, EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, N, wave, lane,
+      node_gemm<HP, EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, mg.NC, wave, lane,
                                     &pf, G + 5 * PK);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
       vec_prefetch(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK, s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
-      node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, N, wave, lane,
+      node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave, lane,
                                              &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
       __syncthreads();
@@ -248,8 +249,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       __syncthreads();
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
-      node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, N, wave, lane, &pf, E + PK);
-      node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, N, wave, lane, &pf);
+      node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, E + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);

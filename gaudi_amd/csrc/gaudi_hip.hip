@@ -52,7 +52,7 @@ struct gaudi_handle {
   std::vector<float> gamma, coef;
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
-      d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as;
+      d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols;
   int steps_per_launch = 25;
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
   // profiling
@@ -166,7 +166,7 @@ static void pack_col(float* dst, const float* W, int H, int ldw, int col) {
 // wave's edge list sorted by receiving node and padded to 32 ("bucketed by degree").
 struct Meta {
   int EW = 32;
-  std::vector<int> order, npairs;
+  std::vector<int> order, npairs, ncols;
   std::vector<uint32_t> edges, seg;
   std::vector<float> emask;
 };
@@ -182,19 +182,32 @@ static int build_meta(int B, int N, const float* node_mask, const float* edge_ma
     int total = 0;
   };
   std::vector<Mol> mols(B);
+  M.ncols.assign(B, 1);
   int maxlen = 0;
   std::vector<std::vector<int>> wl(B * kWaves);
   for (int b = 0; b < B; ++b) {
     Mol& m = mols[b];
     m.nbr.resize(N);
-    for (int i = 0; i < N; ++i)
+    // Edges between two MASKED nodes are dropped: the reference leaves the identity block "padded ring <-> its
+    // orientation node" unmasked (sampling_edm.py:147-159), but a masked node's features are multiplied by node_mask = 0
+    // after every layer and its outputs are masked, and no live node has an edge to it, so those messages reach nothing.
+    // ncols = 1 + the last node that is live or has a live edge: node-level GEMMs stop there (hetero batches padded to
+    // 20 nodes: molecules of up to 6 rings need one 16-node column tile instead of two).
+    int last = 0;
+    for (int i = 0; i < N; ++i) {
+      const bool li = node_mask == nullptr || node_mask[(size_t)b * N + i] != 0.f;
+      if (li) last = i;
       for (int j = 0; j < N; ++j) {
         const float v = edge_mask[((size_t)b * N + i) * N + j];
-        if (v != 0.f) {
+        const bool lj = node_mask == nullptr || node_mask[(size_t)b * N + j] != 0.f;
+        if (v != 0.f && (li || lj)) {
           m.nbr[i].push_back({j, v});
           ++m.total;
+          last = std::max(last, std::max(i, j));
         }
       }
+    }
+    M.ncols[b] = last + 1;
     // longest-processing-time assignment of receiving nodes to waves
     std::vector<int> idx(N);
     for (int i = 0; i < N; ++i) idx[i] = i;
@@ -349,6 +362,8 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   HIPCHECK(h, h->d_emask.reserve(sizeof(float) * M.emask.size()));
   HIPCHECK(h, h->d_npairs.reserve(sizeof(int) * M.npairs.size()));
   HIPCHECK(h, h->d_seg.reserve(sizeof(uint32_t) * M.seg.size()));
+  HIPCHECK(h, h->d_ncols.reserve(sizeof(int) * B));
+  HIPCHECK(h, hipMemcpyAsync(h->d_ncols.p, M.ncols.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, hipMemcpyAsync(h->d_mask.p, node_mask, sizeof(float) * B * N, hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, hipMemcpyAsync(h->d_order.p, M.order.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h, hipMemcpyAsync(h->d_edges.p, M.edges.data(), sizeof(uint32_t) * M.edges.size(), hipMemcpyHostToDevice, h->stream));
@@ -365,6 +380,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   P.emask = h->d_emask.as<float>();
   P.npairs = h->d_npairs.as<int>();
   P.seginfo = h->d_seg.as<uint32_t>();
+  P.ncols = h->d_ncols.as<int>();
   return GAUDI_OK;
 }
 
@@ -420,7 +436,7 @@ void gaudi_destroy(gaudi_handle* h) {
   DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
                     &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
                     &h->d_pred, &h->d_tw, &h->d_stash, &h->d_chain, &h->d_sx, &h->d_stype, &h->d_sn,
-                    &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as};
+                    &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as, &h->d_ncols};
   for (DevBuf* b : bufs) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -875,7 +891,7 @@ int gaudi_host_schedule(int T, float noise_power, float noise_precision, float* 
 
 int gaudi_host_graph_meta(int B, int N, const float* node_mask, const float* edge_mask, int32_t* ew_out,
                           int32_t* order_out, int32_t* npairs_out, uint32_t* seg_out, uint32_t* edges_out,
-                          float* emask_out, int32_t edges_capacity) {
+                          float* emask_out, int32_t edges_capacity, int32_t* ncols_out) {
   if (B <= 0 || N <= 0 || !edge_mask || !ew_out) return GAUDI_E_INVALID;
   Meta M;
   std::string err;
@@ -885,6 +901,7 @@ int gaudi_host_graph_meta(int B, int N, const float* node_mask, const float* edg
   if (order_out) std::memcpy(order_out, M.order.data(), sizeof(int) * B);
   if (npairs_out) std::memcpy(npairs_out, M.npairs.data(), sizeof(int) * B * kWaves);
   if (seg_out) std::memcpy(seg_out, M.seg.data(), sizeof(uint32_t) * B * N);
+  if (ncols_out) std::memcpy(ncols_out, M.ncols.data(), sizeof(int) * B);
   if (edges_out || emask_out) {
     if ((size_t)edges_capacity < M.edges.size()) return GAUDI_E_CAPACITY;
     if (edges_out) std::memcpy(edges_out, M.edges.data(), sizeof(uint32_t) * M.edges.size());

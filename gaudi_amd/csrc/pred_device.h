@@ -163,8 +163,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 3 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
     compute_geo(sm, mg, 1.0f, wave, lane, false);  // gcl.py:308-316
     STAMP(ST_GEO);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, N, wave, lane, &pf, Lw.Bm);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, N, wave, lane, &pf);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Bm);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, &pf);
     for (int idx = tid; idx < N * LD; idx += kThreads) agg[idx] = 0.f;
     STAMP(ST_NODE);
     __syncthreads();
@@ -245,13 +245,13 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     STAMP(ST_EDGE_EPI);
     __syncthreads();
     STAMP(ST_BARRIER);
-    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, N, wave, lane, &pf, Lw.Wn2,
+    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Wn2,
                                   st + 2 * N * HP /* npre -> stash */);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
     vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), PredLayerW::vec_count(HP), tid);
-    node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, N, wave, lane, &pf,
+    node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, &pf,
                                            l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
     STAMP(ST_NODE);
@@ -359,11 +359,11 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     compute_geo(sm, mg, 1.0f, wave, lane, false);
     STAMP(ST_GEO);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
-    node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, N, wave, lane, &pf, Lw.Wn1ht);
+    node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1ht);
     __syncthreads();
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
-    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, N, wave, lane, &pf, Lw.Wn1at);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, N, wave, lane, &pf);
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1at);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, &pf);
     __syncthreads();
     for (int idx = tid; idx < N * LD; idx += kThreads) B4[idx] = 0.f;  // dQ accumulator
     __syncthreads();
@@ -583,7 +583,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     // (f) dh += A^T dP + Bm^T dQ
     STAMP(ST_MISC);
     vec_prefetch(vpf, wb, PredLayerW::vec_off(lay.layer(l > 0 ? l - 1 : 0), HP), PredLayerW::vec_count(HP), tid);
-    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, N, wave, lane, &pf,
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, &pf,
                                    l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
     STAMP(ST_BWD_NODE);

@@ -20,6 +20,7 @@ struct KParams {
   const float* emask;       // [B][4][EW]
   const int* npairs;        // [B][4]
   const uint32_t* seginfo;  // [B][N]
+  const int* ncols;         // [B] node columns the node-level GEMMs have to produce (<= N)
   // tensors (device)
   const float* z_in;        // [B][N][D]
   float* z_out;             // [B][N][D]
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
   }
   MolGraph mg;
   mg.N = N; mg.D = D; mg.EW = EW;
+  mg.NC = P.ncols[b];
   mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg;
   mg.npairs = P.npairs[b * kWaves + wave];
 #pragma unroll

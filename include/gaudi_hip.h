@@ -199,11 +199,13 @@ int gaudi_philox_normal(gaudi_handle* h, uint64_t seed, int64_t sample_offset, i
 int gaudi_host_schedule(int T, float noise_power, float noise_precision, float* gamma_out, float* coef_out);
 /* The live-edge metadata gaudi_* calls derive from (node_mask, edge_mask): per-wave capacity EW (multiple of 32),
  * launch order [B] (heaviest first), 32-edge passes per wave [B][4], per-node segment word [B][N]
- * (wave<<30 | start<<15 | len), and the padded per-wave edge lists [B][4][EW] (i | j<<8) with their mask values.
- * edges_capacity = number of entries edges_out / emask_out can hold (B*4*EW needed). */
+ * (wave<<30 | start<<15 | len), the padded per-wave edge lists [B][4][EW] (i | j<<8) with their mask values, and
+ * ncols [B] = 1 + the last node that is live or touches a live edge (node-level GEMMs stop there).  Live = mask != 0 and
+ * not both endpoints masked (the reference's unmasked "padded ring <-> orientation node" identity edges reach no live
+ * node).  edges_capacity = number of entries edges_out / emask_out can hold (B*4*EW needed). */
 int gaudi_host_graph_meta(int B, int N, const float* node_mask, const float* edge_mask, int32_t* ew_out,
                           int32_t* order_out, int32_t* npairs_out, uint32_t* seg_out, uint32_t* edges_out,
-                          float* emask_out, int32_t edges_capacity);
+                          float* emask_out, int32_t edges_capacity, int32_t* ncols_out /* [B] or NULL */);
 /* Tile packing of a weight block W[o][col0+k] (o,k < H, row stride ldw) into [HP/16][HP/16][16][16]
  * (k-chunk major), optionally transposed: the layout every GEMM of the kernels streams. */
 int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, const float* W, float* packed_out);

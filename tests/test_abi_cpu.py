@@ -71,17 +71,20 @@ def _meta(lib, L, nm, em):
     emask = np.empty(cap, np.float32)
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
     up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    ncols = np.empty(B, np.int32)
     rc = lib.gaudi_host_graph_meta(B, N, L.fptr(nm), L.fptr(em), C.byref(ew), ip(order), ip(npairs), up(seg), up(edges),
-                                   L.fptr(emask), cap)
+                                   L.fptr(emask), cap, ip(ncols))
     assert rc == 0
     EW = ew.value
-    return EW, order, npairs, seg, edges[: B * 4 * EW].reshape(B, 4, EW), emask[: B * 4 * EW].reshape(B, 4, EW)
+    return EW, order, npairs, seg, edges[: B * 4 * EW].reshape(B, 4, EW), emask[: B * 4 * EW].reshape(B, 4, EW), ncols
 
 
 @pytest.mark.parametrize("kind", ["cata", "hetro", "random"])
 def test_host_graph_meta_invariants(kind):
     """Every live edge appears exactly once, in the list of the wave that owns its receiving node, lists are sorted by
-    receiving node, padded to 32 with mask-0 slots, and the launch order is heaviest-first."""
+    receiving node, padded to 32 with mask-0 slots, and the launch order is heaviest-first.  Live = edge_mask != 0 and
+    not both endpoints masked (the reference's unmasked identity edges between a padded ring and its orientation node
+    are dropped: they reach no live node); ncols = 1 + last node that is live or touches a live edge."""
     from oracle import gaudi_oracle as O
     lib, L = _lib()
     rng = np.random.default_rng(3)
@@ -96,9 +99,13 @@ def test_host_graph_meta_invariants(kind):
         em[2] = 0
     B, N = nm.shape[0], nm.shape[1]
     em3 = np.asarray(em, np.float32).reshape(B, N, N)
-    EW, order, npairs, seg, edges, emask = _meta(lib, L, nm, em3)
+    EW, order, npairs, seg, edges, emask, ncols = _meta(lib, L, nm, em3)
     assert EW % 32 == 0 and EW >= 32
-    totals = (em3 != 0).reshape(B, -1).sum(1)
+    nmf = nm.reshape(B, N) != 0
+    live3 = (em3 != 0) & (nmf[:, :, None] | nmf[:, None, :])
+    if kind == "hetro":
+        assert (live3 != (em3 != 0)).any()  # the fixture does contain padded-ring <-> orientation identity edges
+    totals = live3.reshape(B, -1).sum(1)
     assert sorted(order.tolist()) == list(range(B))
     assert all(totals[order[k]] >= totals[order[k + 1]] for k in range(B - 1))
     for b in range(B):
@@ -116,11 +123,13 @@ def test_host_graph_meta_invariants(kind):
                 assert (i, j) not in seen
                 seen[(i, j)] = m
                 assert seg[b, i] >> 30 == w  # owned by this wave
-        want = {(i, j): em3[b, i, j] for i in range(N) for j in range(N) if em3[b, i, j] != 0}
+        want = {(i, j): em3[b, i, j] for i in range(N) for j in range(N) if live3[b, i, j]}
         assert seen == want
+        touched = nmf[b] | live3[b].any(0) | live3[b].any(1)
+        assert ncols[b] == (int(np.nonzero(touched)[0].max()) + 1 if touched.any() else 1)
         for n in range(N):  # segment word: start/len of node n's run inside its wave's list
             w, st, ln = seg[b, n] >> 30, (seg[b, n] >> 15) & 0x7FFF, seg[b, n] & 0x7FFF
-            assert ln == int((em3[b, n] != 0).sum())
+            assert ln == int(live3[b, n].sum())
             if ln:
                 assert np.all((edges[b, w, st:st + ln] & 255) == n)
 
