@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -727,17 +728,56 @@ int gaudi_decode(gaudi_handle* h, int B, int N, const float* z0, const float* no
                    nullptr, x_out, onehot_out, nullptr);
 }
 
+// Largest sub-batch one chain may run at once.  The guided path keeps an activation stash of 2.9 MB per molecule (default
+// sizes) for the whole call; very large requests are cut into sub-batches of whole multiples of 256 molecules (one per
+// CU) that fit `budget` bytes.  Noise is keyed by the global sample index, so the result does not depend on the cut.
+static int max_sub_batch(gaudi_handle* h, int B, int N, bool guided) {
+  if (!guided) return B;
+  const long long dense_ew = ((((long long)N * (N - 1) + kWaves - 1) / kWaves) + 31) / 32 * 32;
+  const long long per_mol = 4LL * pred_stash_floats(N, h->HPP, h->pcfg.n_layers, (int)std::max(32LL, dense_ew));
+  long long budget = 0;
+  if (const char* e = getenv("GAUDI_MAX_WORKSPACE_MB")) budget = atoll(e) * (1LL << 20);
+  const bool forced = budget > 0;
+  if (!forced) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return B;
+    budget = (long long)((free_b + h->d_stash.cap) * 0.8);
+  }
+  long long bmax = std::max(1LL, budget / std::max(1LL, per_mol));
+  if (bmax >= 256) bmax = bmax / 256 * 256;
+  else if (!forced) bmax = std::min<long long>(B, 256);  // let the allocation itself report a too-small device
+  return (int)std::min<long long>(B, bmax);
+}
+
 int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
                  int64_t sample_offset, const float* noise, float std, const float* target_w, float scale,
                  float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag) {
   if (!h || !node_mask || !edge_mask || !x_out || !onehot_out) return GAUDI_E_INVALID;
   if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
-  const int T = h->ecfg.diffusion_steps, F = h->ecfg.in_node_nf;
+  if (target_w && !h->has_pred) return fail(h, GAUDI_E_STATE, "guided sampling needs predictor weights");
+  if (B <= 0 || N <= 0) return fail(h, GAUDI_E_INVALID, "B and N must be positive");
+  HIPCHECK(h, hipSetDevice(h->device));
+  const int T = h->ecfg.diffusion_steps, F = h->ecfg.in_node_nf, D = 3 + F;
+  const int bmax = max_sub_batch(h, B, N, target_w != nullptr);
   int nanc = 0;
-  int rc = run_chain(h, B, N, node_mask, edge_mask, nullptr, true, T - 1, 0, true, noise, 0, T + 2, seed, sample_offset,
-                     std, target_w, scale, z0_out, x_out, onehot_out, &nanc);
-  if (rc) return rc;
-  (void)F;
+  std::vector<float> nz;
+  for (int b0 = 0; b0 < B; b0 += bmax) {
+    const int nb = std::min(bmax, B - b0);
+    const float* nzp = noise;
+    if (noise && nb != B) {  // gather this sub-batch's draws out of [T+2][B][N][D]
+      nz.resize((size_t)(T + 2) * nb * N * D);
+      for (int d = 0; d < T + 2; ++d)
+        std::memcpy(&nz[(size_t)d * nb * N * D], noise + ((size_t)d * B + b0) * N * D, sizeof(float) * (size_t)nb * N * D);
+      nzp = nz.data();
+    }
+    int nan_sub = 0;
+    int rc = run_chain(h, nb, N, node_mask + (size_t)b0 * N, edge_mask + (size_t)b0 * N * N, nullptr, true, T - 1, 0, true,
+                       nzp, 0, T + 2, seed, sample_offset + b0, std, target_w, scale,
+                       z0_out ? z0_out + (size_t)b0 * N * D : nullptr, x_out + (size_t)b0 * N * 3,
+                       onehot_out + (size_t)b0 * N * F, &nan_sub);
+    if (rc) return rc;
+    nanc += nan_sub;
+  }
   finish_sample(B, N, node_mask, x_out, nanc, diag);
   return GAUDI_OK;
 }
