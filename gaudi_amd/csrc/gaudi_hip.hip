@@ -336,6 +336,9 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
       fprintf(stderr, "[stamps] cumulative shares (block 0, wave 0):");
       for (int i = 0; i < ST_N; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * h->stamp_acc[i] / (tot ? tot : 1));
       fprintf(stderr, " total=%llu ticks\n", tot);
+      if (tmp[31])
+        fprintf(stderr, "[stamps] shader clock during this launch: %.0f MHz (%llu cycles / %llu ticks of 100 MHz)\n",
+                100.0 * (double)tmp[30] / (double)tmp[31], tmp[30], tmp[31]);
     }
   }
 #else

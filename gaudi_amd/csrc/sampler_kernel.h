@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
   Stamps g_stamps;
   g_stamps.init();
   const bool stamps_on = P.stamps != nullptr && blockIdx.x == 0 && tid == 0;
+  const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   if (mode == MODE_SAMPLE && P.do_init) {
     __syncthreads();
@@ -257,7 +258,11 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
       if (mode == MODE_SAMPLE && !P.do_decode)
         for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
 #ifdef GAUDI_STAMPS
-      if (stamps_on) for (int i = 0; i < ST_N; ++i) P.stamps[i] = g_stamps.acc[i];
+      if (stamps_on) {
+        for (int i = 0; i < ST_N; ++i) P.stamps[i] = g_stamps.acc[i];
+        P.stamps[30] = __builtin_readcyclecounter() - clk0;         // shader clock
+        P.stamps[31] = __builtin_amdgcn_s_memrealtime() - rt0;      // constant 100 MHz
+      }
 #endif
       if (nan_local) atomicAdd(P.nan_count, nan_local);
       return;
