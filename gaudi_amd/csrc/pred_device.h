@@ -101,8 +101,12 @@ struct PredLayerW {
 __host__ __device__ inline long long pred_stash_node_floats(int N, int HP, int L) {
   return (long long)L * (3LL * N * HP + 4LL * N);
 }
+__host__ __device__ inline long long pred_stash_edge_floats(int HP, int L, int EW) {
+  return (long long)L * kWaves * EW * HP * 2;
+}
+// ... + attention gate a_ij of every edge slot, L x 4 waves x EW floats (the reverse pass needs it before it needs v)
 __host__ __device__ inline long long pred_stash_floats(int N, int HP, int L, int EW) {
-  return pred_stash_node_floats(N, HP, L) + (long long)L * kWaves * EW * HP * 2;
+  return pred_stash_node_floats(N, HP, L) + pred_stash_edge_floats(HP, L, EW) + (long long)L * kWaves * EW;
 }
 // float offset of tile `tile` of wave `wave` in layer l, array arr (0 = v, 1 = cpre), inside the edge part
 __device__ __forceinline__ size_t edge_stash_off(int l, int wave, int tile, int arr, int EW, int HP) {
@@ -125,6 +129,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
   float *h = sm.b0, *p = sm.b1, *q = sm.b2, *agg = sm.b3;
   float* estash = stash + pred_stash_node_floats(N, HP, W.L);
+  float* astash = estash + pred_stash_edge_floats(HP, W.L, mg.EW);
 
   for (int idx = tid; idx < N * 3; idx += kThreads) {  // models.py:439
     const int n = idx / 3, d = idx % 3;
@@ -203,6 +208,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           }
           float a = 1.f;
           if (W.attention) a = sigmoid_f(reduce_groups(sdot) + Lw.ba);
+          if (g == 0) astash[((size_t)l * kWaves + wave) * mg.EW + tp * 32 + e * 16 + c] = a;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             acc[e][t] = acc[e][t] * a * mk2[e];  // e_ij (gcl.py:231-237)
@@ -296,6 +302,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
   float *B0 = sm.b0, *B1 = sm.b1, *B2 = sm.b2, *dh = sm.b3, *B4 = sm.b4;
   const float* estash = stash + pred_stash_node_floats(N, HP, W.L);
+  const float* astash = estash + pred_stash_edge_floats(HP, W.L, EW);
   const float* dpred = sm.pred + 16;
   int ntmax = 0;
 #pragma unroll
@@ -389,30 +396,21 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           float mk[NB];
           f4 gg[NB];
           load_cols<PredSmem<HP>, NB>(sm, mg, wave, tile0 * 16, c, ec, mk, gg);
-          // v and cpre come back from the forward's edge stash (no recompute of W2 / Wc1).  v is needed twice (attention
-          // gate before the first GEMM, gate / SiLU derivatives after it): with NB = 2 it is loaded again rather than
-          // kept, so that only one NB x T quad array (the GEMM input) is live in VGPRs across each GEMM.
-          constexpr bool kKeepV = NB == 1;
+          // cpre, the attention gate and (after the first GEMM) v come back from the forward's stash: no recompute of W2 / Wc1
+          // and only one NB x T quad array (the GEMM input) live in VGPRs across each GEMM.
+          constexpr bool kKeepV = false;
           f4 v[kKeepV ? NB : 1][T], cp[NB][T];
           STAMP(ST_BWD_EDGE);
           float a[NB], tau[NB], dtx[NB], dty[NB], dtz[NB];
 #pragma unroll
           for (int e = 0; e < NB; ++e) {
-            const f4* sv = (const f4*)(estash + edge_stash_off(l, wave, tile0 + e, 0, EW, HP)) + lane;
             const f4* sc = (const f4*)(estash + edge_stash_off(l, wave, tile0 + e, 1, EW, HP)) + lane;
-            f4(&ve)[T] = v[kKeepV ? e : 0];
-#pragma unroll
-            for (int t = 0; t < T; ++t) ve[t] = sv[t * 64];
             if (!last) {
 #pragma unroll
               for (int t = 0; t < T; ++t) cp[e][t] = sc[t * 64];
             }
             my_i[e] = ec[e].i;
-            float sdot = 0.f;
-#pragma unroll
-            for (int t = 0; t < T; ++t) sdot += dot4(silu4(ve[t]), *(const f4*)(Lw.wa + 16 * t + 4 * g));
-            a[e] = 1.f;
-            if (W.attention) a[e] = sigmoid_f(reduce_groups(sdot) + Lw.ba);
+            a[e] = astash[((size_t)l * kWaves + wave) * EW + (tile0 + e) * 16 + c];
             tau[e] = 0.f;
             dtx[e] = sm.dx[4 * ec[e].i + 0];  // dtrans = dx'_i
             dty[e] = sm.dx[4 * ec[e].i + 1];
