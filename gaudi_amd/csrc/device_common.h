@@ -593,20 +593,23 @@ struct SegSum {
     constexpr int LD = HP + 4;
     // all 16 rows are fetched first (independent LDS reads, one latency), then folded in slot order; reading them one
     // by one behind the wave-uniform "node changed" branches serialised 16 LDS round trips per tile
-    f4 row[16];
-    if (lane < HP / 4) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) row[k] = *(const f4*)(scr + k * LD + 4 * lane);
-    }
+    for (int h = 0; h < 2; ++h) {  // two batches of 8 rows: half the registers of one batch of 16, still one latency each
+      f4 row[8];
+      if (lane < HP / 4) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int nk = __builtin_amdgcn_readlane(node_of_col, k);
-      if (nk != cur) {
-        flush(sOut, div, lane);
-        run = splat(0.f);
-        cur = nk;
+        for (int k = 0; k < 8; ++k) row[k] = *(const f4*)(scr + (8 * h + k) * LD + 4 * lane);
       }
-      if (lane < HP / 4) run += row[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int nk = __builtin_amdgcn_readlane(node_of_col, 8 * h + k);
+        if (nk != cur) {
+          flush(sOut, div, lane);
+          run = splat(0.f);
+          cur = nk;
+        }
+        if (lane < HP / 4) run += row[k];
+      }
     }
   }
 };
