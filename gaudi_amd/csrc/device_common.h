@@ -36,6 +36,9 @@ __host__ __device__ constexpr int pick_pf(int T) {
     if (T % d == 0) best = d;
   return best;
 }
+#ifndef GAUDI_SEG_BATCH
+#define GAUDI_SEG_BATCH 8  // rows of a 16-edge tile fetched per batch by the segmented sum
+#endif
 #ifndef GAUDI_KPF
 #define GAUDI_KPF 6
 #endif
@@ -594,15 +597,15 @@ struct SegSum {
     // all 16 rows are fetched first (independent LDS reads, one latency), then folded in slot order; reading them one
     // by one behind the wave-uniform "node changed" branches serialised 16 LDS round trips per tile
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {  // two batches of 8 rows: half the registers of one batch of 16, still one latency each
-      f4 row[8];
+    for (int h = 0; h < 16 / GAUDI_SEG_BATCH; ++h) {  // batches of rows: fewer live registers than one batch of 16, one latency each
+      f4 row[GAUDI_SEG_BATCH];
       if (lane < HP / 4) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) row[k] = *(const f4*)(scr + (8 * h + k) * LD + 4 * lane);
+        for (int k = 0; k < GAUDI_SEG_BATCH; ++k) row[k] = *(const f4*)(scr + (GAUDI_SEG_BATCH * h + k) * LD + 4 * lane);
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int nk = __builtin_amdgcn_readlane(node_of_col, 8 * h + k);
+      for (int k = 0; k < GAUDI_SEG_BATCH; ++k) {
+        const int nk = __builtin_amdgcn_readlane(node_of_col, GAUDI_SEG_BATCH * h + k);
         if (nk != cur) {
           flush(sOut, div, lane);
           run = splat(0.f);
