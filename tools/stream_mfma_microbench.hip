@@ -1,0 +1,118 @@
+// Microbenchmark 2: the node-GEMM weight stream WITH its MFMA work (4 waves, UT=4 tiles per chunk per wave, 13 chunks per
+// matrix, 240 matrices cycled = 41 MB working set).  SCHED 0: ping-pong sets as node_gemm (B loaded at the top, A in the
+// middle); 1: each of four sets refilled right after its MFMAs; 2: loads only (no MFMA); 3: MFMA only (weights loaded once).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 mfma1(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+constexpr int T = 13;
+
+#ifndef NWV
+#define NWV 4
+#endif
+template <int SCHED, int NW>
+__global__ __launch_bounds__(NWV * 64) void k(const float* __restrict__ w, int n_mat, int iters, float* out) {
+  constexpr int UT = (T + NW - 1) / NW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7fffffff, 0x00020000);
+  auto ld = [&](int off_floats) { return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, off_floats * 4, 0)); };
+  f4 acc[UT];
+  for (int u = 0; u < UT; ++u) acc[u] = (f4){0, 0, 0, 0};
+  const float xb = 1.0f + lane * 1e-6f;
+  f4 side[UT];
+  for (int u = 0; u < UT; ++u) side[u] = (f4){0, 0, 0, 0};
+  auto mmx = [&](const f4 (&a)[UT]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < UT; ++u) acc[u] = mfma1(a[u][q], xb, acc[u]);
+  };
+  for (int it = 0; it < iters; ++it) {
+    const int base = (it % n_mat) * (T * T * 256);
+    auto chunk = [&](int cc) { return base + (cc < T ? cc : T - 1) * (T * 256); };
+    int toff[UT];
+    for (int u = 0; u < UT; ++u) { const int t = wave + NW * u; toff[u] = (t < T ? t : wave) * 256; }
+    f4 a0[UT], a1[UT], b0[UT], b1[UT], c0[UT], c1[UT];
+    for (int u = 0; u < UT; ++u) { a0[u] = ld(chunk(0) + toff[u]); a1[u] = ld(chunk(1) + toff[u]); }
+    if (SCHED == 1) for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(2) + toff[u]); b1[u] = ld(chunk(3) + toff[u]); }
+#pragma unroll 1
+    for (int cc = 0; cc < 12; cc += 4) {
+      if (SCHED == 0 || SCHED == 2) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(cc + 2) + toff[u]); b1[u] = ld(chunk(cc + 3) + toff[u]); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (SCHED == 0) { mmx(a0); mmx(a1); } else { for (int u = 0; u < UT; ++u) acc[u] += a0[u] + a1[u]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { a0[u] = ld(chunk(cc + 4) + toff[u]); a1[u] = ld(chunk(cc + 5) + toff[u]); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (SCHED == 0) { mmx(b0); mmx(b1); } else { for (int u = 0; u < UT; ++u) acc[u] += b0[u] + b1[u]; }
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (SCHED == 1) {
+        __builtin_amdgcn_sched_barrier(0); mmx(a0); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) a0[u] = ld(chunk(cc + 4) + toff[u]);
+        __builtin_amdgcn_sched_barrier(0); mmx(a1); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) a1[u] = ld(chunk(cc + 5) + toff[u]);
+        __builtin_amdgcn_sched_barrier(0); mmx(b0); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) b0[u] = ld(chunk(cc + 6) + toff[u]);
+        __builtin_amdgcn_sched_barrier(0); mmx(b1); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) b1[u] = ld(chunk(cc + 7) + toff[u]);
+      } else if (SCHED == 4) {  // concurrency test: MFMAs on static registers while loads stream into others
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(cc + 2) + toff[u]); b1[u] = ld(chunk(cc + 3) + toff[u]); }
+        __builtin_amdgcn_sched_barrier(0);
+        mmx(a0); mmx(a1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { c0[u] = ld(chunk(cc + 4) + toff[u]); c1[u] = ld(chunk(cc + 5) + toff[u]); }
+        __builtin_amdgcn_sched_barrier(0);
+        mmx(a0); mmx(a1);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < UT; ++u) side[u] += b0[u] + b1[u] + c0[u] + c1[u];
+      } else {  // SCHED 3: MFMA only
+        mmx(a0); mmx(a1); mmx(a0); mmx(a1);
+      }
+    }
+    if (SCHED == 0 || SCHED == 1) mmx(a0); else for (int u = 0; u < UT; ++u) acc[u] += a0[u];
+    __syncthreads();
+  }
+  f4 s = acc[0] + side[0];
+  for (int u = 1; u < UT; ++u) s += acc[u] + side[u];
+  out[blockIdx.x * 512 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <int SCHED, int NW>
+void run(const float* dw, int n_mat, int iters, int blocks, float* dout, const char* name) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  k<SCHED, NW><<<blocks, NW * 64>>>(dw, n_mat, 8, dout);
+  (void)hipEventRecord(e0);
+  k<SCHED, NW><<<blocks, NW * 64>>>(dw, n_mat, iters, dout);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  { hipError_t e = hipGetLastError(); if (e != hipSuccess) printf("  launch error: %s\n", hipGetErrorString(e)); }
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  const double bytes = 169.0 * 1024 * iters;
+  printf("%-34s n_mat %3d blocks %3d: %.2f us per 169 KB matrix, %.1f GB/s per CU\n", name, n_mat, blocks, ms * 1e3 / iters,
+         bytes / (ms * 1e-3) / 1e9);
+}
+
+int main() {
+  const int n_mat = 240;
+  float* dw; (void)hipMalloc(&dw, (size_t)n_mat * 169 * 1024);
+  (void)hipMemset(dw, 0, (size_t)n_mat * 169 * 1024);
+  float* dout; (void)hipMalloc(&dout, 256 * 512 * 4);
+  for (int nm : {1, 240}) {
+    run<2, NWV>(dw, nm, 2000, 256, dout, "loads only");
+    run<3, NWV>(dw, nm, 2000, 256, dout, "MFMA only");
+    run<0, NWV>(dw, nm, 2000, 256, dout, "loads + MFMA, ping-pong");
+    run<1, NWV>(dw, nm, 2000, 256, dout, "loads + MFMA, refill-after");
+    run<4, NWV>(dw, nm, 2000, 256, dout, "MFMA on static regs + loads elsewhere");
+  }
+  return 0;
+}
