@@ -4,12 +4,14 @@
 A "step" (--steps K) is ONE complete pass of the hot path over one batch: a full
 ``sample_guidance`` call = 1000 guided reverse-diffusion steps + final decode for B molecules
 (BASELINE.json config C3: cc-PBH 11-ring, batch 256, HOMO-LUMO-gap guidance, default architectures,
-synthetic seeded weights, on-device Philox noise).  With --gpus N the driver launches N ranks
-(torch.distributed.run); each rank samples its own 256 molecules (weak scaling, noise keyed by the
-global sample index) and ONE all_gather over RCCL collects the results at the end of every step.
+synthetic seeded weights, on-device Philox noise).  With --gpus N > 1 the driver launches N ranks
+(torch.distributed.run) and the workload is BASELINE config C5: each rank samples its own 1024 molecules
+(8192 over 8 GPUs; weak scaling, noise keyed by the global sample index) and ONE all_gather over RCCL
+collects the results at the end of every step.
 
 Prints one JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the fused
-per-molecule sampler kernel, bound = fp32 matrix cores) and `cpu_baseline` (the numpy oracle timed on
+per-molecule sampler kernel, bound = fp32 matrix cores, fraction = ISSUED matrix FLOPs / time / peak),
+`secondary` (short C2, C4 and C3-at-1024 passes, N=1 only) and `cpu_baseline` (the numpy oracle timed on
 this host, N=1 only).
 """
 import argparse
@@ -33,7 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2, help="timed sample_guidance calls (1000 reverse steps each)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=None, help="molecules per GPU (default 256; 1024 for c4)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="molecules per GPU (default: 256 = C3/C2 at one GPU; 1024 for c4 and for --gpus > 1 = C5's per-GPU shard)")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "stability"],
                     help="c2 = unguided cata, c3 = gap-guided cata (headline), c4 = hetero mixed 3-10 rings, multi-objective; "
                          "stability = the graph-of-rings stability kernel that follows sampling (SURVEY 8f rank 1)")
@@ -42,6 +45,7 @@ def parse():
     ap.add_argument("--diffusion-steps", type=int, default=1000)
     ap.add_argument("--steps-per-launch", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 / C4 / C3-at-1024 passes after the headline")
     return ap.parse_args()
 
 
@@ -63,15 +67,19 @@ def cpu_baseline(eargs, pargs, esd, psd, guided, T, B):
 
     one(T - 1)  # warm-up
     n_steps, t0 = 0, time.time()
-    while n_steps < 2 or (time.time() - t0 < 12.0 and n_steps < 20):
+    while n_steps < 5 or (time.time() - t0 < 20.0 and n_steps < 20):  # >= 5 timed steps
         one(T - 2 - n_steps)
         n_steps += 1
     per_step = (time.time() - t0) / n_steps
     total = per_step * T * (1.0 + (1.0 / T) * (0.3 if guided else 1.0))  # + decode = one EDM evaluation
+    ref = 0.058 if guided else 0.175
     return dict(value=B / total, unit="molecules/s", cores=os.cpu_count(), kind="port",
                 sample=f"numpy oracle (BLAS threads = all {os.cpu_count()} cores), B={B} x {n_steps} "
-                       f"{'guided' if guided else 'unguided'} reverse steps at N=11, extrapolated x{T} + decode; "
-                       f"{per_step * 1e3:.0f} ms/step")
+                       f"{'guided' if guided else 'unguided'} reverse steps at N=11 after 1 warm-up, extrapolated x{T} + "
+                       f"decode; {per_step * 1e3:.0f} ms/step.  Cross-check (BASELINE.md section 2): the reference's own "
+                       f"PyTorch-CPU path measured {ref} molecules/s on the 8-core build container for this workload -- "
+                       f"use the larger of the two as the CPU figure",
+                reference_torch_cpu_8core=ref)
 
 
 def bench_stability(a):
@@ -117,53 +125,49 @@ def bench_stability(a):
     print(json.dumps(out))
 
 
-def main():
-    a = parse()
-    if a.workload == "stability":
-        return bench_stability(a)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 and world == 1:
-        # convenience: relaunch under torch.distributed.run as a CHILD process (never exec after GPU init)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
-               os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+def graph_meta(nm, em):
+    """The library's own live-edge metadata (32-edge passes per wave, node columns) for the issued-MFMA count."""
+    import ctypes as C
+    from gaudi_amd import _lib
+    lib = _lib.load_library()
+    B, N = nm.shape
+    ew = C.c_int32()
+    npairs = np.zeros((B, 4), np.int32)
+    ncols = np.zeros(B, np.int32)
+    i32 = C.POINTER(C.c_int32)
+    rc = lib.gaudi_host_graph_meta(B, N, _lib.fptr(np.ascontiguousarray(nm, np.float32)),
+                                   _lib.fptr(np.ascontiguousarray(em, np.float32)), C.byref(ew), None,
+                                   npairs.ctypes.data_as(i32), None, None, None, 0, ncols.ctypes.data_as(i32))
+    assert rc == 0, rc
+    return npairs, ncols
 
+
+def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, backend, T, K=5):
+    """Time `steps` complete sampling calls of one workload; returns the contract fields + roofline of its kernel."""
     import torch
     import torch.distributed as dist
     from gaudi_amd import dist as gdist
     from gaudi_amd import flops, synth
     from gaudi_amd.engine import Engine
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the sampler has no CPU fallback")
-    # GAUDI_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing test on a 1-GPU box); the real
-    # multi-GPU run uses RCCL ("nccl") with one GPU per rank.
-    backend = os.environ.get("GAUDI_BENCH_BACKEND", "nccl")
-    gpu = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(gpu)
-    dev = torch.device("cuda", gpu)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    guided = a.workload in ("c3", "c4")
-    hetero = a.workload == "c4"
-    T, K = a.diffusion_steps, 5
-    B = a.batch or (1024 if hetero else 256)
+    guided = workload in ("c3", "c4")
+    hetero = workload == "c4"
     N, F = (20, 12) if hetero else (11, 1)
-    eargs = synth.edm_args(diffusion_steps=T, dataset="hetro" if hetero else "cata")
-    pargs = synth.pred_args(dataset="hetro" if hetero else "cata")
-    esd = synth.synth_edm_state_dict(eargs, F, seed=0)
-    psd = synth.synth_predictor_state_dict(pargs, F, K, seed=1)
-    eng = Engine(gpu)
-    eng.load_edm(eargs, esd)
-    if guided:
-        eng.load_predictor(pargs, psd)
+    ds = "hetro" if hetero else "cata"
+    eargs = synth.edm_args(diffusion_steps=T, dataset=ds)
+    pargs = synth.pred_args(dataset=ds)
+    key = (ds, guided)
+    if key not in eng_cache:
+        eng = Engine(dev.index)
+        esd = synth.synth_edm_state_dict(eargs, F, seed=0)
+        eng.load_edm(eargs, esd)
+        wfloats = sum(v.size for v in esd.values())
+        if guided:
+            psd = synth.synth_predictor_state_dict(pargs, F, K, seed=1)
+            eng.load_predictor(pargs, psd)
+            wfloats += 2 * sum(v.size for v in psd.values())  # + the transposed copies the reverse pass streams
+        eng_cache[key] = (eng, 4 * wfloats)
+    eng, wbytes = eng_cache[key]
     eng.set_steps_per_launch(a.steps_per_launch)
     if hetero:
         # PASs-like batch: 3..10 rings drawn uniformly (seed 1), orientation nodes -> 6..20 graph nodes, N = 20
@@ -171,11 +175,10 @@ def main():
         rings = np.random.default_rng(1 + rank).integers(3, 11, size=B)
         nm3, em_flat, _ = build_masks(rings, 10, True)
         nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
-        live_edges, live_nodes = float(em.sum() / B), float(nm.sum() / B)
     else:
         nm = np.ones((B, N), np.float32)  # 11-ring cata molecules: every node live (sampling_edm.py:176-186)
         em = np.broadcast_to(1.0 - np.eye(N, dtype=np.float32), (B, N, N)).copy()
-        live_edges, live_nodes = float(N * (N - 1)), float(N)
+    live_edges, live_nodes = float(em.sum() / B), float(nm.sum() / B)
     tw = None
     if guided:
         tw = np.zeros(K, np.float32)
@@ -196,12 +199,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for it in range(a.warmup):
+    for it in range(warmup):
         one_pass(-1 - it)
     eng.profile_reset(True)
     sync()
     t0 = time.perf_counter()
-    for it in range(a.steps):
+    for it in range(steps):
         x, h, diag = one_pass(it)
     sync()
     dt = time.perf_counter() - t0
@@ -210,61 +213,132 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n_launch, kern_ms, steps_done = eng.profile_get()
+    eng.profile_reset(False)
     assert x.shape[0] == B * world and np.isfinite(x).all()
+    if rank != 0:
+        return None
+    value = steps * B * world / dt
+    # ---- roofline of the dominant kernel (sampler_kernel<192,208>: EDM + predictor fwd/bwd + update), fp32 matrix cores.
+    # achieved = MFMA FLOPs the kernel ISSUES per launch (counted from its loop structure, 2048 per v_mfma_f32_16x16x4_f32;
+    # the same number rocprofv3's SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 reports) / average launch duration (HIP events on the
+    # handle's stream).  `useful_*` = the factorised algorithm on live edges and unpadded features (what the issued work
+    # is worth); `as_written_*` = the reference's dense concat+Linear formulation, a throughput-equivalent only.
+    npairs, ncols = graph_meta(nm, em)
+    variant = os.environ.get("GAUDI_KERNEL_VARIANT_FOR_FLOPS", "w4")
+    mfma_step = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, pargs if guided else None, variant) for b in range(B))
+    useful_step = B * flops.step_flops_useful(live_edges, live_nodes, F, eargs, pargs if guided else None, K)
+    written_step = B * flops.step_flops_as_written(N, F, eargs, pargs if guided else None, K)
+    edm_only = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, None, variant) for b in range(B))
+    # per launch: `steps_done` reverse steps + one decode pass (= one EDM evaluation) per call, over n_launch launches
+    issued_launch = 2048.0 * (mfma_step * steps_done + edm_only * steps) / max(n_launch, 1)
+    evals = steps_done + steps * (edm_only / max(mfma_step, 1))
+    avg_launch_ms = kern_ms / max(n_launch, 1)
+    achieved = issued_launch / (avg_launch_ms * 1e-3) / 1e12
+    frac = achieved / PEAK_FP32_MATRIX_TFLOPS
+    assert 0.0 < frac <= 1.0, f"roofline.frac = {frac}: the issued-FLOP model or the timing is wrong"
+    stash = 4 * pargs["n_layers"] * ((3 * N * 208 + 4 * N) + 4 * 32 * 208 * 2) if guided else 0
+    hbm_bytes_launch = flops.step_bytes_fused(B, N, F, 0, stash) * steps_done / max(n_launch, 1) + wbytes
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc) and B == 256 and a.steps_per_launch == 25 and T == 1000:  # counters were collected on this shape
+        try:
+            traffic = json.load(open(pmc)).get(f"{workload}_bytes_per_launch")
+        except Exception:
+            traffic = None
+    label = {"c3": f"C3: cc-PBH 11-ring, batch={B}/GPU, {T} steps, HOMO-LUMO-gap guidance (scale 0.6)",
+             "c2": f"C2: cc-PBH 11-ring, batch={B}/GPU, {T} steps, unconditional EDM",
+             "c4": f"C4: PASs-like hetero, 3-10 rings (6-20 graph nodes, N=20: the reference's own cap, "
+                   f"data/aromatic_dataloader.py:285), batch={B}/GPU, {T} steps, multi-objective (OPV) guidance"}[workload]
+    if world > 1 and workload == "c3":
+        label = f"C5: {B * world} guided cc-PBH 11-ring samples sharded over {world} GPUs ({B}/GPU), {T} steps, one RCCL all_gather at the end"
+    return {
+        "metric": ("guided" if guided else "unguided") + f" molecules/sec ({T}-step)",
+        "value": value, "unit": "molecules/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded default-init weights, on-device Philox noise)",
+        "config": {"workload": label, "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
+                   "edm": "nf=192,n_layers=9", "predictor": "nf=196,n_layers=12" if guided else None,
+                   "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
+                   "steps_per_launch": a.steps_per_launch,
+                   "max_graph_nodes": "22 at these hidden sizes (one molecule's working set must fit 160 KiB of LDS)"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                     "frac": frac, "traffic": traffic,
+                     "kernel": "sampler_kernel<192,208>" if guided else "sampler_kernel<192,0>",
+                     "flops_basis": "issued v_mfma_f32_16x16x4_f32 x 2048 FLOP (padding included), counted from the kernel's "
+                                    "loop structure; = SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 x 2048 in profiles/",
+                     "issued_gflop_per_molecule_step": 2048.0 * mfma_step / B / 1e9,
+                     "useful_gflop_per_molecule_step": useful_step / B / 1e9,
+                     "as_written_gflop_per_molecule_step": written_step / B / 1e9,
+                     "useful_tflops": useful_step * evals / (kern_ms * 1e-3) / 1e12,
+                     "useful_frac": useful_step * evals / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                     "as_written_tflops_equivalent": written_step * evals / (kern_ms * 1e-3) / 1e12,
+                     "live_edges_per_molecule": live_edges,
+                     "avg_launch_ms": avg_launch_ms, "launches": n_launch,
+                     "hbm_algorithmic_gbps": hbm_bytes_launch / (avg_launch_ms * 1e-3) / 1e9,
+                     "hbm_frac": hbm_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS},
+        "diag": diag,
+    }
 
+
+def main():
+    a = parse()
+    if a.workload == "stability":
+        return bench_stability(a)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world == 1:
+        # convenience: relaunch under torch.distributed.run as a CHILD process (never exec after GPU init)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+    from gaudi_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the sampler has no CPU fallback")
+    # GAUDI_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing test on a 1-GPU box); the real
+    # multi-GPU run uses RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("GAUDI_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    T, K = a.diffusion_steps, 5
+    # N = 1: BASELINE configs[2] (C3, 256 molecules) -- or configs[1] / configs[3] with --workload.  N > 1: configs[4]
+    # (C5): 1024 guided samples per GPU, 8192 over 8 GPUs.
+    B = a.batch or (1024 if (a.workload == "c4" or world > 1) else 256)
+    engines = {}
+    out = run_workload(a, engines, a.workload, B, a.steps, a.warmup, rank, world, dev, backend, T)
     if rank == 0:
-        mols = a.steps * B * world
-        value = mols / dt
-        # ---- roofline of the dominant kernel (sampler_kernel<192,208>: EDM + predictor fwd/bwd + update)
-        f_written = flops.step_flops_as_written(N, F, eargs, pargs if guided else None, K)
-        f_useful = flops.step_flops_useful(live_edges, live_nodes, F, eargs, pargs if guided else None, K)
-        evals = steps_done + a.steps * (0.3 if guided else 1.0)  # decode pass = one extra EDM evaluation
-        avg_launch_ms = kern_ms / max(n_launch, 1)
-        per_launch_flops = f_written * B * evals / max(n_launch, 1)
-        achieved = per_launch_flops / (avg_launch_ms * 1e-3) / 1e12
-        wbytes = 4 * (sum(v.size for v in esd.values()) + (2 * sum(v.size for v in psd.values()) if guided else 0))
-        # predictor stash per molecule-step: node part (P, Q, npre, x) + edge part (v, cpre of every 16-edge tile)
-        stash = 4 * pargs["n_layers"] * ((3 * N * 208 + 4 * N) + 4 * 32 * 208 * 2) if guided else 0
-        hbm_bytes_launch = flops.step_bytes_fused(B, N, F, 0, stash) * steps_done / max(n_launch, 1) + wbytes
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and B == 256 and a.steps_per_launch == 25:  # counters were collected on this shape
-            try:
-                traffic = json.load(open(pmc)).get(f"{a.workload}_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": ("guided" if guided else "unguided") + f" molecules/sec ({T}-step)",
-            "value": value, "unit": "molecules/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded default-init weights, on-device Philox noise)",
-            "config": {"workload": {"c3": f"C3: cc-PBH 11-ring, batch={B}/GPU, {T} steps, HOMO-LUMO-gap guidance (scale 0.6)",
-                                    "c2": f"C2: cc-PBH 11-ring, batch={B}/GPU, {T} steps, unconditional EDM",
-                                    "c4": f"C4: PASs-like hetero, 3-10 rings (6-20 graph nodes, N=20), batch={B}/GPU, {T} steps, "
-                                          "multi-objective (OPV) guidance"}[a.workload],
-                       "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
-                       "edm": "nf=192,n_layers=9", "predictor": "nf=196,n_layers=12" if guided else None,
-                       "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
-                       "steps_per_launch": a.steps_per_launch},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
-                         "kernel": "sampler_kernel<192,208>" if guided else "sampler_kernel<192,0>",
-                         "live_edges_per_molecule": live_edges,
-                         "avg_launch_ms": avg_launch_ms, "launches": n_launch,
-                         "flops_basis": "as-written reference FLOPs (SURVEY 8d): %.3f GFLOP per molecule-step" % (f_written / 1e9),
-                         "useful_tflops_factorised": f_useful * B * evals / (kern_ms * 1e-3) / 1e12,
-                         "hbm_algorithmic_gbps": hbm_bytes_launch / (avg_launch_ms * 1e-3) / 1e9,
-                         "hbm_frac": hbm_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS},
-            "diag": diag,
-        }
+        if world == 1 and not a.no_secondary and a.workload == "c3":
+            # the other single-GPU configurations, timed by the same harness (short: one or two calls each)
+            sec = {}
+            for wl, b, st, wu in (("c2", 256, 2, 1), ("c4", 1024, 1, 0), ("c3_b1024", 1024, 1, 0)):
+                r = run_workload(a, engines, wl.split("_")[0], b, st, wu, rank, world, dev, backend, T)
+                sec[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": st,
+                           "warmup": wu, "ms_per_step": r["ms_per_step"], "roofline_frac": r["roofline"]["frac"],
+                           "useful_frac": r["roofline"]["useful_frac"], "avg_launch_ms": r["roofline"]["avg_launch_ms"],
+                           "kernel": r["roofline"]["kernel"]}
+            out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline:
+            guided = a.workload in ("c3", "c4")
             out["cpu_baseline"] = cpu_baseline(synth.edm_args(diffusion_steps=T), synth.pred_args(),
                                                 synth.synth_edm_state_dict(synth.edm_args(diffusion_steps=T), 1, seed=0),
                                                 synth.synth_predictor_state_dict(synth.pred_args(), 1, K, seed=1), guided, T,
                                                 256)
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    eng.close()
+    for eng, _ in engines.values():
+        eng.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -84,6 +84,7 @@ EXPORTS = {
     "gaudi_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "gaudi_set_steps_per_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "gaudi_set_readout_nodes": (C.c_int, [C.c_void_p, C.c_int]),
+    "gaudi_set_fix_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
 }
 
 _lib = None

@@ -44,3 +44,15 @@ def load_state_dict(exp_dir_path: str) -> dict:
 
 def args_dict(args) -> dict:
     return dict(vars(args)) if not isinstance(args, dict) else dict(args)
+
+
+def normalize_factors(args: dict):
+    """args.normalize_factors; a namespace without the key gets the reference's argparse default [3, 4, 10]
+    (utils/args_edm.py:48), never an identity normalisation."""
+    nv = args.get("normalize_factors")
+    if nv is None:
+        nv = [3, 4, 10]
+    nv = [float(v) for v in nv]
+    if len(nv) != 3 or not all(v > 0 for v in nv):
+        raise ValueError(f"normalize_factors must be three positive numbers, got {nv}")
+    return nv

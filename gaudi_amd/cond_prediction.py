@@ -23,8 +23,7 @@ def _run(cond_predictor, edm_model, x, h, node_mask, edge_mask, t, noise=None):
     nm = _to_numpy(node_mask).astype(np.float32).reshape(B, N)
     em = (nm[:, :, None] * nm[:, None, :] * (1 - np.eye(N, dtype=np.float32)) if edge_mask is None
           else _to_numpy(edge_mask).astype(np.float32).reshape(B, N, N))
-    seed, off = edm_model.seed, edm_model.sample_offset
-    edm_model.sample_offset += B  # fresh noise on the next call, as successive torch.randn draws would be
+    seed, off = edm_model.next_stream(B)  # fresh noise on the next call, as successive torch.randn draws would be
     return edm_model.engine.predict_noised(x, _to_numpy(h).astype(np.float32), _t_int(t, edm_model.T, B), nm, em,
                                            seed=seed, sample_offset=off, noise=noise)
 

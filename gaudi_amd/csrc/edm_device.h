@@ -299,10 +299,11 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   {
     const float* ow = w + lay.out_w();
     const float* ob = w + lay.out_b();
+    int bad = 0;
     for (int idx = tid; idx < N * 3; idx += kThreads) {
       const int n = idx / 3, d = idx % 3;
-      float v = (sm.x[4 * n + d] - sm.x0[4 * n + d]) * mg.mask[n];
-      if (v != v) v = 0.f;
+      const float v = (sm.x[4 * n + d] - sm.x0[4 * n + d]) * mg.mask[n];
+      bad += v != v;
       sEps[n * D + d] = v;
     }
     const float* hh = sm.h;
@@ -311,7 +312,16 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         N * F, HP, tid, [=](int p, int k) { return ow[(p % F) * HP + k]; },
         [=](int p, int k) { return hh[(p / F) * LD + k]; },
         [=](int p, float acc) { sEps[(p / F) * D + 3 + p % F] = (acc + ob[p % F]) * msk[p / F]; });
-    __syncthreads();
+    // `if torch.any(torch.isnan(vel)): vel = torch.nan_to_num(vel, 0.0)` (models.py:138-141): NaN -> 0, +-inf -> +-FLT_MAX,
+    // triggered per molecule here (the reference looks at the whole batch; see sampler_kernel.h for the one difference)
+    if (__syncthreads_or(bad)) {
+      for (int idx = tid; idx < N * 3; idx += kThreads) {
+        const int n = idx / 3, d = idx % 3;
+        const float v = sEps[n * D + d];
+        sEps[n * D + d] = v != v ? 0.f : fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+      }
+      __syncthreads();
+    }
     if (tid < 3) {
       float s = 0.f, cnt = 0.f;
       for (int n = 0; n < N; ++n) {

@@ -55,11 +55,62 @@ struct gaudi_handle {
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
       d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols;
   int steps_per_launch = 25;
+  bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
+  long long fix_key = 0;      // global sample index whose Philox stream is shared
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
-  // profiling
+  // profiling: launches are bracketed by HIP events on the handle's stream.  A small window of pending pairs is kept;
+  // older pairs are folded into running sums and their events recycled (a T = 1000 callback chain makes 2001 launches).
   bool prof = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events, stab_events;
+  struct EventLog {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, spare;
+    double ms = 0.0;
+    long long n = 0;
+    static constexpr size_t kWindow = 32;
+    hipError_t fold(size_t keep) {
+      while (pending.size() > keep) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(pending.front().second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, pending.front().first, pending.front().second);
+        if (e != hipSuccess) return e;
+        ms += t;
+        ++n;
+        spare.push_back(pending.front());
+        pending.erase(pending.begin());
+      }
+      return hipSuccess;
+    }
+    hipError_t begin(hipStream_t st, std::pair<hipEvent_t, hipEvent_t>& ev) {
+      hipError_t e = fold(kWindow - 1);
+      if (e != hipSuccess) return e;
+      if (!spare.empty()) {
+        ev = spare.back();
+        spare.pop_back();
+      } else {
+        if ((e = hipEventCreate(&ev.first)) != hipSuccess) return e;
+        if ((e = hipEventCreate(&ev.second)) != hipSuccess) return e;
+      }
+      return hipEventRecord(ev.first, st);
+    }
+    hipError_t end(hipStream_t st, const std::pair<hipEvent_t, hipEvent_t>& ev) {
+      pending.push_back(ev);
+      return hipEventRecord(ev.second, st);
+    }
+    void reset(bool destroy) {
+      for (auto& p : pending) spare.push_back(p);
+      pending.clear();
+      if (destroy) {
+        for (auto& p : spare) {
+          (void)hipEventDestroy(p.first);
+          (void)hipEventDestroy(p.second);
+        }
+        spare.clear();
+      }
+      ms = 0.0;
+      n = 0;
+    }
+  } prof_log, stab_log;
   long long prof_steps = 0;
+  std::map<const void*, int> lds_attr;  // largest dynamic-LDS size already granted to each kernel
 #ifdef GAUDI_STAMPS
   DevBuf d_stamps;
   unsigned long long stamp_acc[32] = {0};
@@ -308,13 +359,15 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
   const size_t lds = lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW);
   if (lds > 160 * 1024)
     return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
-  HIPCHECK(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->prof) {
-    HIPCHECK(h, hipEventCreate(&e0));
-    HIPCHECK(h, hipEventCreate(&e1));
-    HIPCHECK(h, hipEventRecord(e0, h->stream));
+  {
+    int& granted = h->lds_attr[(const void*)fn];
+    if ((int)lds > granted) {
+      HIPCHECK(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      granted = (int)lds;
+    }
   }
+  std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+  if (h->prof) HIPCHECK(h, h->prof_log.begin(h->stream, ev));
 #ifdef GAUDI_STAMPS
   KParams PS = P;
   HIPCHECK(h, h->d_stamps.reserve(sizeof(unsigned long long) * 32));
@@ -346,8 +399,7 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
 #endif
   HIPCHECK(h, hipGetLastError());
   if (h->prof) {
-    HIPCHECK(h, hipEventRecord(e1, h->stream));
-    h->prof_events.push_back({e0, e1});
+    HIPCHECK(h, h->prof_log.end(h->stream, ev));
     h->prof_steps += steps;
   }
   return GAUDI_OK;
@@ -433,10 +485,8 @@ void gaudi_destroy(gaudi_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (auto& p : h->prof_events) {
-    (void)hipEventDestroy(p.first);
-    (void)hipEventDestroy(p.second);
-  }
+  h->prof_log.reset(true);
+  h->stab_log.reset(true);
   DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
                     &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
                     &h->d_pred, &h->d_tw, &h->d_stash, &h->d_chain, &h->d_sx, &h->d_stype, &h->d_sn,
@@ -650,13 +700,17 @@ static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, cons
   HIPCHECK(h, h->d_nan.reserve(sizeof(int)));
   HIPCHECK(h, hipMemsetAsync(h->d_nan.p, 0, sizeof(int), h->stream));
   if (z_in) HIPCHECK(h, hipMemcpyAsync(h->d_zin.p, z_in, zb, hipMemcpyHostToDevice, h->stream));
+  const bool fixn = h->fix_noise && do_init;  // whole-chain calls only (gaudi_step / gaudi_decode inject per-molecule draws)
+  const size_t nzb = fixn ? sizeof(float) * N * D : zb;  // bytes of one raw draw
   if (noise) {
-    HIPCHECK(h, h->d_noise.reserve(zb * (size_t)n_draws));
-    HIPCHECK(h, hipMemcpyAsync(h->d_noise.p, noise, zb * (size_t)n_draws, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, h->d_noise.reserve(nzb * (size_t)n_draws));
+    HIPCHECK(h, hipMemcpyAsync(h->d_noise.p, noise, nzb * (size_t)n_draws, hipMemcpyHostToDevice, h->stream));
     P.noise = h->d_noise.as<float>();
   }
   P.draw_base = draw_base;
-  P.draw_stride = (long long)B * N * D;
+  P.draw_stride = fixn ? (long long)N * D : (long long)B * N * D;
+  P.fix_noise = fixn ? 1 : 0;
+  P.fix_key = h->fix_key;
   P.seed = seed;
   P.sample_offset = sample_offset;
   P.std0 = std0;
@@ -767,7 +821,7 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
   for (int b0 = 0; b0 < B; b0 += bmax) {
     const int nb = std::min(bmax, B - b0);
     const float* nzp = noise;
-    if (noise && nb != B) {  // gather this sub-batch's draws out of [T+2][B][N][D]
+    if (noise && nb != B && !h->fix_noise) {  // gather this sub-batch's draws out of [T+2][B][N][D]
       nz.resize((size_t)(T + 2) * nb * N * D);
       for (int d = 0; d < T + 2; ++d)
         std::memcpy(&nz[(size_t)d * nb * N * D], noise + ((size_t)d * B + b0) * N * D, sizeof(float) * (size_t)nb * N * D);
@@ -806,13 +860,16 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
   HIPCHECK(h, h->d_pred.reserve(pb));
   HIPCHECK(h, h->d_dpred.reserve(pb));
   HIPCHECK(h, hipMemsetAsync(h->d_nan.p, 0, sizeof(int), h->stream));
+  const size_t nzb = h->fix_noise ? sizeof(float) * N * D : zb;
   if (noise) {
-    HIPCHECK(h, h->d_noise.reserve(zb * (size_t)(T + 2)));
-    HIPCHECK(h, hipMemcpyAsync(h->d_noise.p, noise, zb * (size_t)(T + 2), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, h->d_noise.reserve(nzb * (size_t)(T + 2)));
+    HIPCHECK(h, hipMemcpyAsync(h->d_noise.p, noise, nzb * (size_t)(T + 2), hipMemcpyHostToDevice, h->stream));
     P.noise = h->d_noise.as<float>();
   }
   P.draw_base = 0;
-  P.draw_stride = (long long)B * N * D;
+  P.draw_stride = h->fix_noise ? (long long)N * D : (long long)B * N * D;
+  P.fix_noise = h->fix_noise ? 1 : 0;
+  P.fix_key = h->fix_key;
   P.seed = seed;
   P.sample_offset = sample_offset;
   P.std0 = std;
@@ -962,16 +1019,9 @@ int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, cons
 
 int gaudi_profile_reset(gaudi_handle* h, int enable) {
   if (!h) return GAUDI_E_INVALID;
-  for (auto& p : h->prof_events) {
-    (void)hipEventDestroy(p.first);
-    (void)hipEventDestroy(p.second);
-  }
-  h->prof_events.clear();
-  for (auto& p : h->stab_events) {
-    (void)hipEventDestroy(p.first);
-    (void)hipEventDestroy(p.second);
-  }
-  h->stab_events.clear();
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->prof_log.reset(false);
+  h->stab_log.reset(false);
   h->prof_steps = 0;
   h->prof = enable != 0;
   return GAUDI_OK;
@@ -980,15 +1030,17 @@ int gaudi_profile_reset(gaudi_handle* h, int enable) {
 int gaudi_profile_get(gaudi_handle* h, int32_t* n_launches, double* total_ms, int64_t* steps_done) {
   if (!h) return GAUDI_E_INVALID;
   HIPCHECK(h, hipStreamSynchronize(h->stream));
-  double tot = 0.0;
-  for (auto& p : h->prof_events) {
-    float ms = 0.f;
-    HIPCHECK(h, hipEventElapsedTime(&ms, p.first, p.second));
-    tot += ms;
-  }
-  if (n_launches) *n_launches = (int32_t)h->prof_events.size();
-  if (total_ms) *total_ms = tot;
+  HIPCHECK(h, h->prof_log.fold(0));
+  if (n_launches) *n_launches = (int32_t)h->prof_log.n;
+  if (total_ms) *total_ms = h->prof_log.ms;
   if (steps_done) *steps_done = h->prof_steps;
+  return GAUDI_OK;
+}
+
+int gaudi_set_fix_noise(gaudi_handle* h, int enable, int64_t key_sample) {
+  if (!h) return GAUDI_E_INVALID;
+  h->fix_noise = enable != 0;
+  h->fix_key = key_sample;
   return GAUDI_OK;
 }
 

@@ -32,6 +32,8 @@ struct KParams {
   long long draw_stride;
   unsigned long long seed;
   long long sample_offset;
+  int fix_noise;            // en_diffusion.py:562-566: every molecule takes the raw draws of ONE sample ...
+  long long fix_key;        // ... the Philox stream of this global sample index (or row 0 of the injected buffer)
   float std0;
   const float* coef;        // [T][4] alpha_ts, eps_coef, sigma, t
   float alpha0, sigma0, sigma_x, nv0, nv1;
@@ -92,9 +94,9 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) mg.npairs_all[w] = P.npairs[b * kWaves + w];
 
-  const uint64_t gsample = (uint64_t)(P.sample_offset + b);
+  const uint64_t gsample = (uint64_t)(P.fix_noise ? P.fix_key : P.sample_offset + b);
   // locals (not references into the kernarg struct) so nothing forces P onto the stack
-  const float* const noise_p = P.noise ? P.noise + (size_t)b * N * D : nullptr;
+  const float* const noise_p = P.noise ? P.noise + (P.fix_noise ? (size_t)0 : (size_t)b * N * D) : nullptr;
   const long long draw_stride = P.draw_stride;
   const int draw_base = P.draw_base;
   const unsigned long long seed = P.seed;
@@ -211,13 +213,21 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
             sZ[n * D + d] = sZ[n * D + d] - sMean[d] * sMask[n];
           }
           __syncthreads();
-          if (guided) {  // zs.nan_to_num(0.) (en_diffusion.py:933-934)
-            for (int e = tid; e < N * D; e += kThreads) {
-              float v = sZ[e];
-              if (v != v) { v = 0.f; ++nan_local; }
-              sZ[e] = v;
+          if (guided) {
+            // `if torch.isnan(zs).any(): zs = zs.nan_to_num(0.)` (en_diffusion.py:933-934): NaN -> 0 and +-inf -> +-FLT_MAX.
+            // The reference tests the whole batch; a workgroup sees one molecule, so the trigger here is "a NaN in THIS
+            // molecule" (differs only for a molecule that holds an inf but no NaN while another molecule holds a NaN).
+            int bad = 0;
+            for (int e = tid; e < N * D; e += kThreads) bad += sZ[e] != sZ[e];
+            nan_local += bad;
+            if (__syncthreads_or(bad)) {
+              for (int e = tid; e < N * D; e += kThreads) {
+                float v = sZ[e];
+                v = v != v ? 0.f : fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+                sZ[e] = v;
+              }
+              __syncthreads();
             }
-            __syncthreads();
           }
           STAMP(ST_UPDATE);
           if (P.chain_out != nullptr) {

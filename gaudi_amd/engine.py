@@ -37,6 +37,7 @@ class Engine:
         self.device = device
         self.edm_args = None
         self.pred_args = None
+        self.fix_noise = False
         self.F = None
         self.K = None
 
@@ -86,7 +87,8 @@ class Engine:
         if emb is None:
             raise GaudiError("state dict has no dynamics.egnn.embedding.weight (mode='gnn_dynamics' is unsupported)")
         F = emb.shape[1] - 1  # in_node_nf is not stored: recover it
-        nv = args.get("normalize_factors", [1, 1, 1])
+        from .checkpoint import normalize_factors
+        nv = normalize_factors(args)
         cfg = EdmConfig(F, int(args["nf"]), int(args["n_layers"]), int(args.get("inv_sublayers", 1)),
                         int(bool(args["attention"])), int(bool(args["tanh"])), float(args["coords_range"]),
                         float(args["norm_constant"]), float(args.get("normalization_factor", 1)),
@@ -189,8 +191,9 @@ class Engine:
         nz = None
         if noise is not None:
             nz = f32(noise)
-            if nz.shape != (self.T + 2, B, N, D):
-                raise GaudiError(f"noise must be [T+2,B,N,3+F] = {(self.T + 2, B, N, D)}, got {nz.shape}")
+            want = (self.T + 2, 1 if self.fix_noise else B, N, D)
+            if nz.shape != want:
+                raise GaudiError(f"noise must be [T+2,{'1' if self.fix_noise else 'B'},N,3+F] = {want}, got {nz.shape}")
         tw = None if target_w is None else f32(target_w)
         x = np.empty((B, N, 3), np.float32)
         h = np.empty((B, N, self.F), np.float32)
@@ -233,8 +236,9 @@ class Engine:
         nz = None
         if noise is not None:
             nz = f32(noise)
-            if nz.shape != (self.T + 2, B, N, D):
-                raise GaudiError(f"noise must be [T+2,B,N,3+F] = {(self.T + 2, B, N, D)}, got {nz.shape}")
+            want = (self.T + 2, 1 if self.fix_noise else B, N, D)
+            if nz.shape != want:
+                raise GaudiError(f"noise must be [T+2,{'1' if self.fix_noise else 'B'},N,3+F] = {want}, got {nz.shape}")
         x = np.empty((B, N, 3), np.float32)
         h = np.empty((B, N, self.F), np.float32)
         z0 = np.empty((B, N, D), np.float32) if return_z0 else None
@@ -296,6 +300,12 @@ class Engine:
         ms = C.c_double()
         self._check(self.lib.gaudi_stability_profile_get(self.h, C.byref(n), C.byref(ms)), "gaudi_stability_profile_get")
         return n.value, ms.value
+
+    def set_fix_noise(self, enable: bool, key_sample: int = 0):
+        """fix_noise=True of the reference (en_diffusion.py:562-566): every molecule of a call receives the raw draws of
+        ONE sample (Philox stream of global sample ``key_sample``, or injected noise of shape [T+2,1,N,3+F])."""
+        self._check(self.lib.gaudi_set_fix_noise(self.h, int(bool(enable)), int(key_sample)), "gaudi_set_fix_noise")
+        self.fix_noise = bool(enable)
 
     def set_steps_per_launch(self, k: int):
         self._check(self.lib.gaudi_set_steps_per_launch(self.h, int(k)), "gaudi_set_steps_per_launch")

@@ -33,7 +33,7 @@ def step_flops_as_written(N, F, edm, pred=None, K=5):
 
 
 def step_flops_useful(n_live_edges, n_nodes, F, edm, pred=None, K=5):
-    """Factorised algorithm, live edges / live nodes only."""
+    """Factorised algorithm, live edges / live nodes only, unpadded H: the work the kernel NEEDS to do."""
     E, Nn = n_live_edges, n_nodes
     H, L, S = edm["nf"], edm["n_layers"], edm.get("inv_sublayers", 1)
     gcl = 2 * Nn * 2 * H * H + 2 * E * (H * H + 5 * H) + 2 * Nn * 3 * H * H
@@ -42,10 +42,54 @@ def step_flops_useful(n_live_edges, n_nodes, F, edm, pred=None, K=5):
     if pred is not None:
         H, L = pred["nf"], pred["n_layers"]
         fwd = 2 * Nn * 2 * H * H + 2 * E * (2 * H * H + 6 * H) + 2 * Nn * 3 * H * H
-        # reverse pass: recompute (W2, Wc1) + transposed (Wc1^T, W2^T) per edge; node level: recompute 5, backward 5
-        bwd = 2 * E * (4 * H * H + 10 * H) + 2 * Nn * 10 * H * H
-        f += L * (fwd + bwd) + 4 * Nn * ((F + 1) * H + H * K)
+        # reverse pass (pre-activations come back from the forward's stash, nothing is recomputed): per edge the two
+        # transposed GEMMs Wc1^T, W2^T; per node Wn2^T, Wn1h^T, Wn1a^T, A^T, B^T.  The last layer has no coordinate branch.
+        bwd = 2 * E * (2 * H * H + 6 * H) + 2 * Nn * 5 * H * H
+        last = 2 * E * (H * H + H)  # Wc1 (forward) and Wc1^T (reverse) of the last layer are never needed
+        f += L * (fwd + bwd) - 2 * last + 4 * Nn * ((F + 1) * H + H * K)
     return f
+
+
+def pad16(h):
+    return (h + 15) // 16 * 16
+
+
+def _pad_hidden_kernel(h):
+    for s in (32, 48, 64, 128, 192, 208, 256):
+        if s >= h:
+            return s
+    raise ValueError(h)
+
+
+def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
+    """v_mfma_f32_16x16x4_f32 instructions (2048 FLOP each) ONE molecule issues per reverse step, counted from the kernel's
+    loop structure (validated against SQ_INSTS_VALU_MFMA_MOPS_F32 / 4: profiles/*pmc_summary.csv).
+
+    variant "w4" (4 waves, 32-edge passes):  edge_units = list of 32-edge passes per wave [4]
+    variant "w8" (8 waves, 16-edge tiles):   edge_units = number of 16-edge tiles of the molecule
+    ncols = node columns the node-level GEMMs produce (16-column tiles, pairs of tiles beyond 16)."""
+    nt = 1 if ncols <= 16 else 2 * (((ncols + 15) // 16 + 1) // 2)
+    if variant == "w4":
+        waves, pairs = 4, sum(edge_units)
+        tiles16 = 2 * pairs
+    else:
+        waves, tiles16 = 8, int(edge_units)
+
+    def node(T, kt):  # K chunks x 4 k-steps x (tile slots of the busiest wave x waves: idle slots recompute a tile)
+        return kt * 4 * (-(-T // waves)) * waves * nt
+
+    def edge(T):  # one 16-edge tile through one T x T matrix
+        return T * T * 4
+
+    Te = _pad_hidden_kernel(edm["nf"]) // 16
+    L, S = edm["n_layers"], edm.get("inv_sublayers", 1)
+    n = L * (S * (node(Te, 5 * Te) + tiles16 * edge(Te)) + node(Te, 2 * Te) + tiles16 * edge(Te))
+    if pred is not None:
+        Tp = _pad_hidden_kernel(pred["nf"]) // 16
+        Lp = pred["n_layers"]
+        fwd = Lp * (node(Tp, 5 * Tp) + tiles16 * edge(Tp)) + (Lp - 1) * tiles16 * edge(Tp)
+        n += 2 * fwd  # the reverse pass issues the same counts with the transposed matrices
+    return n
 
 
 def step_bytes_fused(B, N, F, weight_bytes, stash_bytes_per_mol=0):

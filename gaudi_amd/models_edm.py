@@ -138,9 +138,12 @@ class GaudiModel:
         self.T = int(self.args["diffusion_steps"])
         self.in_node_nf = self.engine.F
         self.n_dims = 3
-        self.norm_values = list(self.args.get("normalize_factors", [1, 1, 1]))
+        self.norm_values = list(checkpoint.normalize_factors(self.args))
         self.norm_biases = (None, 0.0, 0.0)
-        self.seed = 0
+        # Noise streams are keyed by (seed, global sample index, draw, element).  seed = None: drawn from torch's global
+        # generator on first use, so torch.manual_seed controls the chain as it does the reference's torch.randn; every
+        # sampling call then consumes B fresh sample indices (sample_offset advances), as successive randn calls would.
+        self.seed = None
         self.sample_offset = 0
         self.injected_noise = None  # [T+2,B,N,3+F] raw draws (parity tests); None -> on-device Philox
         self.last_diag = None
@@ -162,9 +165,16 @@ class GaudiModel:
         h_cat = (_to_numpy(h_cat) * self.norm_values[1] + self.norm_biases[1]) * nm
         return _like_ref(x), _like_ref(h_cat), h_int
 
+    def next_stream(self, n_samples: int):
+        """-> (seed, sample_offset) for a call that draws noise for ``n_samples`` molecules; advances the offset."""
+        if self.seed is None:
+            import torch
+            self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        off = self.sample_offset
+        self.sample_offset += int(n_samples)
+        return int(self.seed), off
+
     def _run(self, n_samples, node_mask, edge_mask, std, target, scale, fix_noise):
-        if fix_noise:
-            raise GaudiError("fix_noise=True (visualisation chains) is not supported")
         nm = _to_numpy(node_mask).astype(np.float32)
         B, N = nm.shape[0], nm.shape[1]
         if B != n_samples:
@@ -180,14 +190,19 @@ class GaudiModel:
                     "cannot be differentiated on the GPU and there is no CPU fallback")
             if target.cond_predictor.engine is not self.engine:
                 raise GaudiError("the target's predictor must be attached to this model (get_cond_predictor_model(..., model=model))")
-        if isinstance(target, PredTarget):
-            x, h, diag = self.engine.sample_callback(nm.reshape(B, N), em, target.grad, seed=self.seed,
-                                                     sample_offset=self.sample_offset, noise=self.injected_noise,
-                                                     std=std, scale=scale)
-        else:
-            tw = None if target is None else target.weights
-            x, h, diag = self.engine.sample(nm.reshape(B, N), em, seed=self.seed, sample_offset=self.sample_offset,
-                                            noise=self.injected_noise, std=std, target_w=tw, scale=scale)
+        seed, off = self.next_stream(B)
+        # fix_noise (en_diffusion.py:562-566,972-978): one raw draw per call, broadcast over the batch
+        self.engine.set_fix_noise(bool(fix_noise), off)
+        try:
+            if isinstance(target, PredTarget):
+                x, h, diag = self.engine.sample_callback(nm.reshape(B, N), em, target.grad, seed=seed, sample_offset=off,
+                                                         noise=self.injected_noise, std=std, scale=scale)
+            else:
+                tw = None if target is None else target.weights
+                x, h, diag = self.engine.sample(nm.reshape(B, N), em, seed=seed, sample_offset=off,
+                                                noise=self.injected_noise, std=std, target_w=tw, scale=scale)
+        finally:
+            self.engine.set_fix_noise(False, 0)
         self.last_diag = diag
         F = h.shape[2]
         return _like_ref(x), {"categorical": _like_ref(h), "integer": _like_ref(np.zeros((B, N, 0), np.float32))}
@@ -206,9 +221,9 @@ class GaudiModel:
         B, N = nm.shape[0], nm.shape[1]
         K = self.T if keep_frames is None else int(keep_frames)
         assert K <= self.T
+        seed, off = self.next_stream(B)
         chain = self.engine.sample_chain(nm.reshape(B, N), _to_numpy(edge_mask).astype(np.float32).reshape(B, N, N), K,
-                                         seed=self.seed, sample_offset=self.sample_offset, noise=self.injected_noise,
-                                         std=std)
+                                         seed=seed, sample_offset=off, noise=self.injected_noise, std=std)
         return _like_ref(chain.reshape(K * B, N, chain.shape[-1]))
 
     def sample_guidance(self, n_samples, target_function, node_mask, edge_mask, scale=1, fix_noise=False, std=1.0):

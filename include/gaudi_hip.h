@@ -220,6 +220,12 @@ int gaudi_profile_get(gaudi_handle* h, int32_t* n_launches, double* total_ms, in
  * the PADDED N, egnn_predictor/models.py:457).  0 (default) = the N of each call. */
 int gaudi_set_readout_nodes(gaudi_handle* h, int n_pad);
 
+/* fix_noise=True of EnVariationalDiffusion.sample / sample_guidance (en_diffusion.py:562-566, 972-978, 1022-1028): while
+ * enabled, every molecule of a gaudi_sample / gaudi_sample_cb / gaudi_sample_chain call receives the raw N(0,1) draws of ONE
+ * sample -- the Philox stream of global sample index key_sample, or, with injected noise, a buffer [T+2][1][N][3+F] --
+ * masked and mean-centred per molecule exactly as the reference broadcasts its [1,N,.] randn over the batch. */
+int gaudi_set_fix_noise(gaudi_handle* h, int enable, int64_t key_sample);
+
 /* Tuning knob: reverse steps fused into one kernel launch (default 25). */
 int gaudi_set_steps_per_launch(gaudi_handle* h, int steps);
 

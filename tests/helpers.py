@@ -9,10 +9,26 @@ TINY = dict(nf=32, n_layers=2)
 TINY_P = dict(nf=36, n_layers=3)
 
 
-def rel_err(a, b):
+def max_norm_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def elem_err(a, b, atol_frac=0.1):
+    """Element-wise error: the smallest tol for which np.allclose(a, b, rtol=tol, atol=atol_frac*tol*max|b|) holds, i.e.
+    `elem_err < 1e-4` is allclose(rtol=1e-4, atol=1e-5*max|b|): a small component may not hide behind a large one."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    scale = max(np.abs(b).max(), 1e-30)
+    return float((np.abs(a - b) / (np.abs(b) + atol_frac * scale)).max())
+
+
+def rel_err(a, b):
+    """The parity metric of every test: max(max-norm relative error, element-wise error)."""
+    return max(max_norm_err(a, b), elem_err(a, b))
 
 
 def cfg_of(fix, name):
@@ -54,3 +70,17 @@ def nonlinear_target(pred, t):
 
 def nonlinear_target_grad(pred, t):
     return nonlinear_target(pred, t)[1]
+
+
+def rng_noise(seed, shape):
+    """Same stream as tools/make_golden.py:rng_noise (fixtures that store a seed + checksum instead of the draws)."""
+    return np.random.Generator(np.random.Philox(key=seed)).standard_normal(shape).astype(np.float32)
+
+
+def noise_from_fixture(g, shape):
+    noise = rng_noise(int(g["noise_seed"]), shape)
+    T = shape[0] - 2
+    chk = np.array([noise.astype(np.float64).sum(), np.abs(noise).astype(np.float64).sum(), noise[17, 3, 5, 2],
+                    noise[T + 1, 7, 10, 3]])
+    assert np.array_equal(chk, g["noise_checksum"]), "numpy's Philox/normal stream differs from the one the fixture was made with"
+    return noise

@@ -1,0 +1,242 @@
+"""GPU parity evidence added in round 2: full-length (T = 1000) chains at the default architectures against the
+reference (g14), NaN scrubbing (g15), fix_noise (g16), fresh noise per call, the C4 / C5 shapes at full size, and the
+REAL engine under two ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gaudi_amd import synth
+from tests.helpers import TINY, TINY_P, edm_from_cfg, noise_from_fixture, pred_from_cfg, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _default_engine(T=1000, dataset="cata", guided=True):
+    from gaudi_amd.engine import Engine
+    F = synth.num_node_features(dataset)
+    eargs = synth.edm_args(dataset=dataset, diffusion_steps=T)
+    pargs = synth.pred_args(dataset=dataset)
+    eng = Engine(0)
+    eng.load_edm(eargs, synth.synth_edm_state_dict(eargs, F, seed=0))
+    if guided:
+        eng.load_predictor(pargs, synth.synth_predictor_state_dict(pargs, F, 5, seed=1))
+    return eng
+
+
+# ------------------------------------------------------------------------------------------------ g14: T = 1000
+def test_t1000_unguided_chain_vs_reference(golden):
+    """C2's chain length and architecture (B = 8 mixed sizes): 1000 reverse steps in 40 launches of 25, z resident in LDS
+    inside a launch, against the reference's final (x, h) for the same injected noise.  Tolerance 1e-4 (the reference's
+    own fp32-vs-fp64 spread on this chain is 4.5e-6)."""
+    g = golden("g14_long_chains")
+    cfg = json.loads(str(g["cfg"]))
+    T = cfg["T"]
+    nm, em = g["node_mask"], g["edge_mask"]
+    noise = noise_from_fixture(g, (T + 2,) + g["unguided_x"].shape[:2] + (4,))
+    eng = _default_engine(T, guided=False)
+    x, h, d = eng.sample(nm, em, noise=noise, std=cfg["std"])
+    assert rel_err(x, g["unguided_x"]) < TOL
+    assert np.array_equal(h, g["unguided_h"]) and d["nan_count"] == 0
+    eng.close()
+
+
+def test_t1000_guided_chain_vs_reference(golden):
+    """C3's chain: (i) teacher-forced guided steps at 26 points ALONG the reference's own trajectory at 1e-4;
+    (ii) the free-running 1000-step chain held to the reference's own fp32-vs-fp64 spread for this chain (4.1e-2,
+    BASELINE.md section 2: untrained weights amplify rounding noise by ~1/alpha_T)."""
+    g = golden("g14_long_chains")
+    cfg = json.loads(str(g["cfg"]))
+    T = cfg["T"]
+    nm, em = g["node_mask"], g["edge_mask"]
+    noise = noise_from_fixture(g, (T + 2,) + g["guided_x"].shape[:2] + (4,))
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    eng = _default_engine(T)
+    worst = 0.0
+    for i, s in enumerate(g["traj_s"]):
+        zs = eng.step(int(s), g["traj_zt"][i], nm, em, noise[T - int(s)], target_w=w, scale=cfg["scale"])
+        e = rel_err(zs, g["traj_zs"][i])
+        worst = max(worst, e)
+        assert e < TOL, (int(s), e)
+    x, h, d = eng.sample(nm, em, noise=noise, std=cfg["std"], target_w=w, scale=cfg["scale"])
+    assert rel_err(x, g["guided_x"]) < 4.1e-2
+    assert d["nan_count"] == 0 and d["max_masked_leak"] == 0
+    print(f"g14 guided: worst teacher-forced step error {worst:.2e}, free-running chain error {rel_err(x, g['guided_x']):.2e}")
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ g15: NaN scrubbing
+def test_nan_scrubbing_vs_reference(golden):
+    """A NaN planted in the EDM's last coordinate head / in the predictor readout: the reference scrubs phi's velocity
+    (models.py:138-141), eps_hat (en_diffusion.py:881) and the final z_s (:933-934); outputs must match it."""
+    from gaudi_amd.engine import Engine
+    g = golden("g15_nan_scrub")
+    cfg = json.loads(str(g["cfg"]))
+    base = dict(dataset=cfg["dataset"], amp=True)
+    eargs, esd = edm_from_cfg(dict(base, over=TINY, wseed=cfg["eseed"]), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(base, over=TINY_P, wseed=cfg["pseed"]))
+    esd_bad = {k: v.copy() for k, v in esd.items()}
+    esd_bad[str(g["edm_poison_key"])][tuple(g["edm_poison_idx"])] = np.nan
+    psd_bad = {k: v.copy() for k, v in psd.items()}
+    psd_bad[str(g["pred_poison_key"])][tuple(g["pred_poison_idx"])] = np.nan
+    z, nm, em = g["z"], g["node_mask"], g["edge_mask"]
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    bad_edm, bad_pred = Engine(0), Engine(0)
+    bad_edm.load_edm(eargs, esd_bad)
+    bad_edm.load_predictor(pargs, psd)
+    bad_pred.load_edm(eargs, esd)
+    bad_pred.load_predictor(pargs, psd_bad)
+    for s in (999, 500, 0):
+        eps = g[f"s{s}_eps"]
+        t = np.full(z.shape[0], np.float32(s + 1) / np.float32(cfg["T"]), np.float32)
+        assert rel_err(bad_edm.phi(z, t, nm, em), g[f"s{s}_phi_edm_poisoned"]) < TOL
+        assert rel_err(bad_edm.step(s, z, nm, em, eps), g[f"s{s}_zs_unguided_edm_poisoned"]) < TOL
+        assert rel_err(bad_edm.step(s, z, nm, em, eps, target_w=w, scale=0.6), g[f"s{s}_zs_guided_edm_poisoned"]) < TOL
+        zp = bad_pred.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+        assert np.array_equal(zp, g[f"s{s}_zs_guided_pred_poisoned"])  # the reference returns all zeros
+    # the diagnostics count what was scrubbed
+    T = 6
+    eargs6, _ = edm_from_cfg(dict(base, over=TINY, wseed=cfg["eseed"]), diffusion_steps=T)
+    e2 = Engine(0)
+    e2.load_edm(eargs6, esd)
+    e2.load_predictor(pargs, psd_bad)
+    x, h, d = e2.sample(nm, em, seed=1, target_w=w, scale=0.6)
+    assert d["nan_count"] > 0 and np.isfinite(x).all()
+    for e in (bad_edm, bad_pred, e2):
+        e.close()
+
+
+# ------------------------------------------------------------------------------------------------ g16: fix_noise
+def test_fix_noise_vs_reference(golden):
+    from gaudi_amd.models_edm import get_cond_predictor_model, get_model, target_function_max_gap
+    g = golden("g16_fix_noise")
+    cfg = json.loads(str(g["cfg"]))
+    base = dict(dataset=cfg["dataset"], amp=cfg["amp"])
+    eargs, esd = edm_from_cfg(dict(base, over=TINY, wseed=cfg["eseed"]), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(base, over=TINY_P, wseed=cfg["pseed"]))
+    model, _, _ = get_model(eargs, state_dict=esd)
+    pred = get_cond_predictor_model(pargs, model=model, state_dict=psd)
+    nm, em = g["node_mask"], g["edge_mask"]
+    B, N = nm.shape[0], nm.shape[1]
+    model.injected_noise = g["noise"]  # [T+2, 1, N, 3+F]: the reference's randn(1, N, .) per draw
+    x, h = model.sample(B, N, nm, em, fix_noise=True, std=0.7)
+    assert rel_err(x.numpy(), g["x_unguided"]) < TOL and np.array_equal(h["categorical"].numpy(), g["h_unguided"])
+    x, h = model.sample_guidance(B, target_function_max_gap(pred), nm, em, scale=0.6, fix_noise=True, std=1.0)
+    assert rel_err(x.numpy(), g["x_guided"]) < TOL and np.array_equal(h["categorical"].numpy(), g["h_guided"])
+    # production RNG: molecules with identical masks receive identical noise -> identical samples (nodes = [6, 8, 8, 3])
+    model.injected_noise = None
+    model.seed = 3
+    x, _ = model.sample(B, N, nm, em, fix_noise=True)
+    assert np.array_equal(x.numpy()[1], x.numpy()[2])
+    x2, _ = model.sample(B, N, nm, em, fix_noise=False)
+    assert not np.array_equal(x2.numpy()[1], x2.numpy()[2])
+    model.engine.close()
+
+
+# ------------------------------------------------------------------------------------------------ fresh noise per call
+def test_consecutive_calls_draw_fresh_noise():
+    """The reference draws new torch.randn noise in every call (en_diffusion.py:937-956); torch.manual_seed controls it."""
+    import types
+
+    import torch
+
+    from gaudi_amd import eval_validity
+    from gaudi_amd.models_edm import DistributionRings, get_model
+    eargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=10)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=5)
+    nm = np.ones((4, 6, 1), np.float32)
+    em = np.broadcast_to(1 - np.eye(6, dtype=np.float32), (4, 6, 6)).reshape(-1, 1).copy()
+
+    def two_calls(seed):
+        torch.manual_seed(seed)
+        model, _, _ = get_model(eargs, state_dict=esd)
+        a, _ = model.sample(4, 6, nm, em)
+        b, _ = model.sample(4, 6, nm, em)
+        model.engine.close()
+        return a.numpy(), b.numpy()
+
+    a, b = two_calls(123)
+    assert not np.array_equal(a, b)                    # the second call does not replay the first one's noise
+    assert len({a[i].tobytes() for i in range(4)}) == 4  # nor do the slots of one batch share noise
+    a2, b2 = two_calls(123)
+    assert np.array_equal(a, a2) and np.array_equal(b, b2)  # torch.manual_seed reproduces the run
+    a3, _ = two_calls(124)
+    assert not np.array_equal(a, a3)
+    # analyze_and_save loops over batches: no molecule may repeat across batches
+    torch.manual_seed(7)
+    model, _, _ = get_model(eargs, state_dict=esd)
+    args = types.SimpleNamespace(device="cuda", dataset="cata", max_nodes=11, batch_size=8, exp_dir="")
+    _, mols, _ = eval_validity.analyze_and_save(args, model, DistributionRings("cata"), n_samples=32)
+    keys = {(m[0].shape[0], m[0].numpy().tobytes()) for m in mols}
+    assert len(mols) == 32 and len(keys) == 32
+    model.engine.close()
+
+
+# ------------------------------------------------------------------------------------------------ C4 / C5 shapes, full size
+def _props(x, h, d, nm):
+    assert np.isfinite(x).all() and d["nan_count"] == 0
+    assert d["max_masked_leak"] == 0 and d["max_cog_rel"] < 1e-2
+    assert np.array_equal(h.sum(-1) > 0, nm > 0) and np.array_equal(h.sum(-1), nm)
+
+
+def test_c4_full_size_properties():
+    """BASELINE configs[3] at FULL size: hetero F = 12, orientation nodes, mixed 3-10 rings (6-20 graph nodes, N = 20),
+    B = 1024, T = 1000, multi-objective (OPV) guidance."""
+    from gaudi_amd.sampling_edm import build_masks
+    eng = _default_engine(1000, "hetro")
+    B = 1024
+    rings = np.random.default_rng(1).integers(3, 11, size=B)
+    nm3, em_flat, N = build_masks(rings, 10, True)
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    w = np.array([3, 0, 1, 1, 0], np.float32)
+    x, h, d = eng.sample(nm, em, seed=5, target_w=w, scale=0.6)
+    _props(x, h, d, nm)
+    # shard [768, 1024) alone (global-index-keyed noise, global N) == the same rows of the full batch, bit for bit;
+    # this also re-runs those 256 molecules: the chain is bitwise reproducible
+    xs, hs, _ = eng.sample(nm[768:], em[768:], seed=5, sample_offset=768, target_w=w, scale=0.6)
+    assert np.array_equal(xs, x[768:]) and np.array_equal(hs, h[768:])
+    eng.close()
+
+
+def test_c5_per_gpu_shape_properties():
+    """BASELINE configs[4] per-GPU shape: 1024 guided cc-PBH 11-ring samples on one GPU, T = 1000; two shards as the
+    8-GPU run would cut them (sample_offset = global index) reproduce the rows of the single-call batch."""
+    eng = _default_engine(1000, "cata")
+    B, N = 1024, 11
+    nm = np.ones((B, N), np.float32)
+    em = np.broadcast_to(1 - np.eye(N, dtype=np.float32), (B, N, N)).copy()
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    base = 3 * 1024  # this GPU's block of the 8192 global samples
+    x, h, d = eng.sample(nm, em, seed=11, sample_offset=base, target_w=w, scale=0.6)
+    _props(x, h, d, nm)
+    xs, hs, _ = eng.sample(nm[:256], em[:256], seed=11, sample_offset=base, target_w=w, scale=0.6)
+    assert np.array_equal(xs, x[:256]) and np.array_equal(hs, h[:256])
+    xs, hs, _ = eng.sample(nm[900:], em[900:], seed=11, sample_offset=base + 900, target_w=w, scale=0.6)
+    assert np.array_equal(xs, x[900:]) and np.array_equal(hs, h[900:])
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ real engine, 2 ranks
+def test_two_ranks_real_engine(tmp_path):
+    """world_size = 2 (gloo rendezvous, both ranks on this GPU): each rank runs the REAL sampler on its shard with
+    sample_offset = its first global index; the gathered result equals the unsharded run bit for bit."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ref = np.load(tmp_path / "unsharded.npz")
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 6, 6, 11)
+    assert np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["h"], r1["h"])
+    assert np.array_equal(r0["x"], ref["x"]) and np.array_equal(r0["h"], ref["h"])
+    assert np.isfinite(ref["x"]).all()

@@ -645,6 +645,141 @@ def g13_noised_predictor():
     save("g13_noised_predictor", **out)
 
 
+def g14_long_chains():
+    """T = 1000 chains at the DEFAULT architectures (the bench's C2 / C3 weights: EDM seed 0, predictor seed 1), B = 8,
+    N = 11, injected noise regenerated from a seed (checksummed).  Unguided final (x, h); guided final (x, h) plus the
+    reference's own (z_t, z_s) at 26 points of its trajectory for teacher-forced step parity along the real chain."""
+    out = {}
+    T = 1000
+    nodes = [11, 11, 11, 7, 4, 11, 9, 11]
+    B, N, D = len(nodes), 11, 4
+    over = dict(diffusion_steps=T)
+    esd = synth.synth_edm_state_dict(synth.edm_args(**over), 1, seed=0)
+    a, model = build_ref_edm("cata", esd, **over)
+    psd = synth.synth_predictor_state_dict(synth.pred_args(), 1, 5, seed=1)
+    pa, pred = build_ref_pred("cata", psd)
+    noise = rng_noise(1400, (T + 2, B, N, D))
+    out["noise_seed"] = np.int64(1400)
+    out["noise_checksum"] = np.array([np.float64(noise.astype(np.float64).sum()), np.float64(np.abs(noise).astype(np.float64).sum()),
+                                      np.float64(noise[17, 3, 5, 2]), np.float64(noise[T + 1, 7, 10, 3])])
+    a.max_nodes = N
+    import time
+    t0 = time.time()
+    with InjectNoise(list(noise)):
+        x, h, nm, em = ref_sampling.sample_pos_edm(a, model, torch.tensor(nodes), std=1.0)
+    print(f"g14 unguided T=1000: {time.time() - t0:.0f} s")
+    out["unguided_x"], out["unguided_h"] = x.numpy(), h.numpy().astype(np.float32)
+    out["node_mask"], out["edge_mask"] = nm.numpy(), em.numpy()
+
+    def tf_gap(_in, _nm, _em, _t):
+        return -pred(_in, _nm, _em, _t)[:, 1]
+
+    pts = [999, 990, 950, 900, 850, 800, 750, 700, 650, 600, 550, 500, 450, 400, 350, 300, 250, 200, 150, 100, 50, 25, 10, 5, 1, 0]
+    rec = {}
+    orig = model.sample_p_zs_given_zt_guidance
+
+    def wrapped(s, t, zt, node_mask, edge_mask, target_function, scale, fix_noise=False):
+        zs = orig(s, t, zt, node_mask, edge_mask, target_function, scale, fix_noise=fix_noise)
+        si = int(round(float(s[0, 0]) * T))
+        if si in pts:
+            rec[si] = (zt.detach().numpy().copy(), zs.detach().numpy().copy())
+        return zs
+
+    model.sample_p_zs_given_zt_guidance = wrapped
+    t0 = time.time()
+    with InjectNoise(list(noise)):
+        x, h, nm2, em2 = ref_sampling.sample_guidance(a, model, tf_gap, torch.tensor(nodes), scale=0.6, std=1.0)
+    print(f"g14 guided T=1000: {time.time() - t0:.0f} s")
+    model.sample_p_zs_given_zt_guidance = orig
+    assert np.array_equal(nm2.numpy(), nm.numpy()) and sorted(rec) == sorted(pts)
+    out["guided_x"], out["guided_h"] = x.numpy(), h.numpy().astype(np.float32)
+    out["traj_s"] = np.array(pts, np.int32)
+    out["traj_zt"] = np.stack([rec[s][0] for s in pts])
+    out["traj_zs"] = np.stack([rec[s][1] for s in pts])
+    out["cfg"] = np.array(json.dumps(dict(dataset="cata", T=T, eseed=0, pseed=1, nodes=nodes, scale=0.6, std=1.0)))
+    save("g14_long_chains", **out)
+
+
+def g15_nan_scrub():
+    """NaN handling of the reverse steps (edm/egnn/models.py:138-141, en_diffusion.py:881,933-934): a NaN planted in the
+    last block's coordinate head makes phi's velocity NaN (scrubbed to 0 inside phi); a NaN planted in the predictor's
+    readout makes the guidance gradient NaN (z_s scrubbed to 0 at the end of the guided step)."""
+    out = {}
+    T = 1000
+    ds, nodes = "cata", [4, 11, 7, 11]
+    F = 1
+    eargs = synth.edm_args(dataset=ds, **TINY)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=1500, amplify_coord=True)
+    pargs = synth.pred_args(dataset=ds, **TINY_P)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=1510, amplify_coord=True)
+    nm, em, z = case_inputs(ds, nodes, None, seed=1520, guidance_pad=True)
+    B, N, D = z.shape
+    tnm, tem = torch.from_numpy(nm), torch.from_numpy(em)
+    out["z"], out["node_mask"], out["edge_mask"] = z, nm, em
+    esd_bad = {k: v.copy() for k, v in esd.items()}
+    key_e = "dynamics.egnn.e_block_1.gcl_equiv.coord_mlp.4.weight"
+    esd_bad[key_e][0, 3] = np.nan
+    psd_bad = {k: v.copy() for k, v in psd.items()}
+    key_p = "egnn.embedding_out.weight"
+    psd_bad[key_p][1, 5] = np.nan
+    out["edm_poison_key"], out["edm_poison_idx"] = np.array(key_e), np.array([0, 3])
+    out["pred_poison_key"], out["pred_poison_idx"] = np.array(key_p), np.array([1, 5])
+    a, model_bad = build_ref_edm(ds, esd_bad, **TINY)
+    a2, model_ok = build_ref_edm(ds, esd, **TINY)
+    pa, pred_ok = build_ref_pred(ds, psd, **TINY_P)
+    pb, pred_bad = build_ref_pred(ds, psd_bad, **TINY_P)
+    import contextlib, io
+    for s in (999, 500, 0):
+        eps = rng_noise(1530 + s % 7, (B, N, D))
+        st = torch.full((B, 1), s) / T
+        tt = (torch.full((B, 1), s) + 1) / T
+        out[f"s{s}_eps"] = eps
+        with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+            e = model_bad.phi(torch.from_numpy(z), tt, tnm, tem, None).numpy()
+            with InjectNoise([eps]):
+                zu = model_bad.sample_p_zs_given_zt(st, tt, torch.from_numpy(z), tnm, tem, None).numpy()
+            with InjectNoise([eps]):
+                zg = model_bad.sample_p_zs_given_zt_guidance(
+                    st, tt, torch.from_numpy(z), tnm, tem, lambda i, n, m, t: -pred_ok(i, n, m, t)[:, 1], 0.6).numpy()
+            with InjectNoise([eps]):
+                zp = model_ok.sample_p_zs_given_zt_guidance(
+                    st, tt, torch.from_numpy(z), tnm, tem, lambda i, n, m, t: -pred_bad(i, n, m, t)[:, 1], 0.6).numpy()
+        assert np.isfinite(e).all() and np.isfinite(zu).all() and np.isfinite(zg).all() and np.isfinite(zp).all()
+        out[f"s{s}_phi_edm_poisoned"] = e
+        out[f"s{s}_zs_unguided_edm_poisoned"] = zu
+        out[f"s{s}_zs_guided_edm_poisoned"] = zg
+        out[f"s{s}_zs_guided_pred_poisoned"] = zp
+    out["cfg"] = np.array(json.dumps(dict(dataset=ds, eseed=1500, pseed=1510, T=T, nodes=nodes)))
+    save("g15_nan_scrub", **out)
+
+
+def g16_fix_noise():
+    """fix_noise=True (en_diffusion.py:562-566,972-978,1022-1028): ONE raw draw [1,N,3+F] per call is broadcast over the
+    batch and masked / mean-centred per molecule.  Tiny config, T = 50, unguided and guided."""
+    out = {}
+    T = 50
+    ds, nodes = "cata", [6, 8, 8, 3]
+    F = 1
+    over = dict(diffusion_steps=T, **TINY)
+    esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=1600)
+    a, model = build_ref_edm(ds, esd, **over)
+    psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **TINY_P), F, 5, seed=1610)
+    pa, pred = build_ref_pred(ds, psd, **TINY_P)
+    nm, em = masks(ds, nodes, None)
+    B, N, _ = nm.shape
+    noise = rng_noise(1620, (T + 2, 1, N, 3 + F))
+    tnm, tem = torch.from_numpy(nm), torch.from_numpy(em)
+    with InjectNoise(list(noise)):
+        x, h = model.sample(B, N, tnm, tem, fix_noise=True, std=0.7)
+    out["x_unguided"], out["h_unguided"] = x.numpy(), h["categorical"].numpy().astype(np.float32)
+    with InjectNoise(list(noise)):
+        x, h = model.sample_guidance(B, lambda i, n, m, t: -pred(i, n, m, t)[:, 1], tnm, tem, scale=0.6, fix_noise=True, std=1.0)
+    out["x_guided"], out["h_guided"] = x.numpy(), h["categorical"].numpy().astype(np.float32)
+    out["noise"], out["node_mask"], out["edge_mask"] = noise, nm, em
+    out["cfg"] = np.array(json.dumps(dict(dataset=ds, T=T, eseed=1600, pseed=1610, nodes=nodes, amp=False)))
+    save("g16_fix_noise", **out)
+
+
 def g8_checkpoint_roundtrip():
     """The reference's own loader must accept checkpoints written by gaudi_amd.synth.write_checkpoint
     (args.txt + model.pt, with and without the ``module.`` prefix).  Stores nothing but a marker."""
@@ -669,8 +804,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise)
     for w in which:
         fns[w]()
