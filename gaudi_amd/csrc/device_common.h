@@ -148,17 +148,17 @@ __device__ __forceinline__ float ldw1(const WBuf& w, int off_floats) {
 // with few pairs (cata: N*F = 11) one thread per pair walks K = 192..256 elements alone, 11 busy lanes and K dependent
 // steps; then 16 lanes share a pair and fold with 4 shuffles.  With many pairs (hetero: N*F = 240) a thread per pair is the
 // better shape.  Summation order differs between the two shapes, both are fixed (no atomics).
-template <class FA, class FB, class ST>
+template <int NTHR = kThreads, class FA, class FB, class ST>
 __device__ __forceinline__ void small_dots(int P, int K, int tid, FA a, FB b, ST store) {
-  if (P * 16 > 2 * kThreads) {
-    for (int p = tid; p < P; p += kThreads) {
+  if (P * 16 > 2 * NTHR) {
+    for (int p = tid; p < P; p += NTHR) {
       float acc = 0.f;
       for (int k = 0; k < K; ++k) acc += a(p, k) * b(p, k);
       store(p, acc);
     }
   } else {
     const int sub = tid & 15;
-    for (int p0 = 0; p0 < P; p0 += kThreads / 16) {
+    for (int p0 = 0; p0 < P; p0 += NTHR / 16) {
       const int p = p0 + (tid >> 4);
       float acc = 0.f;
       if (p < P)
@@ -185,21 +185,21 @@ struct VecPF {
 };
 // count: floats of the vector block.  Lanes past it do not load: the descriptor's range check looks at the lane offset
 // only (not at the scalar base), so an unguarded tail would read past the end of the weight allocation.
-template <int MAXLOADS>
+template <int MAXLOADS, int NTHR = kThreads>
 __device__ __forceinline__ void vec_prefetch(VecPF<MAXLOADS>& pf, const WBuf& wb, int off, int count, int tid) {
 #pragma unroll
   for (int k = 0; k < MAXLOADS; ++k) {
-    const int idx = tid + k * kThreads;
+    const int idx = tid + k * NTHR;
     pf.r[k] = idx < count
                   ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wb.r, idx * 4, off * 4, 0))
                   : 0.f;
   }
 }
-template <int MAXLOADS>
+template <int MAXLOADS, int NTHR = kThreads>
 __device__ __forceinline__ void vec_commit(const VecPF<MAXLOADS>& pf, float* sVec, int count, int tid) {
 #pragma unroll
   for (int k = 0; k < MAXLOADS; ++k) {
-    const int idx = tid + k * kThreads;
+    const int idx = tid + k * NTHR;
     if (idx < count) sVec[idx] = pf.r[k];
   }
 }

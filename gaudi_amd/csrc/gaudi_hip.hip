@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,8 +54,10 @@ struct gaudi_handle {
   std::vector<float> gamma, coef;
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
-      d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols;
+      d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols, d_soff,
+      d_sidx;
   int steps_per_launch = 25;
+  int variant = 4;            // 4 = one wave per SIMD (sampler_kernel), 8 = two waves per SIMD (sampler_kernel8)
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
   long long fix_key = 0;      // global sample index whose Philox stream is shared
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
@@ -200,12 +203,17 @@ struct Tensors {
 };
 
 // W[o][col0 + k] (row stride ldw), o,k < H  ->  tile-packed [HP/16][HP/16][16][16]: dst[((k/16*T + o/16)*16 + o%16)*16 + k%16]
+// lane_linear (8-wave kernels): inside a tile float4 index L = (k%16/4)*16 + o%16 holds W[o][k .. k+3], i.e. lane L of a
+// wave reads the 16 bytes at offset 16 L whether the tile comes from L2 or from the LDS weight ring
+static bool g_lane_linear = false;
 static void pack_matrix(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
   const int T = HP / 16;
   for (int o = 0; o < H; ++o)
     for (int k = 0; k < H; ++k) {
       const float v = transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k];
-      dst[(((size_t)(k / 16) * T + o / 16) * 16 + o % 16) * 16 + k % 16] = v;
+      const size_t tile = ((size_t)(k / 16) * T + o / 16) * 256;
+      const size_t in = g_lane_linear ? (size_t)(((k % 16) / 4) * 16 + o % 16) * 4 + k % 4 : (size_t)(o % 16) * 16 + k % 16;
+      dst[tile + in] = v;
     }
 }
 static void pack_vec(float* dst, const float* v, int n) { std::memcpy(dst, v, sizeof(float) * n); }
@@ -314,6 +322,127 @@ static int build_meta(int B, int N, const float* node_mask, const float* edge_ma
 }
 
 // -------------------------------------------------------------------------------------------------
+// graph metadata of the 8-wave kernels: ONE flat slot list per molecule -- live edges sorted by receiving node (then by
+// sending node), cut into 16-slot tiles (tile tau -> wave tau & 7, round tau >> 3).  A node's run may straddle two tiles but
+// never three (a run that would is moved to the next tile boundary), so its edge -> node sum has at most two partials.
+struct Meta8 {
+  int S = 16;
+  std::vector<int> order, ntiles, ncols;
+  std::vector<uint32_t> edges, seg;
+  std::vector<float> emask;
+  std::vector<uint16_t> soff, sidx;
+};
+
+static int build_meta8(int B, int N, const float* node_mask, const float* edge_mask, Meta8& M, std::string& err) {
+  if (N > 255) {
+    err = "N > 255 unsupported";
+    return GAUDI_E_CAPACITY;
+  }
+  struct Slot {
+    int i, j;
+    float m;
+    bool live;
+  };
+  std::vector<std::vector<Slot>> slots(B);
+  std::vector<std::vector<std::pair<int, int>>> runs(B);  // per node: (first slot, length)
+  M.ncols.assign(B, 1);
+  M.ntiles.assign(B, 0);
+  std::vector<int> total(B, 0);
+  int max_tiles = 1;
+  for (int b = 0; b < B; ++b) {
+    std::vector<Slot>& sl = slots[b];
+    runs[b].assign(N, {0, 0});
+    int last = 0;
+    for (int i = 0; i < N; ++i) {
+      const bool li = node_mask == nullptr || node_mask[(size_t)b * N + i] != 0.f;
+      if (li) last = i;
+      std::vector<Slot> run;
+      for (int j = 0; j < N; ++j) {
+        const float v = edge_mask[((size_t)b * N + i) * N + j];
+        const bool lj = node_mask == nullptr || node_mask[(size_t)b * N + j] != 0.f;
+        if (v != 0.f && (li || lj)) {  // edges between two masked nodes reach nothing (see build_meta)
+          run.push_back({i, j, v, true});
+          last = std::max(last, std::max(i, j));
+        }
+      }
+      const int L = (int)run.size();
+      if (L == 0) {
+        runs[b][i] = {(int)sl.size(), 0};
+        continue;
+      }
+      if (L > 32) {
+        err = "a node with more than 32 live edges is not supported by the 8-wave kernels";
+        return GAUDI_E_CAPACITY;
+      }
+      const int o = (int)sl.size() % 16;
+      if ((o + L + 15) / 16 > 2) {  // would straddle three tiles: start at the next tile boundary
+        const int prev_i = sl.empty() ? i : sl.back().i;
+        while (sl.size() % 16) sl.push_back({prev_i, prev_i, 0.f, false});
+      }
+      runs[b][i] = {(int)sl.size(), L};
+      sl.insert(sl.end(), run.begin(), run.end());
+      total[b] += L;
+    }
+    if (!sl.empty()) {
+      const int prev_i = sl.back().i;
+      while (sl.size() % 16) sl.push_back({prev_i, prev_i, 0.f, false});
+    }
+    M.ncols[b] = last + 1;
+    M.ntiles[b] = (int)sl.size() / 16;
+    max_tiles = std::max(max_tiles, M.ntiles[b]);
+  }
+  M.S = 16 * max_tiles;
+  if (M.S > 0xffff) {
+    err = "too many edge slots";
+    return GAUDI_E_CAPACITY;
+  }
+  const int S = M.S;
+  M.edges.assign((size_t)B * S, 0);
+  M.emask.assign((size_t)B * S, 0.f);
+  M.seg.assign((size_t)B * N, 0);
+  M.soff.assign((size_t)B * (N + 1), 0);
+  M.sidx.assign((size_t)B * S, 0);
+  for (int b = 0; b < B; ++b) {
+    const std::vector<Slot>& sl = slots[b];
+    const int ns = (int)sl.size();
+    for (int t0 = 0; t0 < ns; t0 += 16) {
+      int c = 0;
+      while (c < 16) {  // segments of equal receiving node inside the tile (padding extends the segment before it)
+        int e = c;
+        while (e + 1 < 16 && sl[t0 + e + 1].i == sl[t0 + c].i) ++e;
+        const int i = sl[t0 + c].i;
+        const int part = runs[b][i].second > 0 && runs[b][i].first < t0 ? 1 : 0;  // the node's run began in an earlier tile
+        for (int k = c; k <= e; ++k) {
+          const Slot& q = sl[t0 + k];
+          M.edges[(size_t)b * S + t0 + k] = (uint32_t)q.i | ((uint32_t)q.j << 8) | ((uint32_t)c << 16) |
+                                            ((uint32_t)(k == e) << 20) | ((uint32_t)part << 21);
+          M.emask[(size_t)b * S + t0 + k] = q.m;
+        }
+        c = e + 1;
+      }
+    }
+    for (int i = 0; i < N; ++i)
+      M.seg[(size_t)b * N + i] = ((uint32_t)runs[b][i].first << 16) | (uint32_t)runs[b][i].second;
+    // slots by SENDING node, ascending slot (= ascending receiving node): the transposed sums of the reverse pass
+    uint16_t* off = &M.soff[(size_t)b * (N + 1)];
+    uint16_t* idx = &M.sidx[(size_t)b * S];
+    int n_out = 0;
+    for (int j = 0; j < N; ++j) {
+      off[j] = (uint16_t)n_out;
+      for (int k = 0; k < ns; ++k)
+        if (sl[k].live && sl[k].j == j) idx[n_out++] = (uint16_t)k;
+    }
+    off[N] = (uint16_t)n_out;
+  }
+  M.order.resize(B);
+  for (int b = 0; b < B; ++b) M.order[b] = b;
+  std::stable_sort(M.order.begin(), M.order.end(), [&](int a, int c) {
+    return M.ntiles[a] != M.ntiles[c] ? M.ntiles[a] > M.ntiles[c] : total[a] > total[c];
+  });
+  return GAUDI_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
 // kernel table: the instantiations live in kern_*.hip (compiled in parallel), each exporting a lookup
 typedef void (*kernel_fn)(const KParams);
 #ifdef GAUDI_STAMP_STUBS  // diagnostic build: only the two production kernels are linked
@@ -336,6 +465,24 @@ static kernel_fn pick_kernel(int hpe, int hpp) {
   return f;
 }
 
+// the 8-wave instantiations (kern8_*.hip)
+#ifdef GAUDI_STAMP_STUBS
+#define GAUDI_KERNEL8_TUS(X)
+#else
+#define GAUDI_KERNEL8_TUS(X) X(edm_small) X(edm_192) X(edm_208) X(edm_256)
+#endif
+#define X(name) kernel_fn gaudi_kern8_##name(int hpe, int hpp);
+GAUDI_KERNEL8_TUS(X)
+#undef X
+static kernel_fn pick_kernel8(int hpe, int hpp) {
+  kernel_fn f = nullptr;
+#define X(name) \
+  if (!f) f = gaudi_kern8_##name(hpe, hpp);
+  GAUDI_KERNEL8_TUS(X)
+#undef X
+  return f;
+}
+
 // smallest instantiated padded hidden size >= H (0 if none)
 static int round_hidden(int H) {
   static const int sizes[] = {32, 48, 64, 128, 192, 208, 256};
@@ -351,12 +498,21 @@ static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW) {
   return sizeof(float) * (common_floats(N, D, EW) + net);
 }
 
+static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S) {
+  size_t net = 0;
+  if (hpe) net = std::max(net, (size_t)(5 * N * (hpe + 4) + 2 * (hpe / 16) * 256 + 8 * N + S * 9 + 8 * hpe));
+  (void)hpp;
+  return sizeof(float) * (common_floats8(N, D, S) + net);
+}
+
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
-  kernel_fn fn = pick_kernel(hpe, hpp);
+  const bool v8 = h->variant == 8;
+  kernel_fn fn = v8 ? pick_kernel8(hpe, hpp) : pick_kernel(hpe, hpp);
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
-                "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")");
-  const size_t lds = lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW);
+                "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
+                    (v8 ? " in the 8-wave family" : ""));
+  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW);
   if (lds > 160 * 1024)
     return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
   {
@@ -395,7 +551,7 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
     }
   }
 #else
-  hipLaunchKernelGGL(fn, dim3(P.B), dim3(kThreads), lds, h->stream, P);
+  hipLaunchKernelGGL(fn, dim3(P.B), dim3(v8 ? w8::kThreads : kThreads), lds, h->stream, P);
 #endif
   HIPCHECK(h, hipGetLastError());
   if (h->prof) {
@@ -406,8 +562,44 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
 }
 
 // upload masks + metadata, fill the graph part of KParams
+static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P) {
+  Meta8 M;
+  std::string err;
+  int rc = build_meta8(B, N, node_mask, edge_mask, M, err);
+  if (rc) return fail(h, rc, err);
+  auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = d.reserve(bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, h->stream);
+  };
+  HIPCHECK(h, up(h->d_ncols, M.ncols.data(), sizeof(int) * B));
+  HIPCHECK(h, up(h->d_mask, node_mask, sizeof(float) * B * N));
+  HIPCHECK(h, up(h->d_order, M.order.data(), sizeof(int) * B));
+  HIPCHECK(h, up(h->d_edges, M.edges.data(), sizeof(uint32_t) * M.edges.size()));
+  HIPCHECK(h, up(h->d_emask, M.emask.data(), sizeof(float) * M.emask.size()));
+  HIPCHECK(h, up(h->d_npairs, M.ntiles.data(), sizeof(int) * B));
+  HIPCHECK(h, up(h->d_seg, M.seg.data(), sizeof(uint32_t) * M.seg.size()));
+  HIPCHECK(h, up(h->d_soff, M.soff.data(), sizeof(uint16_t) * M.soff.size()));
+  HIPCHECK(h, up(h->d_sidx, M.sidx.data(), sizeof(uint16_t) * M.sidx.size()));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));  // M goes out of scope
+  P.B = B;
+  P.N = N;
+  P.EW = M.S;
+  P.node_mask = h->d_mask.as<float>();
+  P.order = h->d_order.as<int>();
+  P.edges = h->d_edges.as<uint32_t>();
+  P.emask = h->d_emask.as<float>();
+  P.npairs = h->d_npairs.as<int>();
+  P.seginfo = h->d_seg.as<uint32_t>();
+  P.ncols = h->d_ncols.as<int>();
+  P.soff = h->d_soff.as<uint16_t>();
+  P.sidx = h->d_sidx.as<uint16_t>();
+  return GAUDI_OK;
+}
+
 static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P) {
   if (B <= 0 || N <= 0) return fail(h, GAUDI_E_INVALID, "B and N must be positive");
+  if (h->variant == 8) return stage_graph8(h, B, N, node_mask, edge_mask, P);
   Meta M;
   std::string err;
   int rc = build_meta(B, N, node_mask, edge_mask, M, err);
@@ -473,6 +665,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return GAUDI_E_HIP;
   gaudi_handle* h = new gaudi_handle();
   h->device = device;
+  if (const char* v = getenv("GAUDI_WAVES")) h->variant = atoi(v) == 8 ? 8 : 4;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return GAUDI_E_HIP;
@@ -490,7 +683,7 @@ void gaudi_destroy(gaudi_handle* h) {
   DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
                     &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
                     &h->d_pred, &h->d_tw, &h->d_stash, &h->d_chain, &h->d_sx, &h->d_stype, &h->d_sn,
-                    &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as, &h->d_ncols};
+                    &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as, &h->d_ncols, &h->d_soff, &h->d_sidx};
   for (DevBuf* b : bufs) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -511,6 +704,9 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   if (!HP) return fail(h, GAUDI_E_INVALID, "no kernel instantiated for this hidden size");
   Tensors T;
   for (int i = 0; i < n; ++i) T.m[names[i]] = {tensors[i], numel[i]};
+  static std::mutex pack_mu;
+  std::lock_guard<std::mutex> pack_lock(pack_mu);
+  g_lane_linear = h->variant == 8;
   EdmLayout lay{HP, F1, L, S};
   std::vector<float> w((size_t)lay.total(), 0.f);
   const std::string p = "dynamics.egnn.";

@@ -4,6 +4,8 @@
 #pragma once
 #include "edm_device.h"
 #include "pred_device.h"
+#include "w8_edm.h"
+#include "w8_pred.h"
 
 namespace gaudi {
 
@@ -21,6 +23,10 @@ struct KParams {
   const int* npairs;        // [B][4]
   const uint32_t* seginfo;  // [B][N]
   const int* ncols;         // [B] node columns the node-level GEMMs have to produce (<= N)
+  // 8-wave kernels (w8_*.h): edges / emask are flat [B][EW] (EW = slot capacity S), npairs = [B] 16-slot tiles per
+  // molecule, seginfo = start << 16 | len, plus the sender lists of the reverse pass
+  const uint16_t* soff;     // [B][N+1]
+  const uint16_t* sidx;     // [B][EW]
   // tensors (device)
   const float* z_in;        // [B][N][D]
   float* z_out;             // [B][N][D]
@@ -58,13 +64,122 @@ struct KParams {
 __host__ __device__ inline int common_floats(int N, int D, int EW) {
   return 3 * align16(N * D) + align16(N) + 16 + 2 * kWaves * EW + align16(N);
 }
+__host__ __device__ inline int common_floats8(int N, int D, int S) {
+  return 3 * align16(N * D) + align16(N) + 16 + 2 * S + align16(N) + align16((N + 1 + S + 1) / 2);
+}
 
-template <int HPE, int HPP>
-__global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
+// ---- kernel variants: what differs between the 4-wave kernels (one wave per SIMD, per-wave edge lists, weights streamed
+// per wave) and the 8-wave kernels (two waves per SIMD, flat 16-slot tiles, LDS-shared weight ring) behind one sampler body
+struct V4 {
+  static constexpr int kThreads = gaudi::kThreads;
+  using Graph = gaudi::MolGraph;
+  template <int HP> using EdmSmem = gaudi::NetSmem<HP>;
+  __host__ __device__ static int graph_floats(int N, int EW) { return 2 * gaudi::kWaves * EW + align16(N); }
+  __device__ __forceinline__ static float* load_graph(const KParams& P, int b, float* base, const float* sMask, Graph& mg, int tid, int wave) {
+    const int N = P.N, EW = P.EW;
+    uint32_t* sEdge = (uint32_t*)base; base += gaudi::kWaves * EW;
+    float* sEm = base; base += gaudi::kWaves * EW;
+    uint32_t* sSeg = (uint32_t*)base; base += align16(N);
+    for (int i = tid; i < N; i += kThreads) sSeg[i] = P.seginfo[b * N + i];
+    for (int i = tid; i < gaudi::kWaves * EW; i += kThreads) {
+      sEdge[i] = P.edges[(size_t)b * gaudi::kWaves * EW + i];
+      sEm[i] = P.emask[(size_t)b * gaudi::kWaves * EW + i];
+    }
+    mg.N = N; mg.D = 3 + P.F; mg.EW = EW;
+    mg.NC = P.ncols[b];
+    mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg;
+    mg.npairs = P.npairs[b * gaudi::kWaves + wave];
+#pragma unroll
+    for (int w = 0; w < gaudi::kWaves; ++w) mg.npairs_all[w] = P.npairs[b * gaudi::kWaves + w];
+    return base;
+  }
+  template <int HP>
+  __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
+                                             float* sMean, float t_val, int tid STAMP_DECL) {
+    gaudi::NetSmem<HP> sm;
+    sm.carve(net, mg.N, mg.EW);
+    gaudi::edm_forward<HP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
+  }
+  // explicit by-value signatures: forwarding references (and a by-reference KParams) made hipcc keep the arguments in
+  // scratch in the largest instantiations, with wrong results / null dereferences on the GPU
+  template <int HP>
+  __device__ __forceinline__ static void guide(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
+                                               float* sMean, float t_val, float sigma, const float* target_w, float scale,
+                                               float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
+                                               const float* dpred_ext) {
+    gaudi::guidance_update<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
+                               tid STAMP_ARGS, phase, dpred_ext);
+  }
+  template <int HP>
+  __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
+                                                    float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
+                                                    float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
+    gaudi::predictor_entry<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash,
+                               tid STAMP_ARGS);
+  }
+};
+
+struct V8 {
+  static constexpr int kThreads = w8::kThreads;
+  using Graph = w8::MolGraph;
+  __host__ __device__ static int graph_floats(int N, int S) { return 2 * S + align16(N) + align16((N + 1 + S + 1) / 2); }
+  __device__ __forceinline__ static float* load_graph(const KParams& P, int b, float* base, const float* sMask, Graph& mg, int tid, int wave) {
+    (void)wave;
+    const int N = P.N, S = P.EW;
+    uint32_t* sEdge = (uint32_t*)base; base += S;
+    float* sEm = base; base += S;
+    uint32_t* sSeg = (uint32_t*)base; base += align16(N);
+    uint16_t* sOff = (uint16_t*)base;
+    uint16_t* sIdx = sOff + (N + 1);
+    base += align16((N + 1 + S + 1) / 2);
+    for (int i = tid; i < N; i += kThreads) sSeg[i] = P.seginfo[b * N + i];
+    for (int i = tid; i < N + 1; i += kThreads) sOff[i] = P.soff[(size_t)b * (N + 1) + i];
+    for (int i = tid; i < S; i += kThreads) {
+      sEdge[i] = P.edges[(size_t)b * S + i];
+      sEm[i] = P.emask[(size_t)b * S + i];
+      sIdx[i] = P.sidx[(size_t)b * S + i];
+    }
+    mg.N = N; mg.D = 3 + P.F; mg.S = S;
+    mg.NC = P.ncols[b];
+    mg.ntiles = P.npairs[b];
+    mg.rounds = (mg.ntiles + w8::kWaves - 1) / w8::kWaves;
+    mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg; mg.soff = sOff; mg.sidx = sIdx;
+    return base;
+  }
+  template <int HP>
+  __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
+                                             float* sMean, float t_val, int tid STAMP_DECL) {
+    w8::NetSmem<HP> sm;
+    sm.carve(net, mg.N, mg.S);
+    w8::edm_forward<HP>(W, mg, sm, sZ, sEps, sMean, t_val, tid);
+  }
+  template <int HP>
+  __device__ __forceinline__ static void guide(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
+                                               float* sMean, float t_val, float sigma, const float* target_w, float scale,
+                                               float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
+                                               const float* dpred_ext) {
+    w8::guidance_update<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash, tid,
+                            phase, dpred_ext);
+  }
+  template <int HP>
+  __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
+                                                    float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
+                                                    float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
+    w8::predictor_entry<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, tid);
+  }
+};
+
+__host__ __device__ inline int common_floats_base(int N, int D) { return 3 * align16(N * D) + align16(N) + 16; }
+
+// V4 -> 256 threads (one wave per SIMD, up to 512 registers); V8 -> 512 threads = two waves per SIMD: the register
+// allocator is held to 256 VGPR + AGPR per lane.  P stays a by-value kernel argument (SGPR-resident).
+template <class V, int HPE, int HPP>
+__global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P) {
+  constexpr int kThreads = V::kThreads;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = P.order[blockIdx.x];
-  const int N = P.N, D = 3 + P.F, EW = P.EW;
+  const int N = P.N, D = 3 + P.F;
 
   // ---- carve the common region
   float* base = smem;
@@ -73,26 +188,9 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
   float* sNz = base; base += align16(N * D);
   float* sMask = base; base += align16(N);
   float* sMean = base; base += 16;
-  uint32_t* sEdge = (uint32_t*)base; base += kWaves * EW;
-  float* sEm = base; base += kWaves * EW;
-  uint32_t* sSeg = (uint32_t*)base; base += align16(N);
-  float* net = base;
-
-  for (int i = tid; i < N; i += kThreads) {
-    sMask[i] = P.node_mask[b * N + i];
-    sSeg[i] = P.seginfo[b * N + i];
-  }
-  for (int i = tid; i < kWaves * EW; i += kThreads) {
-    sEdge[i] = P.edges[(size_t)b * kWaves * EW + i];
-    sEm[i] = P.emask[(size_t)b * kWaves * EW + i];
-  }
-  MolGraph mg;
-  mg.N = N; mg.D = D; mg.EW = EW;
-  mg.NC = P.ncols[b];
-  mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg;
-  mg.npairs = P.npairs[b * kWaves + wave];
-#pragma unroll
-  for (int w = 0; w < kWaves; ++w) mg.npairs_all[w] = P.npairs[b * kWaves + w];
+  for (int i = tid; i < N; i += kThreads) sMask[i] = P.node_mask[b * N + i];
+  typename V::Graph mg;
+  float* net = V::load_graph(P, b, base, sMask, mg, tid, wave);
 
   const uint64_t gsample = (uint64_t)(P.fix_noise ? P.fix_key : P.sample_offset + b);
   // locals (not references into the kernarg struct) so nothing forces P onto the stack
@@ -160,8 +258,6 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
 
   if constexpr (HPE > 0) {
     if (mode == MODE_PHI || mode == MODE_SAMPLE) {
-      NetSmem<HPE> sm;
-      sm.carve(net, N, EW);
       const EdmDev edm = P.edm;
       const int guided = P.guided, T = P.T, s_hi = P.s_hi;
       const int n_steps = mode == MODE_SAMPLE ? (s_hi - P.s_lo + 1) : 0;
@@ -177,7 +273,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
         if (is_step == false && mode == MODE_SAMPLE)               // z_0 is final: publish it
           for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
         const int split = P.split;
-        if (split != 2) edm_forward<HPE>(edm, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
+        if (split != 2) V::template edm<HPE>(edm, mg, net, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
         if (mode == MODE_PHI) {
           for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
         } else if (is_step) {
@@ -199,7 +295,8 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
           if constexpr (HPP > 0) {
             if (guided) {
               // guidance (en_diffusion.py:899-920): predictor at (z_s, t), clip, project, apply
-              guidance_update<HPP>(P.pred, mg, net, sZ, sEps /* grad */, sNz /* scratch */, sMean, cf[3], cf[2],
+              const float t_step = cf[3], sigma_step = cf[2];
+              V::template guide<HPP>(P.pred, mg, net, sZ, sEps /* grad */, sNz /* scratch */, sMean, t_step, sigma_step,
                                    P.target_w, P.scale, split == 1 ? P.pred_out + (size_t)b * P.pred.K : nullptr,
                                    P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS, split,
                                    split == 2 ? P.dpred_in + (size_t)b * P.pred.K : nullptr);
@@ -281,12 +378,18 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(const KParams P) {
   if constexpr (HPP > 0 && HPE == 0) {  // unit-test modes live in the predictor-only kernels
     if (P.mode == MODE_PRED_FWD || P.mode == MODE_PRED_GRAD) {
       const float* dp = P.dpred_in ? P.dpred_in + (size_t)b * P.pred.K : nullptr;
-      predictor_entry<HPP>(P.pred, mg, net, sZ, sEps, sNz, sMean, P.t_in[b], dp, P.mode == MODE_PRED_GRAD,
+      V::template pred_entry<HPP>(P.pred, mg, net, sZ, sEps, sNz, sMean, P.t_in[b], dp, P.mode == MODE_PRED_GRAD,
                            P.pred_out + (size_t)b * P.pred.K, P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS);
       if (P.mode == MODE_PRED_GRAD)
         for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
     }
   }
 }
+
+typedef void (*sampler_fn)(const KParams);
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel = &sampler_kernel_v<V4, HPE, HPP>;
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel8 = &sampler_kernel_v<V8, HPE, HPP>;
 
 }  // namespace gaudi

@@ -1,0 +1,383 @@
+// w8_common.h -- building blocks of the EIGHT-wave sampler kernels (two wavefronts per SIMD, <= 256 registers each).
+//
+// Same contraction orientation as device_common.h (weights = MFMA A operand, graph nodes / edges on the 16 columns), but:
+//   * one molecule is served by 8 waves; an edge-level GEMM gives every wave ONE 16-edge tile (tile tau -> wave tau & 7,
+//     round tau >> 3), so each SIMD hosts two waves whose MFMAs, LDS round trips and epilogues cover each other;
+//   * the weight stream of an edge-level GEMM is fetched from L2 ONCE per workgroup: the T tiles of a K chunk are dealt to
+//     the 8 waves, staged through registers (issued a whole K chunk early, written after the barrier) into a two-slot LDS
+//     ring, and every wave reads its A fragments from LDS (lane-linear 1 KiB tiles: conflict-free ds_read_b128);
+//   * the edge -> node sum is a segmented scan inside the 16-lane DPP rows of the accumulator registers (run boundaries
+//     come from the host's edge list, sorted by receiving node): no LDS transposition scratch, no atomics, fixed order;
+//   * node-level GEMMs deal their output-feature tiles to 8 waves (weights straight from L2, each tile read by one wave).
+// Weight tiles are packed "lane-linear": float4 index L of a 16x16 tile holds W[row = L & 15][k = 4 * (L >> 4) .. +3].
+#pragma once
+#include "device_common.h"
+
+namespace gaudi {
+namespace w8 {
+
+constexpr int kWaves = 8;
+constexpr int kThreads = 512;
+
+// ---------------------------------------------------------------------------------------------
+// DPP row shifts (rows = 16 lanes = the 16 edge columns of a tile; lanes shifted in from outside the row read 0)
+// ---------------------------------------------------------------------------------------------
+template <int SH>
+__device__ __forceinline__ float row_shr(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SH, 0xF, 0xF, true));
+}
+
+// Run bookkeeping of one 16-edge tile, per lane (column c = lane & 15): the edge list is sorted by receiving node, so the
+// edges of a node form a run of consecutive columns.  m1..m8 = 1 where the column 1/2/4/8 to the left belongs to the same
+// run (Hillis-Steele segmented scan); after seg_scan the LAST column of every run holds the run's sum.
+struct RunMask {
+  float m1, m2, m4, m8;
+  __device__ __forceinline__ void set(int c, int run_start) {
+    m1 = c - 1 >= run_start ? 1.f : 0.f;
+    m2 = c - 2 >= run_start ? 1.f : 0.f;
+    m4 = c - 4 >= run_start ? 1.f : 0.f;
+    m8 = c - 8 >= run_start ? 1.f : 0.f;
+  }
+};
+__device__ __forceinline__ float seg_scan1(float x, const RunMask& m) {
+  x = fmaf(row_shr<1>(x), m.m1, x);
+  x = fmaf(row_shr<2>(x), m.m2, x);
+  x = fmaf(row_shr<4>(x), m.m4, x);
+  x = fmaf(row_shr<8>(x), m.m8, x);
+  return x;
+}
+__device__ __forceinline__ f4 seg_scan(f4 v, const RunMask& m) {
+  return (f4){seg_scan1(v[0], m), seg_scan1(v[1], m), seg_scan1(v[2], m), seg_scan1(v[3], m)};
+}
+
+// edge word of a slot: i | j << 8 | run_start << 16 (column inside the tile) | run_end << 20 | part << 21
+__device__ __forceinline__ int ew_i(uint32_t e) { return e & 255; }
+__device__ __forceinline__ int ew_j(uint32_t e) { return (e >> 8) & 255; }
+__device__ __forceinline__ int ew_run_start(uint32_t e) { return (e >> 16) & 15; }
+__device__ __forceinline__ bool ew_run_end(uint32_t e) { return (e >> 20) & 1; }
+__device__ __forceinline__ int ew_part(uint32_t e) { return (e >> 21) & 1; }
+
+// ---------------------------------------------------------------------------------------------
+// Weight ring of the edge-level GEMMs.  A matrix is T x T tiles, k-major ([k/16][o/16] like every packed matrix); group g
+// = the T tiles of K chunk g.  Invariant between trips: slot(par) holds the group consumed next (committed before the
+// barrier that opens the trip), `st` holds the group after it (loads in flight).
+// ---------------------------------------------------------------------------------------------
+template <int HP>
+struct Ring {
+  static constexpr int T = HP / 16;
+  static constexpr int UT = (T + kWaves - 1) / kWaves;
+  static constexpr int kSlotFloats = T * 256;
+  float* base;  // LDS [2][T * 256]
+  int par;
+  f4 st[UT];
+  __device__ __forceinline__ float* slot(int p) const { return base + p * kSlotFloats; }
+};
+
+template <int HP>
+__device__ __forceinline__ void ring_issue(Ring<HP>& r, const WBuf& wb, int group_off, int wave, int lane) {
+#pragma unroll
+  for (int u = 0; u < Ring<HP>::UT; ++u) {
+    const int t = wave + kWaves * u;
+    if (t < Ring<HP>::T) r.st[u] = ldw4(wb, group_off + t * 256, lane);
+  }
+}
+template <int HP>
+__device__ __forceinline__ void ring_commit(const Ring<HP>& r, float* slot, int wave, int lane) {
+#pragma unroll
+  for (int u = 0; u < Ring<HP>::UT; ++u) {
+    const int t = wave + kWaves * u;
+    if (t < Ring<HP>::T) *(f4*)(slot + t * 256 + lane * 4) = r.st[u];
+  }
+}
+// Open a chain of edge GEMMs with matrix W.  PRE: no wave still reads slot(par) (a barrier lies in between).
+template <int HP>
+__device__ __forceinline__ void ring_start(Ring<HP>& r, const WBuf& wb, int W, int wave, int lane) {
+  ring_issue(r, wb, W, wave, lane);
+  ring_commit(r, r.slot(r.par), wave, lane);
+  ring_issue(r, wb, W + Ring<HP>::kSlotFloats, wave, lane);
+}
+// Top of trip cc of a GEMM with matrix W (next matrix of the chain: nextW, -1 = none): the barrier that publishes group cc,
+// then group cc+1 goes to the slot everybody has just left and the loads of group cc+2 are issued.
+template <int HP>
+__device__ __forceinline__ void ring_trip(Ring<HP>& r, const WBuf& wb, int W, int nextW, int cc, int wave, int lane) {
+  constexpr int T = HP / 16;
+  __syncthreads();
+  if (cc + 1 < T || nextW >= 0) ring_commit(r, r.slot(r.par ^ 1), wave, lane);
+  const int g2 = cc + 2;
+  if (g2 < T) ring_issue(r, wb, W + g2 * Ring<HP>::kSlotFloats, wave, lane);
+  else if (nextW >= 0) ring_issue(r, wb, nextW + (g2 - T) * Ring<HP>::kSlotFloats, wave, lane);
+}
+// The T tiles of the current slot against one input chunk: pairs of output tiles, k-step outermost (a dependent accumulate
+// needs 40 cycles, issue is every 32).
+template <int HP>
+__device__ __forceinline__ void ring_mfma(f4 (&acc)[HP / 16], const float* slot_lane, const f4 bin) {
+  constexpr int T = HP / 16;
+  constexpr int NP = (T + 1) / 2;  // pairs of output tiles
+  // A fragments are read one pair ahead (explicit double buffer + fences: left alone, hipcc sinks every ds_read next to its
+  // MFMAs and exposes the LDS latency once per pair)
+  f4 a[2][2];
+  a[0][0] = *(const f4*)(slot_lane);
+  a[0][1] = T > 1 ? *(const f4*)(slot_lane + 256) : a[0][0];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int t0 = 2 * p, cur = p & 1;
+    if (p + 1 < NP) {
+      a[cur ^ 1][0] = *(const f4*)(slot_lane + (t0 + 2) * 256);
+      a[cur ^ 1][1] = t0 + 3 < T ? *(const f4*)(slot_lane + (t0 + 3) * 256) : a[cur ^ 1][0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[t0] = mfma1(a[cur][0][q], bin[q], acc[t0]);
+      if (t0 + 1 < T) acc[t0 + 1] = mfma1(a[cur][1][q], bin[q], acc[t0 + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// acc[t] (features 16t+4g+q of the lane's edge column) = b2 + W2 . silu(u),  u = P[i] + Q[j] + cr r + cd d0  (b1 inside P):
+// Linear(2H+2 -> H) of [h_i | h_j | r | d0] factorised per node (egnn_new.py:42-47,119-129; egnn_predictor/gcl.py:225-231).
+// pp / qq: the lane's P and Q rows (+ 4g).  `active` = this wave owns a tile in this round (idle waves still stage).
+template <int HP>
+__device__ __forceinline__ void edge_gemm_pq(f4 (&acc)[HP / 16], Ring<HP>& ring, const WBuf& wb, int W, int nextW,
+                                             const float* sB2, const float* sCr, const float* sCd, const float* pp,
+                                             const float* qq, float r, float d0, bool active, int wave, int lane) {
+  constexpr int T = HP / 16;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = *(const f4*)(sB2 + 16 * t + 4 * g);
+  f4 bin = silu4(edge_u(pp, qq, sCr, sCd, g, 0, r, d0));
+#pragma unroll 1
+  for (int cc = 0; cc < T; ++cc) {
+    ring_trip<HP>(ring, wb, W, nextW, cc, wave, lane);
+    if (active) {
+      const int ncc = cc + 1 < T ? cc + 1 : T - 1;  // next chunk's activations are generated under this chunk's MFMAs
+      const f4 nb = silu4(edge_u(pp, qq, sCr, sCd, g, ncc, r, d0));
+      ring_mfma<HP>(acc, ring.slot(ring.par) + lane * 4, bin);
+      bin = nb;
+    }
+    ring.par ^= 1;
+  }
+}
+
+// Chained edge GEMM, input already in registers in C/B layout: out = bias + rowinit + W . in
+template <int HP>
+__device__ __forceinline__ void edge_gemm_regs(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], Ring<HP>& ring, const WBuf& wb,
+                                               int W, int nextW, const float* sBias, const float* rowinit, bool active,
+                                               int wave, int lane) {
+  constexpr int T = HP / 16;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f4 b = sBias != nullptr ? *(const f4*)(sBias + 16 * t + 4 * g) : splat(0.f);
+    if (rowinit != nullptr) b = b + *(const f4*)(rowinit + 16 * t + 4 * g);
+    out[t] = b;
+  }
+#pragma unroll
+  for (int cc = 0; cc < T; ++cc) {
+    ring_trip<HP>(ring, wb, W, nextW, cc, wave, lane);
+    if (active) ring_mfma<HP>(out, ring.slot(ring.par) + lane * 4, in[cc]);
+    ring.par ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node-level GEMM on 8 waves:  Y[n][o] = epi( sum_k Wa[o][k] Xa[n][k] (+ sum_k Wb[o][k] Xb[n][k]) + bias[o] )
+// Output-feature tile t belongs to wave t & 7 (tiles t = wave, wave + 8): a wave owns NTW = 0, 1 or 2 tiles and the body
+// is instantiated per NTW (a wave-uniform branch picks it), so no wave issues MFMAs for tiles that do not exist -- with two
+// waves per SIMD a dummy tile would steal matrix time from the partner.
+// ---------------------------------------------------------------------------------------------
+template <int HP>
+struct NodePF {
+  f4 a0[2], a1[2];  // first two K chunks of the wave's (up to) two tiles
+};
+
+template <int HP, int NTW>
+__device__ __forceinline__ void node_prefetch_n(NodePF<HP>& pf, const WBuf& wb, int W, int wave, int lane) {
+  constexpr int T = HP / 16;
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) {
+    const int toff = (wave + kWaves * u) * 256;
+    pf.a0[u] = ldw4n(wb, W + toff, lane);
+    pf.a1[u] = ldw4n(wb, W + (T > 1 ? T : 0) * 256 + toff, lane);
+  }
+}
+template <int HP>
+__device__ __forceinline__ void node_prefetch(NodePF<HP>& pf, const WBuf& wb, int W, int wave, int lane) {
+  constexpr int T = HP / 16;
+  if (wave + kWaves < T) node_prefetch_n<HP, 2>(pf, wb, W, wave, lane);
+  else if (wave < T) node_prefetch_n<HP, 1>(pf, wb, W, wave, lane);
+}
+
+template <int HP, int EPI, bool PRE, int NT, int NTW>
+__device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
+                                               const float* sBias, float* sY, const float* sRes, const float* sMask, int N,
+                                               int wave, int lane, NodePF<HP>* pf, int nextW, float* gPre) {
+  constexpr int T = HP / 16;
+  constexpr int LD = HP + 4;
+  const int c = lane & 15, g = lane >> 4;
+  const int n_tiles = (N + 15) >> 4;
+  int toff[NTW];
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) toff[u] = (wave + kWaves * u) * 256;
+  const int KT = Wb >= 0 ? 2 * T : T;  // two sources run as ONE K loop so the load pipeline never restarts
+  auto chunk = [&](int cc) {  // float offset of K chunk cc (clamped past the end: surplus loads are unused)
+    const int k = cc < KT ? cc : KT - 1;
+    return k < T ? Wa + k * (T * 256) : Wb + (k - T) * (T * 256);
+  };
+  for (int nt0 = 0; nt0 < n_tiles; nt0 += NT) {
+    const float* xa[NT];
+    const float* xb[NT];
+    int node[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      node[j] = (nt0 + j) * 16 + c;
+      const int nclamp = node[j] < N ? node[j] : N - 1;
+      xa[j] = sXa + nclamp * LD + 4 * g;
+      xb[j] = Wb >= 0 ? sXb + nclamp * LD + 4 * g - 16 * T : xa[j];  // indexed by the global chunk number
+    }
+    auto xin = [&](int j, int cc) { return *(const f4*)((cc < T ? xa[j] : xb[j]) + 16 * cc); };
+    // two accumulators per output tile (even / odd K chunks): independent MFMA chains even when the wave owns one tile
+    f4 accE[NT][NTW], accO[NT][NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+      const f4 b = sBias != nullptr ? *(const f4*)(sBias + (toff[u] >> 4) + 4 * g) : splat(0.f);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        accE[j][u] = b;
+        accO[j][u] = splat(0.f);
+      }
+    }
+    f4 a0[NTW], a1[NTW], b0[NTW], b1[NTW];  // ping-pong sets of two K chunks each (roles swapped by unrolling)
+    if (PRE && nt0 == 0) {
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) { a0[u] = pf->a0[u]; a1[u] = pf->a1[u]; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
+        a0[u] = ldw4n(wb, chunk(0) + toff[u], lane);
+        a1[u] = ldw4n(wb, chunk(1) + toff[u], lane);
+      }
+    }
+    auto mm2 = [&](const f4 (&wE)[NTW], const f4 (&xE)[NT], const f4 (&wO)[NTW], const f4 (&xO)[NT]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int u = 0; u < NTW; ++u) {
+            accE[j][u] = mfma1(wE[u][q], xE[j][q], accE[j][u]);
+            accO[j][u] = mfma1(wO[u][q], xO[j][q], accO[j][u]);
+          }
+    };
+    auto mm1 = [&](const f4 (&w)[NTW], int cc) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const f4 x = xin(j, cc);
+#pragma unroll
+          for (int u = 0; u < NTW; ++u) accE[j][u] = mfma1(w[u][q], x[q], accE[j][u]);
+        }
+    };
+    const int main_end = KT / 4 * 4;
+#pragma unroll 1
+    for (int cc = 0; cc < main_end; cc += 4) {
+      f4 x0[NT], x1[NT], x2[NT], x3[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        x0[j] = xin(j, cc);
+        x1[j] = xin(j, cc + 1);
+        x2[j] = xin(j, cc + 2);
+        x3[j] = xin(j, cc + 3);
+      }
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
+        b0[u] = ldw4n(wb, chunk(cc + 2) + toff[u], lane);
+        b1[u] = ldw4n(wb, chunk(cc + 3) + toff[u], lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // LDS reads + set B loads | MFMAs on set A | set A loads | MFMAs on set B
+      mm2(a0, x0, a1, x1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
+        a0[u] = ldw4n(wb, chunk(cc + 4) + toff[u], lane);
+        a1[u] = ldw4n(wb, chunk(cc + 5) + toff[u], lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mm2(b0, x2, b1, x3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // tail: KT % 4 chunks (0..3), the first two already in a0 / a1
+    const int rem = KT - main_end;
+    if (rem >= 3) {
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) b0[u] = ldw4n(wb, chunk(main_end + 2) + toff[u], lane);
+    }
+    if (rem >= 1) mm1(a0, main_end);
+    if (rem >= 2) mm1(a1, main_end + 1);
+    // software pipelining ACROSS calls: the next node GEMM's first tiles travel while this one drains
+    if (nextW >= 0 && nt0 + NT >= n_tiles) node_prefetch_n<HP, NTW>(*pf, wb, nextW, wave, lane);
+    if (rem >= 3) mm1(b0, main_end + 2);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
+        const int t = wave + kWaves * u;
+        const int nd = node[j];
+        if (nd < N) {
+          f4 y = accE[j][u] + accO[j][u];
+          float* dst = sY + nd * LD + 16 * t + 4 * g;
+          if (gPre != nullptr) *(f4*)(gPre + nd * HP + 16 * t + 4 * g) = y;
+          if (EPI == EPI_SILU) y = silu4(y);
+          if (EPI == EPI_RESIDUAL_MASK) {
+            const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
+            y = (r + y) * sMask[nd];
+          }
+          if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
+            const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
+            y = (f4){y[0] * dsilu_f(r[0]), y[1] * dsilu_f(r[1]), y[2] * dsilu_f(r[2]), y[3] * dsilu_f(r[3])};
+          }
+          if (EPI == EPI_ACCUM) y = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g) + y;
+          *(f4*)dst = y;
+        }
+      }
+  }
+}
+
+template <int HP, int EPI, bool PRE = false>
+__device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
+                                          const float* sBias /* LDS [HP] or null */, float* sY, const float* sRes,
+                                          const float* sMask, int N, int wave, int lane, NodePF<HP>* pf = nullptr,
+                                          int nextW = -1, float* gPre = nullptr /* global [N][HP]: pre-epilogue value */) {
+  constexpr int T = HP / 16;
+  if (wave + kWaves < T) {
+    if (N <= 16)
+      node_gemm_body<HP, EPI, PRE, 1, 2>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
+    else
+      node_gemm_body<HP, EPI, PRE, 2, 2>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
+  } else if (wave < T) {
+    if (N <= 16)
+      node_gemm_body<HP, EPI, PRE, 1, 1>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
+    else
+      node_gemm_body<HP, EPI, PRE, 2, 1>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
+  }
+}
+
+// Per-molecule graph metadata prepared by the host (gaudi_hip.hip: build_meta8) and staged in LDS.
+// Slots = the molecule's live edges sorted by receiving node, padded to whole 16-slot tiles; tile tau is served by wave
+// tau & 7 in round tau >> 3.
+struct MolGraph {
+  int N, D, S;            // nodes (padded), 3+F, slot capacity of the batch (multiple of 16)
+  int NC;                 // node columns that matter: 1 + last node that is live or touches a live edge (<= N)
+  int ntiles, rounds;     // 16-slot tiles of THIS molecule, ceil(ntiles / 8)
+  const float* mask;      // LDS [N]
+  const uint32_t* edge;   // LDS [S]  edge words (ew_* above)
+  const float* em;        // LDS [S]  edge_mask value (0 for padding slots)
+  const uint32_t* seg;    // LDS [N]  start << 16 | len : slots whose RECEIVING node is n
+  const uint16_t* soff;   // LDS [N+1] CSR offsets into sidx: slots whose SENDING node is n ...
+  const uint16_t* sidx;   // LDS [S]   ... ascending (= ascending receiving node)
+};
+
+}  // namespace w8
+}  // namespace gaudi

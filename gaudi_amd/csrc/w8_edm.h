@@ -1,0 +1,296 @@
+// w8_edm.h -- EGNN_dynamics._forward (edm/egnn/models.py:83-152, edm/egnn/egnn_new.py) for one molecule held by one
+// 8-wave workgroup.  Input z and output eps_hat live in LDS.  Weight buffer layout = EdmLayout (edm_device.h), matrices
+// packed lane-linear (w8_common.h).
+#pragma once
+#include "edm_device.h"
+#include "w8_common.h"
+
+namespace gaudi {
+namespace w8 {
+
+// LDS working set of one network evaluation
+template <int HP>
+struct NetSmem {
+  float *h, *p, *q;     // [N][HP+4]
+  float *agg, *agg1;    // [N][HP+4] the two partial edge->node sums of a node (its run may straddle two tiles)
+  float* ring;          // [2][T*256] weight ring of the edge GEMMs
+  float *x, *x0;        // [N][4]
+  f4* geo;              // [S] (r, dhat)
+  float* d0;            // [S]
+  float* trans;         // [S][4]
+  float* vec;           // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
+  __host__ __device__ static int floats(int N, int S) {
+    return 5 * N * (HP + 4) + 2 * (HP / 16) * 256 + 8 * N + S * 9 + 8 * HP;
+  }
+  __device__ void carve(float* base, int N, int S) {
+    constexpr int LD = HP + 4;
+    ring = base; base += 2 * (HP / 16) * 256;   // first: 1 KiB tiles stay 16-byte aligned whatever N is
+    h = base; base += N * LD;
+    p = base; base += N * LD;
+    q = base; base += N * LD;
+    agg = base; base += N * LD;
+    agg1 = base; base += N * LD;
+    x = base; base += 4 * N;
+    x0 = base; base += 4 * N;
+    geo = (f4*)base; base += S * 4;
+    d0 = base; base += S;
+    trans = base; base += S * 4;
+    vec = base;
+  }
+};
+
+// r = |x_i - x_j|^2, dhat = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn_new.py:394-400)
+template <class SM>
+__device__ __forceinline__ void compute_geo(const SM& sm, const MolGraph& mg, float norm_constant, int tid, bool write_d0) {
+  for (int slot = tid; slot < mg.ntiles * 16; slot += kThreads) {
+    const uint32_t e = mg.edge[slot];
+    const int i = ew_i(e), j = ew_j(e);
+    const float dx = sm.x[4 * i + 0] - sm.x[4 * j + 0];
+    const float dy = sm.x[4 * i + 1] - sm.x[4 * j + 1];
+    const float dz = sm.x[4 * i + 2] - sm.x[4 * j + 2];
+    const float r = dx * dx + dy * dy + dz * dz;
+    if (write_d0) {
+      sm.d0[slot] = r;
+    } else {
+      const float inv = 1.0f / (sqrtf(r + 1e-8f) + norm_constant);
+      sm.geo[slot] = (f4){r, dx * inv, dy * inv, dz * inv};
+    }
+  }
+}
+
+// x <- (x + sum_j trans_ij / normf) * mask     (egnn_new.py:132-155), fixed ascending-j order
+template <class SM>
+__device__ __forceinline__ void coord_update(const SM& sm, const MolGraph& mg, float normf, int tid) {
+  if (tid < mg.N * 3) {
+    const int n = tid / 3, d = tid % 3;
+    const uint32_t sg = mg.seg[n];
+    const int st = sg >> 16, len = sg & 0xffff;
+    float s = 0.f;
+    for (int k = 0; k < len; ++k) s += sm.trans[(st + k) * 4 + d];
+    sm.x[4 * n + d] = (sm.x[4 * n + d] + s / normf) * mg.mask[n];
+  }
+}
+
+// The lane's view of its 16-edge tile in one round
+struct TileCols {
+  bool active;      // the wave owns a tile in this round
+  int slot;         // the lane's slot (tile * 16 + column)
+  int i, j;         // receiving / sending node of the lane's column
+  bool run_end;     // last column of its run inside the tile
+  int part;         // which partial buffer the run's sum goes to
+  float mk;         // edge_mask value
+  RunMask rm;
+};
+__device__ __forceinline__ TileCols load_tile(const MolGraph& mg, int round, int wave, int c) {
+  TileCols tc;
+  const int tile = round * kWaves + wave;
+  tc.active = tile < mg.ntiles;
+  tc.slot = (tc.active ? tile : 0) * 16 + c;
+  const uint32_t e = mg.edge[tc.slot];
+  tc.i = ew_i(e);
+  tc.j = ew_j(e);
+  tc.run_end = ew_run_end(e);
+  tc.part = ew_part(e);
+  tc.mk = mg.em[tc.slot];
+  tc.rm.set(c, ew_run_start(e));
+  return tc;
+}
+
+// edge -> node sums of one tile: segmented scan down the 16 columns, the last column of each run stores the run's sum into
+// the node's row of partial buffer `part` (a node's run touches at most two tiles: host invariant)
+template <int HP>
+__device__ __forceinline__ void scatter_runs(f4 (&e)[HP / 16], const TileCols& tc, float* agg0, float* agg1, int g) {
+  constexpr int T = HP / 16, LD = HP + 4;
+  float* dst = (tc.part ? agg1 : agg0) + tc.i * LD + 4 * g;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const f4 s = seg_scan(e[t], tc.rm);
+    if (tc.run_end) *(f4*)(dst + 16 * t) = s;
+  }
+}
+
+// eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
+template <int HP>
+__device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP>& sm, const float* sZ,
+                                            float* sEps, float* sMean /* [4] */, float t_val, int tid) {
+  constexpr int LD = HP + 4;
+  constexpr int T = HP / 16;
+  constexpr int PK = HP * HP;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1;
+  EdmLayout lay{HP, F1, W.L, W.S};
+  const float* __restrict__ w = W.w;
+  const WBuf wb = make_wbuf(W.w, W.w_bytes);
+
+  // ---- input split + masking (models.py:88-105): x = z[:, :3]*m ; h = [z[:, 3:]*m , t]
+  for (int idx = tid; idx < N * 3; idx += kThreads) {
+    const int n = idx / 3, d = idx % 3;
+    const float v = sZ[n * D + d] * mg.mask[n];
+    sm.x[4 * n + d] = v;
+    sm.x0[4 * n + d] = v;
+  }
+  // ---- embedding Linear(F+1 -> H)  (egnn_new.py:304)
+  {
+    const float* ew = w + lay.emb_w();
+    const float* eb = w + lay.emb_b();
+    for (int idx = tid; idx < N * HP; idx += kThreads) {
+      const int n = idx / HP, f = idx % HP;
+      float acc = 0.f;
+      const float m = mg.mask[n];
+      for (int k = 0; k < F; ++k) acc += ew[f * F1 + k] * (sZ[n * D + 3 + k] * m);
+      acc += ew[f * F1 + F] * t_val;
+      sm.h[n * LD + f] = acc + eb[f];
+    }
+  }
+  __syncthreads();
+  compute_geo(sm, mg, 0.f, tid, true);  // d0 of the input coordinates (egnn_new.py:301)
+  Ring<HP> ring;
+  ring.base = sm.ring;
+  ring.par = 0;
+  ring_start<HP>(ring, wb, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
+  NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it
+  node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);
+  constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
+  VecPF<NV> vpf;  // the next sub-layer's vectors (GCL: 7 HP + 16 floats, EquivariantUpdate: 5 HP), loaded a phase ahead
+  vec_prefetch<NV, kThreads>(vpf, wb, lay.gcl(0, 0) + 6 * PK, 7 * HP + 16, tid);
+
+  for (int l = 0; l < W.L; ++l) {
+    compute_geo(sm, mg, W.norm_constant, tid, false);  // egnn_new.py:216
+    for (int s = 0; s < W.S; ++s) {
+      // ------------------------------------------------------------------ GCL (egnn_new.py:42-89)
+      const int G = lay.gcl(l, s);  // float offsets into the weight buffer
+      const int Wnext_edge = s + 1 < W.S ? lay.gcl(l, s + 1) + 2 * PK : lay.equ(l) + 2 * PK;
+      vec_commit<NV, kThreads>(vpf, sm.vec, 7 * HP + 16, tid);
+      for (int idx = tid; idx < N * LD; idx += kThreads) {
+        sm.agg[idx] = 0.f;
+        sm.agg1[idx] = 0.f;
+      }
+      __syncthreads();
+      const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
+                  *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
+      const float ba = sm.vec[7 * HP];
+      node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, G + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf,
+                                    G + 3 * PK);  // node MLP weights travel across the edge phase
+      __syncthreads();
+      for (int rd = 0; rd < mg.rounds; ++rd) {
+        const TileCols tc = load_tile(mg, rd, wave, c);
+        const f4 gg = sm.geo[tc.slot];
+        f4 acc[T];
+        edge_gemm_pq<HP>(acc, ring, wb, G + 2 * PK, rd + 1 < mg.rounds ? G + 2 * PK : Wnext_edge, b2, cr, cd,
+                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane);
+        if (tc.active) {
+          float sdot = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const f4 m = silu4(acc[t]);
+            acc[t] = m;
+            const f4 wv = *(const f4*)(wa + 16 * t + 4 * g);
+            sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
+          }
+          float a = 1.f;
+          if (W.attention) a = sigmoid_f(reduce_groups(sdot) + ba);
+          const float sc = a * tc.mk;
+#pragma unroll
+          for (int t = 0; t < T; ++t) acc[t] = acc[t] * sc;
+          scatter_runs<HP>(acc, tc, sm.agg, sm.agg1, g);
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = (partial 0 + partial 1) / normalization_factor
+        const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
+        *(f4*)(sm.agg + n * LD + f) = (*(const f4*)(sm.agg + n * LD + f) + *(const f4*)(sm.agg1 + n * LD + f)) / W.normf;
+      }
+      __syncthreads();
+      node_gemm<HP, EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, mg.NC, wave, lane,
+                                    &pf, G + 5 * PK);
+      __syncthreads();
+      vec_prefetch<NV, kThreads>(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK,
+                                 s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
+      node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave, lane,
+                                             &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
+      __syncthreads();
+    }
+    // -------------------------------------------------------- EquivariantUpdate (egnn_new.py:119-155)
+    {
+      const int E = lay.equ(l);
+      const int Wnext_edge = l + 1 < W.L ? lay.gcl(l + 1, 0) + 2 * PK : -1;
+      vec_commit<NV, kThreads>(vpf, sm.vec, 5 * HP, tid);
+      __syncthreads();
+      const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
+      node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, E + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf,
+                                    l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
+      __syncthreads();
+      for (int rd = 0; rd < mg.rounds; ++rd) {
+        const TileCols tc = load_tile(mg, rd, wave, c);
+        const f4 gg = sm.geo[tc.slot];
+        f4 acc[T];
+        edge_gemm_pq<HP>(acc, ring, wb, E + 2 * PK, rd + 1 < mg.rounds ? E + 2 * PK : Wnext_edge, b2, cr, cd,
+                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane);
+        if (tc.active) {
+          float sdot = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const f4 m = silu4(acc[t]);
+            const f4 wv = *(const f4*)(w3 + 16 * t + 4 * g);
+            sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
+          }
+          const float phi = reduce_groups(sdot);
+          const float tau = (W.use_tanh ? tanhf(phi) * W.coords_range : phi) * tc.mk;
+          if (g == 0) *(f4*)(sm.trans + 4 * tc.slot) = (f4){gg[1] * tau, gg[2] * tau, gg[3] * tau, 0.f};
+        }
+      }
+      if (l + 1 < W.L) vec_prefetch<NV, kThreads>(vpf, wb, lay.gcl(l + 1, 0) + 6 * PK, 7 * HP + 16, tid);
+      __syncthreads();
+      coord_update(sm, mg, W.normf, tid);
+      __syncthreads();
+    }
+  }
+
+  // ---- head: embedding_out * mask (egnn_new.py:316-318); vel = (x - x_in) * mask, masked mean removal
+  //      (models.py:116-152); the time column of h is dropped.
+  {
+    const float* ow = w + lay.out_w();
+    const float* ob = w + lay.out_b();
+    int bad = 0;
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
+      const float v = (sm.x[4 * n + d] - sm.x0[4 * n + d]) * mg.mask[n];
+      bad += v != v;
+      sEps[n * D + d] = v;
+    }
+    const float* hh = sm.h;
+    const float* msk = mg.mask;
+    small_dots<kThreads>(
+        N * F, HP, tid, [=](int p, int k) { return ow[(p % F) * HP + k]; },
+        [=](int p, int k) { return hh[(p / F) * LD + k]; },
+        [=](int p, float acc) { sEps[(p / F) * D + 3 + p % F] = (acc + ob[p % F]) * msk[p / F]; });
+    // `if torch.any(torch.isnan(vel)): vel = torch.nan_to_num(vel, 0.0)` (models.py:138-141), triggered per molecule
+    if (__syncthreads_or(bad)) {
+      for (int idx = tid; idx < N * 3; idx += kThreads) {
+        const int n = idx / 3, d = idx % 3;
+        const float v = sEps[n * D + d];
+        sEps[n * D + d] = v != v ? 0.f : fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+      }
+      __syncthreads();
+    }
+    if (tid < 3) {
+      float s = 0.f, cnt = 0.f;
+      for (int n = 0; n < N; ++n) {
+        s += sEps[n * D + tid];
+        cnt += mg.mask[n];
+      }
+      sMean[tid] = s / fmaxf(cnt, 1.0f);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
+      sEps[n * D + d] = sEps[n * D + d] - sMean[d] * mg.mask[n];
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace w8
+}  // namespace gaudi

@@ -68,9 +68,10 @@ def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
     variant "w4" (4 waves, 32-edge passes):  edge_units = list of 32-edge passes per wave [4]
     variant "w8" (8 waves, 16-edge tiles):   edge_units = number of 16-edge tiles of the molecule
     ncols = node columns the node-level GEMMs produce (16-column tiles, pairs of tiles beyond 16)."""
+    ncols = int(ncols)
     nt = 1 if ncols <= 16 else 2 * (((ncols + 15) // 16 + 1) // 2)
     if variant == "w4":
-        waves, pairs = 4, sum(edge_units)
+        waves, pairs = 4, int(sum(int(v) for v in edge_units))
         tiles16 = 2 * pairs
     else:
         waves, tiles16 = 8, int(edge_units)

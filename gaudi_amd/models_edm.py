@@ -140,11 +140,13 @@ class GaudiModel:
         self.n_dims = 3
         self.norm_values = list(checkpoint.normalize_factors(self.args))
         self.norm_biases = (None, 0.0, 0.0)
-        # Noise streams are keyed by (seed, global sample index, draw, element).  seed = None: drawn from torch's global
-        # generator on first use, so torch.manual_seed controls the chain as it does the reference's torch.randn; every
-        # sampling call then consumes B fresh sample indices (sample_offset advances), as successive randn calls would.
+        # Noise streams are keyed by (seed, global sample index, draw, element).  seed = None: torch's current seed
+        # (torch.initial_seed(), i.e. whatever torch.manual_seed last set -- read, never consumed, so the ring-count draws of
+        # DistributionRings see the same torch stream as in the reference); a new torch.manual_seed restarts the stream.
+        # Every sampling call consumes B fresh sample indices (sample_offset advances), as successive randn calls would.
         self.seed = None
         self.sample_offset = 0
+        self._torch_seed = None
         self.injected_noise = None  # [T+2,B,N,3+F] raw draws (parity tests); None -> on-device Philox
         self.last_diag = None
 
@@ -167,12 +169,16 @@ class GaudiModel:
 
     def next_stream(self, n_samples: int):
         """-> (seed, sample_offset) for a call that draws noise for ``n_samples`` molecules; advances the offset."""
-        if self.seed is None:
+        seed = self.seed
+        if seed is None:
             import torch
-            self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            ts = int(torch.initial_seed())
+            if ts != self._torch_seed:  # first use, or torch.manual_seed was called since: restart the stream
+                self._torch_seed, self.sample_offset = ts, 0
+            seed = ts & (2 ** 62 - 1)
         off = self.sample_offset
         self.sample_offset += int(n_samples)
-        return int(self.seed), off
+        return int(seed), off
 
     def _run(self, n_samples, node_mask, edge_mask, std, target, scale, fix_noise):
         nm = _to_numpy(node_mask).astype(np.float32)

@@ -23,7 +23,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     T, seed = 40, 77
     eargs = synth.edm_args(nf=64, n_layers=3, diffusion_steps=T)
-    pargs = synth.pred_args(nf=68, n_layers=3)
+    pargs = synth.pred_args(nf=60, n_layers=3)  # 60 -> padded to 64: the fused (64, 64) instantiation
     eng = Engine(0)
     eng.load_edm(eargs, synth.synth_edm_state_dict(eargs, 1, seed=11))
     eng.load_predictor(pargs, synth.synth_predictor_state_dict(pargs, 1, 5, seed=12))
@@ -49,4 +49,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        import traceback
+        with open(os.path.join(sys.argv[1], f"err{os.environ.get('RANK', '0')}.txt"), "w") as f:
+            f.write(traceback.format_exc())
+        raise

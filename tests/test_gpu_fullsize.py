@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from gaudi_amd import synth
-from tests.helpers import rel_err
+from tests.helpers import max_norm_err, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -130,7 +130,7 @@ def test_c4_shape_hetero_mixed_guided(O):
     noise = philox_normal(3, 0, 4, 20 * 15, 0, 32).reshape(32, 4, 20, 15)
     em4 = em.reshape(64, 20, 20)[sel]
     xo, ho, _ = O.sample(esd, eargs, nm[sel], em4, noise, pred_sd=psd, pcfg=pargs, target_w=w, scale=0.6)
-    assert rel_err(x[sel], xo) < 1.3e-2
+    assert max_norm_err(x[sel], xo) < 1.3e-2  # the spread is a max-norm figure
     xu, hu, _ = eng.sample(nm[sel], em4, seed=3)
     xou, hou, _ = O.sample(esd, eargs, nm[sel], em4, noise)
     assert rel_err(xu, xou) < TOL and np.array_equal(hu, hou)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from gaudi_amd import synth
-from tests.helpers import TINY, TINY_P, cfg_of, edm_from_cfg, pred_from_cfg, rel_err
+from tests.helpers import TINY, TINY_P, cfg_of, edm_from_cfg, max_norm_err, pred_from_cfg, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -107,7 +107,8 @@ def test_tiny_chains_unguided(golden, name, tol):
                               diffusion_steps=cfg["T"])
     eng = make_engine(eargs, esd)
     x, h, diag = eng.sample(g[name + "_node_mask"], g[name + "_edge_mask"], noise=g[name + "_noise"], std=0.7)
-    assert rel_err(x, g[name + "_x_unguided"]) < tol
+    # documented-spread tolerances (ill-conditioned chains) are max-norm figures; the 1e-4 bar is also element-wise
+    assert (rel_err if tol <= 1e-4 else max_norm_err)(x, g[name + "_x_unguided"]) < tol
     assert np.array_equal(h, g[name + "_h_unguided"])
     eng.close()
 
@@ -177,7 +178,7 @@ def test_tiny_chains_guided(golden, name, tol):
     w[1] = -1
     x, h, diag = eng.sample(g[name + "_node_mask"], g[name + "_edge_mask"], noise=g[name + "_noise"], std=1.0,
                             target_w=w, scale=0.6)
-    assert rel_err(x, g[name + "_x_guided"]) < tol
+    assert (rel_err if tol <= 1e-4 else max_norm_err)(x, g[name + "_x_guided"]) < tol
     assert np.array_equal(h, g[name + "_h_guided"])
     eng.close()
 
@@ -438,6 +439,8 @@ def test_main_from_checkpoint_directories(tmp_path, dp):
     synth.write_checkpoint(str(tmp_path / "pred"), pargs, psd)
     a = checkpoint.get_edm_args(str(tmp_path / "edm"))
     pa = checkpoint.get_cond_predictor_args(str(tmp_path / "pred"))
+    import torch
+    torch.manual_seed(0)  # the model's noise seed follows torch's (as the reference's torch.randn does)
     out = gg.main(a, pa, target="max_gap", batch_size=4, scale=0.6, n_nodes=6)
     x = out["x"].numpy()
     assert x.shape == (4, 6, 3) and np.isfinite(x).all()

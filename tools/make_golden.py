@@ -55,11 +55,13 @@ class FakeLoader:
 class InjectNoise:
     """Replace torch.randn by a queue of pre-drawn tensors (call order: x-noise then h-noise)."""
 
-    def __init__(self, eps_list):
+    def __init__(self, eps_list, dtype=None):
         # eps_list: list of [B,N,3+F] arrays, one per sample_combined_position_feature_noise call
         self.q = []
         for e in eps_list:
             e = torch.from_numpy(np.ascontiguousarray(e))
+            if dtype is not None:
+                e = e.to(dtype)
             self.q.append(e[:, :, :3].contiguous())
             self.q.append(e[:, :, 3:].contiguous())
         self.orig = None
@@ -693,6 +695,18 @@ def g14_long_chains():
     model.sample_p_zs_given_zt_guidance = orig
     assert np.array_equal(nm2.numpy(), nm.numpy()) and sorted(rec) == sorted(pts)
     out["guided_x"], out["guided_h"] = x.numpy(), h.numpy().astype(np.float32)
+    # the reference's OWN rounding sensitivity on exactly these chains: the same model and noise in float64
+    model.double()
+    pred.double()
+    with InjectNoise(list(noise), torch.float64):
+        x64, _, _, _ = ref_sampling.sample_pos_edm(a, model, torch.tensor(nodes), std=1.0)
+    with InjectNoise(list(noise), torch.float64):
+        xg64, _, _, _ = ref_sampling.sample_guidance(a, model, tf_gap, torch.tensor(nodes), scale=0.6, std=1.0)
+    out["unguided_x_fp64"], out["guided_x_fp64"] = x64.numpy(), xg64.numpy()
+    mx = lambda p, q: float(np.abs(p.astype(np.float64) - q.astype(np.float64)).max() / np.abs(q).max())
+    out["spread_unguided"] = np.float64(mx(out["unguided_x"], out["unguided_x_fp64"]))
+    out["spread_guided"] = np.float64(mx(out["guided_x"], out["guided_x_fp64"]))
+    print("g14 reference fp32-vs-fp64 spread: unguided %.2e guided %.2e" % (out["spread_unguided"], out["spread_guided"]))
     out["traj_s"] = np.array(pts, np.int32)
     out["traj_zt"] = np.stack([rec[s][0] for s in pts])
     out["traj_zs"] = np.stack([rec[s][1] for s in pts])
