@@ -467,7 +467,7 @@ static kernel_fn pick_kernel(int hpe, int hpp) {
 
 // the 8-wave instantiations (kern8_*.hip)
 #ifdef GAUDI_STAMP_STUBS
-#define GAUDI_KERNEL8_TUS(X)
+#define GAUDI_KERNEL8_TUS(X) X(edm_192)
 #else
 #define GAUDI_KERNEL8_TUS(X) X(edm_small) X(edm_192) X(edm_208) X(edm_256)
 #endif
@@ -529,7 +529,7 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
   HIPCHECK(h, h->d_stamps.reserve(sizeof(unsigned long long) * 32));
   HIPCHECK(h, hipMemsetAsync(h->d_stamps.p, 0, sizeof(unsigned long long) * 32, h->stream));
   PS.stamps = h->d_stamps.as<unsigned long long>();
-  hipLaunchKernelGGL(fn, dim3(P.B), dim3(kThreads), lds, h->stream, PS);
+  hipLaunchKernelGGL(fn, dim3(P.B), dim3(v8 ? w8::kThreads : kThreads), lds, h->stream, PS);
   {
     unsigned long long tmp[32];
     HIPCHECK(h, hipMemcpyAsync(tmp, h->d_stamps.p, sizeof(tmp), hipMemcpyDeviceToHost, h->stream));

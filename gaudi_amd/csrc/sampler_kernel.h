@@ -151,7 +151,7 @@ struct V8 {
                                              float* sMean, float t_val, int tid STAMP_DECL) {
     w8::NetSmem<HP> sm;
     sm.carve(net, mg.N, mg.S);
-    w8::edm_forward<HP>(W, mg, sm, sZ, sEps, sMean, t_val, tid);
+    w8::edm_forward<HP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
   }
   template <int HP>
   __device__ __forceinline__ static void guide(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad, float* sTmp,

@@ -59,8 +59,16 @@ __device__ __forceinline__ int ew_part(uint32_t e) { return (e >> 21) & 1; }
 
 // ---------------------------------------------------------------------------------------------
 // Weight ring of the edge-level GEMMs.  A matrix is T x T tiles, k-major ([k/16][o/16] like every packed matrix); group g
-// = the T tiles of K chunk g.  Invariant between trips: slot(par) holds the group consumed next (committed before the
-// barrier that opens the trip), `st` holds the group after it (loads in flight).
+// = the T tiles of K chunk g, dealt to the 8 waves (tile t -> wave t & 7).  Two LDS slots + one group in registers.
+// Invariant at the barrier that opens a trip: slot(par) holds the group the trip consumes, nobody reads slot(par ^ 1) any
+// more, and `st` holds the following group (loads issued one trip ago).  In the MIDDLE of its MFMA block every wave stores
+// `st` to slot(par ^ 1) and re-issues the loads of the group after that into the same registers.
+//   * ONE unconditional program point defines and one uses the in-flight registers per trip: with the loads defined on
+//     two control paths hipcc merges them through register copies, i.e. a vmcnt(0) wait per trip; no branches around the
+//     loads either (out-of-range lane offsets instead: such a load returns 0 and fetches nothing);
+//   * mid-block, because that is where a wave's stalls (the CU's vector-memory pipe accepts ~31 B/clk, all eight waves
+//     issue their 1 KiB loads together) are covered by its SIMD partner's MFMAs, and every wave still ENDS its trip on
+//     MFMAs, so nobody holds the next barrier back.
 // ---------------------------------------------------------------------------------------------
 template <int HP>
 struct Ring {
@@ -73,12 +81,15 @@ struct Ring {
   __device__ __forceinline__ float* slot(int p) const { return base + p * kSlotFloats; }
 };
 
+constexpr int kOOBLane = 0x0FFFFFFF;  // lane offset beyond any descriptor's range
+
 template <int HP>
-__device__ __forceinline__ void ring_issue(Ring<HP>& r, const WBuf& wb, int group_off, int wave, int lane) {
+__device__ __forceinline__ void ring_issue(Ring<HP>& r, const WBuf& wb, int group_off, bool have, int wave, int lane) {
+  group_off = __builtin_amdgcn_readfirstlane(group_off);
 #pragma unroll
   for (int u = 0; u < Ring<HP>::UT; ++u) {
     const int t = wave + kWaves * u;
-    if (t < Ring<HP>::T) r.st[u] = ldw4(wb, group_off + t * 256, lane);
+    r.st[u] = ldw4(wb, group_off + (t < Ring<HP>::T ? t : 0) * 256, (have && t < Ring<HP>::T) ? lane : kOOBLane);
   }
 }
 template <int HP>
@@ -92,44 +103,49 @@ __device__ __forceinline__ void ring_commit(const Ring<HP>& r, float* slot, int 
 // Open a chain of edge GEMMs with matrix W.  PRE: no wave still reads slot(par) (a barrier lies in between).
 template <int HP>
 __device__ __forceinline__ void ring_start(Ring<HP>& r, const WBuf& wb, int W, int wave, int lane) {
-  ring_issue(r, wb, W, wave, lane);
+  ring_issue(r, wb, W, true, wave, lane);
   ring_commit(r, r.slot(r.par), wave, lane);
-  ring_issue(r, wb, W + Ring<HP>::kSlotFloats, wave, lane);
+  ring_issue(r, wb, W + Ring<HP>::kSlotFloats, true, wave, lane);
 }
-// Top of trip cc of a GEMM with matrix W (next matrix of the chain: nextW, -1 = none): the barrier that publishes group cc,
-// then group cc+1 goes to the slot everybody has just left and the loads of group cc+2 are issued.
+// Staging step of trip cc of a GEMM with matrix W (next matrix of the chain: nextW, -1 = none)
 template <int HP>
-__device__ __forceinline__ void ring_trip(Ring<HP>& r, const WBuf& wb, int W, int nextW, int cc, int wave, int lane) {
+__device__ __forceinline__ void ring_stage(Ring<HP>& r, const WBuf& wb, int W, int nextW, int cc, int wave, int lane) {
   constexpr int T = HP / 16;
-  __syncthreads();
-  if (cc + 1 < T || nextW >= 0) ring_commit(r, r.slot(r.par ^ 1), wave, lane);
+  ring_commit(r, r.slot(r.par ^ 1), wave, lane);  // at the end of a chain this parks don't-care data in the free slot
   const int g2 = cc + 2;
-  if (g2 < T) ring_issue(r, wb, W + g2 * Ring<HP>::kSlotFloats, wave, lane);
-  else if (nextW >= 0) ring_issue(r, wb, nextW + (g2 - T) * Ring<HP>::kSlotFloats, wave, lane);
+  const int off = g2 < T ? W + g2 * Ring<HP>::kSlotFloats : nextW + (g2 - T) * Ring<HP>::kSlotFloats;
+  ring_issue(r, wb, off, g2 < T || nextW >= 0, wave, lane);
 }
+
 // The T tiles of the current slot against one input chunk: pairs of output tiles, k-step outermost (a dependent accumulate
-// needs 40 cycles, issue is every 32).
-template <int HP>
-__device__ __forceinline__ void ring_mfma(f4 (&acc)[HP / 16], const float* slot_lane, const f4 bin) {
+// needs 40 cycles, issue is every 32).  A fragments are read one pair ahead (explicit double buffer + fences: left alone,
+// hipcc sinks every ds_read next to its MFMAs and exposes the LDS latency once per pair).  `mid` runs between the two
+// halves of the block for every wave; a wave without a tile in this round (`active` false) skips only the MFMAs.
+template <int HP, class MID>
+__device__ __forceinline__ void ring_mfma(f4 (&acc)[HP / 16], const float* slot_lane, const f4 bin, bool active, MID mid) {
   constexpr int T = HP / 16;
   constexpr int NP = (T + 1) / 2;  // pairs of output tiles
-  // A fragments are read one pair ahead (explicit double buffer + fences: left alone, hipcc sinks every ds_read next to its
-  // MFMAs and exposes the LDS latency once per pair)
   f4 a[2][2];
   a[0][0] = *(const f4*)(slot_lane);
   a[0][1] = T > 1 ? *(const f4*)(slot_lane + 256) : a[0][0];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int t0 = 2 * p, cur = p & 1;
+    if (p == NP / 2) {
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (p + 1 < NP) {
       a[cur ^ 1][0] = *(const f4*)(slot_lane + (t0 + 2) * 256);
       a[cur ^ 1][1] = t0 + 3 < T ? *(const f4*)(slot_lane + (t0 + 3) * 256) : a[cur ^ 1][0];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc[t0] = mfma1(a[cur][0][q], bin[q], acc[t0]);
-      if (t0 + 1 < T) acc[t0 + 1] = mfma1(a[cur][1][q], bin[q], acc[t0 + 1]);
+      for (int q = 0; q < 4; ++q) {
+        acc[t0] = mfma1(a[cur][0][q], bin[q], acc[t0]);
+        if (t0 + 1 < T) acc[t0 + 1] = mfma1(a[cur][1][q], bin[q], acc[t0 + 1]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -137,25 +153,31 @@ __device__ __forceinline__ void ring_mfma(f4 (&acc)[HP / 16], const float* slot_
 
 // acc[t] (features 16t+4g+q of the lane's edge column) = b2 + W2 . silu(u),  u = P[i] + Q[j] + cr r + cd d0  (b1 inside P):
 // Linear(2H+2 -> H) of [h_i | h_j | r | d0] factorised per node (egnn_new.py:42-47,119-129; egnn_predictor/gcl.py:225-231).
-// pp / qq: the lane's P and Q rows (+ 4g).  `active` = this wave owns a tile in this round (idle waves still stage).
+// pp / qq: the lane's P and Q rows (+ 4g).  One trip = barrier | MFMAs on group cc with the ring staging in the middle.
+// The two waves of a SIMD generate their input chunk at different points (waves 4-7 right after the barrier, waves 0-3 in the
+// middle of the block, for the NEXT trip): measured 3-4 % better than any common placement (tools/edge_gemm_microbench.hip).
+// What the partner wave hides is LATENCY (LDS, VMEM issue, barrier skew); vector-ALU work is NOT hidden behind fp32 MFMAs --
+// v_mfma_f32_16x16x4_f32 runs at the vector fp32 rate and SQ_VALU_MFMA_COEXEC_CYCLES stays 0 -- so a trip costs its MFMA
+// time plus its VALU time (3832 cycles per trip of 2 x 48 MFMAs against 3072; 3576 without the input generation).
 template <int HP>
 __device__ __forceinline__ void edge_gemm_pq(f4 (&acc)[HP / 16], Ring<HP>& ring, const WBuf& wb, int W, int nextW,
                                              const float* sB2, const float* sCr, const float* sCd, const float* pp,
-                                             const float* qq, float r, float d0, bool active, int wave, int lane) {
+                                             const float* qq, float r, float d0, bool active, int wave, int lane STAMP_DECL) {
   constexpr int T = HP / 16;
   const int g = lane >> 4;
+  const bool late = wave >= kWaves / 2;
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = *(const f4*)(sB2 + 16 * t + 4 * g);
-  f4 bin = silu4(edge_u(pp, qq, sCr, sCd, g, 0, r, d0));
+  f4 bin = silu4(edge_u(pp, qq, sCr, sCd, g, 0, r, d0)), nb = bin;
 #pragma unroll 1
   for (int cc = 0; cc < T; ++cc) {
-    ring_trip<HP>(ring, wb, W, nextW, cc, wave, lane);
-    if (active) {
-      const int ncc = cc + 1 < T ? cc + 1 : T - 1;  // next chunk's activations are generated under this chunk's MFMAs
-      const f4 nb = silu4(edge_u(pp, qq, sCr, sCd, g, ncc, r, d0));
-      ring_mfma<HP>(acc, ring.slot(ring.par) + lane * 4, bin);
-      bin = nb;
-    }
+    __syncthreads();
+    if (late && cc > 0) bin = silu4(edge_u(pp, qq, sCr, sCd, g, cc, r, d0));
+    ring_mfma<HP>(acc, ring.slot(ring.par) + lane * 4, bin, active, [&] {
+      ring_stage<HP>(ring, wb, W, nextW, cc, wave, lane);
+      if (!late) nb = silu4(edge_u(pp, qq, sCr, sCd, g, cc + 1 < T ? cc + 1 : T - 1, r, d0));
+    });
+    if (!late) bin = nb;
     ring.par ^= 1;
   }
 }
@@ -175,8 +197,8 @@ __device__ __forceinline__ void edge_gemm_regs(f4 (&out)[HP / 16], const f4 (&in
   }
 #pragma unroll
   for (int cc = 0; cc < T; ++cc) {
-    ring_trip<HP>(ring, wb, W, nextW, cc, wave, lane);
-    if (active) ring_mfma<HP>(out, ring.slot(ring.par) + lane * 4, in[cc]);
+    __syncthreads();
+    ring_mfma<HP>(out, ring.slot(ring.par) + lane * 4, in[cc], active, [&] { ring_stage<HP>(ring, wb, W, nextW, cc, wave, lane); });
     ring.par ^= 1;
   }
 }

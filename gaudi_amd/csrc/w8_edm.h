@@ -84,7 +84,7 @@ struct TileCols {
 __device__ __forceinline__ TileCols load_tile(const MolGraph& mg, int round, int wave, int c) {
   TileCols tc;
   const int tile = round * kWaves + wave;
-  tc.active = tile < mg.ntiles;
+  tc.active = __builtin_amdgcn_readfirstlane(tile < mg.ntiles ? 1 : 0) != 0;
   tc.slot = (tc.active ? tile : 0) * 16 + c;
   const uint32_t e = mg.edge[tc.slot];
   tc.i = ew_i(e);
@@ -112,7 +112,7 @@ __device__ __forceinline__ void scatter_runs(f4 (&e)[HP / 16], const TileCols& t
 // eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
 template <int HP>
 __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP>& sm, const float* sZ,
-                                            float* sEps, float* sMean /* [4] */, float t_val, int tid) {
+                                            float* sEps, float* sMean /* [4] */, float t_val, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
   constexpr int PK = HP * HP;
@@ -153,9 +153,11 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next sub-layer's vectors (GCL: 7 HP + 16 floats, EquivariantUpdate: 5 HP), loaded a phase ahead
   vec_prefetch<NV, kThreads>(vpf, wb, lay.gcl(0, 0) + 6 * PK, 7 * HP + 16, tid);
+  STAMP(ST_EDM_IO);
 
   for (int l = 0; l < W.L; ++l) {
     compute_geo(sm, mg, W.norm_constant, tid, false);  // egnn_new.py:216
+    STAMP(ST_GEO);
     for (int s = 0; s < W.S; ++s) {
       // ------------------------------------------------------------------ GCL (egnn_new.py:42-89)
       const int G = lay.gcl(l, s);  // float offsets into the weight buffer
@@ -166,19 +168,23 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         sm.agg1[idx] = 0.f;
       }
       __syncthreads();
+      STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
                   *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
       const float ba = sm.vec[7 * HP];
       node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, G + PK);
       node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf,
                                     G + 3 * PK);  // node MLP weights travel across the edge phase
+      STAMP(ST_NODE);
       __syncthreads();
+      STAMP(ST_BARRIER);
       for (int rd = 0; rd < mg.rounds; ++rd) {
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
         edge_gemm_pq<HP>(acc, ring, wb, G + 2 * PK, rd + 1 < mg.rounds ? G + 2 * PK : Wnext_edge, b2, cr, cd,
-                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane);
+                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
+        STAMP(ST_EDGE);
         if (tc.active) {
           float sdot = 0.f;
 #pragma unroll
@@ -195,21 +201,28 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           for (int t = 0; t < T; ++t) acc[t] = acc[t] * sc;
           scatter_runs<HP>(acc, tc, sm.agg, sm.agg1, g);
         }
+        STAMP(ST_EDGE_EPI);
       }
       __syncthreads();
+      STAMP(ST_BARRIER);
       for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = (partial 0 + partial 1) / normalization_factor
         const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
         *(f4*)(sm.agg + n * LD + f) = (*(const f4*)(sm.agg + n * LD + f) + *(const f4*)(sm.agg1 + n * LD + f)) / W.normf;
       }
       __syncthreads();
+      STAMP(ST_MISC);
       node_gemm<HP, EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, mg.NC, wave, lane,
                                     &pf, G + 5 * PK);
+      STAMP(ST_NODE);
       __syncthreads();
+      STAMP(ST_BARRIER);
       vec_prefetch<NV, kThreads>(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK,
                                  s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
       node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave, lane,
                                              &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
+      STAMP(ST_NODE);
       __syncthreads();
+      STAMP(ST_BARRIER);
     }
     // -------------------------------------------------------- EquivariantUpdate (egnn_new.py:119-155)
     {
@@ -217,17 +230,21 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int Wnext_edge = l + 1 < W.L ? lay.gcl(l + 1, 0) + 2 * PK : -1;
       vec_commit<NV, kThreads>(vpf, sm.vec, 5 * HP, tid);
       __syncthreads();
+      STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
       node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, E + PK);
       node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf,
                                     l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
+      STAMP(ST_NODE);
       __syncthreads();
+      STAMP(ST_BARRIER);
       for (int rd = 0; rd < mg.rounds; ++rd) {
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
         edge_gemm_pq<HP>(acc, ring, wb, E + 2 * PK, rd + 1 < mg.rounds ? E + 2 * PK : Wnext_edge, b2, cr, cd,
-                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane);
+                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
+        STAMP(ST_EDGE);
         if (tc.active) {
           float sdot = 0.f;
 #pragma unroll
@@ -240,11 +257,14 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           const float tau = (W.use_tanh ? tanhf(phi) * W.coords_range : phi) * tc.mk;
           if (g == 0) *(f4*)(sm.trans + 4 * tc.slot) = (f4){gg[1] * tau, gg[2] * tau, gg[3] * tau, 0.f};
         }
+        STAMP(ST_EDGE_EPI);
       }
       if (l + 1 < W.L) vec_prefetch<NV, kThreads>(vpf, wb, lay.gcl(l + 1, 0) + 6 * PK, 7 * HP + 16, tid);
       __syncthreads();
+      STAMP(ST_BARRIER);
       coord_update(sm, mg, W.normf, tid);
       __syncthreads();
+      STAMP(ST_MISC);
     }
   }
 
@@ -290,6 +310,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
     }
     __syncthreads();
   }
+  STAMP(ST_EDM_IO);
 }
 
 }  // namespace w8
