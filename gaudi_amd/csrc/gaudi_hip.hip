@@ -49,7 +49,7 @@ struct gaudi_handle {
   gaudi_edm_config ecfg{};
   gaudi_pred_config pcfg{};
   int HPE = 0, HPP = 0;
-  DevBuf edm_w, pred_w, coef_d;
+  DevBuf edm_w, pred_w, coef_d, edm_w4, pred_w4;  // *_w4: row-major tiles for the 4-wave fallback of an 8-wave handle
   size_t edm_w_bytes = 0, pred_w_bytes = 0;
   std::vector<float> gamma, coef;
   // per-call workspaces
@@ -58,6 +58,7 @@ struct gaudi_handle {
       d_sidx;
   int steps_per_launch = 25;
   int variant = 4;            // 4 = one wave per SIMD (sampler_kernel), 8 = two waves per SIMD (sampler_kernel8)
+  int run_variant = 4;        // what the CURRENT call runs on (an 8-wave handle falls back to 4 waves for graphs that do not fit)
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
   long long fix_key = 0;      // global sample index whose Philox stream is shared
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
@@ -467,9 +468,11 @@ static kernel_fn pick_kernel(int hpe, int hpp) {
 
 // the 8-wave instantiations (kern8_*.hip)
 #ifdef GAUDI_STAMP_STUBS
-#define GAUDI_KERNEL8_TUS(X) X(edm_192)
+#define GAUDI_KERNEL8_TUS(X) X(edm_192) X(fused_192_208)
 #else
-#define GAUDI_KERNEL8_TUS(X) X(edm_small) X(edm_192) X(edm_208) X(edm_256)
+#define GAUDI_KERNEL8_TUS(X)                                                                           \
+  X(edm_small) X(edm_192) X(edm_208) X(edm_256) X(pred_small) X(pred_192) X(pred_208) X(pred_256)      \
+  X(fused_tiny) X(fused_128_128) X(fused_192_192) X(fused_192_208) X(fused_208_208) X(fused_256_256)
 #endif
 #define X(name) kernel_fn gaudi_kern8_##name(int hpe, int hpp);
 GAUDI_KERNEL8_TUS(X)
@@ -498,21 +501,43 @@ static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW) {
   return sizeof(float) * (common_floats(N, D, EW) + net);
 }
 
-static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S) {
+static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S) {
   size_t net = 0;
   if (hpe) net = std::max(net, (size_t)(5 * N * (hpe + 4) + 2 * (hpe / 16) * 256 + 8 * N + S * 9 + 8 * hpe));
-  (void)hpp;
-  return sizeof(float) * (common_floats8(N, D, S) + net);
+  if (hpp) net = std::max(net, (size_t)(2 * (hpp / 16) * 256 + 5 * N * (hpp + 4) + 12 * N + S * 10 + 32 + 10 * hpp));
+  return common_floats8(N, D, S) + net;
+}
+// The reverse pass publishes du of every slot pub_ch feature tiles at a time into [b0 | b1 | pubx extra floats]: pick the
+// largest pub_ch that fits 160 KiB, then the extra floats that choice needs.  false: the molecule does not fit.
+static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int& pubx, int& pub_ch) {
+  pubx = 0;
+  pub_ch = 0;
+  const long long cap = 160 * 1024 / 4 - 64;  // floats (a little headroom for the runtime's own static LDS)
+  const long long base = (long long)lds_floats8_base(hpe, hpp, N, D, S);
+  if (base > cap) return false;
+  if (!hpp) return true;
+  const int T = hpp / 16;
+  const long long own = 2LL * N * (hpp + 4);  // b0 + b1 double as the head of the publish buffer
+  pub_ch = w8::pub_chunk_tiles(S, own + (cap - base), T);
+  if (pub_ch < 1) return false;
+  // prefer the smallest chunk that gives the same number of chunks (less LDS, same barriers)
+  const int nch = (T + pub_ch - 1) / pub_ch;
+  pub_ch = (T + nch - 1) / nch;
+  pubx = (int)std::max(0LL, (long long)S * (16 * pub_ch + 4) - own);
+  return true;
+}
+static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx) {
+  return sizeof(float) * (lds_floats8_base(hpe, hpp, N, D, S) + (hpp ? pubx : 0));
 }
 
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
-  const bool v8 = h->variant == 8;
+  const bool v8 = h->run_variant == 8;
   kernel_fn fn = v8 ? pick_kernel8(hpe, hpp) : pick_kernel(hpe, hpp);
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
                     (v8 ? " in the 8-wave family" : ""));
-  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW);
+  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW);
   if (lds > 160 * 1024)
     return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
   {
@@ -562,11 +587,20 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
 }
 
 // upload masks + metadata, fill the graph part of KParams
-static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P) {
+// -> GAUDI_OK, or a positive value = "run this call on the 4-wave kernels" (graph outside the 8-wave kernels' limits)
+static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P, int hpe,
+                        int hpp) {
   Meta8 M;
   std::string err;
   int rc = build_meta8(B, N, node_mask, edge_mask, M, err);
+  if (rc == GAUDI_E_CAPACITY) return 1;
   if (rc) return fail(h, rc, err);
+  if (hpp && M.S > 16 * w8::kWaves) return 1;  // the 8-wave predictor handles one round of tiles
+  if (!pick_kernel8(hpe, hpp)) return 1;
+  int pubx = 0, pub_ch = 0;
+  if (!plan_pub8(hpe, hpp, N, 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf), M.S, pubx, pub_ch)) return 1;
+  P.pubx = pubx;
+  P.pub_ch = pub_ch;
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = d.reserve(bytes);
     if (e != hipSuccess) return e;
@@ -597,9 +631,17 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   return GAUDI_OK;
 }
 
-static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P) {
+// hpe / hpp: padded hidden sizes of the networks this call runs (0 = not used)
+static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P, int hpe,
+                       int hpp) {
   if (B <= 0 || N <= 0) return fail(h, GAUDI_E_INVALID, "B and N must be positive");
-  if (h->variant == 8) return stage_graph8(h, B, N, node_mask, edge_mask, P);
+  h->run_variant = h->variant;
+  if (h->variant == 8) {
+    const int rc8 = stage_graph8(h, B, N, node_mask, edge_mask, P, hpe, hpp);
+    if (rc8 <= 0) return rc8;
+    h->run_variant = 4;  // fall back to the 4-wave kernels for this call
+    P.pubx = P.pub_ch = 0;
+  }
   Meta M;
   std::string err;
   int rc = build_meta(B, N, node_mask, edge_mask, M, err);
@@ -636,7 +678,7 @@ static void fill_edm(gaudi_handle* h, KParams& P) {
   const gaudi_edm_config& c = h->ecfg;
   P.F = c.in_node_nf;
   P.T = c.diffusion_steps;
-  P.edm.w = h->edm_w.as<float>();
+  P.edm.w = (h->variant == 8 && h->run_variant == 4) ? h->edm_w4.as<float>() : h->edm_w.as<float>();
   P.edm.w_bytes = (unsigned)h->edm_w_bytes;
   P.edm.F = c.in_node_nf;
   P.edm.L = c.n_layers;
@@ -680,7 +722,7 @@ void gaudi_destroy(gaudi_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->prof_log.reset(true);
   h->stab_log.reset(true);
-  DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
+  DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->edm_w4, &h->pred_w4, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
                     &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
                     &h->d_pred, &h->d_tw, &h->d_stash, &h->d_chain, &h->d_sx, &h->d_stype, &h->d_sn,
                     &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as, &h->d_ncols, &h->d_soff, &h->d_sidx};
@@ -706,11 +748,14 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   for (int i = 0; i < n; ++i) T.m[names[i]] = {tensors[i], numel[i]};
   static std::mutex pack_mu;
   std::lock_guard<std::mutex> pack_lock(pack_mu);
-  g_lane_linear = h->variant == 8;
   EdmLayout lay{HP, F1, L, S};
-  std::vector<float> w((size_t)lay.total(), 0.f);
   const std::string p = "dynamics.egnn.";
   const int PK = HP * HP;
+  // tile layout: lane-linear for the 8-wave kernels, row-major for the 4-wave ones (kept as the fallback of the 8-wave
+  // variant for graphs that do not fit it)
+  auto pack = [&](bool lane_linear, std::vector<float>& w) {
+  g_lane_linear = lane_linear;
+  w.assign((size_t)lay.total(), 0.f);
   {
     const float* ew = T.get(p + "embedding.weight", (int64_t)H * F1);
     const float* eb = T.get(p + "embedding.bias", H);
@@ -778,10 +823,18 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
     pack_vec(V + 3 * HP, b2, H);
     pack_vec(V + 4 * HP, w3, H);
   }
+  };
+  std::vector<float> w;
+  pack(h->variant == 8, w);
   if (!T.missing.empty()) return fail(h, GAUDI_E_MISSING, "EDM checkpoint tensor missing or mis-shaped: " + T.missing);
   HIPCHECK(h, h->edm_w.reserve(sizeof(float) * w.size()));
   HIPCHECK(h, hipMemcpy(h->edm_w.p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
   h->edm_w_bytes = sizeof(float) * w.size();
+  if (h->variant == 8) {
+    pack(false, w);
+    HIPCHECK(h, h->edm_w4.reserve(sizeof(float) * w.size()));
+    HIPCHECK(h, hipMemcpy(h->edm_w4.p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
+  }
   h->gamma = make_gamma(cfg->diffusion_steps, cfg->noise_power, cfg->noise_precision);
   make_coef(h->gamma, cfg->diffusion_steps, h->coef);
   HIPCHECK(h, h->coef_d.reserve(sizeof(float) * h->coef.size()));
@@ -812,7 +865,7 @@ int gaudi_phi(gaudi_handle* h, int B, int N, const float* z, const float* t, con
   if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
   HIPCHECK(h, hipSetDevice(h->device));
   KParams P{};
-  int rc = stage_graph(h, B, N, node_mask, edge_mask, P);
+  int rc = stage_graph(h, B, N, node_mask, edge_mask, P, h->HPE, 0);
   if (rc) return rc;
   fill_edm(h, P);
   const size_t zb = sizeof(float) * B * N * (3 + P.F);
@@ -883,7 +936,7 @@ static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, cons
   if (target_w && !h->has_pred) return fail(h, GAUDI_E_STATE, "guided sampling needs predictor weights");
   HIPCHECK(h, hipSetDevice(h->device));
   KParams P{};
-  int rc = stage_graph(h, B, N, node_mask, edge_mask, P);
+  int rc = stage_graph(h, B, N, node_mask, edge_mask, P, h->HPE, target_w ? h->HPP : 0);
   if (rc) return rc;
   fill_edm(h, P);
   const int D = 3 + P.F, T = P.T;
@@ -1043,7 +1096,7 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
   if (!h->has_pred) return fail(h, GAUDI_E_STATE, "guided sampling needs predictor weights");
   HIPCHECK(h, hipSetDevice(h->device));
   KParams P{};
-  int rc = stage_graph(h, B, N, node_mask, edge_mask, P);
+  int rc = stage_graph(h, B, N, node_mask, edge_mask, P, h->HPE, h->HPP);
   if (rc) return rc;
   fill_edm(h, P);
   const int D = 3 + P.F, T = P.T, K = h->pcfg.out_nf;

@@ -1,0 +1,10 @@
+// kern8_fused_208_208.hip -- sampler_kernel8 (8 waves, two per SIMD) instantiations [(208, 208)] (own translation unit so the
+// instantiations compile in parallel; looked up by gaudi_hip.hip through gaudi_kern8_fused_208_208).
+#include "sampler_kernel.h"
+
+typedef void (*kernel_fn)(const gaudi::KParams);
+
+kernel_fn gaudi_kern8_fused_208_208(int hpe, int hpp) {
+  if (hpe == 208 && hpp == 208) return gaudi::sampler_kernel8<208, 208>;
+  return nullptr;
+}

@@ -27,6 +27,7 @@ struct KParams {
   // molecule, seginfo = start << 16 | len, plus the sender lists of the reverse pass
   const uint16_t* soff;     // [B][N+1]
   const uint16_t* sidx;     // [B][EW]
+  int pubx, pub_ch;         // reverse pass: extra floats of the du publish buffer, 16-feature tiles published per chunk
   // tensors (device)
   const float* z_in;        // [B][N][D]
   float* z_out;             // [B][N][D]
@@ -143,6 +144,8 @@ struct V8 {
     mg.NC = P.ncols[b];
     mg.ntiles = P.npairs[b];
     mg.rounds = (mg.ntiles + w8::kWaves - 1) / w8::kWaves;
+    mg.pubx = P.pubx;
+    mg.pub_ch = P.pub_ch;
     mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg; mg.soff = sOff; mg.sidx = sIdx;
     return base;
   }
@@ -158,14 +161,15 @@ struct V8 {
                                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
                                                const float* dpred_ext) {
-    w8::guidance_update<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash, tid,
-                            phase, dpred_ext);
+    w8::guidance_update<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
+                            mg.pubx, mg.pub_ch, tid, phase, dpred_ext);
   }
   template <int HP>
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
                                                     float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                     float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
-    w8::predictor_entry<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, tid);
+    w8::predictor_entry<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
+                            mg.pub_ch, tid);
   }
 };
 

@@ -393,6 +393,7 @@ struct MolGraph {
   int N, D, S;            // nodes (padded), 3+F, slot capacity of the batch (multiple of 16)
   int NC;                 // node columns that matter: 1 + last node that is live or touches a live edge (<= N)
   int ntiles, rounds;     // 16-slot tiles of THIS molecule, ceil(ntiles / 8)
+  int pubx, pub_ch;       // predictor reverse pass: see w8_pred.h
   const float* mask;      // LDS [N]
   const uint32_t* edge;   // LDS [S]  edge words (ew_* above)
   const float* em;        // LDS [S]  edge_mask value (0 for padding slots)

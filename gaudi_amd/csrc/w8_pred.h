@@ -1,17 +1,530 @@
-// w8_pred.h -- placeholder until the 8-wave predictor lands: declarations only, so that EDM-only 8-wave kernels build.
+// w8_pred.h -- EGNN_predictor (edm/egnn_predictor/models.py:433-457,543-560; gcl.py:225-316) on the 8-wave kernels: forward
+// with the per-layer activation stash, the hand-written reverse pass that replaces torch.autograd.grad at
+// en_diffusion.py:900-903, and the guidance epilogue (:905-920).  One workgroup (8 waves) = one molecule whose live edges fit
+// ONE round of 16-slot tiles (<= 128 slots; larger graphs run on the 4-wave kernels).  Weight layout = PredLayout
+// (pred_device.h), matrices packed lane-linear.
 #pragma once
 #include "pred_device.h"
 #include "w8_edm.h"
 
 namespace gaudi {
 namespace w8 {
+
 template <int HP>
-__device__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp, float* sMean,
-                                float t_val, float sigma, const float* target_w, float scale, float* pred_out, float readout_div,
-                                float* stash, int tid, int phase, const float* dpred_ext);
+struct PredSmem {
+  float* ring;                    // [2][T*256]
+  float *b2, *b3, *b4;            // [N][HP+4] node buffers (roles change per phase, see below)
+  float *b0, *b1;                 // [N][HP+4] ... these two sit right in front of `pub` and are part of it in the reverse pass
+  float* pub;                     // [pubx] extra floats of the publish buffer (reverse pass: du of every slot, CH tiles at a time)
+  float *x, *x0, *dx;             // [N][4]
+  f4* geo;                        // [S]
+  float *d0, *trans, *dd0;        // [S], [S][4], [S]
+  float* pred;                    // [16] pred | [16] dpred
+  float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
+  __host__ __device__ static int floats(int N, int S, int pubx) {
+    return 2 * (HP / 16) * 256 + 5 * N * (HP + 4) + pubx + 12 * N + S * 10 + 32 + 10 * HP;
+  }
+  __device__ void carve(float* base, int N, int S, int pubx) {
+    constexpr int LD = HP + 4;
+    ring = base; base += 2 * (HP / 16) * 256;
+    b2 = base; base += N * LD;
+    b3 = base; base += N * LD;
+    b4 = base; base += N * LD;
+    b0 = base; base += N * LD;
+    b1 = base; base += N * LD;
+    pub = base; base += pubx;
+    x = base; base += 4 * N;
+    x0 = base; base += 4 * N;
+    dx = base; base += 4 * N;
+    geo = (f4*)base; base += S * 4;
+    d0 = base; base += S;
+    trans = base; base += S * 4;
+    dd0 = base; base += S;
+    pred = base; base += 32;
+    vec = base;
+  }
+};
+
+// stash per molecule: node part  L x { P [N][HP] | Q [N][HP] | npre [N][HP] | x [N][4] }
+//                     edge part  L x (S/16 tiles) x { v | cpre } x [HP/16][64 lanes] float4   (accumulator layout)
+//                     gate part  L x S floats (attention gate a_ij of every slot)
+__host__ __device__ inline long long pred_stash_floats8(int N, int HP, int L, int S) {
+  return pred_stash_node_floats(N, HP, L) + (long long)L * S * HP * 2 + (long long)L * S;
+}
+__device__ __forceinline__ size_t edge_stash_off8(int l, int tile, int arr, int S, int HP) {
+  return (((size_t)l * (S / 16) + tile) * 2 + arr) * (size_t)(16 * HP);
+}
+
+// largest number of 16-feature tiles per publish chunk that fits `avail` floats for S slots (row = 16 CH + 4 floats)
+__host__ __device__ inline int pub_chunk_tiles(int S, long long avail_floats, int T) {
+  int ch = (int)((avail_floats / (S > 0 ? S : 1) - 4) / 16);
+  return ch > T ? T : ch;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: pred[K] -> sm.pred[0..K)
+// buffers: h = b0, P = b1, Q = b2, agg = b3, second agg partial = b4
+// ---------------------------------------------------------------------------------------------
 template <int HP>
-__device__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp, float* sMean,
-                                float t_val, const float* dpred, bool want_grad, float* pred_out, float readout_div, float* stash,
-                                int tid);
+__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* sZ,
+                                             float t_val, float* stash, float readout_div, int tid) {
+  constexpr int LD = HP + 4;
+  constexpr int T = HP / 16;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1, K = W.K, S = mg.S;
+  PredLayout lay{HP, F1, K, W.L};
+  const float* __restrict__ w = W.w;
+  const WBuf wb = make_wbuf(W.w, W.w_bytes);
+  float *h = sm.b0, *p = sm.b1, *q = sm.b2, *agg = sm.b3, *agg1 = sm.b4;
+  float* estash = stash + pred_stash_node_floats(N, HP, W.L);
+  float* astash = estash + (size_t)W.L * S * HP * 2;
+
+  for (int idx = tid; idx < N * 3; idx += kThreads) {  // models.py:439
+    const int n = idx / 3, d = idx % 3;
+    const float v = sZ[n * D + d] * mg.mask[n];
+    sm.x[4 * n + d] = v;
+    sm.x0[4 * n + d] = v;
+  }
+  {
+    const float* ew = w + lay.emb_w();
+    const float* eb = w + lay.emb_b();
+    for (int idx = tid; idx < N * HP; idx += kThreads) {
+      const int n = idx / HP, f = idx % HP;
+      float acc = 0.f;
+      const float m = mg.mask[n];
+      for (int k = 0; k < F; ++k) acc += ew[f * F1 + k] * (sZ[n * D + 3 + k] * m);
+      acc += ew[f * F1 + F] * t_val;
+      h[n * LD + f] = acc + eb[f];
+    }
+  }
+  __syncthreads();
+  compute_geo(sm, mg, 0.f, tid, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
+  Ring<HP> ring;
+  ring.base = sm.ring;
+  ring.par = 0;
+  ring_start<HP>(ring, wb, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
+  NodePF<HP> pf;
+  node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane);
+  constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
+  VecPF<NV> vpf;  // the next layer's vectors, loaded one node GEMM ahead
+  vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(0), HP), PredLayerW::vec_count(HP), tid);
+
+  for (int l = 0; l < W.L; ++l) {
+    const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
+    const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
+    vec_commit<NV, kThreads>(vpf, sm.vec, PredLayerW::vec_count(HP), tid);
+    for (int idx = tid; idx < N * LD; idx += kThreads) {
+      agg[idx] = 0.f;
+      agg1[idx] = 0.f;
+    }
+    float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
+    for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 3 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
+    compute_geo(sm, mg, 1.0f, tid, false);  // gcl.py:308-316
+    __syncthreads();
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Bm);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1h);
+    __syncthreads();
+    for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // P, Q -> stash
+      const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
+      ((f4*)st)[idx] = *(const f4*)(p + n * LD + f);
+      ((f4*)(st + N * HP))[idx] = *(const f4*)(q + n * LD + f);
+    }
+    {
+      const TileCols tc = load_tile(mg, 0, wave, c);
+      const f4 gg = sm.geo[tc.slot];
+      f4 acc[T];
+      edge_gemm_pq<HP>(acc, ring, wb, Lw.W2, last ? -1 : Lw.Wc1, Lw.b2, Lw.cr, Lw.cd, p + tc.i * LD + 4 * g,
+                       q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane);
+      const int tile = tc.slot >> 4;
+      if (tc.active) {
+        {  // v (pre-activation of m) -> edge stash for the reverse pass
+          f4* sv = (f4*)(estash + edge_stash_off8(l, tile, 0, S, HP)) + lane;
+#pragma unroll
+          for (int t = 0; t < T; ++t) sv[t * 64] = acc[t];
+        }
+        float sdot = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const f4 m = silu4(acc[t]);
+          acc[t] = m;
+          sdot += dot4(m, *(const f4*)(Lw.wa + 16 * t + 4 * g));
+        }
+        float a = 1.f;
+        if (W.attention) a = sigmoid_f(reduce_groups(sdot) + Lw.ba);
+        if (g == 0) astash[(size_t)l * S + tc.slot] = a;
+        const float sc = a * tc.mk;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = acc[t] * sc;  // e_ij (gcl.py:231-237)
+        scatter_runs<HP>(acc, tc, agg, agg1, g);
+      }
+      if (!last) {  // coord_model (gcl.py:252-278): trans = dhat * tanh(wc2 . silu(Wc1 e + bc1)) * R * mask
+        f4 cp[T];
+        edge_gemm_regs<HP>(cp, acc, ring, wb, Lw.Wc1, lay.layer(l + 1) + 2 * HP * HP, Lw.bc1, nullptr, tc.active, wave, lane);
+        if (tc.active) {
+          f4* sc = (f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
+#pragma unroll
+          for (int t = 0; t < T; ++t) sc[t * 64] = cp[t];
+          float sdot = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) sdot += dot4(silu4(cp[t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
+          const float phi = reduce_groups(sdot);
+          const float tau = (W.use_tanh ? tanhf(phi) * W.coords_range_layer : phi) * tc.mk;
+          if (g == 0) *(f4*)(sm.trans + 4 * tc.slot) = (f4){gg[1] * tau, gg[2] * tau, gg[3] * tau, 0.f};
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = partial 0 + partial 1
+      const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
+      *(f4*)(agg + n * LD + f) = *(const f4*)(agg + n * LD + f) + *(const f4*)(agg1 + n * LD + f);
+    }
+    __syncthreads();
+    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Wn2,
+                                  st + 2 * N * HP /* npre -> stash */);
+    __syncthreads();
+    vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), PredLayerW::vec_count(HP), tid);
+    node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, &pf,
+                                           l + 1 < W.L ? lay.layer(l + 1) : -1);
+    if (!last) coord_update(sm, mg, 1.0f, tid);
+    __syncthreads();
+  }
+  // readout: mean over the PADDED node count of (embedding_out(h) * mask)   (models.py:553-557, :457)
+  {
+    const float* ow = w + lay.out_w();
+    const float* ob = w + lay.out_b();
+    const float* msk = mg.mask;
+    small_dots<kThreads>(
+        N * K, HP, tid, [=](int qq, int f) { return ow[(qq % K) * HP + f]; },
+        [=](int qq, int f) { return h[(qq / K) * LD + f]; },
+        [=](int qq, float acc) { p[qq] = (acc + ob[qq % K]) * msk[qq / K]; });
+    __syncthreads();
+    if (tid < K) {
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s += p[n * K + tid];
+      sm.pred[tid] = s / readout_div;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reverse pass: sGrad[N][D] = d( sum_k dpred[k] * pred[k] ) / dz      (dpred in sm.pred[16..16+K))
+// buffer roles per layer:  B0 = b0: dagg -> publish buffer    B1 = b1: Q (from the stash) -> publish buffer
+//                          B2 = b2: P (stash) -> dP            B3 = b3: dh (running)
+//                          B4 = b4: npre (stash) -> dnpre -> dQ
+// pub_ch = 16-feature tiles of du published per chunk into [b0 | b1 | pub] (row = 16 pub_ch + 4 floats per slot)
+// ---------------------------------------------------------------------------------------------
+template <int HP>
+__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
+                                              float* sGrad, float readout_div, int pub_ch, int tid, const float* sZin = nullptr) {
+  constexpr int LD = HP + 4;
+  constexpr int T = HP / 16;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1, K = W.K, S = mg.S;
+  PredLayout lay{HP, F1, K, W.L};
+  const float* __restrict__ w = W.w;
+  const WBuf wb = make_wbuf(W.w, W.w_bytes);
+  float *B0 = sm.b0, *B1 = sm.b1, *B2 = sm.b2, *dh = sm.b3, *B4 = sm.b4;
+  float* pub = sm.b0;  // [slots][16 pub_ch + 4]
+  const int PLD = 16 * pub_ch + 4;
+  const float* estash = stash + pred_stash_node_floats(N, HP, W.L);
+  const float* astash = estash + (size_t)W.L * S * HP * 2;
+  const float* dpred = sm.pred + 16;
+  const int nslots = mg.ntiles * 16;
+
+  if (sZin != nullptr) {
+    // split-step mode: the forward ran in an earlier launch; rebuild the two input-geometry tensors it left in LDS
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
+      const float v = sZin[n * D + d] * mg.mask[n];
+      sm.x[4 * n + d] = v;
+      sm.x0[4 * n + d] = v;
+    }
+    __syncthreads();
+    compute_geo(sm, mg, 0.f, tid, true);
+    __syncthreads();
+  }
+  // readout backward: dh = mask * (dpred / N_pad) . W_out
+  {
+    const float* ow = w + lay.out_w();
+    for (int idx = tid; idx < N * HP; idx += kThreads) {
+      const int n = idx / HP, f = idx % HP;
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc += (dpred[k] / readout_div) * ow[k * HP + f];
+      dh[n * LD + f] = acc * mg.mask[n];
+    }
+    for (int idx = tid; idx < N * 4; idx += kThreads) sm.dx[idx] = 0.f;
+    for (int idx = tid; idx < S; idx += kThreads) sm.dd0[idx] = 0.f;
+  }
+  __syncthreads();
+
+  Ring<HP> ring;
+  ring.base = sm.ring;
+  ring.par = 0;
+  {
+    const int L0 = lay.layer(W.L - 1);
+    ring_start<HP>(ring, wb, L0 + 9 * HP * HP /* W2^T of the last layer (its coordinate branch is skipped) */, wave, lane);
+  }
+  NodePF<HP> pf;
+  node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane);
+  constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
+  VecPF<NV> vpf;
+  vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(W.L - 1), HP), PredLayerW::vec_count(HP), tid);
+  for (int l = W.L - 1; l >= 0; --l) {
+    const bool last = l == W.L - 1;
+    const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
+    vec_commit<NV, kThreads>(vpf, sm.vec, PredLayerW::vec_count(HP), tid);
+    const float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
+    // (a) reload P -> B2, Q -> B1, npre -> B4, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
+    for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
+      const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
+      const f4 pv = ((const f4*)st)[idx], qv = ((const f4*)(st + N * HP))[idx], nv = ((const f4*)(st + 2 * N * HP))[idx];
+      *(f4*)(B2 + n * LD + f) = pv;
+      *(f4*)(B1 + n * LD + f) = qv;
+      *(f4*)(B4 + n * LD + f) = nv;
+      *(f4*)(dh + n * LD + f) = *(const f4*)(dh + n * LD + f) * mg.mask[n];
+    }
+    for (int idx = tid; idx < N; idx += kThreads) {
+      *(f4*)(sm.x + 4 * idx) = ((const f4*)(st + 3 * N * HP))[idx];
+      *(f4*)(sm.dx + 4 * idx) = *(const f4*)(sm.dx + 4 * idx) * mg.mask[idx];
+    }
+    __syncthreads();
+    compute_geo(sm, mg, 1.0f, tid, false);
+    // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
+    node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1ht);
+    __syncthreads();
+    // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1at);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, &pf);
+    __syncthreads();
+    // (e) edge pass: MLP chain backward for the wave's tile, then du of all slots is published CH feature tiles at a time
+    //     and every thread sums one (node, 4 features) of dP_i = sum_j du_ij (receiver runs) and dQ_j = sum_i du_ij
+    //     (sender lists) in slot order -- no atomics, fixed order
+    {
+      const TileCols tc = load_tile(mg, 0, wave, c);
+      const int tile = tc.slot >> 4;
+      const f4 gg = sm.geo[tc.slot];
+      const float d0v = sm.d0[tc.slot];
+      f4 du[T];
+      float a = 0.f, tau = 0.f, dtx = 0.f, dty = 0.f, dtz = 0.f;
+      {
+        f4 de[T];
+        if (tc.active) {
+          a = astash[(size_t)l * S + tc.slot];
+          dtx = sm.dx[4 * tc.i + 0];  // dtrans = dx'_i
+          dty = sm.dx[4 * tc.i + 1];
+          dtz = sm.dx[4 * tc.i + 2];
+        }
+        if (!last) {
+          f4 cp[T];
+          if (tc.active) {
+            const f4* sc = (const f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
+#pragma unroll
+            for (int t = 0; t < T; ++t) cp[t] = sc[t * 64];
+            float sd2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) sd2 += dot4(silu4(cp[t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
+            const float phi = reduce_groups(sd2);
+            const float th = tanhf(phi);
+            tau = W.use_tanh ? th * W.coords_range_layer : phi;
+            const float dtau = (dtx * gg[1] + dty * gg[2] + dtz * gg[3]) * tc.mk;
+            const float dphi = W.use_tanh ? dtau * W.coords_range_layer * (1.0f - th * th) : dtau;
+#pragma unroll
+            for (int t = 0; t < T; ++t)  // dcpre = dphi * wc2 * silu'(cpre)
+              cp[t] = *(const f4*)(Lw.wc2 + 16 * t + 4 * g) * dphi * dsilu4(cp[t]);
+          } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) cp[t] = splat(0.f);
+          }
+          edge_gemm_regs<HP>(de, cp, ring, wb, Lw.Wc1t, Lw.W2t, nullptr, B0 + tc.i * LD /* + dagg_i (agg_i = sum_j e_ij) */,
+                             tc.active, wave, lane);
+        } else {
+#pragma unroll
+          for (int t = 0; t < T; ++t) de[t] = *(const f4*)(B0 + tc.i * LD + 16 * t + 4 * g);
+        }
+        if (tc.active) {
+          // e = m * a * mask ; a = sigmoid(wa . m + ba)
+          f4 ve[T];
+          const f4* sv = (const f4*)(estash + edge_stash_off8(l, tile, 0, S, HP)) + lane;
+#pragma unroll
+          for (int t = 0; t < T; ++t) ve[t] = sv[t * 64];
+          float dadot = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) dadot += dot4(de[t], silu4(ve[t]));
+          const float da = reduce_groups(dadot) * tc.mk;
+          const float ds = W.attention ? da * a * (1.0f - a) : 0.f;
+          const float am = a * tc.mk;
+#pragma unroll
+          for (int t = 0; t < T; ++t)  // dv = (de*a*mask + ds*wa) * silu'(v)
+            de[t] = (de[t] * am + *(const f4*)(Lw.wa + 16 * t + 4 * g) * ds) * dsilu4(ve[t]);
+        }
+        // next edge GEMM of the chain: Wc1^T of layer l-1 (W2^T when that layer is ... never the last), none after layer 0
+        edge_gemm_regs<HP>(du, de, ring, wb, Lw.W2t, l > 0 ? lay.layer(l - 1) + 10 * HP * HP : -1, nullptr, nullptr, tc.active,
+                           wave, lane);  // dt1
+      }
+      if (tc.active) {
+        // du = dt1 * silu'(u) ; dr = cr . du ; dd0 = cd . du
+        const float* pp = B2 + tc.i * LD + 4 * g;
+        const float* qq = B1 + tc.j * LD + 4 * g;
+        float drdot = 0.f, dd0dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const f4 u = edge_u(pp, qq, Lw.cr, Lw.cd, g, t, gg[0], d0v);
+          du[t] = du[t] * dsilu4(u);
+          drdot += dot4(du[t], *(const f4*)(Lw.cr + 16 * t + 4 * g));
+          dd0dot += dot4(du[t], *(const f4*)(Lw.cd + 16 * t + 4 * g));
+        }
+        const float dr = reduce_groups(drdot), dd0v = reduce_groups(dd0dot);
+        if (g == 0) {
+          // d/d(diff) of r = |diff|^2 and dhat = diff / (sqrt(r + 1e-8) + 1)   (gcl.py:308-316)
+          const int i = tc.i, j = tc.j;
+          const float fx = sm.x[4 * i + 0] - sm.x[4 * j + 0];
+          const float fy = sm.x[4 * i + 1] - sm.x[4 * j + 1];
+          const float fz = sm.x[4 * i + 2] - sm.x[4 * j + 2];
+          const float nrm = sqrtf(gg[0] + 1e-8f), den = nrm + 1.0f;
+          const float cx = dtx * tau * tc.mk, cy = dty * tau * tc.mk, cz = dtz * tau * tc.mk;
+          const float k1 = (cx * fx + cy * fy + cz * fz) / (den * den * nrm);
+          *(f4*)(sm.trans + 4 * tc.slot) = (f4){cx / den - fx * k1 + 2.0f * fx * dr, cy / den - fy * k1 + 2.0f * fy * dr,
+                                                cz / den - fz * k1 + 2.0f * fz * dr, 0.f};
+          sm.dd0[tc.slot] += dd0v;
+        }
+      }
+      __syncthreads();  // every wave is done with P (B2), Q (B1) and dagg (B0): the publish buffer may overwrite B0 / B1
+      for (int t0 = 0; t0 < T; t0 += pub_ch) {
+        const int t1 = t0 + pub_ch < T ? t0 + pub_ch : T;
+        if (tc.active) {
+          float* row = pub + tc.slot * PLD + 4 * g - 16 * t0;
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            if (t >= t0 && t < t1) *(f4*)(row + 16 * t) = du[t];
+        }
+        __syncthreads();
+        const int nf4 = (t1 - t0) * 4;  // float4 per slot in this chunk
+        for (int idx = tid; idx < N * nf4; idx += kThreads) {
+          const int n = idx / nf4, f = 4 * (idx % nf4);
+          const uint32_t sg = mg.seg[n];
+          const int rs = sg >> 16, rl = sg & 0xffff;
+          f4 sp = splat(0.f), sq = splat(0.f);
+          for (int k = 0; k < rl; ++k) sp += *(const f4*)(pub + (rs + k) * PLD + f);
+          const int s0 = mg.soff[n], s1 = mg.soff[n + 1];
+          for (int k = s0; k < s1; ++k) sq += *(const f4*)(pub + (int)mg.sidx[k] * PLD + f);
+          *(f4*)(B2 + n * LD + 16 * t0 + f) = sp;  // dP_n
+          *(f4*)(B4 + n * LD + 16 * t0 + f) = sq;  // dQ_n
+        }
+        __syncthreads();
+      }
+      node_prefetch<HP>(pf, wb, Lw.At, wave, lane);
+    }
+    // dx <- dx*mask + sum_{e: i=n} ddiff_e - sum_{e: j=n} ddiff_e, in slot order
+    if (tid < N * 3) {
+      const int n = tid / 3, d = tid % 3;
+      const uint32_t sg = mg.seg[n];
+      const int rs = sg >> 16, rl = sg & 0xffff;
+      float acc = sm.dx[4 * n + d];
+      for (int k = 0; k < rl; ++k) acc += sm.trans[4 * (rs + k) + d];
+      const int s0 = mg.soff[n], s1 = mg.soff[n + 1];
+      for (int k = s0; k < s1; ++k) acc -= sm.trans[4 * (int)mg.sidx[k] + d];
+      sm.dx[4 * n + d] = acc;
+    }
+    // (f) dh += A^T dP + Bm^T dQ
+    vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l > 0 ? l - 1 : 0), HP), PredLayerW::vec_count(HP), tid);
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, &pf,
+                                   l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
+    __syncthreads();
+  }
+  (void)nslots;
+
+  // embedding backward (time column dropped), d0 backward, input masking
+  {
+    const float* ew = w + lay.emb_w();
+    if (tid < N * 3) {
+      const int n = tid / 3, d = tid % 3;
+      const uint32_t sg = mg.seg[n];
+      const int rs = sg >> 16, rl = sg & 0xffff;
+      float acc = sm.dx[4 * n + d];
+      for (int k = 0; k < rl; ++k) {
+        const int s = rs + k, j = ew_j(mg.edge[s]);
+        acc += 2.0f * (sm.x0[4 * n + d] - sm.x0[4 * j + d]) * sm.dd0[s];
+      }
+      const int s0 = mg.soff[n], s1 = mg.soff[n + 1];
+      for (int k = s0; k < s1; ++k) {
+        const int s = mg.sidx[k], i = ew_i(mg.edge[s]);
+        acc -= 2.0f * (sm.x0[4 * i + d] - sm.x0[4 * n + d]) * sm.dd0[s];
+      }
+      sGrad[n * D + d] = acc * mg.mask[n];
+    }
+    const float* msk = mg.mask;
+    small_dots<kThreads>(
+        N * F, HP, tid, [=](int qq, int f) { return ew[f * F1 + qq % F]; },
+        [=](int qq, int f) { return dh[(qq / F) * LD + f]; },
+        [=](int qq, float acc) { sGrad[(qq / F) * D + 3 + qq % F] = acc * msk[qq / F]; });
+  }
+  __syncthreads();
+}
+
+// unit-test entry: pred (and optionally grad into sGrad) for z in sZ
+template <int HP>
+__device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
+                                                float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
+                                                float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid) {
+  (void)sTmp; (void)sMean;
+  PredSmem<HP> sm;
+  sm.carve(net, mg.N, mg.S, pubx);
+  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid);
+  if (tid < W.K) {
+    if (pred_out) pred_out[tid] = sm.pred[tid];
+    sm.pred[16 + tid] = dpred ? dpred[tid] : 0.f;
+  }
+  __syncthreads();
+  if (want_grad) pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid);
+}
+
+// guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
+// phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
+// (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
+template <int HP>
+__device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
+                                                float* sTmp, float* sMean, float t_val, float sigma, const float* target_w,
+                                                float scale, float* pred_out, float readout_div, float* stash, int pubx,
+                                                int pub_ch, int tid, int phase, const float* dpred_ext) {
+  (void)sTmp;
+  const int N = mg.N, D = mg.D;
+  PredSmem<HP> sm;
+  sm.carve(net, N, mg.S, pubx);
+  if (phase != 2) pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid);
+  if (tid < W.K) {
+    if (pred_out && phase != 2) pred_out[tid] = sm.pred[tid];
+    // energy = scale * sum_b T(pred_b)  ->  d(energy)/dpred = scale * dT/dpred
+    sm.pred[16 + tid] = (phase == 2 ? dpred_ext[tid] : target_w[tid]) * scale;
+  }
+  __syncthreads();
+  if (phase == 1) return;
+  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid, phase == 2 ? sZ : nullptr);
+  // clip_coef = min(1, 10 / (||g||_2 + 1e-6)) over all N*(3+F) entries   (en_diffusion.py:905-909)
+  if (tid < 64) {
+    float s = 0.f;
+    for (int e = tid; e < N * D; e += 64) s += sGrad[e] * sGrad[e];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (tid == 0) sMean[4] = fminf(10.0f / (sqrtf(s) + 1e-6f), 1.0f);
+  }
+  __syncthreads();
+  const float coef = sMean[4];
+  for (int e = tid; e < N * D; e += kThreads) sGrad[e] *= coef;
+  __syncthreads();
+  if (tid < 3) {  // masked mean of the x part of the gradient (en_diffusion.py:911-919)
+    float s = 0.f, cnt = 0.f;
+    for (int n = 0; n < N; ++n) { s += sGrad[n * D + tid]; cnt += mg.mask[n]; }
+    sMean[tid] = s / fmaxf(cnt, 1.0f);
+  }
+  __syncthreads();
+  for (int e = tid; e < N * D; e += kThreads) {
+    const int n = e / D, d = e % D;
+    float gv = sGrad[e];
+    if (d < 3) gv = gv - sMean[d] * mg.mask[n];
+    sZ[e] = sZ[e] - sigma * gv;
+  }
+  __syncthreads();
+}
+
 }  // namespace w8
 }  // namespace gaudi
