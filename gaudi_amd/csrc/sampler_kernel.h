@@ -120,6 +120,103 @@ struct V4 {
   }
 };
 
+// ---- out-of-line phases of the 8-wave kernels.  Inlined into one 40k-instruction function, the denoiser, the predictor and
+// its reverse pass are register-allocated together and hipcc spills ~200 VGPRs whose reloads land next to the deep weight
+// prefetch queues (a scratch load shares the in-order vmcnt counter with them).  As separate functions each phase gets its
+// own allocation; the call passes sizes and global pointers only and the callee re-derives every LDS pointer from the
+// dynamic-LDS symbol itself, so LDS accesses keep their address space (ds_* instructions, not flat_*).
+struct Lds8 {
+  float *sZ, *sEps, *sNz, *sMask, *sMean, *net;
+  uint32_t *sEdge, *sSeg;
+  float* sEm;
+  uint16_t *sOff, *sIdx;
+};
+__device__ __forceinline__ Lds8 carve_lds8(float* smem, int N, int D, int S) {
+  Lds8 L;
+  float* base = smem;
+  L.sZ = base; base += align16(N * D);
+  L.sEps = base; base += align16(N * D);
+  L.sNz = base; base += align16(N * D);
+  L.sMask = base; base += align16(N);
+  L.sMean = base; base += 16;
+  L.sEdge = (uint32_t*)base; base += S;
+  L.sEm = base; base += S;
+  L.sSeg = (uint32_t*)base; base += align16(N);
+  L.sOff = (uint16_t*)base;
+  L.sIdx = L.sOff + (N + 1);
+  base += align16((N + 1 + S + 1) / 2);
+  L.net = base;
+  return L;
+}
+struct Graph8Args {
+  int N, D, S, NC, ntiles, pubx, pub_ch;
+};
+__device__ __forceinline__ w8::MolGraph graph8(const Lds8& L, const Graph8Args& a) {
+  w8::MolGraph mg;
+  mg.N = a.N; mg.D = a.D; mg.S = a.S; mg.NC = a.NC;
+  mg.ntiles = a.ntiles;
+  mg.rounds = (a.ntiles + w8::kWaves - 1) / w8::kWaves;
+  mg.pubx = a.pubx; mg.pub_ch = a.pub_ch;
+  mg.mask = L.sMask; mg.edge = L.sEdge; mg.em = L.sEm; mg.seg = L.sSeg; mg.soff = L.sOff; mg.sidx = L.sIdx;
+  return mg;
+}
+// Function arguments arrive in VGPRs: without these the callee treats every size, offset and buffer descriptor as
+// divergent (vector ALU address arithmetic, a waterfall loop around every buffer_load).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uni(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <class T>
+__device__ __forceinline__ T* uni(T* p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ Graph8Args uni(const Graph8Args& a) {
+  return Graph8Args{uni(a.N), uni(a.D), uni(a.S), uni(a.NC), uni(a.ntiles), uni(a.pubx), uni(a.pub_ch)};
+}
+__device__ __forceinline__ EdmDev uni(const EdmDev& w) {
+  return EdmDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.L), uni(w.S), uni(w.attention), uni(w.use_tanh), uni(w.coords_range),
+                uni(w.norm_constant), uni(w.normf)};
+}
+__device__ __forceinline__ PredDev uni(const PredDev& w) {
+  return PredDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.K), uni(w.L), uni(w.attention), uni(w.use_tanh), uni(w.coords_range_layer)};
+}
+#ifndef GAUDI_STAMPS
+template <int HP>
+__device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, float t_val_) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const EdmDev W = uni(W_);
+  const Graph8Args ga = uni(ga_);
+  const float t_val = uni(t_val_);
+  const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
+  const w8::MolGraph mg = graph8(L, ga);
+  w8::NetSmem<HP> sm;
+  sm.carve(L.net, ga.N, ga.S);
+  w8::edm_forward<HP>(W, mg, sm, L.sZ, L.sEps, L.sMean, t_val, (int)threadIdx.x);
+}
+template <int HP>
+__device__ __attribute__((noinline)) void guide8_call(PredDev W_, Graph8Args ga_, float t_val_, float sigma_,
+                                                      const float* target_w_, float scale_, float* pred_out_, float readout_div_,
+                                                      float* stash_, int phase_, const float* dpred_ext_) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const PredDev W = uni(W_);
+  const Graph8Args ga = uni(ga_);
+  const float t_val = uni(t_val_), sigma = uni(sigma_), scale = uni(scale_), readout_div = uni(readout_div_);
+  const float* target_w = uni(target_w_);
+  float* pred_out = uni(pred_out_);
+  float* stash = uni(stash_);
+  const int phase = uni(phase_);
+  const float* dpred_ext = uni(dpred_ext_);
+  const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
+  const w8::MolGraph mg = graph8(L, ga);
+  w8::guidance_update<HP>(W, mg, L.net, L.sZ, L.sEps, L.sNz, L.sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
+                          ga.pubx, ga.pub_ch, (int)threadIdx.x, phase, dpred_ext);
+}
+#endif
+
 struct V8 {
   static constexpr int kThreads = w8::kThreads;
   using Graph = w8::MolGraph;
@@ -149,27 +246,40 @@ struct V8 {
     mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg; mg.soff = sOff; mg.sidx = sIdx;
     return base;
   }
+  __device__ __forceinline__ static Graph8Args gargs(const Graph& mg) {
+    return Graph8Args{mg.N, mg.D, mg.S, mg.NC, mg.ntiles, mg.pubx, mg.pub_ch};
+  }
   template <int HP>
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
                                              float* sMean, float t_val, int tid STAMP_DECL) {
+#ifdef GAUDI_STAMPS
     w8::NetSmem<HP> sm;
     sm.carve(net, mg.N, mg.S);
     w8::edm_forward<HP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
+#else
+    (void)net; (void)sZ; (void)sEps; (void)sMean; (void)tid;
+    edm8_call<HP>(W, gargs(mg), t_val);
+#endif
   }
   template <int HP>
   __device__ __forceinline__ static void guide(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
                                                const float* dpred_ext) {
+#ifdef GAUDI_STAMPS
     w8::guidance_update<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
-                            mg.pubx, mg.pub_ch, tid, phase, dpred_ext);
+                            mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext);
+#else
+    (void)net; (void)sZ; (void)sGrad; (void)sTmp; (void)sMean; (void)tid;
+    guide8_call<HP>(W, gargs(mg), t_val, sigma, target_w, scale, pred_out, readout_div, stash, phase, dpred_ext);
+#endif
   }
   template <int HP>
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
                                                     float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                     float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
     w8::predictor_entry<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
-                            mg.pub_ch, tid);
+                            mg.pub_ch, tid STAMP_ARGS);
   }
 };
 

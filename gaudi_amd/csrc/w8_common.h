@@ -259,15 +259,18 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
       xb[j] = Wb >= 0 ? sXb + nclamp * LD + 4 * g - 16 * T : xa[j];  // indexed by the global chunk number
     }
     auto xin = [&](int j, int cc) { return *(const f4*)((cc < T ? xa[j] : xb[j]) + 16 * cc); };
-    // two accumulators per output tile (even / odd K chunks): independent MFMA chains even when the wave owns one tile
-    f4 accE[NT][NTW], accO[NT][NTW];
+    // One accumulator per (column tile, output tile); a wave that owns a single output tile of a single column tile gets a
+    // second one for the odd K chunks (a dependent accumulate needs 40 cycles, issue is every 32).
+    constexpr bool kSplit = NT * NTW == 1;
+    constexpr int NA = kSplit ? 2 : 1;
+    f4 acc[NA][NT][NTW];
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
       const f4 b = sBias != nullptr ? *(const f4*)(sBias + (toff[u] >> 4) + 4 * g) : splat(0.f);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        accE[j][u] = b;
-        accO[j][u] = splat(0.f);
+        acc[0][j][u] = b;
+        if (kSplit) acc[NA - 1][j][u] = splat(0.f);
       }
     }
     f4 a0[NTW], a1[NTW], b0[NTW], b1[NTW];  // ping-pong sets of two K chunks each (roles swapped by unrolling)
@@ -281,16 +284,34 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
         a1[u] = ldw4n(wb, chunk(1) + toff[u], lane);
       }
     }
-    auto mm2 = [&](const f4 (&wE)[NTW], const f4 (&xE)[NT], const f4 (&wO)[NTW], const f4 (&xO)[NT]) {
+    // two K chunks: k-step outermost over the independent accumulators
+    auto mm2 = [&](const f4 (&wE)[NTW], int ce, const f4 (&wO)[NTW], int co) {
+      f4 xE[NT], xO[NT];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int j = 0; j < NT; ++j) {
+        xE[j] = xin(j, ce);
+        xO[j] = xin(j, co);
+      }
+      if (kSplit) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int q = 0; q < 4; ++q) {
+          acc[0][0][0] = mfma1(wE[0][q], xE[0][q], acc[0][0][0]);
+          acc[NA - 1][0][0] = mfma1(wO[0][q], xO[0][q], acc[NA - 1][0][0]);
+        }
+      } else {
 #pragma unroll
-          for (int u = 0; u < NTW; ++u) {
-            accE[j][u] = mfma1(wE[u][q], xE[j][q], accE[j][u]);
-            accO[j][u] = mfma1(wO[u][q], xO[j][q], accO[j][u]);
-          }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) acc[0][j][u] = mfma1(wE[u][q], xE[j][q], acc[0][j][u]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) acc[0][j][u] = mfma1(wO[u][q], xO[j][q], acc[0][j][u]);
+      }
     };
     auto mm1 = [&](const f4 (&w)[NTW], int cc) {
 #pragma unroll
@@ -299,27 +320,19 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
         for (int j = 0; j < NT; ++j) {
           const f4 x = xin(j, cc);
 #pragma unroll
-          for (int u = 0; u < NTW; ++u) accE[j][u] = mfma1(w[u][q], x[q], accE[j][u]);
+          for (int u = 0; u < NTW; ++u) acc[0][j][u] = mfma1(w[u][q], x[q], acc[0][j][u]);
         }
     };
     const int main_end = KT / 4 * 4;
 #pragma unroll 1
     for (int cc = 0; cc < main_end; cc += 4) {
-      f4 x0[NT], x1[NT], x2[NT], x3[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        x0[j] = xin(j, cc);
-        x1[j] = xin(j, cc + 1);
-        x2[j] = xin(j, cc + 2);
-        x3[j] = xin(j, cc + 3);
-      }
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {
         b0[u] = ldw4n(wb, chunk(cc + 2) + toff[u], lane);
         b1[u] = ldw4n(wb, chunk(cc + 3) + toff[u], lane);
       }
-      __builtin_amdgcn_sched_barrier(0);  // LDS reads + set B loads | MFMAs on set A | set A loads | MFMAs on set B
-      mm2(a0, x0, a1, x1);
+      __builtin_amdgcn_sched_barrier(0);  // set B loads | LDS reads + MFMAs on set A | set A loads | LDS reads + MFMAs on set B
+      mm2(a0, cc, a1, cc + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {
@@ -327,7 +340,7 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
         a1[u] = ldw4n(wb, chunk(cc + 5) + toff[u], lane);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mm2(b0, x2, b1, x3);
+      mm2(b0, cc + 2, b1, cc + 3);
       __builtin_amdgcn_sched_barrier(0);
     }
     // tail: KT % 4 chunks (0..3), the first two already in a0 / a1
@@ -348,7 +361,7 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
         const int t = wave + kWaves * u;
         const int nd = node[j];
         if (nd < N) {
-          f4 y = accE[j][u] + accO[j][u];
+          f4 y = kSplit ? acc[0][j][u] + acc[NA - 1][j][u] : acc[0][j][u];
           float* dst = sY + nd * LD + 16 * t + 4 * g;
           if (gPre != nullptr) *(f4*)(gPre + nd * HP + 16 * t + 4 * g) = y;
           if (EPI == EPI_SILU) y = silu4(y);

@@ -67,7 +67,7 @@ __host__ __device__ inline int pub_chunk_tiles(int S, long long avail_floats, in
 // ---------------------------------------------------------------------------------------------
 template <int HP>
 __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* sZ,
-                                             float t_val, float* stash, float readout_div, int tid) {
+                                             float t_val, float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -121,20 +121,25 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 3 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
     compute_geo(sm, mg, 1.0f, tid, false);  // gcl.py:308-316
     __syncthreads();
+    STAMP(ST_STAGE);
     node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Bm);
     node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1h);
+    STAMP(ST_NODE);
     __syncthreads();
+    STAMP(ST_BARRIER);
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // P, Q -> stash
       const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
       ((f4*)st)[idx] = *(const f4*)(p + n * LD + f);
       ((f4*)(st + N * HP))[idx] = *(const f4*)(q + n * LD + f);
     }
     {
+      STAMP(ST_STASH);
       const TileCols tc = load_tile(mg, 0, wave, c);
       const f4 gg = sm.geo[tc.slot];
       f4 acc[T];
       edge_gemm_pq<HP>(acc, ring, wb, Lw.W2, last ? -1 : Lw.Wc1, Lw.b2, Lw.cr, Lw.cd, p + tc.i * LD + 4 * g,
-                       q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane);
+                       q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
+      STAMP(ST_EDGE);
       const int tile = tc.slot >> 4;
       if (tc.active) {
         {  // v (pre-activation of m) -> edge stash for the reverse pass
@@ -157,9 +162,11 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         for (int t = 0; t < T; ++t) acc[t] = acc[t] * sc;  // e_ij (gcl.py:231-237)
         scatter_runs<HP>(acc, tc, agg, agg1, g);
       }
+      STAMP(ST_EDGE_EPI);
       if (!last) {  // coord_model (gcl.py:252-278): trans = dhat * tanh(wc2 . silu(Wc1 e + bc1)) * R * mask
         f4 cp[T];
         edge_gemm_regs<HP>(cp, acc, ring, wb, Lw.Wc1, lay.layer(l + 1) + 2 * HP * HP, Lw.bc1, nullptr, tc.active, wave, lane);
+        STAMP(ST_EDGE);
         if (tc.active) {
           f4* sc = (f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
 #pragma unroll
@@ -171,22 +178,29 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           const float tau = (W.use_tanh ? tanhf(phi) * W.coords_range_layer : phi) * tc.mk;
           if (g == 0) *(f4*)(sm.trans + 4 * tc.slot) = (f4){gg[1] * tau, gg[2] * tau, gg[3] * tau, 0.f};
         }
+        STAMP(ST_EDGE_EPI);
       }
     }
     __syncthreads();
+    STAMP(ST_BARRIER);
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = partial 0 + partial 1
       const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
       *(f4*)(agg + n * LD + f) = *(const f4*)(agg + n * LD + f) + *(const f4*)(agg1 + n * LD + f);
     }
     __syncthreads();
+    STAMP(ST_MISC);
     node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Wn2,
                                   st + 2 * N * HP /* npre -> stash */);
+    STAMP(ST_NODE);
     __syncthreads();
+    STAMP(ST_BARRIER);
     vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), PredLayerW::vec_count(HP), tid);
     node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, &pf,
                                            l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
+    STAMP(ST_NODE);
     __syncthreads();
+    STAMP(ST_BARRIER);
   }
   // readout: mean over the PADDED node count of (embedding_out(h) * mask)   (models.py:553-557, :457)
   {
@@ -216,7 +230,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 // ---------------------------------------------------------------------------------------------
 template <int HP>
 __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
-                                              float* sGrad, float readout_div, int pub_ch, int tid, const float* sZin = nullptr) {
+                                              float* sGrad, float readout_div, int pub_ch, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -290,6 +304,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     }
     __syncthreads();
     compute_geo(sm, mg, 1.0f, tid, false);
+    STAMP(ST_STASH);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
     node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1ht);
     __syncthreads();
@@ -297,6 +312,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     node_gemm<HP, EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1at);
     node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, &pf);
     __syncthreads();
+    STAMP(ST_BWD_NODE);
     // (e) edge pass: MLP chain backward for the wave's tile, then du of all slots is published CH feature tiles at a time
     //     and every thread sums one (node, 4 features) of dP_i = sum_j du_ij (receiver runs) and dQ_j = sum_i du_ij
     //     (sender lists) in slot order -- no atomics, fixed order
@@ -336,8 +352,10 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 #pragma unroll
             for (int t = 0; t < T; ++t) cp[t] = splat(0.f);
           }
+          STAMP(ST_B_DCP);
           edge_gemm_regs<HP>(de, cp, ring, wb, Lw.Wc1t, Lw.W2t, nullptr, B0 + tc.i * LD /* + dagg_i (agg_i = sum_j e_ij) */,
                              tc.active, wave, lane);
+          STAMP(ST_B_DE);
         } else {
 #pragma unroll
           for (int t = 0; t < T; ++t) de[t] = *(const f4*)(B0 + tc.i * LD + 16 * t + 4 * g);
@@ -358,9 +376,11 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           for (int t = 0; t < T; ++t)  // dv = (de*a*mask + ds*wa) * silu'(v)
             de[t] = (de[t] * am + *(const f4*)(Lw.wa + 16 * t + 4 * g) * ds) * dsilu4(ve[t]);
         }
+        STAMP(ST_B_DV);
         // next edge GEMM of the chain: Wc1^T of layer l-1 (W2^T when that layer is ... never the last), none after layer 0
         edge_gemm_regs<HP>(du, de, ring, wb, Lw.W2t, l > 0 ? lay.layer(l - 1) + 10 * HP * HP : -1, nullptr, nullptr, tc.active,
                            wave, lane);  // dt1
+        STAMP(ST_B_DT1);
       }
       if (tc.active) {
         // du = dt1 * silu'(u) ; dr = cr . du ; dd0 = cd . du
@@ -389,6 +409,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           sm.dd0[tc.slot] += dd0v;
         }
       }
+      STAMP(ST_B_DU);
       __syncthreads();  // every wave is done with P (B2), Q (B1) and dagg (B0): the publish buffer may overwrite B0 / B1
       for (int t0 = 0; t0 < T; t0 += pub_ch) {
         const int t1 = t0 + pub_ch < T ? t0 + pub_ch : T;
@@ -414,6 +435,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         __syncthreads();
       }
       node_prefetch<HP>(pf, wb, Lw.At, wave, lane);
+      STAMP(ST_BWD_COL);
     }
     // dx <- dx*mask + sum_{e: i=n} ddiff_e - sum_{e: j=n} ddiff_e, in slot order
     if (tid < N * 3) {
@@ -431,6 +453,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, &pf,
                                    l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
+    STAMP(ST_BWD_NODE);
   }
   (void)nslots;
 
@@ -466,17 +489,17 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 template <int HP>
 __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
-                                                float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid) {
+                                                float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid STAMP_DECL) {
   (void)sTmp; (void)sMean;
   PredSmem<HP> sm;
   sm.carve(net, mg.N, mg.S, pubx);
-  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid);
+  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
     if (pred_out) pred_out[tid] = sm.pred[tid];
     sm.pred[16 + tid] = dpred ? dpred[tid] : 0.f;
   }
   __syncthreads();
-  if (want_grad) pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid);
+  if (want_grad) pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS);
 }
 
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
@@ -486,12 +509,12 @@ template <int HP>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, float sigma, const float* target_w,
                                                 float scale, float* pred_out, float readout_div, float* stash, int pubx,
-                                                int pub_ch, int tid, int phase, const float* dpred_ext) {
+                                                int pub_ch, int tid STAMP_DECL, int phase, const float* dpred_ext) {
   (void)sTmp;
   const int N = mg.N, D = mg.D;
   PredSmem<HP> sm;
   sm.carve(net, N, mg.S, pubx);
-  if (phase != 2) pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid);
+  if (phase != 2) pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
     if (pred_out && phase != 2) pred_out[tid] = sm.pred[tid];
     // energy = scale * sum_b T(pred_b)  ->  d(energy)/dpred = scale * dT/dpred
@@ -499,7 +522,7 @@ __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph
   }
   __syncthreads();
   if (phase == 1) return;
-  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid, phase == 2 ? sZ : nullptr);
+  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
   // clip_coef = min(1, 10 / (||g||_2 + 1e-6)) over all N*(3+F) entries   (en_diffusion.py:905-909)
   if (tid < 64) {
     float s = 0.f;
