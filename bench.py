@@ -142,6 +142,23 @@ def graph_meta(nm, em):
     return npairs, ncols
 
 
+def graph_meta8(nm, em):
+    """16-slot tiles per molecule and node columns of the 8-wave kernels."""
+    import ctypes as C
+    from gaudi_amd import _lib
+    lib = _lib.load_library()
+    B, N = nm.shape
+    slots = C.c_int32()
+    ntiles = np.zeros(B, np.int32)
+    ncols = np.zeros(B, np.int32)
+    i32 = C.POINTER(C.c_int32)
+    rc = lib.gaudi_host_graph_meta8(B, N, _lib.fptr(np.ascontiguousarray(nm, np.float32)),
+                                    _lib.fptr(np.ascontiguousarray(em, np.float32)), C.byref(slots), None,
+                                    ntiles.ctypes.data_as(i32), None, None, None, None, None, 0, ncols.ctypes.data_as(i32))
+    assert rc == 0, rc
+    return ntiles, ncols
+
+
 def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, backend, T, K=5):
     """Time `steps` complete sampling calls of one workload; returns the contract fields + roofline of its kernel."""
     import torch
@@ -223,8 +240,9 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     # the same number rocprofv3's SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 reports) / average launch duration (HIP events on the
     # handle's stream).  `useful_*` = the factorised algorithm on live edges and unpadded features (what the issued work
     # is worth); `as_written_*` = the reference's dense concat+Linear formulation, a throughput-equivalent only.
-    npairs, ncols = graph_meta(nm, em)
-    variant = os.environ.get("GAUDI_KERNEL_VARIANT_FOR_FLOPS", "w4")
+    variant = "w%d" % eng.kernel_variant()[1]
+    units, ncols = graph_meta8(nm, em) if variant == "w8" else graph_meta(nm, em)
+    npairs = units
     mfma_step = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, pargs if guided else None, variant) for b in range(B))
     useful_step = B * flops.step_flops_useful(live_edges, live_nodes, F, eargs, pargs if guided else None, K)
     written_step = B * flops.step_flops_as_written(N, F, eargs, pargs if guided else None, K)
@@ -263,7 +281,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                    "max_graph_nodes": "22 at these hidden sizes (one molecule's working set must fit 160 KiB of LDS)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                      "frac": frac, "traffic": traffic,
-                     "kernel": "sampler_kernel<192,208>" if guided else "sampler_kernel<192,0>",
+                     "kernel": ("sampler_kernel_v<V8,192,%s>" if variant == "w8" else "sampler_kernel_v<V4,192,%s>") % ("208" if guided else "0"),
+                     "kernel_variant": "8 waves per molecule (two per SIMD)" if variant == "w8" else "4 waves per molecule",
                      "flops_basis": "issued v_mfma_f32_16x16x4_f32 x 2048 FLOP (padding included), counted from the kernel's "
                                     "loop structure; = SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 x 2048 in profiles/",
                      "issued_gflop_per_molecule_step": 2048.0 * mfma_step / B / 1e9,

@@ -85,6 +85,10 @@ EXPORTS = {
     "gaudi_set_steps_per_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "gaudi_set_readout_nodes": (C.c_int, [C.c_void_p, C.c_int]),
     "gaudi_set_fix_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
+    "gaudi_host_graph_meta8": (C.c_int, [C.c_int, C.c_int, FP, FP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), FP,
+                                         C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_int32, C.POINTER(C.c_int32)]),
+    "gaudi_kernel_variant": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 _lib = None

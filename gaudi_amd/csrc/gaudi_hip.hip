@@ -57,7 +57,7 @@ struct gaudi_handle {
       d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols, d_soff,
       d_sidx;
   int steps_per_launch = 25;
-  int variant = 4;            // 4 = one wave per SIMD (sampler_kernel), 8 = two waves per SIMD (sampler_kernel8)
+  int variant = 8;            // 8 = two waves per SIMD (sampler_kernel8, default), 4 = one wave per SIMD (GAUDI_WAVES=4)
   int run_variant = 4;        // what the CURRENT call runs on (an 8-wave handle falls back to 4 waves for graphs that do not fit)
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
   long long fix_key = 0;      // global sample index whose Philox stream is shared
@@ -707,7 +707,8 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return GAUDI_E_HIP;
   gaudi_handle* h = new gaudi_handle();
   h->device = device;
-  if (const char* v = getenv("GAUDI_WAVES")) h->variant = atoi(v) == 8 ? 8 : 4;
+  if (const char* v = getenv("GAUDI_WAVES")) h->variant = atoi(v) == 4 ? 4 : 8;
+  h->run_variant = h->variant;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return GAUDI_E_HIP;
@@ -1256,6 +1257,36 @@ int gaudi_host_graph_meta(int B, int N, const float* node_mask, const float* edg
     if (edges_out) std::memcpy(edges_out, M.edges.data(), sizeof(uint32_t) * M.edges.size());
     if (emask_out) std::memcpy(emask_out, M.emask.data(), sizeof(float) * M.emask.size());
   }
+  return GAUDI_OK;
+}
+
+int gaudi_host_graph_meta8(int B, int N, const float* node_mask, const float* edge_mask, int32_t* slots_out,
+                           int32_t* order_out, int32_t* ntiles_out, uint32_t* seg_out, uint32_t* edges_out, float* emask_out,
+                           uint16_t* soff_out, uint16_t* sidx_out, int32_t edges_capacity, int32_t* ncols_out) {
+  if (B <= 0 || N <= 0 || !edge_mask || !slots_out) return GAUDI_E_INVALID;
+  Meta8 M;
+  std::string err;
+  const int rc = build_meta8(B, N, node_mask, edge_mask, M, err);
+  if (rc) return rc;
+  *slots_out = M.S;
+  if (order_out) std::memcpy(order_out, M.order.data(), sizeof(int) * B);
+  if (ntiles_out) std::memcpy(ntiles_out, M.ntiles.data(), sizeof(int) * B);
+  if (seg_out) std::memcpy(seg_out, M.seg.data(), sizeof(uint32_t) * B * N);
+  if (ncols_out) std::memcpy(ncols_out, M.ncols.data(), sizeof(int) * B);
+  if (soff_out) std::memcpy(soff_out, M.soff.data(), sizeof(uint16_t) * M.soff.size());
+  if (edges_out || emask_out || sidx_out) {
+    if ((size_t)edges_capacity < M.edges.size()) return GAUDI_E_CAPACITY;
+    if (edges_out) std::memcpy(edges_out, M.edges.data(), sizeof(uint32_t) * M.edges.size());
+    if (emask_out) std::memcpy(emask_out, M.emask.data(), sizeof(float) * M.emask.size());
+    if (sidx_out) std::memcpy(sidx_out, M.sidx.data(), sizeof(uint16_t) * M.sidx.size());
+  }
+  return GAUDI_OK;
+}
+
+int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* last_call) {
+  if (!h) return GAUDI_E_INVALID;
+  if (configured) *configured = h->variant;
+  if (last_call) *last_call = h->run_variant;
   return GAUDI_OK;
 }
 

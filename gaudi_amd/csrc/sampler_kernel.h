@@ -197,23 +197,30 @@ __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, f
   sm.carve(L.net, ga.N, ga.S);
   w8::edm_forward<HP>(W, mg, sm, L.sZ, L.sEps, L.sMean, t_val, (int)threadIdx.x);
 }
+// the predictor's forward and reverse passes are separate functions too (the reverse pass holds three 52-register
+// operand sets at its peak; allocated together with the forward it spilled twice as much)
 template <int HP>
-__device__ __attribute__((noinline)) void guide8_call(PredDev W_, Graph8Args ga_, float t_val_, float sigma_,
-                                                      const float* target_w_, float scale_, float* pred_out_, float readout_div_,
-                                                      float* stash_, int phase_, const float* dpred_ext_) {
+__device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args ga_, float t_val_, float* stash_, float readout_div_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PredDev W = uni(W_);
   const Graph8Args ga = uni(ga_);
-  const float t_val = uni(t_val_), sigma = uni(sigma_), scale = uni(scale_), readout_div = uni(readout_div_);
-  const float* target_w = uni(target_w_);
-  float* pred_out = uni(pred_out_);
-  float* stash = uni(stash_);
-  const int phase = uni(phase_);
-  const float* dpred_ext = uni(dpred_ext_);
   const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
   const w8::MolGraph mg = graph8(L, ga);
-  w8::guidance_update<HP>(W, mg, L.net, L.sZ, L.sEps, L.sNz, L.sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
-                          ga.pubx, ga.pub_ch, (int)threadIdx.x, phase, dpred_ext);
+  w8::PredSmem<HP> sm;
+  sm.carve(L.net, ga.N, ga.S, ga.pubx);
+  w8::pred_forward<HP>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
+}
+template <int HP>
+__device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args ga_, float* stash_, float readout_div_, int resume_) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const PredDev W = uni(W_);
+  const Graph8Args ga = uni(ga_);
+  const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
+  const w8::MolGraph mg = graph8(L, ga);
+  w8::PredSmem<HP> sm;
+  sm.carve(L.net, ga.N, ga.S, ga.pubx);
+  w8::pred_backward<HP>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
+                        uni(resume_) ? L.sZ : nullptr);
 }
 #endif
 
@@ -270,8 +277,14 @@ struct V8 {
     w8::guidance_update<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
                             mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext);
 #else
-    (void)net; (void)sZ; (void)sGrad; (void)sTmp; (void)sMean; (void)tid;
-    guide8_call<HP>(W, gargs(mg), t_val, sigma, target_w, scale, pred_out, readout_div, stash, phase, dpred_ext);
+    (void)sTmp;
+    w8::PredSmem<HP> sm;
+    sm.carve(net, mg.N, mg.S, mg.pubx);
+    if (phase != 2) pred_fwd8_call<HP>(W, gargs(mg), t_val, stash, readout_div);
+    w8::guidance_seed<HP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
+    if (phase == 1) return;
+    pred_bwd8_call<HP>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0);
+    w8::guidance_apply(mg, sZ, sGrad, sMean, sigma, tid);
 #endif
   }
   template <int HP>

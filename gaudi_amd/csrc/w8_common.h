@@ -285,13 +285,7 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
       }
     }
     // two K chunks: k-step outermost over the independent accumulators
-    auto mm2 = [&](const f4 (&wE)[NTW], int ce, const f4 (&wO)[NTW], int co) {
-      f4 xE[NT], xO[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        xE[j] = xin(j, ce);
-        xO[j] = xin(j, co);
-      }
+    auto mm2 = [&](const f4 (&wE)[NTW], const f4 (&xE)[NT], const f4 (&wO)[NTW], const f4 (&xO)[NT]) {
       if (kSplit) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -326,13 +320,21 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
     const int main_end = KT / 4 * 4;
 #pragma unroll 1
     for (int cc = 0; cc < main_end; cc += 4) {
+      f4 x0[NT], x1[NT], x2[NT], x3[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        x0[j] = xin(j, cc);
+        x1[j] = xin(j, cc + 1);
+        x2[j] = xin(j, cc + 2);
+        x3[j] = xin(j, cc + 3);
+      }
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {
         b0[u] = ldw4n(wb, chunk(cc + 2) + toff[u], lane);
         b1[u] = ldw4n(wb, chunk(cc + 3) + toff[u], lane);
       }
-      __builtin_amdgcn_sched_barrier(0);  // set B loads | LDS reads + MFMAs on set A | set A loads | LDS reads + MFMAs on set B
-      mm2(a0, cc, a1, cc + 1);
+      __builtin_amdgcn_sched_barrier(0);  // LDS reads + set B loads | MFMAs on set A | set A loads | MFMAs on set B
+      mm2(a0, x0, a1, x1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {
@@ -340,7 +342,7 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
         a1[u] = ldw4n(wb, chunk(cc + 5) + toff[u], lane);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mm2(b0, cc + 2, b1, cc + 3);
+      mm2(b0, x2, b1, x3);
       __builtin_amdgcn_sched_barrier(0);
     }
     // tail: KT % 4 chunks (0..3), the first two already in a0 / a1

@@ -502,6 +502,11 @@ __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph
   if (want_grad) pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS);
 }
 
+template <int HP>
+__device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP>& sm, const float* target_w, float scale,
+                                              float* pred_out, int tid, int phase, const float* dpred_ext);
+__device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, float* sGrad, float* sMean, float sigma, int tid);
+
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 // phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
 // (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
@@ -515,14 +520,26 @@ __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph
   PredSmem<HP> sm;
   sm.carve(net, N, mg.S, pubx);
   if (phase != 2) pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
+  guidance_seed<HP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
+  if (phase == 1) return;
+  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
+  guidance_apply(mg, sZ, sGrad, sMean, sigma, tid);
+}
+
+// pred -> pred_out (split mode) and the seed of the reverse pass: d(energy)/dpred = scale * dT/dpred
+template <int HP>
+__device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP>& sm, const float* target_w, float scale,
+                                              float* pred_out, int tid, int phase, const float* dpred_ext) {
   if (tid < W.K) {
     if (pred_out && phase != 2) pred_out[tid] = sm.pred[tid];
-    // energy = scale * sum_b T(pred_b)  ->  d(energy)/dpred = scale * dT/dpred
     sm.pred[16 + tid] = (phase == 2 ? dpred_ext[tid] : target_w[tid]) * scale;
   }
   __syncthreads();
-  if (phase == 1) return;
-  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
+}
+
+// clip, project, apply (en_diffusion.py:905-920)
+__device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, float* sGrad, float* sMean, float sigma, int tid) {
+  const int N = mg.N, D = mg.D;
   // clip_coef = min(1, 10 / (||g||_2 + 1e-6)) over all N*(3+F) entries   (en_diffusion.py:905-909)
   if (tid < 64) {
     float s = 0.f;

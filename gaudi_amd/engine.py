@@ -307,5 +307,11 @@ class Engine:
         self._check(self.lib.gaudi_set_fix_noise(self.h, int(bool(enable)), int(key_sample)), "gaudi_set_fix_noise")
         self.fix_noise = bool(enable)
 
+    def kernel_variant(self):
+        """-> (configured, last_call): 8 = eight waves per molecule (default), 4 = four waves (GAUDI_WAVES=4 or fallback)."""
+        a, b = C.c_int32(), C.c_int32()
+        self._check(self.lib.gaudi_kernel_variant(self.h, C.byref(a), C.byref(b)), "gaudi_kernel_variant")
+        return a.value, b.value
+
     def set_steps_per_launch(self, k: int):
         self._check(self.lib.gaudi_set_steps_per_launch(self.h, int(k)), "gaudi_set_steps_per_launch")

@@ -76,8 +76,8 @@ def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
     else:
         waves, tiles16 = 8, int(edge_units)
 
-    def node(T, kt):  # K chunks x 4 k-steps x (tile slots of the busiest wave x waves: idle slots recompute a tile)
-        return kt * 4 * (-(-T // waves)) * waves * nt
+    def node(T, kt):  # K chunks x 4 k-steps x output tiles (the 4-wave kernels recompute a tile in idle tile slots)
+        return kt * 4 * ((-(-T // waves)) * waves if variant == "w4" else T) * nt
 
     def edge(T):  # one 16-edge tile through one T x T matrix
         return T * T * 4

@@ -206,6 +206,20 @@ int gaudi_host_schedule(int T, float noise_power, float noise_precision, float* 
 int gaudi_host_graph_meta(int B, int N, const float* node_mask, const float* edge_mask, int32_t* ew_out,
                           int32_t* order_out, int32_t* npairs_out, uint32_t* seg_out, uint32_t* edges_out,
                           float* emask_out, int32_t edges_capacity, int32_t* ncols_out /* [B] or NULL */);
+/* The metadata of the 8-wave kernels (default): per molecule ONE flat slot list = its live edges sorted by receiving node
+ * (then sending node), padded to whole 16-slot tiles (tile tau -> wave tau & 7 of the workgroup, round tau >> 3).
+ * slots_out = slot capacity of the batch (multiple of 16); ntiles [B]; seg [B][N] = first_slot << 16 | run length of the
+ * edges RECEIVED by a node; edge words [B][slots] = i | j << 8 | run_start_column << 16 | run_end << 20 | partial << 21
+ * (a node's run touches at most two tiles; partial = 1 for its second tile) with their mask values; soff [B][N+1] / sidx
+ * [B][slots] = CSR lists of the slots whose SENDING node is n (ascending), which the reverse pass sums over. */
+int gaudi_host_graph_meta8(int B, int N, const float* node_mask, const float* edge_mask, int32_t* slots_out,
+                           int32_t* order_out, int32_t* ntiles_out, uint32_t* seg_out, uint32_t* edges_out, float* emask_out,
+                           uint16_t* soff_out, uint16_t* sidx_out, int32_t edges_capacity, int32_t* ncols_out);
+/* Kernel family of a handle: 8 = eight waves per molecule, two per SIMD (default); 4 = four waves, one per SIMD
+ * (environment GAUDI_WAVES=4 at gaudi_create, and the per-call fallback of an 8-wave handle for graphs beyond the 8-wave
+ * kernels' limits: more than 128 edge slots with guidance, a node with more than 32 live edges, LDS).  last_call = what the
+ * most recent call ran on. */
+int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
 /* Tile packing of a weight block W[o][col0+k] (o,k < H, row stride ldw) into [HP/16][HP/16][16][16]
  * (k-chunk major), optionally transposed: the layout every GEMM of the kernels streams. */
 int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, const float* W, float* packed_out);

@@ -51,8 +51,14 @@ def test_fullsize_guided_step_vs_oracle(O, dataset, nodes, w):
     w = np.asarray(w, np.float32)
     for s in (999, 400, 0):
         got = eng.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+        # amplified coordinate heads + 1/alpha_{t|s} make this step sensitive to rounding: at s = 999 the fp32 oracle itself
+        # sits 5.9e-5 (element-wise) from its own float64 evaluation, the kernel 4.4e-5, and the two fp32 results 1.0e-4
+        # from each other.  The 1e-4 bar is therefore applied against the float64 evaluation of the same restatement
+        # (what both approximate); against the fp32 oracle the two rounding errors add up.
+        want64 = O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6, dtype=np.float64)
+        assert rel_err(got, want64) < TOL, s
         want = O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6)
-        assert rel_err(got, want) < TOL, s
+        assert rel_err(got, want) < 2 * TOL and max_norm_err(got, want) < TOL, s
         got_u = eng.step(s, z, nm, em, eps)
         assert rel_err(got_u, O.step_unguided(esd, eargs, gamma, s, z, nm, em, eps)) < TOL, s
     eng.close()

@@ -1,0 +1,97 @@
+"""Both kernel families behind the same ABI: the 8-wave kernels (two waves per SIMD, default) and the 4-wave kernels
+(GAUDI_WAVES=4, and the per-call fallback of an 8-wave handle).  The whole GPU suite runs on the default; the core parity
+tests are repeated here on the 4-wave family, and the fallback rule is exercised."""
+import numpy as np
+import pytest
+
+from gaudi_amd import synth
+from tests import test_gpu_parity as P
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def waves4(monkeypatch):
+    monkeypatch.setenv("GAUDI_WAVES", "4")
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import gaudi_oracle
+    return gaudi_oracle
+
+
+def test_default_is_eight_waves_and_env_selects_four(monkeypatch, O):
+    from gaudi_amd.engine import Engine
+    eargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=10)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=3)
+    nm, em = O.build_masks([5, 7], 7, False)
+    z = np.random.default_rng(0).standard_normal((2, 7, 4)).astype(np.float32) * nm
+    t = np.array([0.3, 0.6], np.float32)
+    outs = []
+    for env, want in ((None, 8), ("4", 4), ("8", 8)):
+        if env is None:
+            monkeypatch.delenv("GAUDI_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("GAUDI_WAVES", env)
+        eng = Engine(0)
+        eng.load_edm(eargs, esd)
+        outs.append(eng.phi(z, t, nm, em))
+        assert eng.kernel_variant() == (want, want)
+        eng.close()
+    # the two families sum in different orders: equal to rounding, both equal to the oracle at 1e-4
+    want = O.edm_phi(esd, eargs, z, t, nm, em)
+    assert rel_err(outs[0], want) < 1e-4 and rel_err(outs[1], want) < 1e-4
+    assert np.array_equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("name", ["cata_tiny_amp", "hetro_tiny_amp", "cata_full", "hetro_full_amp"])
+def test_four_wave_phi(waves4, golden, O, name):
+    P.test_phi_vs_reference(golden, O, name)
+
+
+@pytest.mark.parametrize("name", ["cata_tiny_amp", "hetro_full_amp"])
+def test_four_wave_predictor(waves4, golden, O, name):
+    P.test_predictor_forward_and_gradient(golden, O, name)
+
+
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_four_wave_guided_steps(waves4, golden, O, name):
+    P.test_guided_steps_teacher_forced(golden, O, name)
+
+
+def test_four_wave_chain_and_entry_points(waves4, golden):
+    P.test_tiny_chains_guided(golden, "hetro_tiny", 1e-4)
+    P.test_c1_end_to_end_unguided(golden)
+    P.test_sample_chain(golden, "cata")
+
+
+def test_eight_wave_handle_falls_back_for_large_graphs(monkeypatch, O):
+    """More than 128 edge slots with guidance (a dense 14-node graph has 182 edges) is outside the 8-wave predictor's single
+    round of tiles: the call runs on the 4-wave kernels of the same handle and still matches the oracle."""
+    monkeypatch.delenv("GAUDI_WAVES", raising=False)
+    from gaudi_amd.engine import Engine
+    eargs = synth.edm_args(nf=64, n_layers=2, diffusion_steps=20)
+    pargs = synth.pred_args(nf=60, n_layers=2)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=5, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=6, amplify_coord=True)
+    eng = Engine(0)
+    eng.load_edm(eargs, esd)
+    eng.load_predictor(pargs, psd)
+    N = 14
+    nm, em = O.build_masks([14, 9, 14], N, False)
+    rng = np.random.default_rng(1)
+    z = rng.standard_normal((3, N, 4)).astype(np.float32) * nm
+    z[:, :, :3] -= z[:, :, :3].sum(1, keepdims=True) / nm.sum(1, keepdims=True) * nm
+    eps = rng.standard_normal(z.shape).astype(np.float32)
+    gamma = O.gamma_table("polynomial_2", 20, 1e-5)
+    w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
+    got = eng.step(11, z, nm, em, eps, target_w=w, scale=0.7)
+    assert eng.kernel_variant() == (8, 4)
+    assert rel_err(got, O.step_guided(esd, eargs, psd, pargs, gamma, 11, z, nm, em, eps, w, 0.7)) < 1e-4
+    # the unguided step of the same graph runs on the 8-wave denoiser (several rounds of tiles)
+    got_u = eng.step(11, z, nm, em, eps)
+    assert eng.kernel_variant() == (8, 8)
+    assert rel_err(got_u, O.step_unguided(esd, eargs, gamma, 11, z, nm, em, eps)) < 1e-4
+    eng.close()
