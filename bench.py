@@ -258,7 +258,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     hbm_bytes_launch = flops.step_bytes_fused(B, N, F, 0, stash) * steps_done / max(n_launch, 1) + wbytes
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and B == 256 and a.steps_per_launch == 25 and T == 1000:  # counters were collected on this shape
+    if os.path.exists(pmc) and B == (1024 if hetero else 256) and a.steps_per_launch == 25 and T == 1000:  # shape of the PMC passes
         try:
             traffic = json.load(open(pmc)).get(f"{workload}_bytes_per_launch")
         except Exception:
