@@ -420,6 +420,15 @@ __device__ __forceinline__ f4 edge_u(const float* p, const float* q, const float
   return *(const f4*)(p + 16 * cc) + *(const f4*)(q + 16 * cc) + crv * r + cdv * d0;
 }
 
+// "K tail" (8-wave kernels): a hidden size with H % 16 == 4 (196, 36) leaves 4 valid inputs in the last K chunk -- exactly
+// one MFMA k-step.  That chunk is packed with input 16(T-1)+g on lane group g, element 0 (both operands), and costs one
+// MFMA per tile instead of four.  u of the tail chunk for the lane's edge column; p / q point at the row + 4g.
+__device__ __forceinline__ f4 edge_u_tail(const float* p, const float* q, const float* sCr, const float* sCd, int g, int T,
+                                          float r, float d0) {
+  const int f = 16 * (T - 1) + g;
+  return (f4){p[f - 4 * g] + q[f - 4 * g] + sCr[f] * r + sCd[f] * d0, 0.f, 0.f, 0.f};
+}
+
 template <int HP, int NE>
 __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const WBuf& wb, int W2, const float* sB2,
                                                   const float* sCr, const float* sCd,

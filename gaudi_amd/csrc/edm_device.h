@@ -31,6 +31,7 @@ struct EdmDev {
   unsigned w_bytes;
   int F, L, S, attention, use_tanh;
   float coords_range, norm_constant, normf;
+  int ktail;  // 8-wave kernels: the last K chunk of every matrix holds 4 valid inputs, packed as ONE k-step (w8_common.h)
 };
 
 // Per-molecule graph metadata prepared on the host (gaudi_hip.hip: build_meta) and staged in LDS.

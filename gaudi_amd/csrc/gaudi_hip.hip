@@ -207,13 +207,17 @@ struct Tensors {
 // lane_linear (8-wave kernels): inside a tile float4 index L = (k%16/4)*16 + o%16 holds W[o][k .. k+3], i.e. lane L of a
 // wave reads the 16 bytes at offset 16 L whether the tile comes from L2 or from the LDS weight ring
 static bool g_lane_linear = false;
+// K tail (8-wave kernels, H % 16 == 4): the last K chunk carries its 4 valid inputs on element 0 of the four lane groups
+static bool g_ktail = false;
+static bool has_ktail(int H, int HP) { return HP - H == 12; }
 static void pack_matrix(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
   const int T = HP / 16;
   for (int o = 0; o < H; ++o)
     for (int k = 0; k < H; ++k) {
       const float v = transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k];
       const size_t tile = ((size_t)(k / 16) * T + o / 16) * 256;
-      const size_t in = g_lane_linear ? (size_t)(((k % 16) / 4) * 16 + o % 16) * 4 + k % 4 : (size_t)(o % 16) * 16 + k % 16;
+      size_t in = g_lane_linear ? (size_t)(((k % 16) / 4) * 16 + o % 16) * 4 + k % 4 : (size_t)(o % 16) * 16 + k % 16;
+      if (g_lane_linear && g_ktail && k / 16 == T - 1) in = (size_t)((k % 16) * 16 + o % 16) * 4;  // k % 16 < 4 here
       dst[tile + in] = v;
     }
 }
@@ -688,6 +692,7 @@ static void fill_edm(gaudi_handle* h, KParams& P) {
   P.edm.coords_range = c.coords_range;
   P.edm.norm_constant = c.norm_constant;
   P.edm.normf = c.normalization_factor;
+  P.edm.ktail = h->run_variant == 8 && has_ktail(c.hidden_nf, h->HPE);
   P.coef = h->coef_d.as<float>();
   const float g0 = h->gamma[0];
   P.alpha0 = sqrtf(sigmoid_host(-g0));
@@ -756,6 +761,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   // variant for graphs that do not fit it)
   auto pack = [&](bool lane_linear, std::vector<float>& w) {
   g_lane_linear = lane_linear;
+  g_ktail = lane_linear && has_ktail(H, HP);
   w.assign((size_t)lay.total(), 0.f);
   {
     const float* ew = T.get(p + "embedding.weight", (int64_t)H * F1);
@@ -791,12 +797,17 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
         ba = T.get(q + "att_mlp.0.bias", 1);
       }
       if (!(W1 && b1 && W2 && b2 && Wn1 && bn1 && Wn2 && bn2) || (cfg->attention && !(wa && ba))) continue;
+      const bool kt = g_ktail;  // only the matrices of the edge-level GEMMs carry the K tail
+      g_ktail = false;
       pack_matrix(G, W1, H, ld1, 0, HP);
       pack_matrix(G + PK, W1, H, ld1, H, HP);
+      g_ktail = kt;
       pack_matrix(G + 2 * PK, W2, H, H, 0, HP);
+      g_ktail = false;
       pack_matrix(G + 3 * PK, Wn1, H, 2 * H, 0, HP);
       pack_matrix(G + 4 * PK, Wn1, H, 2 * H, H, HP);
       pack_matrix(G + 5 * PK, Wn2, H, H, 0, HP);
+      g_ktail = kt;
       pack_col(V, W1, H, ld1, 2 * H);
       pack_col(V + HP, W1, H, ld1, 2 * H + 1);
       pack_vec(V + 2 * HP, b1, H);
@@ -815,8 +826,11 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
     const float* b2 = T.get(q + "coord_mlp.2.bias", H);
     const float* w3 = T.get(q + "coord_mlp.4.weight", H);
     if (!(W1 && b1 && W2 && b2 && w3)) continue;
+    const bool kt = g_ktail;
+    g_ktail = false;
     pack_matrix(E, W1, H, ld1, 0, HP);
     pack_matrix(E + PK, W1, H, ld1, H, HP);
+    g_ktail = kt;
     pack_matrix(E + 2 * PK, W2, H, H, 0, HP);
     pack_col(V, W1, H, ld1, 2 * H);
     pack_col(V + HP, W1, H, ld1, 2 * H + 1);
@@ -1293,6 +1307,8 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
 int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, const float* W, float* packed_out) {
   if (H < 1 || HP < H || HP % 16 || !W || !packed_out) return GAUDI_E_INVALID;
   std::memset(packed_out, 0, sizeof(float) * (size_t)HP * HP);
+  g_lane_linear = false;
+  g_ktail = false;
   pack_matrix(packed_out, W, H, ldw, col0, HP, transpose != 0);
   return GAUDI_OK;
 }

@@ -34,6 +34,7 @@ struct PredDev {
   unsigned w_bytes;
   int F, K, L, attention, use_tanh;
   float coords_range_layer;  // coords_range / n_layers (egnn_predictor/models.py:515)
+  int ktail;                 // as EdmDev::ktail
 };
 
 template <int HP>

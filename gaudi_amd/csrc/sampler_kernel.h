@@ -179,10 +179,10 @@ __device__ __forceinline__ Graph8Args uni(const Graph8Args& a) {
 }
 __device__ __forceinline__ EdmDev uni(const EdmDev& w) {
   return EdmDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.L), uni(w.S), uni(w.attention), uni(w.use_tanh), uni(w.coords_range),
-                uni(w.norm_constant), uni(w.normf)};
+                uni(w.norm_constant), uni(w.normf), uni(w.ktail)};
 }
 __device__ __forceinline__ PredDev uni(const PredDev& w) {
-  return PredDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.K), uni(w.L), uni(w.attention), uni(w.use_tanh), uni(w.coords_range_layer)};
+  return PredDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.K), uni(w.L), uni(w.attention), uni(w.use_tanh), uni(w.coords_range_layer), uni(w.ktail)};
 }
 #ifndef GAUDI_STAMPS
 template <int HP>

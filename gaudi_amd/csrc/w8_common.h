@@ -11,6 +11,8 @@
 //   * node-level GEMMs deal their output-feature tiles to 8 waves (weights straight from L2, each tile read by one wave).
 // Weight tiles are packed "lane-linear": float4 index L of a 16x16 tile holds W[row = L & 15][k = 4 * (L >> 4) .. +3].
 #pragma once
+#include <type_traits>
+
 #include "device_common.h"
 
 namespace gaudi {
@@ -77,6 +79,7 @@ struct Ring {
   static constexpr int kSlotFloats = T * 256;
   float* base;  // LDS [2][T * 256]
   int par;
+  bool ktail;   // last K chunk = one k-step (device_common.h: edge_u_tail)
   f4 st[UT];
   __device__ __forceinline__ float* slot(int p) const { return base + p * kSlotFloats; }
 };
@@ -121,7 +124,18 @@ __device__ __forceinline__ void ring_stage(Ring<HP>& r, const WBuf& wb, int W, i
 // needs 40 cycles, issue is every 32).  A fragments are read one pair ahead (explicit double buffer + fences: left alone,
 // hipcc sinks every ds_read next to its MFMAs and exposes the LDS latency once per pair).  `mid` runs between the two
 // halves of the block for every wave; a wave without a tile in this round (`active` false) skips only the MFMAs.
-template <int HP, class MID>
+// The last accumulator tile of a chained GEMM as the B operand of a K-tail chunk: lane (column c, group g) takes element g of
+// group 0's lane c (features 16(T-1) .. +3 live there), element 0.
+// (__shfl, not a hand-written ds_bpermute + integer select: hipcc folded that form to "element 0 for every group" --
+// /tmp-probe verified on the GPU; the __shfl form moves the right elements)
+__device__ __forceinline__ f4 tail_to_b(f4 v, int c, int g) {
+  const float t0 = __shfl(v[0], c, 64), t1 = __shfl(v[1], c, 64), t2 = __shfl(v[2], c, 64), t3 = __shfl(v[3], c, 64);
+  return (f4){g == 0 ? t0 : g == 1 ? t1 : g == 2 ? t2 : t3, 0.f, 0.f, 0.f};
+}
+
+// NQ = k-steps of this chunk: 4, or 1 for a K-tail chunk (compile-time: a run-time count splits the MFMA block into
+// basic blocks and costs far more than the tail saves)
+template <int HP, int NQ, class MID>
 __device__ __forceinline__ void ring_mfma(f4 (&acc)[HP / 16], const float* slot_lane, const f4 bin, bool active, MID mid) {
   constexpr int T = HP / 16;
   constexpr int NP = (T + 1) / 2;  // pairs of output tiles
@@ -142,7 +156,7 @@ __device__ __forceinline__ void ring_mfma(f4 (&acc)[HP / 16], const float* slot_
     __builtin_amdgcn_sched_barrier(0);
     if (active) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         acc[t0] = mfma1(a[cur][0][q], bin[q], acc[t0]);
         if (t0 + 1 < T) acc[t0 + 1] = mfma1(a[cur][1][q], bin[q], acc[t0 + 1]);
       }
@@ -168,18 +182,31 @@ __device__ __forceinline__ void edge_gemm_pq(f4 (&acc)[HP / 16], Ring<HP>& ring,
   const bool late = wave >= kWaves / 2;
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = *(const f4*)(sB2 + 16 * t + 4 * g);
-  f4 bin = silu4(edge_u(pp, qq, sCr, sCd, g, 0, r, d0)), nb = bin;
-#pragma unroll 1
-  for (int cc = 0; cc < T; ++cc) {
+  const bool ktail = ring.ktail;
+  auto gen = [&](int cc) { return silu4(edge_u(pp, qq, sCr, sCd, g, cc, r, d0)); };  // silu(u) of input chunk cc, B layout
+  auto gen_last = [&] {  // ... of the last chunk: one k-step when the matrix carries a K tail
+    return ktail ? silu4(edge_u_tail(pp, qq, sCr, sCd, g, T, r, d0)) : gen(T - 1);
+  };
+  f4 bin = T > 1 ? gen(0) : gen_last(), nb = bin;
+  // one trip; NQ k-steps; `last_next`: the chunk generated for the next trip is the last one
+  auto trip = [&](int cc, auto nq_tag, bool cur_last, bool next_last) {
+    constexpr int NQ = decltype(nq_tag)::value;
     __syncthreads();
-    if (late && cc > 0) bin = silu4(edge_u(pp, qq, sCr, sCd, g, cc, r, d0));
-    ring_mfma<HP>(acc, ring.slot(ring.par) + lane * 4, bin, active, [&] {
+    if (late && cc > 0) bin = cur_last ? gen_last() : gen(cc);
+    ring_mfma<HP, NQ>(acc, ring.slot(ring.par) + lane * 4, bin, active, [&] {
       ring_stage<HP>(ring, wb, W, nextW, cc, wave, lane);
-      if (!late) nb = silu4(edge_u(pp, qq, sCr, sCd, g, cc + 1 < T ? cc + 1 : T - 1, r, d0));
+      if (!late) nb = next_last ? gen_last() : gen(cc + 1 < T ? cc + 1 : T - 1);
     });
     if (!late) bin = nb;
     ring.par ^= 1;
-  }
+  };
+  using Q4 = std::integral_constant<int, 4>;
+  using Q1 = std::integral_constant<int, 1>;
+#pragma unroll 1
+  for (int cc = 0; cc < T - 2; ++cc) trip(cc, Q4{}, false, false);
+  if (T > 1) trip(T - 2, Q4{}, false, true);  // generates the last chunk for waves 0-3
+  if (ktail) trip(T - 1, Q1{}, true, true);
+  else trip(T - 1, Q4{}, true, true);
 }
 
 // Chained edge GEMM, input already in registers in C/B layout: out = bias + rowinit + W . in
@@ -195,10 +222,15 @@ __device__ __forceinline__ void edge_gemm_regs(f4 (&out)[HP / 16], const f4 (&in
     if (rowinit != nullptr) b = b + *(const f4*)(rowinit + 16 * t + 4 * g);
     out[t] = b;
   }
+  const int c = lane & 15;
 #pragma unroll
   for (int cc = 0; cc < T; ++cc) {
     __syncthreads();
-    ring_mfma<HP>(out, ring.slot(ring.par) + lane * 4, in[cc], active, [&] { ring_stage<HP>(ring, wb, W, nextW, cc, wave, lane); });
+    auto stage = [&] { ring_stage<HP>(ring, wb, W, nextW, cc, wave, lane); };
+    if (cc == T - 1 && ring.ktail)
+      ring_mfma<HP, 1>(out, ring.slot(ring.par) + lane * 4, tail_to_b(in[cc], c, g), active, stage);
+    else
+      ring_mfma<HP, 4>(out, ring.slot(ring.par) + lane * 4, in[cc], active, stage);
     ring.par ^= 1;
   }
 }

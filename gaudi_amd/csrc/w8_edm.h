@@ -147,6 +147,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   Ring<HP> ring;
   ring.base = sm.ring;
   ring.par = 0;
+  ring.ktail = W.ktail != 0;
   ring_start<HP>(ring, wb, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
   NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it
   node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);

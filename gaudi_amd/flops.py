@@ -79,16 +79,17 @@ def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
     def node(T, kt):  # K chunks x 4 k-steps x output tiles (the 4-wave kernels recompute a tile in idle tile slots)
         return kt * 4 * ((-(-T // waves)) * waves if variant == "w4" else T) * nt
 
-    def edge(T):  # one 16-edge tile through one T x T matrix
-        return T * T * 4
+    def edge(T, nf=0):  # one 16-edge tile through one T x T matrix; the 8-wave kernels issue a K tail (nf % 16 == 4) as 1 k-step
+        ksteps = 4 * T - 3 if (variant != "w4" and nf % 16 == 4 and 16 * T - nf == 12) else 4 * T
+        return T * ksteps
 
     Te = _pad_hidden_kernel(edm["nf"]) // 16
     L, S = edm["n_layers"], edm.get("inv_sublayers", 1)
-    n = L * (S * (node(Te, 5 * Te) + tiles16 * edge(Te)) + node(Te, 2 * Te) + tiles16 * edge(Te))
+    n = L * (S * (node(Te, 5 * Te) + tiles16 * edge(Te, edm["nf"])) + node(Te, 2 * Te) + tiles16 * edge(Te, edm["nf"]))
     if pred is not None:
         Tp = _pad_hidden_kernel(pred["nf"]) // 16
         Lp = pred["n_layers"]
-        fwd = Lp * (node(Tp, 5 * Tp) + tiles16 * edge(Tp)) + (Lp - 1) * tiles16 * edge(Tp)
+        fwd = Lp * (node(Tp, 5 * Tp) + tiles16 * edge(Tp, pred["nf"])) + (Lp - 1) * tiles16 * edge(Tp, pred["nf"])
         n += 2 * fwd  # the reverse pass issues the same counts with the transposed matrices
     return n
 

@@ -95,3 +95,33 @@ def test_eight_wave_handle_falls_back_for_large_graphs(monkeypatch, O):
     assert eng.kernel_variant() == (8, 8)
     assert rel_err(got_u, O.step_unguided(esd, eargs, gamma, 11, z, nm, em, eps)) < 1e-4
     eng.close()
+
+
+@pytest.mark.parametrize("nf_e,nf_p", [(36, 36), (20, 20), (20, 36)])
+def test_eight_wave_k_tail_widths(monkeypatch, O, nf_e, nf_p):
+    """Hidden widths with nf % 16 == 4 (the default predictor's 196 is one): the 8-wave edge GEMMs issue the last K chunk of
+    W2 / Wc1 (and their transposes) as one k-step from a specially packed 16 x 16 tile.  Both networks, T = 2 and T = 3."""
+    monkeypatch.delenv("GAUDI_WAVES", raising=False)
+    from gaudi_amd.engine import Engine
+    eargs = synth.edm_args(nf=nf_e, n_layers=2, diffusion_steps=20, dataset="hetro")
+    pargs = synth.pred_args(nf=nf_p, n_layers=3, dataset="hetro")
+    F = synth.num_node_features("hetro")
+    esd = synth.synth_edm_state_dict(eargs, F, seed=7, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=8, amplify_coord=True)
+    eng = Engine(0)
+    eng.load_edm(eargs, esd)
+    eng.load_predictor(pargs, psd)
+    nm, em = O.build_masks([5, 3, 4, 1, 2], 5, True)  # 10 nodes, at most 90 edges: one round of 8-wave tiles
+    rng = np.random.default_rng(2)
+    z = rng.standard_normal((5, nm.shape[1], 3 + F)).astype(np.float32) * nm
+    z[:, :, :3] -= z[:, :, :3].sum(1, keepdims=True) / nm.sum(1, keepdims=True) * nm
+    eps = rng.standard_normal(z.shape).astype(np.float32)
+    gamma = O.gamma_table("polynomial_2", 20, 1e-5)
+    w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
+    t = np.linspace(0.1, 0.9, 5).astype(np.float32)
+    assert rel_err(eng.phi(z, t, nm, em), O.edm_phi(esd, eargs, z, t, nm, em)) < 2e-5
+    for s in (15, 3):
+        got = eng.step(s, z, nm, em, eps, target_w=w, scale=0.7)
+        assert eng.kernel_variant() == (8, 8)
+        assert rel_err(got, O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.7)) < 1e-4, s
+    eng.close()

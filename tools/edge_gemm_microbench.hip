@@ -23,6 +23,7 @@ __global__ __launch_bounds__(512) void k(const float* w, unsigned wbytes, int nm
   w8::Ring<HP> ring;
   ring.base = ring_mem;
   ring.par = 0;
+  ring.ktail = false;
   w8::ring_start<HP>(ring, wb, 0, wave, lane);
   const bool active = wave < nactive;
   const int i = (wave + c) % N, j = (wave * 3 + c) % N;

@@ -24,3 +24,13 @@ for wv in ("8", "4"):
         print("waves", wv, "s", s, "maxnorm %.2e elem %.2e" % (max_norm_err(got, want[s]), elem_err(got, want[s])), "worst elem", k, got[k], want[s][k], "max|b|", np.abs(want[s]).max())
         if s in want64: print("   vs fp64 oracle: maxnorm %.2e elem %.2e ; fp32 oracle vs fp64: %.2e %.2e" % (max_norm_err(got, want64[s]), elem_err(got, want64[s]), max_norm_err(want[s], want64[s]), elem_err(want[s], want64[s])))
     eng.close()
+wantu = {s: O.step_unguided(esd, eargs, gamma, s, z, nm, em, eps) for s in (999, 400, 0)}
+wantu64 = O.step_unguided(esd, eargs, gamma, 999, z, nm, em, eps, dtype=np.float64)
+for wv in ("8", "4"):
+    os.environ["GAUDI_WAVES"] = wv
+    eng = Engine(0); eng.load_edm(eargs, esd)
+    for s in (999, 400, 0):
+        got = eng.step(s, z, nm, em, eps)
+        print("unguided waves", wv, "s", s, "maxnorm %.2e elem %.2e" % (max_norm_err(got, wantu[s]), elem_err(got, wantu[s])))
+        if s == 999: print("   vs fp64: %.2e %.2e; fp32 oracle vs fp64 %.2e %.2e" % (max_norm_err(got, wantu64), elem_err(got, wantu64), max_norm_err(wantu[s], wantu64), elem_err(wantu[s], wantu64)))
+    eng.close()

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
             if (t0 + 1 < T) acc[t0 + 1] = mfma1(bin[(q + 1) & 3], bin[q], acc[t0 + 1]);
           }
       } else {
-        w8::ring_mfma<HP>(acc, slot, bin, true, [] {});
+        w8::ring_mfma<HP, 4>(acc, slot, bin, true, [] {});
       }
     }
     par ^= 1;
