@@ -89,6 +89,7 @@ EXPORTS = {
                                          C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), FP,
                                          C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_int32, C.POINTER(C.c_int32)]),
     "gaudi_kernel_variant": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gaudi_edge_math": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 _lib = None

@@ -32,6 +32,8 @@ struct EdmDev {
   int F, L, S, attention, use_tanh;
   float coords_range, norm_constant, normf;
   int ktail;  // 8-wave kernels: the last K chunk of every matrix holds 4 valid inputs, packed as ONE k-step (w8_common.h)
+  const float* ws;     // split-bf16 images of the edge-GEMM matrices (w8_split.h), or nullptr
+  unsigned ws_bytes;
 };
 
 // Per-molecule graph metadata prepared on the host (gaudi_hip.hip: build_meta) and staged in LDS.

@@ -50,7 +50,8 @@ struct gaudi_handle {
   gaudi_pred_config pcfg{};
   int HPE = 0, HPP = 0;
   DevBuf edm_w, pred_w, coef_d, edm_w4, pred_w4;  // *_w4: row-major tiles for the 4-wave fallback of an 8-wave handle
-  size_t edm_w_bytes = 0, pred_w_bytes = 0;
+  DevBuf edm_ws, pred_ws;                         // split-bf16 images of the edge-GEMM matrices (w8_split.h)
+  size_t edm_w_bytes = 0, pred_w_bytes = 0, edm_ws_bytes = 0, pred_ws_bytes = 0;
   std::vector<float> gamma, coef;
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
@@ -59,6 +60,8 @@ struct gaudi_handle {
   int steps_per_launch = 25;
   int variant = 8;            // 8 = two waves per SIMD (sampler_kernel8, default), 4 = one wave per SIMD (GAUDI_WAVES=4)
   int run_variant = 4;        // what the CURRENT call runs on (an 8-wave handle falls back to 4 waves for graphs that do not fit)
+  bool split = true;          // 8-wave kernels: edge GEMMs on the bf16 matrix pipe with 3-way split operands (GAUDI_EDGE_MATH=fp32: off)
+  bool run_split = false;     // ... and whether the CURRENT call uses them (needs a larger LDS weight ring)
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
   long long fix_key = 0;      // global sample index whose Philox stream is shared
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
@@ -220,6 +223,43 @@ static void pack_matrix(float* dst, const float* W, int H, int ldw, int col0, in
       if (g_lane_linear && g_ktail && k / 16 == T - 1) in = (size_t)((k % 16) * 16 + o % 16) * 4;  // k % 16 < 4 here
       dst[tile + in] = v;
     }
+}
+// Split-bf16 image of an edge-GEMM matrix (w8_split.h): units of 1 KiB ordered [K chunk m][output tile t][piece p]; lane L
+// = (row L & 15, group g = L >> 4) holds 8 bf16: slots 0-3 = inputs 16(2m) + 4g .. +3, slots 4-7 = inputs 16(2m+1) + 4g .. +3.
+// Pieces by round-to-nearest-even: w = p0 + p1 + p2 exactly.
+static uint16_t bf16_rne(float x) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf16_to_f(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+static void pack_matrix_split(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose) {
+  const int T = HP / 16;
+  uint16_t* d = (uint16_t*)dst;
+  for (int o = 0; o < H; ++o)
+    for (int k = 0; k < H; ++k) {
+      float v = transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k];
+      const int tile = k / 16, m = tile / 2, g = (k % 16) / 4, e = 4 * (tile & 1) + (k & 3), t = o / 16, L = g * 16 + o % 16;
+      for (int pc = 0; pc < 3; ++pc) {
+        const uint16_t b = bf16_rne(v);
+        d[((size_t)((m * T + t) * 3 + pc) * 64 + L) * 8 + e] = b;
+        v -= bf16_to_f(b);
+      }
+    }
+}
+// An edge-GEMM matrix: the fp32 tiles (K tail included where the width has one) and, when a split buffer is being filled,
+// its split image at twice the float offset
+static float* g_wbase = nullptr;
+static std::vector<float>* g_ws = nullptr;
+static void pack_edge_matrix(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
+  pack_matrix(dst, W, H, ldw, col0, HP, transpose);
+  if (g_ws != nullptr) pack_matrix_split(g_ws->data() + 2 * (size_t)(dst - g_wbase), W, H, ldw, col0, HP, transpose);
 }
 static void pack_vec(float* dst, const float* v, int n) { std::memcpy(dst, v, sizeof(float) * n); }
 static void pack_col(float* dst, const float* W, int H, int ldw, int col) {
@@ -490,6 +530,24 @@ static kernel_fn pick_kernel8(int hpe, int hpp) {
   return f;
 }
 
+// ... and their split-bf16 edge-GEMM versions (kern8s_*.hip); a size without one runs on the fp32-MFMA kernel
+#ifdef GAUDI_STAMP_STUBS
+#define GAUDI_KERNEL8S_TUS(X) X(edm_192) X(fused_192_208)
+#else
+#define GAUDI_KERNEL8S_TUS(X) X(edm_small) X(edm_192) X(pred_small) X(pred_208) X(fused_tiny) X(fused_192_208)
+#endif
+#define X(name) kernel_fn gaudi_kern8s_##name(int hpe, int hpp);
+GAUDI_KERNEL8S_TUS(X)
+#undef X
+static kernel_fn pick_kernel8s(int hpe, int hpp) {
+  kernel_fn f = nullptr;
+#define X(name) \
+  if (!f) f = gaudi_kern8s_##name(hpe, hpp);
+  GAUDI_KERNEL8S_TUS(X)
+#undef X
+  return f;
+}
+
 // smallest instantiated padded hidden size >= H (0 if none)
 static int round_hidden(int H) {
   static const int sizes[] = {32, 48, 64, 128, 192, 208, 256};
@@ -505,19 +563,19 @@ static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW) {
   return sizeof(float) * (common_floats(N, D, EW) + net);
 }
 
-static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S) {
+static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, bool split) {
   size_t net = 0;
-  if (hpe) net = std::max(net, (size_t)(5 * N * (hpe + 4) + 2 * (hpe / 16) * 256 + 8 * N + S * 9 + 8 * hpe));
-  if (hpp) net = std::max(net, (size_t)(2 * (hpp / 16) * 256 + 5 * N * (hpp + 4) + 12 * N + S * 10 + 32 + 10 * hpp));
+  if (hpe) net = std::max(net, (size_t)(5 * N * (hpe + 4) + w8::edge_ring_floats(hpe, split) + 8 * N + S * 9 + 8 * hpe));
+  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + 5 * N * (hpp + 4) + 12 * N + S * 10 + 32 + 10 * hpp));
   return common_floats8(N, D, S) + net;
 }
 // The reverse pass publishes du of every slot pub_ch feature tiles at a time into [b0 | b1 | pubx extra floats]: pick the
 // largest pub_ch that fits 160 KiB, then the extra floats that choice needs.  false: the molecule does not fit.
-static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int& pubx, int& pub_ch) {
+static bool plan_pub8(int hpe, int hpp, int N, int D, int S, bool split, int& pubx, int& pub_ch) {
   pubx = 0;
   pub_ch = 0;
   const long long cap = 160 * 1024 / 4 - 64;  // floats (a little headroom for the runtime's own static LDS)
-  const long long base = (long long)lds_floats8_base(hpe, hpp, N, D, S);
+  const long long base = (long long)lds_floats8_base(hpe, hpp, N, D, S, split);
   if (base > cap) return false;
   if (!hpp) return true;
   const int T = hpp / 16;
@@ -530,18 +588,18 @@ static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int& pubx, int& pub
   pubx = (int)std::max(0LL, (long long)S * (16 * pub_ch + 4) - own);
   return true;
 }
-static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx) {
-  return sizeof(float) * (lds_floats8_base(hpe, hpp, N, D, S) + (hpp ? pubx : 0));
+static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, bool split) {
+  return sizeof(float) * (lds_floats8_base(hpe, hpp, N, D, S, split) + (hpp ? pubx : 0));
 }
 
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
   const bool v8 = h->run_variant == 8;
-  kernel_fn fn = v8 ? pick_kernel8(hpe, hpp) : pick_kernel(hpe, hpp);
+  kernel_fn fn = v8 ? (h->run_split ? pick_kernel8s(hpe, hpp) : pick_kernel8(hpe, hpp)) : pick_kernel(hpe, hpp);
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
                     (v8 ? " in the 8-wave family" : ""));
-  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW);
+  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW);
   if (lds > 160 * 1024)
     return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
   {
@@ -602,7 +660,11 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   if (hpp && M.S > 16 * w8::kWaves) return 1;  // the 8-wave predictor handles one round of tiles
   if (!pick_kernel8(hpe, hpp)) return 1;
   int pubx = 0, pub_ch = 0;
-  if (!plan_pub8(hpe, hpp, N, 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf), M.S, pubx, pub_ch)) return 1;
+  const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
+  // split-bf16 edge GEMMs when the kernel exists and its larger weight ring fits; else fp32 MFMAs; else 4 waves
+  h->run_split = h->split && pick_kernel8s(hpe, hpp) && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) &&
+                 plan_pub8(hpe, hpp, N, Dz, M.S, true, pubx, pub_ch);
+  if (!h->run_split && !plan_pub8(hpe, hpp, N, Dz, M.S, false, pubx, pub_ch)) return 1;
   P.pubx = pubx;
   P.pub_ch = pub_ch;
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
@@ -640,10 +702,12 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
                        int hpp) {
   if (B <= 0 || N <= 0) return fail(h, GAUDI_E_INVALID, "B and N must be positive");
   h->run_variant = h->variant;
+  h->run_split = false;
   if (h->variant == 8) {
     const int rc8 = stage_graph8(h, B, N, node_mask, edge_mask, P, hpe, hpp);
     if (rc8 <= 0) return rc8;
     h->run_variant = 4;  // fall back to the 4-wave kernels for this call
+    h->run_split = false;
     P.pubx = P.pub_ch = 0;
   }
   Meta M;
@@ -693,6 +757,8 @@ static void fill_edm(gaudi_handle* h, KParams& P) {
   P.edm.norm_constant = c.norm_constant;
   P.edm.normf = c.normalization_factor;
   P.edm.ktail = h->run_variant == 8 && has_ktail(c.hidden_nf, h->HPE);
+  P.edm.ws = h->edm_ws.as<float>();
+  P.edm.ws_bytes = (unsigned)h->edm_ws_bytes;
   P.coef = h->coef_d.as<float>();
   const float g0 = h->gamma[0];
   P.alpha0 = sqrtf(sigmoid_host(-g0));
@@ -713,6 +779,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   gaudi_handle* h = new gaudi_handle();
   h->device = device;
   if (const char* v = getenv("GAUDI_WAVES")) h->variant = atoi(v) == 4 ? 4 : 8;
+  if (const char* v = getenv("GAUDI_EDGE_MATH")) h->split = std::string(v) != "fp32";
   h->run_variant = h->variant;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -728,7 +795,7 @@ void gaudi_destroy(gaudi_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->prof_log.reset(true);
   h->stab_log.reset(true);
-  DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->edm_w4, &h->pred_w4, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
+  DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->edm_w4, &h->pred_w4, &h->edm_ws, &h->pred_ws, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
                     &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
                     &h->d_pred, &h->d_tw, &h->d_stash, &h->d_chain, &h->d_sx, &h->d_stype, &h->d_sn,
                     &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as, &h->d_ncols, &h->d_soff, &h->d_sidx};
@@ -759,10 +826,13 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   const int PK = HP * HP;
   // tile layout: lane-linear for the 8-wave kernels, row-major for the 4-wave ones (kept as the fallback of the 8-wave
   // variant for graphs that do not fit it)
-  auto pack = [&](bool lane_linear, std::vector<float>& w) {
+  auto pack = [&](bool lane_linear, std::vector<float>& w, std::vector<float>* ws) {
   g_lane_linear = lane_linear;
   g_ktail = lane_linear && has_ktail(H, HP);
   w.assign((size_t)lay.total(), 0.f);
+  if (ws) ws->assign(2 * (size_t)lay.total(), 0.f);
+  g_wbase = w.data();
+  g_ws = ws;
   {
     const float* ew = T.get(p + "embedding.weight", (int64_t)H * F1);
     const float* eb = T.get(p + "embedding.bias", H);
@@ -802,7 +872,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
       pack_matrix(G, W1, H, ld1, 0, HP);
       pack_matrix(G + PK, W1, H, ld1, H, HP);
       g_ktail = kt;
-      pack_matrix(G + 2 * PK, W2, H, H, 0, HP);
+      pack_edge_matrix(G + 2 * PK, W2, H, H, 0, HP);
       g_ktail = false;
       pack_matrix(G + 3 * PK, Wn1, H, 2 * H, 0, HP);
       pack_matrix(G + 4 * PK, Wn1, H, 2 * H, H, HP);
@@ -831,22 +901,30 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
     pack_matrix(E, W1, H, ld1, 0, HP);
     pack_matrix(E + PK, W1, H, ld1, H, HP);
     g_ktail = kt;
-    pack_matrix(E + 2 * PK, W2, H, H, 0, HP);
+    pack_edge_matrix(E + 2 * PK, W2, H, H, 0, HP);
     pack_col(V, W1, H, ld1, 2 * H);
     pack_col(V + HP, W1, H, ld1, 2 * H + 1);
     pack_vec(V + 2 * HP, b1, H);
     pack_vec(V + 3 * HP, b2, H);
     pack_vec(V + 4 * HP, w3, H);
   }
+  g_ws = nullptr;
   };
-  std::vector<float> w;
-  pack(h->variant == 8, w);
+  std::vector<float> w, ws;
+  const bool want_split = h->variant == 8 && h->split;
+  pack(h->variant == 8, w, want_split ? &ws : nullptr);
   if (!T.missing.empty()) return fail(h, GAUDI_E_MISSING, "EDM checkpoint tensor missing or mis-shaped: " + T.missing);
   HIPCHECK(h, h->edm_w.reserve(sizeof(float) * w.size()));
   HIPCHECK(h, hipMemcpy(h->edm_w.p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
   h->edm_w_bytes = sizeof(float) * w.size();
+  h->edm_ws_bytes = 0;
+  if (want_split) {
+    HIPCHECK(h, h->edm_ws.reserve(sizeof(float) * ws.size()));
+    HIPCHECK(h, hipMemcpy(h->edm_ws.p, ws.data(), sizeof(float) * ws.size(), hipMemcpyHostToDevice));
+    h->edm_ws_bytes = sizeof(float) * ws.size();
+  }
   if (h->variant == 8) {
-    pack(false, w);
+    pack(false, w, nullptr);
     HIPCHECK(h, h->edm_w4.reserve(sizeof(float) * w.size()));
     HIPCHECK(h, hipMemcpy(h->edm_w4.p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
   }
@@ -1301,6 +1379,13 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
   if (!h) return GAUDI_E_INVALID;
   if (configured) *configured = h->variant;
   if (last_call) *last_call = h->run_variant;
+  return GAUDI_OK;
+}
+
+int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_call) {
+  if (!h) return GAUDI_E_INVALID;
+  if (configured) *configured = (h->variant == 8 && h->split) ? 1 : 0;
+  if (last_call) *last_call = h->run_split ? 1 : 0;
   return GAUDI_OK;
 }
 

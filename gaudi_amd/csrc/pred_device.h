@@ -35,6 +35,8 @@ struct PredDev {
   int F, K, L, attention, use_tanh;
   float coords_range_layer;  // coords_range / n_layers (egnn_predictor/models.py:515)
   int ktail;                 // as EdmDev::ktail
+  const float* ws;           // as EdmDev::ws
+  unsigned ws_bytes;
 };
 
 template <int HP>

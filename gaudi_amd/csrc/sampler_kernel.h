@@ -179,13 +179,14 @@ __device__ __forceinline__ Graph8Args uni(const Graph8Args& a) {
 }
 __device__ __forceinline__ EdmDev uni(const EdmDev& w) {
   return EdmDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.L), uni(w.S), uni(w.attention), uni(w.use_tanh), uni(w.coords_range),
-                uni(w.norm_constant), uni(w.normf), uni(w.ktail)};
+                uni(w.norm_constant), uni(w.normf), uni(w.ktail), uni(w.ws), uni(w.ws_bytes)};
 }
 __device__ __forceinline__ PredDev uni(const PredDev& w) {
-  return PredDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.K), uni(w.L), uni(w.attention), uni(w.use_tanh), uni(w.coords_range_layer), uni(w.ktail)};
+  return PredDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.K), uni(w.L), uni(w.attention), uni(w.use_tanh), uni(w.coords_range_layer), uni(w.ktail), uni(w.ws),
+                 uni(w.ws_bytes)};
 }
 #ifndef GAUDI_STAMPS
-template <int HP>
+template <int HP, bool SP>
 __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, float t_val_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const EdmDev W = uni(W_);
@@ -193,39 +194,42 @@ __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, f
   const float t_val = uni(t_val_);
   const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
   const w8::MolGraph mg = graph8(L, ga);
-  w8::NetSmem<HP> sm;
+  w8::NetSmem<HP, SP> sm;
   sm.carve(L.net, ga.N, ga.S);
-  w8::edm_forward<HP>(W, mg, sm, L.sZ, L.sEps, L.sMean, t_val, (int)threadIdx.x);
+  w8::edm_forward<HP, SP>(W, mg, sm, L.sZ, L.sEps, L.sMean, t_val, (int)threadIdx.x);
 }
 // the predictor's forward and reverse passes are separate functions too (the reverse pass holds three 52-register
 // operand sets at its peak; allocated together with the forward it spilled twice as much)
-template <int HP>
+template <int HP, bool SP>
 __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args ga_, float t_val_, float* stash_, float readout_div_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PredDev W = uni(W_);
   const Graph8Args ga = uni(ga_);
   const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
   const w8::MolGraph mg = graph8(L, ga);
-  w8::PredSmem<HP> sm;
+  w8::PredSmem<HP, SP> sm;
   sm.carve(L.net, ga.N, ga.S, ga.pubx);
-  w8::pred_forward<HP>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
+  w8::pred_forward<HP, SP>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
 }
-template <int HP>
+template <int HP, bool SP>
 __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args ga_, float* stash_, float readout_div_, int resume_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PredDev W = uni(W_);
   const Graph8Args ga = uni(ga_);
   const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
   const w8::MolGraph mg = graph8(L, ga);
-  w8::PredSmem<HP> sm;
+  w8::PredSmem<HP, SP> sm;
   sm.carve(L.net, ga.N, ga.S, ga.pubx);
-  w8::pred_backward<HP>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
+  w8::pred_backward<HP, SP>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
                         uni(resume_) ? L.sZ : nullptr);
 }
 #endif
 
-struct V8 {
+// SP: edge GEMMs on the bf16 matrix pipe with three-way split operands (w8_split.h); otherwise fp32 MFMAs
+template <bool SP>
+struct V8T {
   static constexpr int kThreads = w8::kThreads;
+  static constexpr bool kSplit = SP;
   using Graph = w8::MolGraph;
   __host__ __device__ static int graph_floats(int N, int S) { return 2 * S + align16(N) + align16((N + 1 + S + 1) / 2); }
   __device__ __forceinline__ static float* load_graph(const KParams& P, int b, float* base, const float* sMask, Graph& mg, int tid, int wave) {
@@ -260,12 +264,12 @@ struct V8 {
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
                                              float* sMean, float t_val, int tid STAMP_DECL) {
 #ifdef GAUDI_STAMPS
-    w8::NetSmem<HP> sm;
+    w8::NetSmem<HP, SP> sm;
     sm.carve(net, mg.N, mg.S);
-    w8::edm_forward<HP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
+    w8::edm_forward<HP, SP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
 #else
     (void)net; (void)sZ; (void)sEps; (void)sMean; (void)tid;
-    edm8_call<HP>(W, gargs(mg), t_val);
+    edm8_call<HP, SP>(W, gargs(mg), t_val);
 #endif
   }
   template <int HP>
@@ -274,16 +278,16 @@ struct V8 {
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
                                                const float* dpred_ext) {
 #ifdef GAUDI_STAMPS
-    w8::guidance_update<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
+    w8::guidance_update<HP, SP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
                             mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext);
 #else
     (void)sTmp;
-    w8::PredSmem<HP> sm;
+    w8::PredSmem<HP, SP> sm;
     sm.carve(net, mg.N, mg.S, mg.pubx);
-    if (phase != 2) pred_fwd8_call<HP>(W, gargs(mg), t_val, stash, readout_div);
-    w8::guidance_seed<HP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
+    if (phase != 2) pred_fwd8_call<HP, SP>(W, gargs(mg), t_val, stash, readout_div);
+    w8::guidance_seed<HP, SP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
     if (phase == 1) return;
-    pred_bwd8_call<HP>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0);
+    pred_bwd8_call<HP, SP>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0);
     w8::guidance_apply(mg, sZ, sGrad, sMean, sigma, tid);
 #endif
   }
@@ -291,10 +295,12 @@ struct V8 {
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
                                                     float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                     float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
-    w8::predictor_entry<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
+    w8::predictor_entry<HP, SP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
                             mg.pub_ch, tid STAMP_ARGS);
   }
 };
+using V8 = V8T<false>;
+using V8S = V8T<true>;
 
 __host__ __device__ inline int common_floats_base(int N, int D) { return 3 * align16(N * D) + align16(N) + 16; }
 
@@ -518,5 +524,7 @@ template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel = &sampler_kernel_v<V4, HPE, HPP>;
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8 = &sampler_kernel_v<V8, HPE, HPP>;
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel8s = &sampler_kernel_v<V8S, HPE, HPP>;
 
 }  // namespace gaudi

@@ -4,27 +4,28 @@
 #pragma once
 #include "edm_device.h"
 #include "w8_common.h"
+#include "w8_split.h"
 
 namespace gaudi {
 namespace w8 {
 
 // LDS working set of one network evaluation
-template <int HP>
+template <int HP, bool SP = false>
 struct NetSmem {
   float *h, *p, *q;     // [N][HP+4]
   float *agg, *agg1;    // [N][HP+4] the two partial edge->node sums of a node (its run may straddle two tiles)
-  float* ring;          // [2][T*256] weight ring of the edge GEMMs
+  float* ring;          // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats)
   float *x, *x0;        // [N][4]
   f4* geo;              // [S] (r, dhat)
   float* d0;            // [S]
   float* trans;         // [S][4]
   float* vec;           // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
   __host__ __device__ static int floats(int N, int S) {
-    return 5 * N * (HP + 4) + 2 * (HP / 16) * 256 + 8 * N + S * 9 + 8 * HP;
+    return 5 * N * (HP + 4) + EdgeRing<HP, SP>::kFloats + 8 * N + S * 9 + 8 * HP;
   }
   __device__ void carve(float* base, int N, int S) {
     constexpr int LD = HP + 4;
-    ring = base; base += 2 * (HP / 16) * 256;   // first: 1 KiB tiles stay 16-byte aligned whatever N is
+    ring = base; base += EdgeRing<HP, SP>::kFloats;   // first: 1 KiB tiles stay 16-byte aligned whatever N is
     h = base; base += N * LD;
     p = base; base += N * LD;
     q = base; base += N * LD;
@@ -110,8 +111,8 @@ __device__ __forceinline__ void scatter_runs(f4 (&e)[HP / 16], const TileCols& t
 }
 
 // eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
-template <int HP>
-__device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP>& sm, const float* sZ,
+template <int HP, bool SP = false>
+__device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP, SP>& sm, const float* sZ,
                                             float* sEps, float* sMean /* [4] */, float t_val, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -121,6 +122,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   EdmLayout lay{HP, F1, W.L, W.S};
   const float* __restrict__ w = W.w;
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
+  const WBuf wbe = SP ? make_wbuf(W.ws, W.ws_bytes) : wb;  // edge-GEMM matrices (w8_split.h)
 
   // ---- input split + masking (models.py:88-105): x = z[:, :3]*m ; h = [z[:, 3:]*m , t]
   for (int idx = tid; idx < N * 3; idx += kThreads) {
@@ -144,11 +146,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   }
   __syncthreads();
   compute_geo(sm, mg, 0.f, tid, true);  // d0 of the input coordinates (egnn_new.py:301)
-  Ring<HP> ring;
-  ring.base = sm.ring;
-  ring.par = 0;
-  ring.ktail = W.ktail != 0;
-  ring_start<HP>(ring, wb, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
+  typename EdgeRing<HP, SP>::type ring;
+  er_init<HP>(ring, sm.ring, W.ktail != 0);
+  er_start<HP>(ring, wbe, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
   NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it
   node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);
   constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
@@ -183,7 +183,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
-        edge_gemm_pq<HP>(acc, ring, wb, G + 2 * PK, rd + 1 < mg.rounds ? G + 2 * PK : Wnext_edge, b2, cr, cd,
+        er_gemm_pq<HP>(acc, ring, wbe, G + 2 * PK, rd + 1 < mg.rounds ? G + 2 * PK : Wnext_edge, b2, cr, cd,
                          sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
         STAMP(ST_EDGE);
         if (tc.active) {
@@ -243,7 +243,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
-        edge_gemm_pq<HP>(acc, ring, wb, E + 2 * PK, rd + 1 < mg.rounds ? E + 2 * PK : Wnext_edge, b2, cr, cd,
+        er_gemm_pq<HP>(acc, ring, wbe, E + 2 * PK, rd + 1 < mg.rounds ? E + 2 * PK : Wnext_edge, b2, cr, cd,
                          sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
         STAMP(ST_EDGE);
         if (tc.active) {

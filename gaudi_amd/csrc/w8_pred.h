@@ -10,9 +10,9 @@
 namespace gaudi {
 namespace w8 {
 
-template <int HP>
+template <int HP, bool SP = false>
 struct PredSmem {
-  float* ring;                    // [2][T*256]
+  float* ring;                    // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats)
   float *b2, *b3, *b4;            // [N][HP+4] node buffers (roles change per phase, see below)
   float *b0, *b1;                 // [N][HP+4] ... these two sit right in front of `pub` and are part of it in the reverse pass
   float* pub;                     // [pubx] extra floats of the publish buffer (reverse pass: du of every slot, CH tiles at a time)
@@ -22,11 +22,11 @@ struct PredSmem {
   float* pred;                    // [16] pred | [16] dpred
   float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
   __host__ __device__ static int floats(int N, int S, int pubx) {
-    return 2 * (HP / 16) * 256 + 5 * N * (HP + 4) + pubx + 12 * N + S * 10 + 32 + 10 * HP;
+    return EdgeRing<HP, SP>::kFloats + 5 * N * (HP + 4) + pubx + 12 * N + S * 10 + 32 + 10 * HP;
   }
   __device__ void carve(float* base, int N, int S, int pubx) {
     constexpr int LD = HP + 4;
-    ring = base; base += 2 * (HP / 16) * 256;
+    ring = base; base += EdgeRing<HP, SP>::kFloats;
     b2 = base; base += N * LD;
     b3 = base; base += N * LD;
     b4 = base; base += N * LD;
@@ -65,8 +65,8 @@ __host__ __device__ inline int pub_chunk_tiles(int S, long long avail_floats, in
 // forward: pred[K] -> sm.pred[0..K)
 // buffers: h = b0, P = b1, Q = b2, agg = b3, second agg partial = b4
 // ---------------------------------------------------------------------------------------------
-template <int HP>
-__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* sZ,
+template <int HP, bool SP = false>
+__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP>& sm, const float* sZ,
                                              float t_val, float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -75,6 +75,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   PredLayout lay{HP, F1, K, W.L};
   const float* __restrict__ w = W.w;
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
+  const WBuf wbe = SP ? make_wbuf(W.ws, W.ws_bytes) : wb;  // edge-GEMM matrices (w8_split.h)
   float *h = sm.b0, *p = sm.b1, *q = sm.b2, *agg = sm.b3, *agg1 = sm.b4;
   float* estash = stash + pred_stash_node_floats(N, HP, W.L);
   float* astash = estash + (size_t)W.L * S * HP * 2;
@@ -99,11 +100,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   }
   __syncthreads();
   compute_geo(sm, mg, 0.f, tid, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
-  Ring<HP> ring;
-  ring.base = sm.ring;
-  ring.par = 0;
-  ring.ktail = W.ktail != 0;
-  ring_start<HP>(ring, wb, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
+  typename EdgeRing<HP, SP>::type ring;
+  er_init<HP>(ring, sm.ring, W.ktail != 0);
+  er_start<HP>(ring, wbe, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
   NodePF<HP> pf;
   node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane);
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
@@ -140,7 +139,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       const TileCols tc = load_tile(mg, 0, wave, c);
       const f4 gg = sm.geo[tc.slot];
       f4 acc[T];
-      edge_gemm_pq<HP>(acc, ring, wb, Lw.W2, last ? -1 : Lw.Wc1, Lw.b2, Lw.cr, Lw.cd, p + tc.i * LD + 4 * g,
+      er_gemm_pq<HP>(acc, ring, wbe, Lw.W2, last ? -1 : Lw.Wc1, Lw.b2, Lw.cr, Lw.cd, p + tc.i * LD + 4 * g,
                        q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
       STAMP(ST_EDGE);
       const int tile = tc.slot >> 4;
@@ -168,7 +167,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       STAMP(ST_EDGE_EPI);
       if (!last) {  // coord_model (gcl.py:252-278): trans = dhat * tanh(wc2 . silu(Wc1 e + bc1)) * R * mask
         f4 cp[T];
-        edge_gemm_regs<HP>(cp, acc, ring, wb, Lw.Wc1, lay.layer(l + 1) + 2 * HP * HP, Lw.bc1, nullptr, tc.active, wave, lane);
+        er_gemm_regs<HP>(cp, acc, ring, wbe, Lw.Wc1, lay.layer(l + 1) + 2 * HP * HP, Lw.bc1, nullptr, tc.active, wave, lane);
         STAMP(ST_EDGE);
         if (tc.active) {
           f4* sc = (f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
@@ -231,8 +230,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 //                          B4 = b4: npre (stash) -> dnpre -> dQ
 // pub_ch = 16-feature tiles of du published per chunk into [b0 | b1 | pub] (row = 16 pub_ch + 4 floats per slot)
 // ---------------------------------------------------------------------------------------------
-template <int HP>
-__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
+template <int HP, bool SP = false>
+__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP>& sm, const float* stash,
                                               float* sGrad, float readout_div, int pub_ch, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -241,6 +240,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   PredLayout lay{HP, F1, K, W.L};
   const float* __restrict__ w = W.w;
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
+  const WBuf wbe = SP ? make_wbuf(W.ws, W.ws_bytes) : wb;  // edge-GEMM matrices (w8_split.h)
   float *B0 = sm.b0, *B1 = sm.b1, *B2 = sm.b2, *dh = sm.b3, *B4 = sm.b4;
   float* pub = sm.b0;  // [slots][16 pub_ch + 4]
   const int PLD = 16 * pub_ch + 4;
@@ -275,13 +275,11 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   }
   __syncthreads();
 
-  Ring<HP> ring;
-  ring.base = sm.ring;
-  ring.par = 0;
-  ring.ktail = W.ktail != 0;
+  typename EdgeRing<HP, SP>::type ring;
+  er_init<HP>(ring, sm.ring, W.ktail != 0);
   {
     const int L0 = lay.layer(W.L - 1);
-    ring_start<HP>(ring, wb, L0 + 9 * HP * HP /* W2^T of the last layer (its coordinate branch is skipped) */, wave, lane);
+    er_start<HP>(ring, wbe, L0 + 9 * HP * HP /* W2^T of the last layer (its coordinate branch is skipped) */, wave, lane);
   }
   NodePF<HP> pf;
   node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane);
@@ -357,7 +355,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             for (int t = 0; t < T; ++t) cp[t] = splat(0.f);
           }
           STAMP(ST_B_DCP);
-          edge_gemm_regs<HP>(de, cp, ring, wb, Lw.Wc1t, Lw.W2t, nullptr, B0 + tc.i * LD /* + dagg_i (agg_i = sum_j e_ij) */,
+          er_gemm_regs<HP>(de, cp, ring, wbe, Lw.Wc1t, Lw.W2t, nullptr, B0 + tc.i * LD /* + dagg_i (agg_i = sum_j e_ij) */,
                              tc.active, wave, lane);
           STAMP(ST_B_DE);
         } else {
@@ -382,7 +380,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         }
         STAMP(ST_B_DV);
         // next edge GEMM of the chain: Wc1^T of layer l-1 (W2^T when that layer is ... never the last), none after layer 0
-        edge_gemm_regs<HP>(du, de, ring, wb, Lw.W2t, l > 0 ? lay.layer(l - 1) + 10 * HP * HP : -1, nullptr, nullptr, tc.active,
+        er_gemm_regs<HP>(du, de, ring, wbe, Lw.W2t, l > 0 ? lay.layer(l - 1) + 10 * HP * HP : -1, nullptr, nullptr, tc.active,
                            wave, lane);  // dt1
         STAMP(ST_B_DT1);
       }
@@ -490,49 +488,49 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 }
 
 // unit-test entry: pred (and optionally grad into sGrad) for z in sZ
-template <int HP>
+template <int HP, bool SP = false>
 __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                 float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid STAMP_DECL) {
   (void)sTmp; (void)sMean;
-  PredSmem<HP> sm;
+  PredSmem<HP, SP> sm;
   sm.carve(net, mg.N, mg.S, pubx);
-  pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
+  pred_forward<HP, SP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
     if (pred_out) pred_out[tid] = sm.pred[tid];
     sm.pred[16 + tid] = dpred ? dpred[tid] : 0.f;
   }
   __syncthreads();
-  if (want_grad) pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS);
+  if (want_grad) pred_backward<HP, SP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS);
 }
 
-template <int HP>
-__device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP>& sm, const float* target_w, float scale,
+template <int HP, bool SP = false>
+__device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP, SP>& sm, const float* target_w, float scale,
                                               float* pred_out, int tid, int phase, const float* dpred_ext);
 __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, float* sGrad, float* sMean, float sigma, int tid);
 
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 // phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
 // (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
-template <int HP>
+template <int HP, bool SP = false>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, float sigma, const float* target_w,
                                                 float scale, float* pred_out, float readout_div, float* stash, int pubx,
                                                 int pub_ch, int tid STAMP_DECL, int phase, const float* dpred_ext) {
   (void)sTmp;
   const int N = mg.N, D = mg.D;
-  PredSmem<HP> sm;
+  PredSmem<HP, SP> sm;
   sm.carve(net, N, mg.S, pubx);
-  if (phase != 2) pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
-  guidance_seed<HP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
+  if (phase != 2) pred_forward<HP, SP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
+  guidance_seed<HP, SP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
   if (phase == 1) return;
-  pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
+  pred_backward<HP, SP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
   guidance_apply(mg, sZ, sGrad, sMean, sigma, tid);
 }
 
 // pred -> pred_out (split mode) and the seed of the reverse pass: d(energy)/dpred = scale * dT/dpred
-template <int HP>
-__device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP>& sm, const float* target_w, float scale,
+template <int HP, bool SP>
+__device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP, SP>& sm, const float* target_w, float scale,
                                               float* pred_out, int tid, int phase, const float* dpred_ext) {
   if (tid < W.K) {
     if (pred_out && phase != 2) pred_out[tid] = sm.pred[tid];

@@ -1,0 +1,307 @@
+// w8_split.h -- edge-level GEMMs of the 8-wave kernels on the bf16 matrix pipe with fp32-equivalent accuracy.
+//
+// v_mfma_f32_16x16x4_f32 runs at the vector fp32 rate (64 FLOP/clk/SIMD); v_mfma_f32_16x16x32_bf16 at 16x that.  Every fp32
+// operand is split into three bf16 pieces (round-to-nearest each time: x = h + m + l EXACTLY, |m| <= 2^-9 |x|, |l| <= 2^-17
+// |x|) and a product a.b is accumulated in fp32 from the six piece products of weight >= 2^-18:
+//     ah.bh + ah.bm + am.bh + am.bm + ah.bl + al.bh          (dropped: am.bl + al.bm + al.bl <= 2^-24.4 |a.b|)
+// Piece products are exact in fp32 (8 x 8 significant bits), so the only error beside the fp32 accumulation is the dropped
+// tail -- below the rounding error of ONE fp32 multiply (2^-24 |a.b|).  Measured against float64 the result is as close as
+// the fp32-MFMA GEMM (tests/test_gpu_split.py, tools/split_gemm_microbench.hip).  Six 16-cycle instructions replace eight
+// 32-cycle ones per 32 inputs: 2.67x less matrix time, and vector-ALU work co-issues with bf16 MFMAs (it does not with
+// fp32 MFMAs).
+//
+// Layout.  K is consumed in chunks of 32 inputs = two 16-feature tiles (2m, 2m+1); lane (column c, group g) carries inputs
+// 16(2m) + 4g .. +3 in slots 0-3 and 16(2m+1) + 4g .. +3 in slots 4-7, which is exactly the accumulator layout of two output
+// tiles of the previous GEMM of a chain.  The host packs each matrix as units of 1 KiB: unit (m, t, p) = piece p of output
+// tile t against chunk m, lane L = (row L & 15, group L >> 4) holding its 8 bf16 A-operand slots (16 B): one conflict-free
+// ds_read_b128 per unit.  Units are ordered [m][t][p]; a ring group = the CH tiles x 3 pieces one trip consumes.
+#pragma once
+#include "w8_common.h"
+
+#ifndef GAUDI_SPLIT_CH
+#define GAUDI_SPLIT_CH 0  // output tiles per ring trip (0 = all T: one trip per K chunk)
+#endif
+
+namespace gaudi {
+namespace w8 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+typedef __attribute__((ext_vector_type(2))) float f2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+
+struct B3 {
+  u4 h, m, l;  // the lane's 8 inputs of a K chunk, three bf16 pieces each (slot e in bits 16(e&1) of word e>>1)
+};
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){a, b}, bf2));
+}
+struct P3 {
+  uint32_t h, m, l;
+};
+__device__ __forceinline__ P3 split2(float a, float b) {
+  P3 r;
+  r.h = pk_bf16(a, b);
+  const float ra = a - __builtin_bit_cast(float, r.h << 16), rb = b - __builtin_bit_cast(float, r.h & 0xffff0000u);
+  r.m = pk_bf16(ra, rb);
+  r.l = pk_bf16(ra - __builtin_bit_cast(float, r.m << 16), rb - __builtin_bit_cast(float, r.m & 0xffff0000u));
+  return r;
+}
+__device__ __forceinline__ B3 split8(const f4 lo, const f4 hi) {
+  const P3 p0 = split2(lo[0], lo[1]), p1 = split2(lo[2], lo[3]), p2 = split2(hi[0], hi[1]), p3 = split2(hi[2], hi[3]);
+  B3 r;
+  r.h = (u4){p0.h, p1.h, p2.h, p3.h};
+  r.m = (u4){p0.m, p1.m, p2.m, p3.m};
+  r.l = (u4){p0.l, p1.l, p2.l, p3.l};
+  return r;
+}
+__device__ __forceinline__ f4 mfma_bf(const u4 a, const u4 b, const f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+
+// Geometry of a split matrix: T tiles, NC = ceil(T/2) K chunks, trips of CH output tiles (NH per chunk)
+template <int HP>
+struct SplitGeo {
+  static constexpr int T = HP / 16;
+  static constexpr int NC = (T + 1) / 2;
+  // output tiles per trip: all T, unless that leaves a matrix with a single trip (the ring runs two trips ahead and knows
+  // only the current and the next matrix of a chain)
+  static constexpr int CH0 = GAUDI_SPLIT_CH > 0 ? (GAUDI_SPLIT_CH < T ? GAUDI_SPLIT_CH : T) : T;
+  static constexpr int CH = (NC == 1 && CH0 == T && T > 1) ? (T + 1) / 2 : CH0;
+  static constexpr int NH = (T + CH - 1) / CH;
+  static constexpr int kTrips = NC * NH;
+  static constexpr int kUnit = 256;                    // floats (1 KiB)
+  static constexpr int kSlotFloats = CH * 3 * kUnit;   // LDS per ring slot
+  static constexpr int kMatFloats = NC * T * 3 * kUnit;  // one packed matrix
+  static constexpr int UT = (CH * 3 + kWaves - 1) / kWaves;
+  // trip tr = (chunk m = tr / NH, part h = tr % NH): tiles [h CH, min(T, (h+1) CH))
+  __host__ __device__ static constexpr int tiles_of(int h) { return (h + 1) * CH <= T ? CH : T - h * CH; }
+  __host__ __device__ static constexpr int group_off(int tr) { return ((tr / NH) * T + (tr % NH) * CH) * 3 * kUnit; }
+};
+
+template <int HP>
+struct RingS {
+  using G = SplitGeo<HP>;
+  float* base;  // LDS [2][kSlotFloats]
+  int par;
+  f4 st[G::UT];
+  __device__ __forceinline__ float* slot(int p) const { return base + p * G::kSlotFloats; }
+};
+
+// group of trip `tr` of the matrix at float offset W (tr >= kTrips: trip tr - kTrips of nextW; nextW < 0: nothing)
+template <int HP>
+__device__ __forceinline__ void rings_issue(RingS<HP>& r, const WBuf& wb, int W, int nextW, int tr, int wave, int lane) {
+  using G = SplitGeo<HP>;
+  const bool nxt = tr >= G::kTrips;
+  const int t2 = nxt ? tr - G::kTrips : tr;
+  const bool have = !nxt || nextW >= 0;
+  const int units = G::tiles_of(t2 % G::NH) * 3;
+  const int off = __builtin_amdgcn_readfirstlane((nxt ? nextW : W) + G::group_off(t2));
+#pragma unroll
+  for (int u = 0; u < G::UT; ++u) {
+    const int un = wave + kWaves * u;
+    r.st[u] = ldw4(wb, off + (un < units ? un : 0) * G::kUnit, (have && un < units) ? lane : kOOBLane);
+  }
+}
+template <int HP>
+__device__ __forceinline__ void rings_commit(const RingS<HP>& r, float* slot, int wave, int lane) {
+  using G = SplitGeo<HP>;
+#pragma unroll
+  for (int u = 0; u < G::UT; ++u) {
+    const int un = wave + kWaves * u;
+    if (un < G::CH * 3) *(f4*)(slot + un * G::kUnit + lane * 4) = r.st[u];
+  }
+}
+template <int HP>
+__device__ __forceinline__ void rings_start(RingS<HP>& r, const WBuf& wb, int W, int wave, int lane) {
+  rings_issue(r, wb, W, -1, 0, wave, lane);
+  rings_commit(r, r.slot(r.par), wave, lane);
+  rings_issue(r, wb, W, -1, 1, wave, lane);
+}
+template <int HP>
+__device__ __forceinline__ void rings_stage(RingS<HP>& r, const WBuf& wb, int W, int nextW, int tr, int wave, int lane) {
+  rings_commit(r, r.slot(r.par ^ 1), wave, lane);
+  rings_issue(r, wb, W, nextW, tr + 2, wave, lane);
+}
+
+// One trip: NT output tiles (acc[t0 .. t0+NT)) against the K chunk in `b`; A units one tile ahead in registers.
+template <int HP, int NT, class MID>
+__device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, const B3& b, bool active, MID mid) {  // NOLINT
+  constexpr int U = SplitGeo<HP>::kUnit;
+  f4 a[2][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) a[0][p] = *(const f4*)(slot_lane + p * U);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int cur = t & 1;
+    if (t == NT / 2) {
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t + 1 < NT) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[cur ^ 1][p] = *(const f4*)(slot_lane + ((t + 1) * 3 + p) * U);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (active) {
+      const u4 ah = __builtin_bit_cast(u4, a[cur][0]), am = __builtin_bit_cast(u4, a[cur][1]), al = __builtin_bit_cast(u4, a[cur][2]);
+      f4 c = acc[t];
+      c = mfma_bf(al, b.h, c);  // small terms first
+      c = mfma_bf(ah, b.l, c);
+      c = mfma_bf(am, b.m, c);
+      c = mfma_bf(am, b.h, c);
+      c = mfma_bf(ah, b.m, c);
+      c = mfma_bf(ah, b.h, c);
+      acc[t] = c;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// acc = b2 + W2 . silu(u) (see edge_gemm_pq); weights in split format at float offset W of wb
+template <int HP>
+__device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP>& ring, const WBuf& wb, int W, int nextW,
+                                               const float* sB2, const float* sCr, const float* sCd, const float* pp,
+                                               const float* qq, float r, float d0, bool active, int wave, int lane) {
+  using G = SplitGeo<HP>;
+  constexpr int T = G::T;
+  const int g = lane >> 4;
+  const bool late = wave >= kWaves / 2;
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = *(const f4*)(sB2 + 16 * t + 4 * g);
+  auto gen = [&](int m) {  // split silu(u) of K chunk m (tiles 2m, 2m+1; an odd T leaves the upper half of the last chunk 0)
+    const f4 lo = silu4(edge_u(pp, qq, sCr, sCd, g, 2 * m, r, d0));
+    const f4 hi = 2 * m + 1 < T ? silu4(edge_u(pp, qq, sCr, sCd, g, 2 * m + 1 < T ? 2 * m + 1 : 0, r, d0)) : splat(0.f);
+    return split8(lo, hi);
+  };
+  B3 bin = gen(0), nb = bin;
+  static_assert(G::NH <= 3, "at most three trips per K chunk");
+#pragma unroll 1
+  for (int m = 0; m < G::NC; ++m) {
+    auto trip = [&](auto h_tag) {
+      constexpr int h = decltype(h_tag)::value;
+      const int tr = m * G::NH + h;
+      __syncthreads();
+#ifndef SPLIT_NO_GEN
+      if (late && h == 0 && m > 0) bin = gen(m);
+#endif
+      rings_mfma<HP, G::tiles_of(h)>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
+#ifndef SPLIT_NO_STAGE
+        rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
+#endif
+#ifndef SPLIT_NO_GEN
+        if (!late && h == G::NH - 1) nb = gen(m + 1 < G::NC ? m + 1 : m);
+#endif
+      });
+      ring.par ^= 1;
+    };
+    trip(std::integral_constant<int, 0>{});
+    if constexpr (G::NH > 1) trip(std::integral_constant<int, 1>{});
+    if constexpr (G::NH > 2) trip(std::integral_constant<int, 2>{});
+    if (!late) bin = nb;
+  }
+}
+
+// Chained edge GEMM, input in registers (accumulator layout of the previous GEMM): out = bias + rowinit + W . in
+template <int HP>
+__device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], RingS<HP>& ring, const WBuf& wb,
+                                                 int W, int nextW, const float* sBias, const float* rowinit, bool active,
+                                                 int wave, int lane) {
+  using G = SplitGeo<HP>;
+  constexpr int T = G::T;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f4 b = sBias != nullptr ? *(const f4*)(sBias + 16 * t + 4 * g) : splat(0.f);
+    if (rowinit != nullptr) b = b + *(const f4*)(rowinit + 16 * t + 4 * g);
+    out[t] = b;
+  }
+  static_assert(G::NH <= 3, "at most three trips per K chunk");
+#pragma unroll
+  for (int m = 0; m < G::NC; ++m) {
+    const B3 bin = split8(in[2 * m], 2 * m + 1 < T ? in[2 * m + 1 < T ? 2 * m + 1 : 0] : splat(0.f));
+    auto trip = [&](auto h_tag) {
+      constexpr int h = decltype(h_tag)::value;
+      const int tr = m * G::NH + h;
+      __syncthreads();
+      rings_mfma<HP, G::tiles_of(h)>(out + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active,
+                                     [&] { rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane); });
+      ring.par ^= 1;
+    };
+    trip(std::integral_constant<int, 0>{});
+    if constexpr (G::NH > 1) trip(std::integral_constant<int, 1>{});
+    if constexpr (G::NH > 2) trip(std::integral_constant<int, 2>{});
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One interface over both edge-GEMM engines (SP = split-bf16).  Matrix offsets are the fp32 weight buffer's float offsets
+// in both cases: the split image of the matrix at float offset W lives at float offset 2 W of its own buffer (a split
+// matrix is 1.5x, for an odd tile count up to 1.62x, the size of the fp32 one; the holes are never touched).
+// ---------------------------------------------------------------------------------------------
+template <int HP, bool SP>
+struct EdgeRing {
+  using type = Ring<HP>;
+  static constexpr int kFloats = 2 * (HP / 16) * 256;
+};
+template <int HP>
+struct EdgeRing<HP, true> {
+  using type = RingS<HP>;
+  static constexpr int kFloats = 2 * SplitGeo<HP>::kSlotFloats;
+};
+__host__ __device__ constexpr int edge_ring_floats(int HP, bool split) {
+  const int T = HP / 16;
+  const int CH0 = GAUDI_SPLIT_CH > 0 ? (GAUDI_SPLIT_CH < T ? GAUDI_SPLIT_CH : T) : T;
+  const int CH = ((T + 1) / 2 == 1 && CH0 == T && T > 1) ? (T + 1) / 2 : CH0;  // = SplitGeo<HP>::CH
+  return split ? 2 * CH * 3 * 256 : 2 * T * 256;
+}
+static_assert(edge_ring_floats(32, true) == 2 * SplitGeo<32>::kSlotFloats && edge_ring_floats(208, true) == 2 * SplitGeo<208>::kSlotFloats &&
+                  edge_ring_floats(48, true) == 2 * SplitGeo<48>::kSlotFloats,
+              "host LDS planning and SplitGeo disagree");
+__device__ __forceinline__ int split_off(int W) { return W < 0 ? -1 : 2 * W; }
+
+template <int HP>
+__device__ __forceinline__ void er_init(Ring<HP>& r, float* base, bool ktail) {
+  r.base = base;
+  r.par = 0;
+  r.ktail = ktail;
+}
+template <int HP>
+__device__ __forceinline__ void er_init(RingS<HP>& r, float* base, bool) {
+  r.base = base;
+  r.par = 0;
+}
+template <int HP>
+__device__ __forceinline__ void er_start(Ring<HP>& r, const WBuf& wb, int W, int wave, int lane) {
+  ring_start<HP>(r, wb, W, wave, lane);
+}
+template <int HP>
+__device__ __forceinline__ void er_start(RingS<HP>& r, const WBuf& wb, int W, int wave, int lane) {
+  rings_start<HP>(r, wb, split_off(W), wave, lane);
+}
+template <int HP>
+__device__ __forceinline__ void er_gemm_pq(f4 (&acc)[HP / 16], Ring<HP>& ring, const WBuf& wb, int W, int nextW, const float* sB2,
+                                           const float* sCr, const float* sCd, const float* pp, const float* qq, float r, float d0,
+                                           bool active, int wave, int lane STAMP_DECL) {
+  edge_gemm_pq<HP>(acc, ring, wb, W, nextW, sB2, sCr, sCd, pp, qq, r, d0, active, wave, lane STAMP_ARGS);
+}
+template <int HP>
+__device__ __forceinline__ void er_gemm_pq(f4 (&acc)[HP / 16], RingS<HP>& ring, const WBuf& wb, int W, int nextW, const float* sB2,
+                                           const float* sCr, const float* sCd, const float* pp, const float* qq, float r, float d0,
+                                           bool active, int wave, int lane STAMP_DECL) {
+  edge_gemm_pq_s<HP>(acc, ring, wb, split_off(W), split_off(nextW), sB2, sCr, sCd, pp, qq, r, d0, active, wave, lane);
+}
+template <int HP>
+__device__ __forceinline__ void er_gemm_regs(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], Ring<HP>& ring, const WBuf& wb, int W,
+                                             int nextW, const float* sBias, const float* rowinit, bool active, int wave, int lane) {
+  edge_gemm_regs<HP>(out, in, ring, wb, W, nextW, sBias, rowinit, active, wave, lane);
+}
+template <int HP>
+__device__ __forceinline__ void er_gemm_regs(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], RingS<HP>& ring, const WBuf& wb, int W,
+                                             int nextW, const float* sBias, const float* rowinit, bool active, int wave, int lane) {
+  edge_gemm_regs_s<HP>(out, in, ring, wb, split_off(W), split_off(nextW), sBias, rowinit, active, wave, lane);
+}
+
+}  // namespace w8
+}  // namespace gaudi

@@ -313,5 +313,12 @@ class Engine:
         self._check(self.lib.gaudi_kernel_variant(self.h, C.byref(a), C.byref(b)), "gaudi_kernel_variant")
         return a.value, b.value
 
+    def edge_math(self):
+        """-> (configured, last_call): 1 = edge GEMMs on the bf16 matrix pipe with exactly split fp32 operands (default on the
+        8-wave kernels), 0 = fp32 matrix instructions (GAUDI_EDGE_MATH=fp32, the 4-wave kernels, or the LDS fallback)."""
+        a, b = C.c_int32(), C.c_int32()
+        self._check(self.lib.gaudi_edge_math(self.h, C.byref(a), C.byref(b)), "gaudi_edge_math")
+        return a.value, b.value
+
     def set_steps_per_launch(self, k: int):
         self._check(self.lib.gaudi_set_steps_per_launch(self.h, int(k)), "gaudi_set_steps_per_launch")

@@ -220,6 +220,12 @@ int gaudi_host_graph_meta8(int B, int N, const float* node_mask, const float* ed
  * kernels' limits: more than 128 edge slots with guidance, a node with more than 32 live edges, LDS).  last_call = what the
  * most recent call ran on. */
 int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
+/* Arithmetic of the edge-level GEMMs (the W2 / Wc1 contractions and their transposes, edm/egnn/egnn_new.py:42-47 and
+ * edm/egnn_predictor/gcl.py:225-231) on the 8-wave kernels: 1 = every fp32 operand split exactly into three bf16 pieces, six
+ * piece products accumulated in fp32 on the bf16 matrix pipe (error against float64 not larger than the fp32 matrix
+ * instruction's: tests/test_gpu_split.py); 0 = v_mfma_f32_16x16x4_f32 (environment GAUDI_EDGE_MATH=fp32 at gaudi_create,
+ * the 4-wave kernels, and the per-call fallback when the larger LDS weight ring of the split form does not fit). */
+int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
 /* Tile packing of a weight block W[o][col0+k] (o,k < H, row stride ldw) into [HP/16][HP/16][16][16]
  * (k-chunk major), optionally transposed: the layout every GEMM of the kernels streams. */
 int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, const float* W, float* packed_out);

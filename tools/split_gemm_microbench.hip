@@ -1,0 +1,267 @@
+// Microbenchmark + numerics probe of the split-bf16 edge GEMM (w8_split.h) next to the fp32-MFMA one (w8_common.h).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gaudi_amd/csrc tools/split_gemm_microbench.hip -o split_mb && ./split_mb
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "w8_split.h"
+using namespace gaudi;
+
+static uint16_t bf16_rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf16_f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// W[o][k] (H x H, row-major) -> split units [m][t][p]
+template <int HP>
+static void pack_split(std::vector<float>& dst, const std::vector<float>& W, int H) {
+  using G = w8::SplitGeo<HP>;
+  dst.assign(G::kMatFloats, 0.f);
+  uint16_t* d = (uint16_t*)dst.data();
+  for (int m = 0; m < G::NC; ++m)
+    for (int t = 0; t < G::T; ++t)
+      for (int L = 0; L < 64; ++L)
+        for (int e = 0; e < 8; ++e) {
+          const int row = L & 15, g = L >> 4, tile = 2 * m + (e >> 2), k = 16 * tile + 4 * g + (e & 3), o = 16 * t + row;
+          float w = (tile < G::T && k < H && o < H) ? W[(size_t)o * H + k] : 0.f;
+          for (int p = 0; p < 3; ++p) {
+            const uint16_t b = bf16_rne(w);
+            d[((size_t)((m * G::T + t) * 3 + p) * 64 + L) * 8 + e] = b;
+            w -= bf16_f(b);
+          }
+        }
+}
+// lane-linear fp32 tiles [k/16][o/16], float4 index L = (row L & 15, k-quad L >> 4)
+template <int HP>
+static void pack_f32(std::vector<float>& dst, const std::vector<float>& W, int H) {
+  constexpr int T = HP / 16;
+  dst.assign((size_t)T * T * 256, 0.f);
+  for (int kc = 0; kc < T; ++kc)
+    for (int t = 0; t < T; ++t)
+      for (int L = 0; L < 64; ++L)
+        for (int q = 0; q < 4; ++q) {
+          const int o = 16 * t + (L & 15), k = 16 * kc + 4 * (L >> 4) + q;
+          dst[((size_t)(kc * T + t) * 64 + L) * 4 + q] = (o < H && k < H) ? W[(size_t)o * H + k] : 0.f;
+        }
+}
+
+template <int HP, bool SPLIT>
+__global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, int nmat, float* out, unsigned long long* cyc,
+                                              int gemms, int nactive) {
+  constexpr int T = HP / 16, LD = HP + 4, N = 11;
+  using G = w8::SplitGeo<HP>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int ring_floats = SPLIT ? 2 * G::kSlotFloats : 2 * T * 256;
+  float* sP = smem + ring_floats;
+  float* sQ = sP + N * LD;
+  float* vec = sQ + N * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
+  for (int i = tid; i < 2 * N * LD + 3 * HP; i += 512) sP[i] = 0.01f * ((i * 7) % 13) - 0.05f;
+  __syncthreads();
+  const WBuf wb = make_wbuf(w, wbytes);
+  const bool active = wave < nactive;
+  const int i = (wave + c) % N, j = (wave * 3 + c) % N;
+  f4 total = splat(0.f);
+  constexpr int MF = SPLIT ? G::kMatFloats : T * T * 256;
+  w8::Ring<HP> ring;
+  w8::RingS<HP> rs;
+  if (SPLIT) {
+    rs.base = smem;
+    rs.par = 0;
+    w8::rings_start<HP>(rs, wb, 0, wave, lane);
+  } else {
+    ring.base = smem;
+    ring.par = 0;
+    ring.ktail = false;
+    w8::ring_start<HP>(ring, wb, 0, wave, lane);
+  }
+  const unsigned long long w0 = wall_clock64();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int m = 0; m < gemms; ++m) {
+    const int W = (m % nmat) * MF, nextW = ((m + 1) % nmat) * MF;
+    f4 acc[T];
+    if (SPLIT)
+      w8::edge_gemm_pq_s<HP>(acc, rs, wb, W, nextW, vec, vec + HP, vec + 2 * HP, sP + i * LD + 4 * g, sQ + j * LD + 4 * g, 0.3f,
+                             0.7f, active, wave, lane);
+    else
+      w8::edge_gemm_pq<HP>(acc, ring, wb, W, nextW, vec, vec + HP, vec + 2 * HP, sP + i * LD + 4 * g, sQ + j * LD + 4 * g, 0.3f,
+                           0.7f, active, wave, lane);
+#pragma unroll
+    for (int t = 0; t < T; ++t) total = total + acc[t];
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * 512 + tid] = total[0] + total[1] + total[2] + total[3];
+  if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+  if (tid == 0 && blockIdx.x == 0) cyc[gridDim.x * 8] = wall_clock64() - w0;
+}
+
+// numerics: out[e][o] = sum_k W[o][k] in[e][k] for 128 edge columns (8 waves x 16), chained-GEMM form
+template <int HP, bool SPLIT>
+__global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, const float* in, float* out) {
+  constexpr int T = HP / 16;
+  using G = w8::SplitGeo<HP>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
+  const WBuf wb = make_wbuf(w, wbytes);
+  f4 x[T], y[T];
+  const int e = wave * 16 + c;
+#pragma unroll
+  for (int t = 0; t < T; ++t) x[t] = *(const f4*)(in + (size_t)e * HP + 16 * t + 4 * g);
+  if (SPLIT) {
+    w8::RingS<HP> rs;
+    rs.base = smem;
+    rs.par = 0;
+    w8::rings_start<HP>(rs, wb, 0, wave, lane);
+    w8::edge_gemm_regs_s<HP>(y, x, rs, wb, 0, -1, nullptr, nullptr, true, wave, lane);
+  } else {
+    w8::Ring<HP> ring;
+    ring.base = smem;
+    ring.par = 0;
+    ring.ktail = false;
+    w8::ring_start<HP>(ring, wb, 0, wave, lane);
+    w8::edge_gemm_regs<HP>(y, x, ring, wb, 0, -1, nullptr, nullptr, true, wave, lane);
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) *(f4*)(out + (size_t)e * HP + 16 * t + 4 * g) = y[t];
+}
+
+template <int HP, bool SPLIT>
+static size_t ring_bytes() {
+  return (SPLIT ? 2 * w8::SplitGeo<HP>::kSlotFloats : 2 * (HP / 16) * 256) * 4;
+}
+
+template <int HP, bool SPLIT>
+void run_time(int nactive, int blocks, int nmat) {
+  constexpr int T = HP / 16;
+  using G = w8::SplitGeo<HP>;
+  const size_t mf = SPLIT ? G::kMatFloats : T * T * 256, wfloats = mf * nmat;
+  float *out, *w;
+  unsigned long long* cyc;
+  hipMalloc(&w, wfloats * 4);
+  {
+    std::vector<uint16_t> h(wfloats * 2);
+    std::mt19937 rng(1);
+    for (auto& v : h) v = SPLIT ? bf16_rne(0.1f * ((int)(rng() % 2001) - 1000) / 1000.f) : 0;
+    if (!SPLIT) {
+      float* f = (float*)h.data();
+      for (size_t i = 0; i < wfloats; ++i) f[i] = 0.1f * ((int)(rng() % 2001) - 1000) / 1000.f;
+    }
+    hipMemcpy(w, h.data(), wfloats * 4, hipMemcpyHostToDevice);
+  }
+  hipMalloc(&out, blocks * 512 * 4);
+  hipMalloc(&cyc, blocks * 8 * 8 + 8);
+  const int gemms = 200;
+  const size_t lds = ring_bytes<HP, SPLIT>() + (2 * 11 * (HP + 4) + 3 * HP) * 4;
+  hipFuncSetAttribute((const void*)k_time<HP, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_time<HP, SPLIT>), dim3(blocks), dim3(512), lds, 0, w, (unsigned)(wfloats * 4), nmat, out, cyc, gemms,
+                       nactive);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (hipGetLastError() != hipSuccess) printf("launch error\n");
+  unsigned long long hc[2];
+  hipMemcpy(&hc[0], cyc, 8, hipMemcpyDeviceToHost);
+  hipMemcpy(&hc[1], cyc + blocks * 8, 8, hipMemcpyDeviceToHost);
+  printf("[memtime %llu ticks, wall %llu ticks of 100 MHz => memtime runs at %.0f MHz] ", hc[0], hc[1], 100.0 * hc[0] / hc[1]);
+  printf("%s edge_gemm_pq HP=%d CH=%d active=%d blocks=%d matrices=%d (%.1f MB) LDS %zu B: %.2f us per GEMM (K=%d)\n",
+         SPLIT ? "split-bf16" : "fp32-mfma ", HP, SPLIT ? G::CH : 0, nactive, blocks, nmat, wfloats * 4 / 1e6, lds, ms * 1e3 / gemms, HP);
+  hipFree(out);
+  hipFree(cyc);
+  hipFree(w);
+}
+
+template <int HP>
+void run_num(int H) {
+  constexpr int E = 128;
+  std::mt19937 rng(7);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<float> W((size_t)H * H), in((size_t)E * HP, 0.f);
+  for (auto& v : W) v = nd(rng) / std::sqrt((float)H);
+  for (int e = 0; e < E; ++e)
+    for (int k = 0; k < H; ++k) in[(size_t)e * HP + k] = nd(rng) * (1.f + (e % 5));
+  std::vector<double> ref((size_t)E * H);
+  std::vector<float> ref32((size_t)E * H);
+  double refmax = 0;
+  for (int e = 0; e < E; ++e)
+    for (int o = 0; o < H; ++o) {
+      double s = 0;
+      float s32 = 0.f;
+      for (int k = 0; k < H; ++k) {
+        s += (double)W[(size_t)o * H + k] * in[(size_t)e * HP + k];
+        s32 = fmaf(W[(size_t)o * H + k], in[(size_t)e * HP + k], s32);
+      }
+      ref[(size_t)e * H + o] = s;
+      ref32[(size_t)e * H + o] = s32;
+      refmax = std::max(refmax, std::fabs(s));
+    }
+  float *din, *dout, *dw;
+  hipMalloc(&din, in.size() * 4);
+  hipMalloc(&dout, in.size() * 4);
+  hipMemcpy(din, in.data(), in.size() * 4, hipMemcpyHostToDevice);
+  for (int split = 0; split < 2; ++split) {
+    std::vector<float> pk;
+    if (split) pack_split<HP>(pk, W, H);
+    else pack_f32<HP>(pk, W, H);
+    hipMalloc(&dw, pk.size() * 4);
+    hipMemcpy(dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice);
+    const size_t lds = split ? ring_bytes<HP, true>() : ring_bytes<HP, false>();
+    if (split) {
+      hipFuncSetAttribute((const void*)k_num<HP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_num<HP, true>), dim3(1), dim3(512), lds, 0, dw, (unsigned)(pk.size() * 4), din, dout);
+    } else {
+      hipFuncSetAttribute((const void*)k_num<HP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_num<HP, false>), dim3(1), dim3(512), lds, 0, dw, (unsigned)(pk.size() * 4), din, dout);
+    }
+    std::vector<float> got(in.size());
+    hipMemcpy(got.data(), dout, got.size() * 4, hipMemcpyDeviceToHost);
+    double emax = 0, erms = 0, e32 = 0;
+    for (int e = 0; e < E; ++e)
+      for (int o = 0; o < H; ++o) {
+        const double d = got[(size_t)e * HP + o] - ref[(size_t)e * H + o];
+        emax = std::max(emax, std::fabs(d));
+        erms += d * d;
+        e32 = std::max(e32, std::fabs((double)ref32[(size_t)e * H + o] - ref[(size_t)e * H + o]));
+      }
+    printf("numerics H=%d HP=%d %s: max|err| vs float64 = %.3e (rms %.3e) of max|ref| %.3e -> %.2e relative; host fmaf chain: %.2e\n", H, HP,
+           split ? "split-bf16 x6" : "fp32 MFMA    ", emax, std::sqrt(erms / (E * H)), refmax, emax / refmax, e32 / refmax);
+    hipFree(dw);
+  }
+  hipFree(din);
+  hipFree(dout);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) {
+    run_time<208, true>(7, 256, 48);
+    run_time<208, true>(7, 1, 48);
+    return 0;
+  }
+  run_num<192>(192);
+  run_num<208>(196);
+  run_num<48>(36);
+  run_time<192, false>(7, 256, 27);
+  run_time<192, true>(7, 256, 27);
+  run_time<192, true>(8, 256, 27);
+  run_time<208, false>(7, 256, 48);
+  run_time<208, true>(7, 256, 48);
+  run_time<208, true>(7, 1, 48);
+  return 0;
+}
