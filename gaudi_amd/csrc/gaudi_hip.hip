@@ -239,13 +239,20 @@ static float bf16_to_f(uint16_t b) {
   std::memcpy(&f, &u, 4);
   return f;
 }
+// K tail (g_ktail, odd tile count >= 3 = SplitGeo::kTailOK): the last chunk holds only the tail tile; it is stored as T fp32
+// tiles in pack_matrix's K-tail form and issued as one fp32 k-step per tile.
 static void pack_matrix_split(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose) {
   const int T = HP / 16;
+  const bool tail = g_ktail && (T & 1) && T >= 3;
   uint16_t* d = (uint16_t*)dst;
   for (int o = 0; o < H; ++o)
     for (int k = 0; k < H; ++k) {
       float v = transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k];
       const int tile = k / 16, m = tile / 2, g = (k % 16) / 4, e = 4 * (tile & 1) + (k & 3), t = o / 16, L = g * 16 + o % 16;
+      if (tail && tile == T - 1) {  // k % 16 < 4 here
+        dst[(size_t)(m * T * 3 + t) * 256 + (size_t)((k % 16) * 16 + o % 16) * 4] = v;
+        continue;
+      }
       for (int pc = 0; pc < 3; ++pc) {
         const uint16_t b = bf16_rne(v);
         d[((size_t)((m * T + t) * 3 + pc) * 64 + L) * 8 + e] = b;

@@ -147,7 +147,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   __syncthreads();
   compute_geo(sm, mg, 0.f, tid, true);  // d0 of the input coordinates (egnn_new.py:301)
   typename EdgeRing<HP, SP>::type ring;
-  er_init<HP>(ring, sm.ring, W.ktail != 0);
+  er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
   er_start<HP>(ring, wbe, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
   NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it
   node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);

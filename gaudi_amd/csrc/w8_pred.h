@@ -101,7 +101,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   __syncthreads();
   compute_geo(sm, mg, 0.f, tid, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
   typename EdgeRing<HP, SP>::type ring;
-  er_init<HP>(ring, sm.ring, W.ktail != 0);
+  er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
   er_start<HP>(ring, wbe, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
   NodePF<HP> pf;
   node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane);
@@ -276,7 +276,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   __syncthreads();
 
   typename EdgeRing<HP, SP>::type ring;
-  er_init<HP>(ring, sm.ring, W.ktail != 0);
+  er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
   {
     const int L0 = lay.layer(W.L - 1);
     er_start<HP>(ring, wbe, L0 + 9 * HP * HP /* W2^T of the last layer (its coordinate branch is skipped) */, wave, lane);

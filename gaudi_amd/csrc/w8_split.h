@@ -21,6 +21,9 @@
 #ifndef GAUDI_SPLIT_CH
 #define GAUDI_SPLIT_CH 0  // output tiles per ring trip (0 = all T: one trip per K chunk)
 #endif
+#ifndef GAUDI_SPLIT_GLDS
+#define GAUDI_SPLIT_GLDS 1  // 1: the ring is filled by global_load_lds_dwordx4 (no staging registers, no ds_write)
+#endif
 
 namespace gaudi {
 namespace w8 {
@@ -29,6 +32,14 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
 typedef __attribute__((ext_vector_type(2))) float f2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 struct B3 {
   u4 h, m, l;  // the lane's 8 inputs of a K chunk, three bf16 pieces each (slot e in bits 16(e&1) of word e>>1)
@@ -75,6 +86,9 @@ struct SplitGeo {
   static constexpr int kSlotFloats = CH * 3 * kUnit;   // LDS per ring slot
   static constexpr int kMatFloats = NC * T * 3 * kUnit;  // one packed matrix
   static constexpr int UT = (CH * 3 + kWaves - 1) / kWaves;
+  // K tail (nf % 16 == 4, odd tile count: the last chunk is the tail tile alone): that chunk is stored as T fp32 tiles in
+  // the K-tail form of w8_common.h (input 16(T-1)+g on lane group g, element 0) and issued as ONE fp32 k-step per tile
+  static constexpr bool kTailOK = (T & 1) && T >= 3 && NH == 1;
   // trip tr = (chunk m = tr / NH, part h = tr % NH): tiles [h CH, min(T, (h+1) CH))
   __host__ __device__ static constexpr int tiles_of(int h) { return (h + 1) * CH <= T ? CH : T - h * CH; }
   __host__ __device__ static constexpr int group_off(int tr) { return ((tr / NH) * T + (tr % NH) * CH) * 3 * kUnit; }
@@ -85,18 +99,52 @@ struct RingS {
   using G = SplitGeo<HP>;
   float* base;  // LDS [2][kSlotFloats]
   int par;
+  bool ktail;   // the matrices carry a K tail (SplitGeo::kTailOK widths only)
+#if GAUDI_SPLIT_GLDS
+  const float* gbase;  // the split weight buffer (LDS-DMA loads take a plain global address)
+#else
   f4 st[G::UT];
+#endif
   __device__ __forceinline__ float* slot(int p) const { return base + p * G::kSlotFloats; }
 };
 
 // group of trip `tr` of the matrix at float offset W (tr >= kTrips: trip tr - kTrips of nextW; nextW < 0: nothing)
+#if GAUDI_SPLIT_GLDS
+// LDS-DMA: unit un of the group goes straight to slot + un KiB (wave-uniform LDS base + 16 B per lane)
+template <int HP>
+__device__ __forceinline__ void rings_dma(const RingS<HP>& r, float* slot, int W, int nextW, int tr, int wave, int lane) {
+  using G = SplitGeo<HP>;
+  const bool nxt = tr >= G::kTrips;
+  const int t2 = nxt ? tr - G::kTrips : tr;
+  if (nxt && nextW < 0) return;
+  const int units = (G::kTailOK && r.ktail && t2 == G::kTrips - 1) ? G::T : G::tiles_of(t2 % G::NH) * 3;
+  const int off = __builtin_amdgcn_readfirstlane((nxt ? nextW : W) + G::group_off(t2));
+#pragma unroll
+  for (int u = 0; u < G::UT; ++u) {
+    const int un = wave + kWaves * u;
+    if (un < units)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r.gbase + off + un * G::kUnit + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(slot + un * G::kUnit), 16, 0, 0);
+  }
+}
+template <int HP>
+__device__ __forceinline__ void rings_start(RingS<HP>& r, const WBuf&, int W, int wave, int lane) {
+  rings_dma(r, r.slot(r.par), W, -1, 0, wave, lane);
+}
+// trip tr has passed its opening barrier: nobody reads slot(par ^ 1) any more; the group of trip tr + 1 must have landed
+// at the next barrier (__syncthreads waits vmcnt(0))
+template <int HP>
+__device__ __forceinline__ void rings_stage(RingS<HP>& r, const WBuf&, int W, int nextW, int tr, int wave, int lane) {
+  rings_dma(r, r.slot(r.par ^ 1), W, nextW, tr + 1, wave, lane);
+}
+#else
 template <int HP>
 __device__ __forceinline__ void rings_issue(RingS<HP>& r, const WBuf& wb, int W, int nextW, int tr, int wave, int lane) {
   using G = SplitGeo<HP>;
   const bool nxt = tr >= G::kTrips;
   const int t2 = nxt ? tr - G::kTrips : tr;
   const bool have = !nxt || nextW >= 0;
-  const int units = G::tiles_of(t2 % G::NH) * 3;
+  const int units = (G::kTailOK && r.ktail && t2 == G::kTrips - 1) ? G::T : G::tiles_of(t2 % G::NH) * 3;
   const int off = __builtin_amdgcn_readfirstlane((nxt ? nextW : W) + G::group_off(t2));
 #pragma unroll
   for (int u = 0; u < G::UT; ++u) {
@@ -123,6 +171,17 @@ template <int HP>
 __device__ __forceinline__ void rings_stage(RingS<HP>& r, const WBuf& wb, int W, int nextW, int tr, int wave, int lane) {
   rings_commit(r, r.slot(r.par ^ 1), wave, lane);
   rings_issue(r, wb, W, nextW, tr + 2, wave, lane);
+}
+#endif
+
+// The barrier that opens a trip.  With LDS-DMA the group this trip reads was written by global_load_lds instructions of ALL
+// waves: each wave retires its own (vmcnt) before the barrier -- hipcc does not track these loads for the __syncthreads
+// fence on every path (seen in the ISA: barriers with lgkmcnt(0) only, and a run-to-run difference in the results).
+__device__ __forceinline__ void trip_barrier() {
+#if GAUDI_SPLIT_GLDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  __syncthreads();
 }
 
 // One trip: NT output tiles (acc[t0 .. t0+NT)) against the K chunk in `b`; A units one tile ahead in registers.
@@ -159,6 +218,25 @@ __device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, cons
   }
 }
 
+// The K-tail trip: one fp32 k-step per output tile (A = element 0 of the tile's lane-linear float4, B = the lane group's input)
+template <int HP, class MID>
+__device__ __forceinline__ void rings_mfma_tail(f4 (&acc)[HP / 16], const float* slot_lane, float b, bool active, MID mid) {
+  constexpr int T = HP / 16;
+  float a[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) a[t] = slot_lane[t * SplitGeo<HP>::kUnit];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t == T / 2) {
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (active) acc[t] = mfma1(a[t], b, acc[t]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // acc = b2 + W2 . silu(u) (see edge_gemm_pq); weights in split format at float offset W of wb
 template <int HP>
 __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP>& ring, const WBuf& wb, int W, int nextW,
@@ -177,18 +255,19 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP>& ri
   };
   B3 bin = gen(0), nb = bin;
   static_assert(G::NH <= 3, "at most three trips per K chunk");
-#pragma unroll 1
-  for (int m = 0; m < G::NC; ++m) {
+  const bool tail = G::kTailOK && ring.ktail;
+  auto chunk = [&](int m) {
     auto trip = [&](auto h_tag) {
       constexpr int h = decltype(h_tag)::value;
       const int tr = m * G::NH + h;
-      __syncthreads();
+      trip_barrier();
+      if (GAUDI_SPLIT_GLDS == 2) rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
 #ifndef SPLIT_NO_GEN
       if (late && h == 0 && m > 0) bin = gen(m);
 #endif
       rings_mfma<HP, G::tiles_of(h)>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
 #ifndef SPLIT_NO_STAGE
-        rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
+        if (GAUDI_SPLIT_GLDS != 2) rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
 #endif
 #ifndef SPLIT_NO_GEN
         if (!late && h == G::NH - 1) nb = gen(m + 1 < G::NC ? m + 1 : m);
@@ -200,6 +279,18 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP>& ri
     if constexpr (G::NH > 1) trip(std::integral_constant<int, 1>{});
     if constexpr (G::NH > 2) trip(std::integral_constant<int, 2>{});
     if (!late) bin = nb;
+  };
+  const int full = tail ? G::NC - 1 : G::NC;  // one copy of the chunk body: the tail only shortens the rolled loop
+#pragma unroll 1
+  for (int m = 0; m < full; ++m) chunk(m);
+  if constexpr (G::kTailOK) {
+    if (tail) {
+      trip_barrier();
+      const float bt = silu_f(edge_u_tail(pp, qq, sCr, sCd, g, T, r, d0)[0]);
+      rings_mfma_tail<HP>(acc, ring.slot(ring.par) + lane * 4, bt, active,
+                          [&] { rings_stage<HP>(ring, wb, W, nextW, G::kTrips - 1, wave, lane); });
+      ring.par ^= 1;
+    }
   }
 }
 
@@ -218,21 +309,35 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
     out[t] = b;
   }
   static_assert(G::NH <= 3, "at most three trips per K chunk");
-#pragma unroll
-  for (int m = 0; m < G::NC; ++m) {
+  const int c = lane & 15;
+  auto chunk = [&](auto m_tag) {
+    constexpr int m = decltype(m_tag)::value;
     const B3 bin = split8(in[2 * m], 2 * m + 1 < T ? in[2 * m + 1 < T ? 2 * m + 1 : 0] : splat(0.f));
     auto trip = [&](auto h_tag) {
       constexpr int h = decltype(h_tag)::value;
-      const int tr = m * G::NH + h;
-      __syncthreads();
-      rings_mfma<HP, G::tiles_of(h)>(out + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active,
-                                     [&] { rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane); });
+      constexpr int tr = m * G::NH + h;
+      trip_barrier();
+      if (GAUDI_SPLIT_GLDS == 2) rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
+      rings_mfma<HP, G::tiles_of(h)>(out + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
+        if (GAUDI_SPLIT_GLDS != 2) rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
+      });
       ring.par ^= 1;
     };
     trip(std::integral_constant<int, 0>{});
     if constexpr (G::NH > 1) trip(std::integral_constant<int, 1>{});
     if constexpr (G::NH > 2) trip(std::integral_constant<int, 2>{});
+  };
+  static_for<G::NC - 1>([&](auto m_tag) { chunk(m_tag); });
+  if constexpr (G::kTailOK) {
+    if (ring.ktail) {
+      trip_barrier();
+      rings_mfma_tail<HP>(out, ring.slot(ring.par) + lane * 4, tail_to_b(in[T - 1], c, g)[0], active,
+                          [&] { rings_stage<HP>(ring, wb, W, nextW, G::kTrips - 1, wave, lane); });
+      ring.par ^= 1;
+      return;
+    }
   }
+  chunk(std::integral_constant<int, G::NC - 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -262,15 +367,21 @@ static_assert(edge_ring_floats(32, true) == 2 * SplitGeo<32>::kSlotFloats && edg
 __device__ __forceinline__ int split_off(int W) { return W < 0 ? -1 : 2 * W; }
 
 template <int HP>
-__device__ __forceinline__ void er_init(Ring<HP>& r, float* base, bool ktail) {
+__device__ __forceinline__ void er_init(Ring<HP>& r, float* base, bool ktail, const float*) {
   r.base = base;
   r.par = 0;
   r.ktail = ktail;
 }
 template <int HP>
-__device__ __forceinline__ void er_init(RingS<HP>& r, float* base, bool) {
+__device__ __forceinline__ void er_init(RingS<HP>& r, float* base, bool ktail, const float* ws) {
   r.base = base;
   r.par = 0;
+  r.ktail = ktail;
+#if GAUDI_SPLIT_GLDS
+  r.gbase = ws;
+#else
+  (void)ws;
+#endif
 }
 template <int HP>
 __device__ __forceinline__ void er_start(Ring<HP>& r, const WBuf& wb, int W, int wave, int lane) {

@@ -76,8 +76,7 @@ __global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, i
   w8::Ring<HP> ring;
   w8::RingS<HP> rs;
   if (SPLIT) {
-    rs.base = smem;
-    rs.par = 0;
+    w8::er_init<HP>(rs, smem, false, w);
     w8::rings_start<HP>(rs, wb, 0, wave, lane);
   } else {
     ring.base = smem;
@@ -120,8 +119,7 @@ __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, co
   for (int t = 0; t < T; ++t) x[t] = *(const f4*)(in + (size_t)e * HP + 16 * t + 4 * g);
   if (SPLIT) {
     w8::RingS<HP> rs;
-    rs.base = smem;
-    rs.par = 0;
+    w8::er_init<HP>(rs, smem, false, w);
     w8::rings_start<HP>(rs, wb, 0, wave, lane);
     w8::edge_gemm_regs_s<HP>(y, x, rs, wb, 0, -1, nullptr, nullptr, true, wave, lane);
   } else {
