@@ -159,8 +159,9 @@ def graph_meta8(nm, em):
     return ntiles, ncols
 
 
-def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, backend, T, K=5):
-    """Time `steps` complete sampling calls of one workload; returns the contract fields + roofline of its kernel."""
+def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, backend, T, K=5, edge_math=None):
+    """Time `steps` complete sampling calls of one workload; returns the contract fields + roofline of its kernel.
+    edge_math="fp32": a handle created with GAUDI_EDGE_MATH=fp32 (edge GEMMs on fp32 matrix instructions)."""
     import torch
     import torch.distributed as dist
     from gaudi_amd import dist as gdist
@@ -173,9 +174,19 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     ds = "hetro" if hetero else "cata"
     eargs = synth.edm_args(diffusion_steps=T, dataset=ds)
     pargs = synth.pred_args(dataset=ds)
-    key = (ds, guided)
+    key = (ds, guided, edge_math)
     if key not in eng_cache:
-        eng = Engine(dev.index)
+        saved = os.environ.get("GAUDI_EDGE_MATH")
+        if edge_math is not None:
+            os.environ["GAUDI_EDGE_MATH"] = edge_math  # read once, by gaudi_create
+        try:
+            eng = Engine(dev.index)
+        finally:
+            if edge_math is not None:
+                if saved is None:
+                    del os.environ["GAUDI_EDGE_MATH"]
+                else:
+                    os.environ["GAUDI_EDGE_MATH"] = saved
         esd = synth.synth_edm_state_dict(eargs, F, seed=0)
         eng.load_edm(eargs, esd)
         wfloats = sum(v.size for v in esd.values())
@@ -235,25 +246,38 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     if rank != 0:
         return None
     value = steps * B * world / dt
-    # ---- roofline of the dominant kernel (sampler_kernel<192,208>: EDM + predictor fwd/bwd + update), fp32 matrix cores.
-    # achieved = MFMA FLOPs the kernel ISSUES per launch (counted from its loop structure, 2048 per v_mfma_f32_16x16x4_f32;
-    # the same number rocprofv3's SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 reports) / average launch duration (HIP events on the
-    # handle's stream).  `useful_*` = the factorised algorithm on live edges and unpadded features (what the issued work
-    # is worth); `as_written_*` = the reference's dense concat+Linear formulation, a throughput-equivalent only.
-    variant = "w%d" % eng.kernel_variant()[1]
-    units, ncols = graph_meta8(nm, em) if variant == "w8" else graph_meta(nm, em)
+    # ---- roofline of the dominant kernel (sampler_kernel_v<..,192,208>: EDM + predictor fwd/bwd + update) against the matrix
+    # pipe.  Issued instructions are counted from the kernel's loop structure (flops.step_mfma_counts; the same numbers
+    # rocprofv3's SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 and _BF16 / 32 report): fp32 v_mfma_f32_16x16x4_f32 (2048 FLOP, peak
+    # 157.3 TFLOP/s) and, on the split-operand edge GEMMs, v_mfma_f32_16x16x32_bf16 (16384 FLOP, peak 2516.6).
+    #   achieved = all issued matrix FLOPs / launch time;  frac = time the pipe needs at peak / launch time
+    #            = (F32 / 157.3 + BF16 / 2516.6) / t, i.e. the matrix-pipe busy fraction at the nominal clock;
+    #   peak = achieved / frac (the blend of the two peaks this instruction mix could reach).
+    # `useful_*` = the factorised algorithm on live edges and unpadded features in fp32 FLOPs (what the issued work is
+    # worth); `as_written_*` = the reference's dense concat+Linear formulation, a throughput-equivalent only.
+    wv = eng.kernel_variant()[1]
+    variant = "w4" if wv == 4 else ("w8s" if eng.edge_math()[1] else "w8")
+    units, ncols = graph_meta(nm, em) if variant == "w4" else graph_meta8(nm, em)
     npairs = units
-    mfma_step = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, pargs if guided else None, variant) for b in range(B))
-    useful_step = B * flops.step_flops_useful(live_edges, live_nodes, F, eargs, pargs if guided else None, K)
-    written_step = B * flops.step_flops_as_written(N, F, eargs, pargs if guided else None, K)
-    edm_only = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, None, variant) for b in range(B))
+    pa = pargs if guided else None
+    cnt = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, pa, variant) for b in range(B)], dtype=np.float64).sum(0)
+    cnt_edm = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, None, variant) for b in range(B)], dtype=np.float64).sum(0)
+    equiv_variant = "w8" if variant == "w8s" else variant  # the same work issued as fp32 matrix instructions
+    mfma_step = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, pa, equiv_variant) for b in range(B))
+    edm_only = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, None, equiv_variant) for b in range(B))
+    useful_step = B * flops.step_flops_useful(live_edges, live_nodes, F, eargs, pa, K)
+    written_step = B * flops.step_flops_as_written(N, F, eargs, pa, K)
     # per launch: `steps_done` reverse steps + one decode pass (= one EDM evaluation) per call, over n_launch launches
-    issued_launch = 2048.0 * (mfma_step * steps_done + edm_only * steps) / max(n_launch, 1)
+    per_launch = (cnt * steps_done + cnt_edm * steps) / max(n_launch, 1)
+    f32_flop, bf_flop = per_launch[0] * flops.FLOP_MFMA_F32, per_launch[1] * flops.FLOP_MFMA_BF16
     evals = steps_done + steps * (edm_only / max(mfma_step, 1))
     avg_launch_ms = kern_ms / max(n_launch, 1)
-    achieved = issued_launch / (avg_launch_ms * 1e-3) / 1e12
-    frac = achieved / PEAK_FP32_MATRIX_TFLOPS
-    assert 0.0 < frac <= 1.0, f"roofline.frac = {frac}: the issued-FLOP model or the timing is wrong"
+    t_launch = avg_launch_ms * 1e-3
+    achieved = (f32_flop + bf_flop) / t_launch / 1e12
+    frac = (f32_flop / flops.PEAK_F32_TFLOPS + bf_flop / flops.PEAK_BF16_TFLOPS) / 1e12 / t_launch
+    assert 0.0 < frac <= 1.0, f"roofline.frac = {frac}: the issued-instruction model or the timing is wrong"
+    peak = achieved / frac
+    equiv_launch = 2048.0 * (mfma_step * steps_done + edm_only * steps) / max(n_launch, 1)
     stash = 4 * pargs["n_layers"] * ((3 * N * 208 + 4 * N) + 4 * 32 * 208 * 2) if guided else 0
     hbm_bytes_launch = flops.step_bytes_fused(B, N, F, 0, stash) * steps_done / max(n_launch, 1) + wbytes
     traffic = None
@@ -273,23 +297,35 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
         "metric": ("guided" if guided else "unguided") + f" molecules/sec ({T}-step)",
         "value": value, "unit": "molecules/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded default-init weights, on-device Philox noise)",
+        "dtype": "f32", "edge_gemm_math": "bf16x3 split operands, f32 accumulate" if variant == "w8s" else "f32",
+        "data": "synthetic (seeded default-init weights, on-device Philox noise)",
         "config": {"workload": label, "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
                    "edm": "nf=192,n_layers=9", "predictor": "nf=196,n_layers=12" if guided else None,
                    "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
                    "steps_per_launch": a.steps_per_launch,
                    "max_graph_nodes": "22 at these hidden sizes (one molecule's working set must fit 160 KiB of LDS)"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": frac, "traffic": traffic,
-                     "kernel": ("sampler_kernel_v<V8,192,%s>" if variant == "w8" else "sampler_kernel_v<V4,192,%s>") % ("208" if guided else "0"),
-                     "kernel_variant": "8 waves per molecule (two per SIMD)" if variant == "w8" else "4 waves per molecule",
-                     "flops_basis": "issued v_mfma_f32_16x16x4_f32 x 2048 FLOP (padding included), counted from the kernel's "
-                                    "loop structure; = SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 x 2048 in profiles/",
+                     "kernel": "sampler_kernel_v<%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8S"}[variant], "208" if guided else "0"),
+                     "kernel_variant": {"w4": "4 waves per molecule, fp32 matrix instructions",
+                                        "w8": "8 waves per molecule (two per SIMD), fp32 matrix instructions",
+                                        "w8s": "8 waves per molecule (two per SIMD); edge GEMMs: fp32 operands split exactly "
+                                               "into 3 bf16 pieces, 6 piece products accumulated in fp32 on the bf16 matrix "
+                                               "pipe (error vs float64 <= the fp32 instruction's: tests/test_gpu_split.py); "
+                                               "node GEMMs: fp32 matrix instructions"}[variant],
+                     "flops_basis": "issued matrix instructions counted from the kernel's loop structure (padding included): "
+                                    "v_mfma_f32_16x16x4_f32 x 2048 FLOP at 157.3 TFLOP/s + v_mfma_f32_16x16x32_bf16 x 16384 FLOP "
+                                    "at 2516.6 TFLOP/s; frac = matrix-pipe time at peak / launch time; = SQ_INSTS_VALU_MFMA_MOPS_"
+                                    "F32 / 4 and _BF16 / 32 in profiles/",
+                     "issued_fp32_mfma_per_launch": per_launch[0], "issued_bf16_mfma_per_launch": per_launch[1],
+                     "peak_fp32_matrix_tflops": flops.PEAK_F32_TFLOPS, "peak_bf16_matrix_tflops": flops.PEAK_BF16_TFLOPS,
+                     "fp32_equivalent_tflops": equiv_launch / t_launch / 1e12,
+                     "fp32_equivalent_frac_of_fp32_peak": equiv_launch / t_launch / 1e12 / flops.PEAK_F32_TFLOPS,
                      "issued_gflop_per_molecule_step": 2048.0 * mfma_step / B / 1e9,
                      "useful_gflop_per_molecule_step": useful_step / B / 1e9,
                      "as_written_gflop_per_molecule_step": written_step / B / 1e9,
                      "useful_tflops": useful_step * evals / (kern_ms * 1e-3) / 1e12,
-                     "useful_frac": useful_step * evals / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                     "useful_frac": useful_step * evals / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,  # of the fp32 peak
                      "as_written_tflops_equivalent": written_step * evals / (kern_ms * 1e-3) / 1e12,
                      "live_edges_per_molecule": live_edges,
                      "avg_launch_ms": avg_launch_ms, "launches": n_launch,
@@ -341,12 +377,15 @@ def main():
         if world == 1 and not a.no_secondary and a.workload == "c3":
             # the other single-GPU configurations, timed by the same harness (short: one or two calls each)
             sec = {}
-            for wl, b, st, wu in (("c2", 256, 2, 1), ("c4", 1024, 1, 0), ("c3_b1024", 1024, 1, 0)):
-                r = run_workload(a, engines, wl.split("_")[0], b, st, wu, rank, world, dev, backend, T)
+            for wl, b, st, wu, math in (("c2", 256, 2, 1, None), ("c4", 1024, 1, 0, None), ("c3_b1024", 1024, 1, 0, None),
+                                        ("c3_fp32_mfma", 256, 2, 1, "fp32"), ("c2_fp32_mfma", 256, 2, 1, "fp32")):
+                r = run_workload(a, engines, wl.split("_")[0], b, st, wu, rank, world, dev, backend, T, edge_math=math)
                 sec[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": st,
                            "warmup": wu, "ms_per_step": r["ms_per_step"], "roofline_frac": r["roofline"]["frac"],
-                           "useful_frac": r["roofline"]["useful_frac"], "avg_launch_ms": r["roofline"]["avg_launch_ms"],
-                           "kernel": r["roofline"]["kernel"]}
+                           "useful_frac": r["roofline"]["useful_frac"],
+                           "fp32_equivalent_frac_of_fp32_peak": r["roofline"]["fp32_equivalent_frac_of_fp32_peak"],
+                           "avg_launch_ms": r["roofline"]["avg_launch_ms"], "kernel": r["roofline"]["kernel"],
+                           "edge_gemm_math": r["edge_gemm_math"]}
             out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline:
             guided = a.workload in ("c3", "c4")

@@ -61,12 +61,24 @@ def _pad_hidden_kernel(h):
     raise ValueError(h)
 
 
-def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
-    """v_mfma_f32_16x16x4_f32 instructions (2048 FLOP each) ONE molecule issues per reverse step, counted from the kernel's
-    loop structure (validated against SQ_INSTS_VALU_MFMA_MOPS_F32 / 4: profiles/*pmc_summary.csv).
+FLOP_MFMA_F32 = 2048      # v_mfma_f32_16x16x4_f32: 16 x 16 x 4 MACs
+FLOP_MFMA_BF16 = 16384    # v_mfma_f32_16x16x32_bf16: 16 x 16 x 32 MACs
+PEAK_F32_TFLOPS = 157.3   # 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2516.6  # ... x 1024 FLOP/clk (dense)
 
-    variant "w4" (4 waves, 32-edge passes):  edge_units = list of 32-edge passes per wave [4]
-    variant "w8" (8 waves, 16-edge tiles):   edge_units = number of 16-edge tiles of the molecule
+
+def _has_ktail(nf, HP):
+    return nf % 16 == 4 and HP - nf == 12
+
+
+def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4"):
+    """(fp32, bf16) matrix instructions ONE molecule issues per reverse step, counted from the kernels' loop structure
+    (validated against SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 and SQ_INSTS_VALU_MFMA_MOPS_BF16 / 32: profiles/*pmc_summary.csv).
+
+    variant "w4"  (4 waves, 32-edge passes):  edge_units = list of 32-edge passes per wave [4]
+    variant "w8"  (8 waves, 16-edge tiles, fp32 MFMAs):        edge_units = number of 16-edge tiles of the molecule
+    variant "w8s" (8 waves, edge GEMMs on split-bf16 operands: six v_mfma_f32_16x16x32_bf16 per output tile and 32 inputs,
+                   a K tail as one fp32 k-step per tile; node GEMMs as w8)
     ncols = node columns the node-level GEMMs produce (16-column tiles, pairs of tiles beyond 16)."""
     ncols = int(ncols)
     nt = 1 if ncols <= 16 else 2 * (((ncols + 15) // 16 + 1) // 2)
@@ -79,19 +91,33 @@ def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
     def node(T, kt):  # K chunks x 4 k-steps x output tiles (the 4-wave kernels recompute a tile in idle tile slots)
         return kt * 4 * ((-(-T // waves)) * waves if variant == "w4" else T) * nt
 
-    def edge(T, nf=0):  # one 16-edge tile through one T x T matrix; the 8-wave kernels issue a K tail (nf % 16 == 4) as 1 k-step
-        ksteps = 4 * T - 3 if (variant != "w4" and nf % 16 == 4 and 16 * T - nf == 12) else 4 * T
-        return T * ksteps
+    def edge(T, nf):  # one 16-edge tile through one T x T matrix -> (fp32, bf16)
+        tail = variant != "w4" and _has_ktail(nf, 16 * T)
+        if variant == "w8s":
+            tail = tail and T % 2 == 1 and T >= 3
+            nc = (T + 1) // 2 - (1 if tail else 0)
+            return (T if tail else 0), nc * T * 6
+        return T * (4 * T - 3 if tail else 4 * T), 0
 
+    f32 = bf = 0
     Te = _pad_hidden_kernel(edm["nf"]) // 16
     L, S = edm["n_layers"], edm.get("inv_sublayers", 1)
-    n = L * (S * (node(Te, 5 * Te) + tiles16 * edge(Te, edm["nf"])) + node(Te, 2 * Te) + tiles16 * edge(Te, edm["nf"]))
+    e32, ebf = edge(Te, edm["nf"])
+    f32 += L * (S * (node(Te, 5 * Te) + tiles16 * e32) + node(Te, 2 * Te) + tiles16 * e32)
+    bf += L * (S + 1) * tiles16 * ebf
     if pred is not None:
         Tp = _pad_hidden_kernel(pred["nf"]) // 16
         Lp = pred["n_layers"]
-        fwd = Lp * (node(Tp, 5 * Tp) + tiles16 * edge(Tp, pred["nf"])) + (Lp - 1) * tiles16 * edge(Tp, pred["nf"])
-        n += 2 * fwd  # the reverse pass issues the same counts with the transposed matrices
-    return n
+        e32, ebf = edge(Tp, pred["nf"])
+        n_edge = 2 * (2 * Lp - 1)  # W2 + Wc1 per layer (no Wc1 in the last), the same again transposed in the reverse pass
+        f32 += 2 * Lp * node(Tp, 5 * Tp) + n_edge * tiles16 * e32
+        bf += n_edge * tiles16 * ebf
+    return f32, bf
+
+
+def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
+    """fp32 matrix instructions per molecule-step of the fp32-MFMA kernel families (see step_mfma_counts)."""
+    return step_mfma_counts(edge_units, ncols, edm, pred, variant)[0]
 
 
 def step_bytes_fused(B, N, F, weight_bytes, stash_bytes_per_mol=0):
