@@ -256,7 +256,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     # `useful_*` = the factorised algorithm on live edges and unpadded features in fp32 FLOPs (what the issued work is
     # worth); `as_written_*` = the reference's dense concat+Linear formulation, a throughput-equivalent only.
     wv = eng.kernel_variant()[1]
-    variant = "w4" if wv == 4 else ("w8s" if eng.edge_math()[1] else "w8")
+    em_mode = eng.edge_math()[1]  # 0 fp32 instructions, 1 split operands (full LDS weight ring), 2 split (half ring)
+    variant = "w4" if wv == 4 else ("w8s" if em_mode else "w8")
     units, ncols = graph_meta(nm, em) if variant == "w4" else graph_meta8(nm, em)
     npairs = units
     pa = pargs if guided else None
@@ -306,7 +307,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                    "max_graph_nodes": "22 at these hidden sizes (one molecule's working set must fit 160 KiB of LDS)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": frac, "traffic": traffic,
-                     "kernel": "sampler_kernel_v<%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8S"}[variant], "208" if guided else "0"),
+                     "kernel": "sampler_kernel_v<%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
+                                                                 "208" if guided else "0"),
                      "kernel_variant": {"w4": "4 waves per molecule, fp32 matrix instructions",
                                         "w8": "8 waves per molecule (two per SIMD), fp32 matrix instructions",
                                         "w8s": "8 waves per molecule (two per SIMD); edge GEMMs: fp32 operands split exactly "

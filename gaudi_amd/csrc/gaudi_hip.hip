@@ -61,7 +61,7 @@ struct gaudi_handle {
   int variant = 8;            // 8 = two waves per SIMD (sampler_kernel8, default), 4 = one wave per SIMD (GAUDI_WAVES=4)
   int run_variant = 4;        // what the CURRENT call runs on (an 8-wave handle falls back to 4 waves for graphs that do not fit)
   bool split = true;          // 8-wave kernels: edge GEMMs on the bf16 matrix pipe with 3-way split operands (GAUDI_EDGE_MATH=fp32: off)
-  bool run_split = false;     // ... and whether the CURRENT call uses them (needs a larger LDS weight ring)
+  int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
   long long fix_key = 0;      // global sample index whose Philox stream is shared
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
@@ -555,6 +555,27 @@ static kernel_fn pick_kernel8s(int hpe, int hpp) {
   return f;
 }
 
+// ... and with the half-size ring (kern8h_*.hip): larger molecules
+#ifdef GAUDI_STAMP_STUBS
+#define GAUDI_KERNEL8H_TUS(X) X(fused_192_208)
+#else
+#define GAUDI_KERNEL8H_TUS(X) X(edm_192) X(fused_tiny) X(fused_192_208)
+#endif
+#define X(name) kernel_fn gaudi_kern8h_##name(int hpe, int hpp);
+GAUDI_KERNEL8H_TUS(X)
+#undef X
+static kernel_fn pick_kernel8h(int hpe, int hpp) {
+  kernel_fn f = nullptr;
+#define X(name) \
+  if (!f) f = gaudi_kern8h_##name(hpe, hpp);
+  GAUDI_KERNEL8H_TUS(X)
+#undef X
+  return f;
+}
+static kernel_fn pick_kernel8_mode(int hpe, int hpp, int mode) {
+  return mode == 1 ? pick_kernel8s(hpe, hpp) : mode == 2 ? pick_kernel8h(hpe, hpp) : pick_kernel8(hpe, hpp);
+}
+
 // smallest instantiated padded hidden size >= H (0 if none)
 static int round_hidden(int H) {
   static const int sizes[] = {32, 48, 64, 128, 192, 208, 256};
@@ -570,7 +591,7 @@ static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW) {
   return sizeof(float) * (common_floats(N, D, EW) + net);
 }
 
-static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, bool split) {
+static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split) {
   size_t net = 0;
   if (hpe) net = std::max(net, (size_t)(5 * N * (hpe + 4) + w8::edge_ring_floats(hpe, split) + 8 * N + S * 9 + 8 * hpe));
   if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + 5 * N * (hpp + 4) + 12 * N + S * 10 + 32 + 10 * hpp));
@@ -578,7 +599,7 @@ static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, bool split
 }
 // The reverse pass publishes du of every slot pub_ch feature tiles at a time into [b0 | b1 | pubx extra floats]: pick the
 // largest pub_ch that fits 160 KiB, then the extra floats that choice needs.  false: the molecule does not fit.
-static bool plan_pub8(int hpe, int hpp, int N, int D, int S, bool split, int& pubx, int& pub_ch) {
+static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pubx, int& pub_ch) {
   pubx = 0;
   pub_ch = 0;
   const long long cap = 160 * 1024 / 4 - 64;  // floats (a little headroom for the runtime's own static LDS)
@@ -595,13 +616,13 @@ static bool plan_pub8(int hpe, int hpp, int N, int D, int S, bool split, int& pu
   pubx = (int)std::max(0LL, (long long)S * (16 * pub_ch + 4) - own);
   return true;
 }
-static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, bool split) {
+static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, int split) {
   return sizeof(float) * (lds_floats8_base(hpe, hpp, N, D, S, split) + (hpp ? pubx : 0));
 }
 
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
   const bool v8 = h->run_variant == 8;
-  kernel_fn fn = v8 ? (h->run_split ? pick_kernel8s(hpe, hpp) : pick_kernel8(hpe, hpp)) : pick_kernel(hpe, hpp);
+  kernel_fn fn = v8 ? pick_kernel8_mode(hpe, hpp, h->run_split) : pick_kernel(hpe, hpp);
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
@@ -669,9 +690,11 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   int pubx = 0, pub_ch = 0;
   const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
   // split-bf16 edge GEMMs when the kernel exists and its larger weight ring fits; else fp32 MFMAs; else 4 waves
-  h->run_split = h->split && pick_kernel8s(hpe, hpp) && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) &&
-                 plan_pub8(hpe, hpp, N, Dz, M.S, true, pubx, pub_ch);
-  if (!h->run_split && !plan_pub8(hpe, hpp, N, Dz, M.S, false, pubx, pub_ch)) return 1;
+  h->run_split = 0;
+  if (h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes))
+    for (int mode = 1; mode <= 2 && !h->run_split; ++mode)
+      if (pick_kernel8_mode(hpe, hpp, mode) && plan_pub8(hpe, hpp, N, Dz, M.S, mode, pubx, pub_ch)) h->run_split = mode;
+  if (!h->run_split && !plan_pub8(hpe, hpp, N, Dz, M.S, 0, pubx, pub_ch)) return 1;
   P.pubx = pubx;
   P.pub_ch = pub_ch;
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
@@ -709,12 +732,12 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
                        int hpp) {
   if (B <= 0 || N <= 0) return fail(h, GAUDI_E_INVALID, "B and N must be positive");
   h->run_variant = h->variant;
-  h->run_split = false;
+  h->run_split = 0;
   if (h->variant == 8) {
     const int rc8 = stage_graph8(h, B, N, node_mask, edge_mask, P, hpe, hpp);
     if (rc8 <= 0) return rc8;
     h->run_variant = 4;  // fall back to the 4-wave kernels for this call
-    h->run_split = false;
+    h->run_split = 0;
     P.pubx = P.pub_ch = 0;
   }
   Meta M;
@@ -1392,7 +1415,7 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
 int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_call) {
   if (!h) return GAUDI_E_INVALID;
   if (configured) *configured = (h->variant == 8 && h->split) ? 1 : 0;
-  if (last_call) *last_call = h->run_split ? 1 : 0;
+  if (last_call) *last_call = h->run_split;
   return GAUDI_OK;
 }
 

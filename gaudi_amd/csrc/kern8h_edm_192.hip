@@ -1,0 +1,10 @@
+// kern8h_edm_192.hip -- sampler_kernel8h (8 waves, edge GEMMs on split-bf16 operands with the half-size weight ring: w8_split.h, SplitGeo MODE 2) instantiations [(192, 0)] (own translation unit so the
+// instantiations compile in parallel; looked up by gaudi_hip.hip through gaudi_kern8h_edm_192).
+#include "sampler_kernel.h"
+
+typedef void (*kernel_fn)(const gaudi::KParams);
+
+kernel_fn gaudi_kern8h_edm_192(int hpe, int hpp) {
+  if (hpe == 192 && hpp == 0) return gaudi::sampler_kernel8h<192, 0>;
+  return nullptr;
+}

@@ -1,0 +1,13 @@
+// kern8h_fused_tiny.hip -- sampler_kernel8h (8 waves, edge GEMMs on split-bf16 operands with the half-size weight ring: w8_split.h, SplitGeo MODE 2) instantiations [(32, 48), (32, 32), (48, 48), (64, 64)] (own translation unit so the
+// instantiations compile in parallel; looked up by gaudi_hip.hip through gaudi_kern8h_fused_tiny).
+#include "sampler_kernel.h"
+
+typedef void (*kernel_fn)(const gaudi::KParams);
+
+kernel_fn gaudi_kern8h_fused_tiny(int hpe, int hpp) {
+  if (hpe == 32 && hpp == 48) return gaudi::sampler_kernel8h<32, 48>;
+  if (hpe == 32 && hpp == 32) return gaudi::sampler_kernel8h<32, 32>;
+  if (hpe == 48 && hpp == 48) return gaudi::sampler_kernel8h<48, 48>;
+  if (hpe == 64 && hpp == 64) return gaudi::sampler_kernel8h<64, 64>;
+  return nullptr;
+}

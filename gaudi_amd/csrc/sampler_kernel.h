@@ -186,7 +186,7 @@ __device__ __forceinline__ PredDev uni(const PredDev& w) {
                  uni(w.ws_bytes)};
 }
 #ifndef GAUDI_STAMPS
-template <int HP, bool SP>
+template <int HP, int SP>
 __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, float t_val_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const EdmDev W = uni(W_);
@@ -200,7 +200,7 @@ __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, f
 }
 // the predictor's forward and reverse passes are separate functions too (the reverse pass holds three 52-register
 // operand sets at its peak; allocated together with the forward it spilled twice as much)
-template <int HP, bool SP>
+template <int HP, int SP>
 __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args ga_, float t_val_, float* stash_, float readout_div_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PredDev W = uni(W_);
@@ -211,7 +211,7 @@ __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args 
   sm.carve(L.net, ga.N, ga.S, ga.pubx);
   w8::pred_forward<HP, SP>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
 }
-template <int HP, bool SP>
+template <int HP, int SP>
 __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args ga_, float* stash_, float readout_div_, int resume_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PredDev W = uni(W_);
@@ -226,10 +226,10 @@ __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args 
 #endif
 
 // SP: edge GEMMs on the bf16 matrix pipe with three-way split operands (w8_split.h); otherwise fp32 MFMAs
-template <bool SP>
+template <int SP>
 struct V8T {
   static constexpr int kThreads = w8::kThreads;
-  static constexpr bool kSplit = SP;
+  static constexpr int kSplit = SP;
   using Graph = w8::MolGraph;
   __host__ __device__ static int graph_floats(int N, int S) { return 2 * S + align16(N) + align16((N + 1 + S + 1) / 2); }
   __device__ __forceinline__ static float* load_graph(const KParams& P, int b, float* base, const float* sMask, Graph& mg, int tid, int wave) {
@@ -299,8 +299,9 @@ struct V8T {
                             mg.pub_ch, tid STAMP_ARGS);
   }
 };
-using V8 = V8T<false>;
-using V8S = V8T<true>;
+using V8 = V8T<0>;
+using V8S = V8T<1>;   // split operands, full weight ring
+using V8H = V8T<2>;   // split operands, half ring (two trips per K chunk)
 
 __host__ __device__ inline int common_floats_base(int N, int D) { return 3 * align16(N * D) + align16(N) + 16; }
 
@@ -526,5 +527,7 @@ template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8 = &sampler_kernel_v<V8, HPE, HPP>;
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8s = &sampler_kernel_v<V8S, HPE, HPP>;
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel8h = &sampler_kernel_v<V8H, HPE, HPP>;
 
 }  // namespace gaudi

@@ -10,7 +10,7 @@ namespace gaudi {
 namespace w8 {
 
 // LDS working set of one network evaluation
-template <int HP, bool SP = false>
+template <int HP, int SP = 0>
 struct NetSmem {
   float *h, *p, *q;     // [N][HP+4]
   float *agg, *agg1;    // [N][HP+4] the two partial edge->node sums of a node (its run may straddle two tiles)
@@ -111,7 +111,7 @@ __device__ __forceinline__ void scatter_runs(f4 (&e)[HP / 16], const TileCols& t
 }
 
 // eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
-template <int HP, bool SP = false>
+template <int HP, int SP = 0>
 __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP, SP>& sm, const float* sZ,
                                             float* sEps, float* sMean /* [4] */, float t_val, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;

@@ -10,7 +10,7 @@
 namespace gaudi {
 namespace w8 {
 
-template <int HP, bool SP = false>
+template <int HP, int SP = 0>
 struct PredSmem {
   float* ring;                    // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats)
   float *b2, *b3, *b4;            // [N][HP+4] node buffers (roles change per phase, see below)
@@ -65,7 +65,7 @@ __host__ __device__ inline int pub_chunk_tiles(int S, long long avail_floats, in
 // forward: pred[K] -> sm.pred[0..K)
 // buffers: h = b0, P = b1, Q = b2, agg = b3, second agg partial = b4
 // ---------------------------------------------------------------------------------------------
-template <int HP, bool SP = false>
+template <int HP, int SP = 0>
 __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP>& sm, const float* sZ,
                                              float t_val, float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
@@ -230,7 +230,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 //                          B4 = b4: npre (stash) -> dnpre -> dQ
 // pub_ch = 16-feature tiles of du published per chunk into [b0 | b1 | pub] (row = 16 pub_ch + 4 floats per slot)
 // ---------------------------------------------------------------------------------------------
-template <int HP, bool SP = false>
+template <int HP, int SP = 0>
 __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP>& sm, const float* stash,
                                               float* sGrad, float readout_div, int pub_ch, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
@@ -488,7 +488,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 }
 
 // unit-test entry: pred (and optionally grad into sGrad) for z in sZ
-template <int HP, bool SP = false>
+template <int HP, int SP = 0>
 __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                 float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid STAMP_DECL) {
@@ -504,7 +504,7 @@ __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph
   if (want_grad) pred_backward<HP, SP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS);
 }
 
-template <int HP, bool SP = false>
+template <int HP, int SP = 0>
 __device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP, SP>& sm, const float* target_w, float scale,
                                               float* pred_out, int tid, int phase, const float* dpred_ext);
 __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, float* sGrad, float* sMean, float sigma, int tid);
@@ -512,7 +512,7 @@ __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, fl
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 // phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
 // (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
-template <int HP, bool SP = false>
+template <int HP, int SP = 0>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, float sigma, const float* target_w,
                                                 float scale, float* pred_out, float readout_div, float* stash, int pubx,
@@ -529,7 +529,7 @@ __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph
 }
 
 // pred -> pred_out (split mode) and the seed of the reverse pass: d(energy)/dpred = scale * dT/dpred
-template <int HP, bool SP>
+template <int HP, int SP>
 __device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP, SP>& sm, const float* target_w, float scale,
                                               float* pred_out, int tid, int phase, const float* dpred_ext) {
   if (tid < W.K) {

@@ -18,9 +18,6 @@
 #pragma once
 #include "w8_common.h"
 
-#ifndef GAUDI_SPLIT_CH
-#define GAUDI_SPLIT_CH 0  // output tiles per ring trip (0 = all T: one trip per K chunk)
-#endif
 #ifndef GAUDI_SPLIT_GLDS
 #define GAUDI_SPLIT_GLDS 1  // 1: the ring is filled by global_load_lds_dwordx4 (no staging registers, no ds_write)
 #endif
@@ -71,15 +68,16 @@ __device__ __forceinline__ f4 mfma_bf(const u4 a, const u4 b, const f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
 }
 
-// Geometry of a split matrix: T tiles, NC = ceil(T/2) K chunks, trips of CH output tiles (NH per chunk)
-template <int HP>
+// Geometry of a split matrix: T tiles, NC = ceil(T/2) K chunks, trips of CH output tiles (NH per chunk).
+// MODE 1: a trip = a whole chunk (CH = T; ring = 2 x 3T KiB).  MODE 2: two trips per chunk (CH = ceil(T/2); ring = half of
+// that, one more barrier per chunk): the form for molecules whose node buffers leave no room for the full ring.
+template <int HP, int MODE>
 struct SplitGeo {
+  static_assert(MODE == 1 || MODE == 2, "split mode");
   static constexpr int T = HP / 16;
   static constexpr int NC = (T + 1) / 2;
-  // output tiles per trip: all T, unless that leaves a matrix with a single trip (the ring runs two trips ahead and knows
-  // only the current and the next matrix of a chain)
-  static constexpr int CH0 = GAUDI_SPLIT_CH > 0 ? (GAUDI_SPLIT_CH < T ? GAUDI_SPLIT_CH : T) : T;
-  static constexpr int CH = (NC == 1 && CH0 == T && T > 1) ? (T + 1) / 2 : CH0;
+  // a matrix needs at least two trips (the ring runs a trip ahead and knows only the current and the next matrix of a chain)
+  static constexpr int CH = (MODE == 2 || NC == 1) && T > 1 ? (T + 1) / 2 : T;  // output tiles per trip
   static constexpr int NH = (T + CH - 1) / CH;
   static constexpr int kTrips = NC * NH;
   static constexpr int kUnit = 256;                    // floats (1 KiB)
@@ -87,16 +85,17 @@ struct SplitGeo {
   static constexpr int kMatFloats = NC * T * 3 * kUnit;  // one packed matrix
   static constexpr int UT = (CH * 3 + kWaves - 1) / kWaves;
   // K tail (nf % 16 == 4, odd tile count: the last chunk is the tail tile alone): that chunk is stored as T fp32 tiles in
-  // the K-tail form of w8_common.h (input 16(T-1)+g on lane group g, element 0) and issued as ONE fp32 k-step per tile
-  static constexpr bool kTailOK = (T & 1) && T >= 3 && NH == 1;
-  // trip tr = (chunk m = tr / NH, part h = tr % NH): tiles [h CH, min(T, (h+1) CH))
+  // the K-tail form of w8_common.h (input 16(T-1)+g on lane group g, element 0) and issued as ONE trip of one fp32 k-step
+  // per tile
+  static constexpr bool kTailOK = (T & 1) && T >= 3;
+  static constexpr int kTripsTail = (NC - 1) * NH + 1;
+  static_assert(!kTailOK || T <= CH * 3, "the fp32 tail tiles must fit one ring slot");
   __host__ __device__ static constexpr int tiles_of(int h) { return (h + 1) * CH <= T ? CH : T - h * CH; }
-  __host__ __device__ static constexpr int group_off(int tr) { return ((tr / NH) * T + (tr % NH) * CH) * 3 * kUnit; }
 };
 
-template <int HP>
+template <int HP, int MODE>
 struct RingS {
-  using G = SplitGeo<HP>;
+  using G = SplitGeo<HP, MODE>;
   float* base;  // LDS [2][kSlotFloats]
   int par;
   bool ktail;   // the matrices carry a K tail (SplitGeo::kTailOK widths only)
@@ -108,17 +107,36 @@ struct RingS {
   __device__ __forceinline__ float* slot(int p) const { return base + p * G::kSlotFloats; }
 };
 
-// group of trip `tr` of the matrix at float offset W (tr >= kTrips: trip tr - kTrips of nextW; nextW < 0: nothing)
+// Group of trip `tr` of a chain: trips 0 .. n-1 belong to the matrix at float offset W, trip n + k is trip k of nextW
+// (nextW < 0: nothing follows).  n = kTrips, or kTripsTail when the matrices carry a K tail (their last chunk is ONE trip of
+// T fp32 tiles).  -> float offset of the group, its 1 KiB units; false: nothing to load.
+template <int HP, int MODE>
+__device__ __forceinline__ bool trip_group(const RingS<HP, MODE>& r, int W, int nextW, int tr, int& off, int& units) {
+  using G = SplitGeo<HP, MODE>;
+  const bool tail = G::kTailOK && r.ktail;
+  const int n = tail ? G::kTripsTail : G::kTrips;
+  const bool nxt = tr >= n;
+  const int t2 = nxt ? tr - n : tr;
+  const int base = nxt ? nextW : W;
+  if (tail && t2 == n - 1) {
+    units = G::T;
+    off = base + (G::NC - 1) * G::T * 3 * G::kUnit;
+  } else {
+    const int m = t2 / G::NH, h = t2 % G::NH;
+    units = G::tiles_of(h) * 3;
+    off = base + (m * G::T + h * G::CH) * 3 * G::kUnit;
+  }
+  off = __builtin_amdgcn_readfirstlane(off);
+  units = __builtin_amdgcn_readfirstlane(units);
+  return !(nxt && nextW < 0);
+}
 #if GAUDI_SPLIT_GLDS
 // LDS-DMA: unit un of the group goes straight to slot + un KiB (wave-uniform LDS base + 16 B per lane)
-template <int HP>
-__device__ __forceinline__ void rings_dma(const RingS<HP>& r, float* slot, int W, int nextW, int tr, int wave, int lane) {
-  using G = SplitGeo<HP>;
-  const bool nxt = tr >= G::kTrips;
-  const int t2 = nxt ? tr - G::kTrips : tr;
-  if (nxt && nextW < 0) return;
-  const int units = (G::kTailOK && r.ktail && t2 == G::kTrips - 1) ? G::T : G::tiles_of(t2 % G::NH) * 3;
-  const int off = __builtin_amdgcn_readfirstlane((nxt ? nextW : W) + G::group_off(t2));
+template <int HP, int MODE>
+__device__ __forceinline__ void rings_dma(const RingS<HP, MODE>& r, float* slot, int W, int nextW, int tr, int wave, int lane) {
+  using G = SplitGeo<HP, MODE>;
+  int off, units;
+  if (!trip_group(r, W, nextW, tr, off, units)) return;
 #pragma unroll
   for (int u = 0; u < G::UT; ++u) {
     const int un = wave + kWaves * u;
@@ -127,48 +145,46 @@ __device__ __forceinline__ void rings_dma(const RingS<HP>& r, float* slot, int W
                                        (__attribute__((address_space(3))) void*)(slot + un * G::kUnit), 16, 0, 0);
   }
 }
-template <int HP>
-__device__ __forceinline__ void rings_start(RingS<HP>& r, const WBuf&, int W, int wave, int lane) {
+template <int HP, int MODE>
+__device__ __forceinline__ void rings_start(RingS<HP, MODE>& r, const WBuf&, int W, int wave, int lane) {
   rings_dma(r, r.slot(r.par), W, -1, 0, wave, lane);
 }
 // trip tr has passed its opening barrier: nobody reads slot(par ^ 1) any more; the group of trip tr + 1 must have landed
-// at the next barrier (__syncthreads waits vmcnt(0))
-template <int HP>
-__device__ __forceinline__ void rings_stage(RingS<HP>& r, const WBuf&, int W, int nextW, int tr, int wave, int lane) {
+// at the next barrier (trip_barrier waits vmcnt(0))
+template <int HP, int MODE>
+__device__ __forceinline__ void rings_stage(RingS<HP, MODE>& r, const WBuf&, int W, int nextW, int tr, int wave, int lane) {
   rings_dma(r, r.slot(r.par ^ 1), W, nextW, tr + 1, wave, lane);
 }
 #else
-template <int HP>
-__device__ __forceinline__ void rings_issue(RingS<HP>& r, const WBuf& wb, int W, int nextW, int tr, int wave, int lane) {
-  using G = SplitGeo<HP>;
-  const bool nxt = tr >= G::kTrips;
-  const int t2 = nxt ? tr - G::kTrips : tr;
-  const bool have = !nxt || nextW >= 0;
-  const int units = (G::kTailOK && r.ktail && t2 == G::kTrips - 1) ? G::T : G::tiles_of(t2 % G::NH) * 3;
-  const int off = __builtin_amdgcn_readfirstlane((nxt ? nextW : W) + G::group_off(t2));
+// register staging (kept for comparison: tools/split_gemm_microbench.hip): loads issued two trips ahead, stored mid-trip
+template <int HP, int MODE>
+__device__ __forceinline__ void rings_issue(RingS<HP, MODE>& r, const WBuf& wb, int W, int nextW, int tr, int wave, int lane) {
+  using G = SplitGeo<HP, MODE>;
+  int off, units;
+  const bool have = trip_group(r, W, nextW, tr, off, units);
 #pragma unroll
   for (int u = 0; u < G::UT; ++u) {
     const int un = wave + kWaves * u;
-    r.st[u] = ldw4(wb, off + (un < units ? un : 0) * G::kUnit, (have && un < units) ? lane : kOOBLane);
+    r.st[u] = ldw4(wb, (have ? off : 0) + (un < units ? un : 0) * G::kUnit, (have && un < units) ? lane : kOOBLane);
   }
 }
-template <int HP>
-__device__ __forceinline__ void rings_commit(const RingS<HP>& r, float* slot, int wave, int lane) {
-  using G = SplitGeo<HP>;
+template <int HP, int MODE>
+__device__ __forceinline__ void rings_commit(const RingS<HP, MODE>& r, float* slot, int wave, int lane) {
+  using G = SplitGeo<HP, MODE>;
 #pragma unroll
   for (int u = 0; u < G::UT; ++u) {
     const int un = wave + kWaves * u;
     if (un < G::CH * 3) *(f4*)(slot + un * G::kUnit + lane * 4) = r.st[u];
   }
 }
-template <int HP>
-__device__ __forceinline__ void rings_start(RingS<HP>& r, const WBuf& wb, int W, int wave, int lane) {
+template <int HP, int MODE>
+__device__ __forceinline__ void rings_start(RingS<HP, MODE>& r, const WBuf& wb, int W, int wave, int lane) {
   rings_issue(r, wb, W, -1, 0, wave, lane);
   rings_commit(r, r.slot(r.par), wave, lane);
   rings_issue(r, wb, W, -1, 1, wave, lane);
 }
-template <int HP>
-__device__ __forceinline__ void rings_stage(RingS<HP>& r, const WBuf& wb, int W, int nextW, int tr, int wave, int lane) {
+template <int HP, int MODE>
+__device__ __forceinline__ void rings_stage(RingS<HP, MODE>& r, const WBuf& wb, int W, int nextW, int tr, int wave, int lane) {
   rings_commit(r, r.slot(r.par ^ 1), wave, lane);
   rings_issue(r, wb, W, nextW, tr + 2, wave, lane);
 }
@@ -185,9 +201,9 @@ __device__ __forceinline__ void trip_barrier() {
 }
 
 // One trip: NT output tiles (acc[t0 .. t0+NT)) against the K chunk in `b`; A units one tile ahead in registers.
-template <int HP, int NT, class MID>
+template <int HP, int MODE, int NT, class MID>
 __device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, const B3& b, bool active, MID mid) {  // NOLINT
-  constexpr int U = SplitGeo<HP>::kUnit;
+  constexpr int U = SplitGeo<HP, MODE>::kUnit;
   f4 a[2][3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) a[0][p] = *(const f4*)(slot_lane + p * U);
@@ -219,12 +235,12 @@ __device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, cons
 }
 
 // The K-tail trip: one fp32 k-step per output tile (A = element 0 of the tile's lane-linear float4, B = the lane group's input)
-template <int HP, class MID>
+template <int HP, int MODE, class MID>
 __device__ __forceinline__ void rings_mfma_tail(f4 (&acc)[HP / 16], const float* slot_lane, float b, bool active, MID mid) {
   constexpr int T = HP / 16;
   float a[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) a[t] = slot_lane[t * SplitGeo<HP>::kUnit];
+  for (int t = 0; t < T; ++t) a[t] = slot_lane[t * SplitGeo<HP, MODE>::kUnit];
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -238,11 +254,11 @@ __device__ __forceinline__ void rings_mfma_tail(f4 (&acc)[HP / 16], const float*
 }
 
 // acc = b2 + W2 . silu(u) (see edge_gemm_pq); weights in split format at float offset W of wb
-template <int HP>
-__device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP>& ring, const WBuf& wb, int W, int nextW,
+template <int HP, int MODE>
+__device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MODE>& ring, const WBuf& wb, int W, int nextW,
                                                const float* sB2, const float* sCr, const float* sCd, const float* pp,
                                                const float* qq, float r, float d0, bool active, int wave, int lane) {
-  using G = SplitGeo<HP>;
+  using G = SplitGeo<HP, MODE>;
   constexpr int T = G::T;
   const int g = lane >> 4;
   const bool late = wave >= kWaves / 2;
@@ -261,13 +277,13 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP>& ri
       constexpr int h = decltype(h_tag)::value;
       const int tr = m * G::NH + h;
       trip_barrier();
-      if (GAUDI_SPLIT_GLDS == 2) rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
+      if (GAUDI_SPLIT_GLDS == 2) rings_stage(ring, wb, W, nextW, tr, wave, lane);
 #ifndef SPLIT_NO_GEN
       if (late && h == 0 && m > 0) bin = gen(m);
 #endif
-      rings_mfma<HP, G::tiles_of(h)>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
+      rings_mfma<HP, MODE, G::tiles_of(h)>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
 #ifndef SPLIT_NO_STAGE
-        if (GAUDI_SPLIT_GLDS != 2) rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
+        if (GAUDI_SPLIT_GLDS != 2) rings_stage(ring, wb, W, nextW, tr, wave, lane);
 #endif
 #ifndef SPLIT_NO_GEN
         if (!late && h == G::NH - 1) nb = gen(m + 1 < G::NC ? m + 1 : m);
@@ -287,19 +303,19 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP>& ri
     if (tail) {
       trip_barrier();
       const float bt = silu_f(edge_u_tail(pp, qq, sCr, sCd, g, T, r, d0)[0]);
-      rings_mfma_tail<HP>(acc, ring.slot(ring.par) + lane * 4, bt, active,
-                          [&] { rings_stage<HP>(ring, wb, W, nextW, G::kTrips - 1, wave, lane); });
+      rings_mfma_tail<HP, MODE>(acc, ring.slot(ring.par) + lane * 4, bt, active,
+                          [&] { rings_stage(ring, wb, W, nextW, G::kTripsTail - 1, wave, lane); });
       ring.par ^= 1;
     }
   }
 }
 
 // Chained edge GEMM, input in registers (accumulator layout of the previous GEMM): out = bias + rowinit + W . in
-template <int HP>
-__device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], RingS<HP>& ring, const WBuf& wb,
+template <int HP, int MODE>
+__device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], RingS<HP, MODE>& ring, const WBuf& wb,
                                                  int W, int nextW, const float* sBias, const float* rowinit, bool active,
                                                  int wave, int lane) {
-  using G = SplitGeo<HP>;
+  using G = SplitGeo<HP, MODE>;
   constexpr int T = G::T;
   const int g = lane >> 4;
 #pragma unroll
@@ -317,9 +333,9 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
       constexpr int h = decltype(h_tag)::value;
       constexpr int tr = m * G::NH + h;
       trip_barrier();
-      if (GAUDI_SPLIT_GLDS == 2) rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
-      rings_mfma<HP, G::tiles_of(h)>(out + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
-        if (GAUDI_SPLIT_GLDS != 2) rings_stage<HP>(ring, wb, W, nextW, tr, wave, lane);
+      if (GAUDI_SPLIT_GLDS == 2) rings_stage(ring, wb, W, nextW, tr, wave, lane);
+      rings_mfma<HP, MODE, G::tiles_of(h)>(out + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
+        if (GAUDI_SPLIT_GLDS != 2) rings_stage(ring, wb, W, nextW, tr, wave, lane);
       });
       ring.par ^= 1;
     };
@@ -331,8 +347,8 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
   if constexpr (G::kTailOK) {
     if (ring.ktail) {
       trip_barrier();
-      rings_mfma_tail<HP>(out, ring.slot(ring.par) + lane * 4, tail_to_b(in[T - 1], c, g)[0], active,
-                          [&] { rings_stage<HP>(ring, wb, W, nextW, G::kTrips - 1, wave, lane); });
+      rings_mfma_tail<HP, MODE>(out, ring.slot(ring.par) + lane * 4, tail_to_b(in[T - 1], c, g)[0], active,
+                          [&] { rings_stage(ring, wb, W, nextW, G::kTripsTail - 1, wave, lane); });
       ring.par ^= 1;
       return;
     }
@@ -341,28 +357,27 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
 }
 
 // ---------------------------------------------------------------------------------------------
-// One interface over both edge-GEMM engines (SP = split-bf16).  Matrix offsets are the fp32 weight buffer's float offsets
+// One interface over both edge-GEMM engines.  Matrix offsets are the fp32 weight buffer's float offsets
 // in both cases: the split image of the matrix at float offset W lives at float offset 2 W of its own buffer (a split
 // matrix is 1.5x, for an odd tile count up to 1.62x, the size of the fp32 one; the holes are never touched).
 // ---------------------------------------------------------------------------------------------
-template <int HP, bool SP>
+template <int HP, int SP>  // SP: 0 = fp32 matrix instructions, 1 / 2 = split operands with the full / half ring (SplitGeo)
 struct EdgeRing {
+  using type = RingS<HP, SP>;
+  static constexpr int kFloats = 2 * SplitGeo<HP, SP>::kSlotFloats;
+};
+template <int HP>
+struct EdgeRing<HP, 0> {
   using type = Ring<HP>;
   static constexpr int kFloats = 2 * (HP / 16) * 256;
 };
-template <int HP>
-struct EdgeRing<HP, true> {
-  using type = RingS<HP>;
-  static constexpr int kFloats = 2 * SplitGeo<HP>::kSlotFloats;
-};
-__host__ __device__ constexpr int edge_ring_floats(int HP, bool split) {
+__host__ __device__ constexpr int edge_ring_floats(int HP, int mode) {
   const int T = HP / 16;
-  const int CH0 = GAUDI_SPLIT_CH > 0 ? (GAUDI_SPLIT_CH < T ? GAUDI_SPLIT_CH : T) : T;
-  const int CH = ((T + 1) / 2 == 1 && CH0 == T && T > 1) ? (T + 1) / 2 : CH0;  // = SplitGeo<HP>::CH
-  return split ? 2 * CH * 3 * 256 : 2 * T * 256;
+  const int CH = (mode == 2 || (T + 1) / 2 == 1) && T > 1 ? (T + 1) / 2 : T;  // = SplitGeo<HP, mode>::CH
+  return mode ? 2 * CH * 3 * 256 : 2 * T * 256;
 }
-static_assert(edge_ring_floats(32, true) == 2 * SplitGeo<32>::kSlotFloats && edge_ring_floats(208, true) == 2 * SplitGeo<208>::kSlotFloats &&
-                  edge_ring_floats(48, true) == 2 * SplitGeo<48>::kSlotFloats,
+static_assert(edge_ring_floats(32, 1) == 2 * SplitGeo<32, 1>::kSlotFloats && edge_ring_floats(208, 1) == 2 * SplitGeo<208, 1>::kSlotFloats &&
+                  edge_ring_floats(48, 2) == 2 * SplitGeo<48, 2>::kSlotFloats && edge_ring_floats(208, 2) == 2 * SplitGeo<208, 2>::kSlotFloats,
               "host LDS planning and SplitGeo disagree");
 __device__ __forceinline__ int split_off(int W) { return W < 0 ? -1 : 2 * W; }
 
@@ -372,8 +387,8 @@ __device__ __forceinline__ void er_init(Ring<HP>& r, float* base, bool ktail, co
   r.par = 0;
   r.ktail = ktail;
 }
-template <int HP>
-__device__ __forceinline__ void er_init(RingS<HP>& r, float* base, bool ktail, const float* ws) {
+template <int HP, int MODE>
+__device__ __forceinline__ void er_init(RingS<HP, MODE>& r, float* base, bool ktail, const float* ws) {
   r.base = base;
   r.par = 0;
   r.ktail = ktail;
@@ -387,9 +402,9 @@ template <int HP>
 __device__ __forceinline__ void er_start(Ring<HP>& r, const WBuf& wb, int W, int wave, int lane) {
   ring_start<HP>(r, wb, W, wave, lane);
 }
-template <int HP>
-__device__ __forceinline__ void er_start(RingS<HP>& r, const WBuf& wb, int W, int wave, int lane) {
-  rings_start<HP>(r, wb, split_off(W), wave, lane);
+template <int HP, int MODE>
+__device__ __forceinline__ void er_start(RingS<HP, MODE>& r, const WBuf& wb, int W, int wave, int lane) {
+  rings_start(r, wb, split_off(W), wave, lane);
 }
 template <int HP>
 __device__ __forceinline__ void er_gemm_pq(f4 (&acc)[HP / 16], Ring<HP>& ring, const WBuf& wb, int W, int nextW, const float* sB2,
@@ -397,21 +412,21 @@ __device__ __forceinline__ void er_gemm_pq(f4 (&acc)[HP / 16], Ring<HP>& ring, c
                                            bool active, int wave, int lane STAMP_DECL) {
   edge_gemm_pq<HP>(acc, ring, wb, W, nextW, sB2, sCr, sCd, pp, qq, r, d0, active, wave, lane STAMP_ARGS);
 }
-template <int HP>
-__device__ __forceinline__ void er_gemm_pq(f4 (&acc)[HP / 16], RingS<HP>& ring, const WBuf& wb, int W, int nextW, const float* sB2,
+template <int HP, int MODE>
+__device__ __forceinline__ void er_gemm_pq(f4 (&acc)[HP / 16], RingS<HP, MODE>& ring, const WBuf& wb, int W, int nextW, const float* sB2,
                                            const float* sCr, const float* sCd, const float* pp, const float* qq, float r, float d0,
                                            bool active, int wave, int lane STAMP_DECL) {
-  edge_gemm_pq_s<HP>(acc, ring, wb, split_off(W), split_off(nextW), sB2, sCr, sCd, pp, qq, r, d0, active, wave, lane);
+  edge_gemm_pq_s(acc, ring, wb, split_off(W), split_off(nextW), sB2, sCr, sCd, pp, qq, r, d0, active, wave, lane);
 }
 template <int HP>
 __device__ __forceinline__ void er_gemm_regs(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], Ring<HP>& ring, const WBuf& wb, int W,
                                              int nextW, const float* sBias, const float* rowinit, bool active, int wave, int lane) {
   edge_gemm_regs<HP>(out, in, ring, wb, W, nextW, sBias, rowinit, active, wave, lane);
 }
-template <int HP>
-__device__ __forceinline__ void er_gemm_regs(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], RingS<HP>& ring, const WBuf& wb, int W,
+template <int HP, int MODE>
+__device__ __forceinline__ void er_gemm_regs(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], RingS<HP, MODE>& ring, const WBuf& wb, int W,
                                              int nextW, const float* sBias, const float* rowinit, bool active, int wave, int lane) {
-  edge_gemm_regs_s<HP>(out, in, ring, wb, split_off(W), split_off(nextW), sBias, rowinit, active, wave, lane);
+  edge_gemm_regs_s(out, in, ring, wb, split_off(W), split_off(nextW), sBias, rowinit, active, wave, lane);
 }
 
 }  // namespace w8

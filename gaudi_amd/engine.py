@@ -315,7 +315,8 @@ class Engine:
 
     def edge_math(self):
         """-> (configured, last_call): 1 = edge GEMMs on the bf16 matrix pipe with exactly split fp32 operands (default on the
-        8-wave kernels), 0 = fp32 matrix instructions (GAUDI_EDGE_MATH=fp32, the 4-wave kernels, or the LDS fallback)."""
+        8-wave kernels; last_call 2 = the same with the half-size LDS weight ring), 0 = fp32 matrix instructions
+        (GAUDI_EDGE_MATH=fp32, the 4-wave kernels, or the LDS fallback)."""
         a, b = C.c_int32(), C.c_int32()
         self._check(self.lib.gaudi_edge_math(self.h, C.byref(a), C.byref(b)), "gaudi_edge_math")
         return a.value, b.value

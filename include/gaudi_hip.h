@@ -224,7 +224,9 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
  * edm/egnn_predictor/gcl.py:225-231) on the 8-wave kernels: 1 = every fp32 operand split exactly into three bf16 pieces, six
  * piece products accumulated in fp32 on the bf16 matrix pipe (error against float64 not larger than the fp32 matrix
  * instruction's: tests/test_gpu_split.py); 0 = v_mfma_f32_16x16x4_f32 (environment GAUDI_EDGE_MATH=fp32 at gaudi_create,
- * the 4-wave kernels, and the per-call fallback when the larger LDS weight ring of the split form does not fit). */
+ * the 4-wave kernels, and the per-call fallback when the LDS weight ring of the split form does not fit).  last_call: 1 =
+ * split with the full ring (a 32-input chunk of all output tiles per trip), 2 = split with the half ring (two trips per
+ * chunk: molecules whose node buffers leave less LDS), 0 = fp32 instructions. */
 int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
 /* Tile packing of a weight block W[o][col0+k] (o,k < H, row stride ldw) into [HP/16][HP/16][16][16]
  * (k-chunk major), optionally transposed: the layout every GEMM of the kernels streams. */

@@ -98,9 +98,10 @@ def test_split_error_vs_float64_is_not_larger_than_the_fp32_instructions(monkeyp
         assert es < 1e-5, errs
 
 
-def test_split_falls_back_to_fp32_instructions_when_its_ring_does_not_fit(monkeypatch, O):
-    """The split weight ring is 3x the fp32 one (two slots of a 32-input chunk in three pieces).  A 20-node hetero molecule
-    with the default widths leaves no room for it: the call runs on the fp32-instruction 8-wave kernel of the same handle."""
+def test_split_ring_size_follows_the_lds_budget(monkeypatch, O):
+    """The full split weight ring is 3x the fp32 one (two slots of a 32-input chunk in three pieces).  A 20-node hetero
+    molecule with the default widths leaves no room for it: the call runs on the half-ring form (two trips per chunk) of
+    the same handle; both forms match the oracle."""
     eargs = synth.edm_args(dataset="hetro", diffusion_steps=20, n_layers=2)
     pargs = synth.pred_args(dataset="hetro", n_layers=2)
     F = synth.num_node_features("hetro")
@@ -109,7 +110,7 @@ def test_split_falls_back_to_fp32_instructions_when_its_ring_does_not_fit(monkey
     eng = _engine(monkeypatch, None, eargs, esd, pargs, psd)
     gamma = O.gamma_table("polynomial_2", 20, 1e-5)
     w = np.array([3.0, 0.0, 1.0, 1.0, 0.0], np.float32)
-    for rings, want_split in (([10, 6, 9], 0), ([5, 3, 4], 1)):
+    for rings, want_split in (([10, 6, 9], 2), ([5, 3, 4], 1)):
         nm, em = O.build_masks(rings, max(rings), True)
         B, N = nm.shape[0], nm.shape[1]
         rng = np.random.default_rng(3)

@@ -9,6 +9,9 @@
 #include <vector>
 #include "w8_split.h"
 using namespace gaudi;
+#ifndef SPLIT_MODE
+#define SPLIT_MODE 1  // 2: half ring
+#endif
 
 static uint16_t bf16_rne(float x) {
   uint32_t u;
@@ -25,7 +28,7 @@ static float bf16_f(uint16_t h) {
 // W[o][k] (H x H, row-major) -> split units [m][t][p]
 template <int HP>
 static void pack_split(std::vector<float>& dst, const std::vector<float>& W, int H) {
-  using G = w8::SplitGeo<HP>;
+  using G = w8::SplitGeo<HP, SPLIT_MODE>;
   dst.assign(G::kMatFloats, 0.f);
   uint16_t* d = (uint16_t*)dst.data();
   for (int m = 0; m < G::NC; ++m)
@@ -59,7 +62,7 @@ template <int HP, bool SPLIT>
 __global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, int nmat, float* out, unsigned long long* cyc,
                                               int gemms, int nactive) {
   constexpr int T = HP / 16, LD = HP + 4, N = 11;
-  using G = w8::SplitGeo<HP>;
+  using G = w8::SplitGeo<HP, SPLIT_MODE>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int ring_floats = SPLIT ? 2 * G::kSlotFloats : 2 * T * 256;
   float* sP = smem + ring_floats;
@@ -74,10 +77,10 @@ __global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, i
   f4 total = splat(0.f);
   constexpr int MF = SPLIT ? G::kMatFloats : T * T * 256;
   w8::Ring<HP> ring;
-  w8::RingS<HP> rs;
+  w8::RingS<HP, SPLIT_MODE> rs;
   if (SPLIT) {
-    w8::er_init<HP>(rs, smem, false, w);
-    w8::rings_start<HP>(rs, wb, 0, wave, lane);
+    w8::er_init(rs, smem, false, w);
+    w8::rings_start(rs, wb, 0, wave, lane);
   } else {
     ring.base = smem;
     ring.par = 0;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, i
     const int W = (m % nmat) * MF, nextW = ((m + 1) % nmat) * MF;
     f4 acc[T];
     if (SPLIT)
-      w8::edge_gemm_pq_s<HP>(acc, rs, wb, W, nextW, vec, vec + HP, vec + 2 * HP, sP + i * LD + 4 * g, sQ + j * LD + 4 * g, 0.3f,
+      w8::edge_gemm_pq_s(acc, rs, wb, W, nextW, vec, vec + HP, vec + 2 * HP, sP + i * LD + 4 * g, sQ + j * LD + 4 * g, 0.3f,
                              0.7f, active, wave, lane);
     else
       w8::edge_gemm_pq<HP>(acc, ring, wb, W, nextW, vec, vec + HP, vec + 2 * HP, sP + i * LD + 4 * g, sQ + j * LD + 4 * g, 0.3f,
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, i
 template <int HP, bool SPLIT>
 __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, const float* in, float* out) {
   constexpr int T = HP / 16;
-  using G = w8::SplitGeo<HP>;
+  using G = w8::SplitGeo<HP, SPLIT_MODE>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
   const WBuf wb = make_wbuf(w, wbytes);
@@ -118,10 +121,10 @@ __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, co
 #pragma unroll
   for (int t = 0; t < T; ++t) x[t] = *(const f4*)(in + (size_t)e * HP + 16 * t + 4 * g);
   if (SPLIT) {
-    w8::RingS<HP> rs;
-    w8::er_init<HP>(rs, smem, false, w);
-    w8::rings_start<HP>(rs, wb, 0, wave, lane);
-    w8::edge_gemm_regs_s<HP>(y, x, rs, wb, 0, -1, nullptr, nullptr, true, wave, lane);
+    w8::RingS<HP, SPLIT_MODE> rs;
+    w8::er_init(rs, smem, false, w);
+    w8::rings_start(rs, wb, 0, wave, lane);
+    w8::edge_gemm_regs_s(y, x, rs, wb, 0, -1, nullptr, nullptr, true, wave, lane);
   } else {
     w8::Ring<HP> ring;
     ring.base = smem;
@@ -136,13 +139,13 @@ __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, co
 
 template <int HP, bool SPLIT>
 static size_t ring_bytes() {
-  return (SPLIT ? 2 * w8::SplitGeo<HP>::kSlotFloats : 2 * (HP / 16) * 256) * 4;
+  return (SPLIT ? 2 * w8::SplitGeo<HP, SPLIT_MODE>::kSlotFloats : 2 * (HP / 16) * 256) * 4;
 }
 
 template <int HP, bool SPLIT>
 void run_time(int nactive, int blocks, int nmat) {
   constexpr int T = HP / 16;
-  using G = w8::SplitGeo<HP>;
+  using G = w8::SplitGeo<HP, SPLIT_MODE>;
   const size_t mf = SPLIT ? G::kMatFloats : T * T * 256, wfloats = mf * nmat;
   float *out, *w;
   unsigned long long* cyc;

@@ -20,7 +20,7 @@ def one(pattern):
     return hits[0] if hits else None
 
 
-for wl in ("c3", "c2", "c4", "stab"):
+for wl in ("c3", "c2", "c4", "c3fp32", "stab"):
     f = one(f"{wl}/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, f"{tag}_{'stability' if wl == 'stab' else wl}_kernel_stats.csv"))
