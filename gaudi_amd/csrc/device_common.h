@@ -82,6 +82,12 @@ __device__ __forceinline__ float dsilu_f(float x) {
   float s = sigmoid_f(x);
   return s * (1.0f + x * (1.0f - s));
 }
+// silu(x) and silu'(x) from one sigmoid
+__device__ __forceinline__ float silu_dsilu_f(float x, float& d) {
+  const float s = sigmoid_f(x);
+  d = s * (1.0f + x * (1.0f - s));
+  return x * s;
+}
 __device__ __forceinline__ f4 silu4(f4 u) {
   f4 r;
   r[0] = silu_f(u[0]); r[1] = silu_f(u[1]); r[2] = silu_f(u[2]); r[3] = silu_f(u[3]);

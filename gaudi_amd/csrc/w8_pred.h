@@ -46,10 +46,12 @@ struct PredSmem {
 };
 
 // stash per molecule: node part  L x { P [N][HP] | Q [N][HP] | npre [N][HP] | x [N][4] }
-//                     edge part  L x (S/16 tiles) x { v | cpre } x [HP/16][64 lanes] float4   (accumulator layout)
-//                     gate part  L x S floats (attention gate a_ij of every slot)
+//                     edge part  L x (S/16 tiles) x { v | silu'(cpre) } x [HP/16][64 lanes] float4   (accumulator layout)
+//                     gate part  L x S floats (attention gate a_ij of every slot) | L x S floats (phi_ij = wc2 . silu(cpre))
+// The coordinate branch stashes what the reverse pass consumes -- silu'(cpre) and the scalar phi, both by-products of the
+// forward's own sigmoid -- instead of cpre: the reverse pass then needs no transcendental on those 208 features per edge.
 __host__ __device__ inline long long pred_stash_floats8(int N, int HP, int L, int S) {
-  return pred_stash_node_floats(N, HP, L) + (long long)L * S * HP * 2 + (long long)L * S;
+  return pred_stash_node_floats(N, HP, L) + (long long)L * S * HP * 2 + 2LL * L * S;
 }
 __device__ __forceinline__ size_t edge_stash_off8(int l, int tile, int arr, int S, int HP) {
   return (((size_t)l * (S / 16) + tile) * 2 + arr) * (size_t)(16 * HP);
@@ -79,6 +81,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   float *h = sm.b0, *p = sm.b1, *q = sm.b2, *agg = sm.b3, *agg1 = sm.b4;
   float* estash = stash + pred_stash_node_floats(N, HP, W.L);
   float* astash = estash + (size_t)W.L * S * HP * 2;
+  float* pstash = astash + (size_t)W.L * S;
 
   for (int idx = tid; idx < N * 3; idx += kThreads) {  // models.py:439
     const int n = idx / 3, d = idx % 3;
@@ -171,12 +174,21 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         STAMP(ST_EDGE);
         if (tc.active) {
           f4* sc = (f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
-#pragma unroll
-          for (int t = 0; t < T; ++t) sc[t * 64] = cp[t];
           float sdot = 0.f;
 #pragma unroll
-          for (int t = 0; t < T; ++t) sdot += dot4(silu4(cp[t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
+          for (int t = 0; t < T; ++t) {
+            f4 sl, ds;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float d;
+              sl[q] = silu_dsilu_f(cp[t][q], d);
+              ds[q] = d;
+            }
+            sc[t * 64] = ds;
+            sdot += dot4(sl, *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
+          }
           const float phi = reduce_groups(sdot);
+          if (g == 0) pstash[(size_t)l * S + tc.slot] = phi;
           const float tau = (W.use_tanh ? tanhf(phi) * W.coords_range_layer : phi) * tc.mk;
           if (g == 0) *(f4*)(sm.trans + 4 * tc.slot) = (f4){gg[1] * tau, gg[2] * tau, gg[3] * tau, 0.f};
         }
@@ -246,6 +258,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   const int PLD = 16 * pub_ch + 4;
   const float* estash = stash + pred_stash_node_floats(N, HP, W.L);
   const float* astash = estash + (size_t)W.L * S * HP * 2;
+  const float* pstash = astash + (size_t)W.L * S;
   const float* dpred = sm.pred + 16;
   const int nslots = mg.ntiles * 16;
 
@@ -338,18 +351,15 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           if (tc.active) {
             const f4* sc = (const f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
 #pragma unroll
-            for (int t = 0; t < T; ++t) cp[t] = sc[t * 64];
-            float sd2 = 0.f;
-#pragma unroll
-            for (int t = 0; t < T; ++t) sd2 += dot4(silu4(cp[t]), *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
-            const float phi = reduce_groups(sd2);
+            for (int t = 0; t < T; ++t) cp[t] = sc[t * 64];  // silu'(cpre)
+            const float phi = pstash[(size_t)l * S + tc.slot];
             const float th = tanhf(phi);
             tau = W.use_tanh ? th * W.coords_range_layer : phi;
             const float dtau = (dtx * gg[1] + dty * gg[2] + dtz * gg[3]) * tc.mk;
             const float dphi = W.use_tanh ? dtau * W.coords_range_layer * (1.0f - th * th) : dtau;
 #pragma unroll
             for (int t = 0; t < T; ++t)  // dcpre = dphi * wc2 * silu'(cpre)
-              cp[t] = *(const f4*)(Lw.wc2 + 16 * t + 4 * g) * dphi * dsilu4(cp[t]);
+              cp[t] = *(const f4*)(Lw.wc2 + 16 * t + 4 * g) * dphi * cp[t];
           } else {
 #pragma unroll
             for (int t = 0; t < T; ++t) cp[t] = splat(0.f);

@@ -19,7 +19,7 @@
 #include "w8_common.h"
 
 #ifndef GAUDI_SPLIT_GLDS
-#define GAUDI_SPLIT_GLDS 1  // 1: the ring is filled by global_load_lds_dwordx4 (no staging registers, no ds_write)
+#define GAUDI_SPLIT_GLDS 1  // 1: the ring is filled by global_load_lds_dwordx4 (no staging registers, no ds_write); 0: register staging
 #endif
 
 namespace gaudi {
@@ -201,22 +201,30 @@ __device__ __forceinline__ void trip_barrier() {
 }
 
 // One trip: NT output tiles (acc[t0 .. t0+NT)) against the K chunk in `b`; A units one tile ahead in registers.
+#ifndef GAUDI_SPLIT_PD
+#define GAUDI_SPLIT_PD 1  // A units are read this many output tiles ahead of their MFMAs
+#endif
 template <int HP, int MODE, int NT, class MID>
 __device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, const B3& b, bool active, MID mid) {  // NOLINT
   constexpr int U = SplitGeo<HP, MODE>::kUnit;
-  f4 a[2][3];
+  constexpr int PD = GAUDI_SPLIT_PD, NB = PD + 1;
+  f4 a[NB][3];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) a[0][p] = *(const f4*)(slot_lane + p * U);
+  for (int d = 0; d < PD; ++d)
+    if (d < NT) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[d][p] = *(const f4*)(slot_lane + (d * 3 + p) * U);
+    }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int cur = t & 1;
+    const int cur = t % NB;
     if (t == NT / 2) {
       mid();
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (t + 1 < NT) {
+    if (t + PD < NT) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[cur ^ 1][p] = *(const f4*)(slot_lane + ((t + 1) * 3 + p) * U);
+      for (int p = 0; p < 3; ++p) a[(t + PD) % NB][p] = *(const f4*)(slot_lane + ((t + PD) * 3 + p) * U);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (active) {
@@ -277,17 +285,10 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
       constexpr int h = decltype(h_tag)::value;
       const int tr = m * G::NH + h;
       trip_barrier();
-      if (GAUDI_SPLIT_GLDS == 2) rings_stage(ring, wb, W, nextW, tr, wave, lane);
-#ifndef SPLIT_NO_GEN
       if (late && h == 0 && m > 0) bin = gen(m);
-#endif
       rings_mfma<HP, MODE, G::tiles_of(h)>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
-#ifndef SPLIT_NO_STAGE
-        if (GAUDI_SPLIT_GLDS != 2) rings_stage(ring, wb, W, nextW, tr, wave, lane);
-#endif
-#ifndef SPLIT_NO_GEN
+        rings_stage(ring, wb, W, nextW, tr, wave, lane);
         if (!late && h == G::NH - 1) nb = gen(m + 1 < G::NC ? m + 1 : m);
-#endif
       });
       ring.par ^= 1;
     };
@@ -333,10 +334,8 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
       constexpr int h = decltype(h_tag)::value;
       constexpr int tr = m * G::NH + h;
       trip_barrier();
-      if (GAUDI_SPLIT_GLDS == 2) rings_stage(ring, wb, W, nextW, tr, wave, lane);
-      rings_mfma<HP, MODE, G::tiles_of(h)>(out + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
-        if (GAUDI_SPLIT_GLDS != 2) rings_stage(ring, wb, W, nextW, tr, wave, lane);
-      });
+      rings_mfma<HP, MODE, G::tiles_of(h)>(out + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active,
+                                           [&] { rings_stage(ring, wb, W, nextW, tr, wave, lane); });
       ring.par ^= 1;
     };
     trip(std::integral_constant<int, 0>{});
