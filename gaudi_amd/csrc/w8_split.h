@@ -194,6 +194,9 @@ __device__ __forceinline__ void rings_stage(RingS<HP, MODE>& r, const WBuf& wb, 
 // waves: each wave retires its own (vmcnt) before the barrier -- hipcc does not track these loads for the __syncthreads
 // fence on every path (seen in the ISA: barriers with lgkmcnt(0) only, and a run-to-run difference in the results).
 __device__ __forceinline__ void trip_barrier() {
+#ifdef MB_NO_BARRIER  // timing experiment only (tools/split_gemm_microbench.hip): results are wrong without it
+  return;
+#endif
 #if GAUDI_SPLIT_GLDS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -269,7 +272,6 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
   using G = SplitGeo<HP, MODE>;
   constexpr int T = G::T;
   const int g = lane >> 4;
-  const bool late = wave >= kWaves / 2;
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = *(const f4*)(sB2 + 16 * t + 4 * g);
   auto gen = [&](int m) {  // split silu(u) of K chunk m (tiles 2m, 2m+1; an odd T leaves the upper half of the last chunk 0)
@@ -285,17 +287,18 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
       constexpr int h = decltype(h_tag)::value;
       const int tr = m * G::NH + h;
       trip_barrier();
-      if (late && h == 0 && m > 0) bin = gen(m);
       rings_mfma<HP, MODE, G::tiles_of(h)>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
         rings_stage(ring, wb, W, nextW, tr, wave, lane);
-        if (!late && h == G::NH - 1) nb = gen(m + 1 < G::NC ? m + 1 : m);
+        // every wave generates the NEXT chunk in the middle of its block (vector work co-issues with bf16 MFMAs; the
+        // staggered placement of the fp32 form is 2 % slower here, generation right after the barrier 7 %)
+        if (h == G::NH - 1) nb = gen(m + 1 < G::NC ? m + 1 : m);
       });
       ring.par ^= 1;
     };
     trip(std::integral_constant<int, 0>{});
     if constexpr (G::NH > 1) trip(std::integral_constant<int, 1>{});
     if constexpr (G::NH > 2) trip(std::integral_constant<int, 2>{});
-    if (!late) bin = nb;
+    bin = nb;
   };
   const int full = tail ? G::NC - 1 : G::NC;  // one copy of the chunk body: the tail only shortens the rolled loop
 #pragma unroll 1
