@@ -4,6 +4,6 @@
 set -e
 cd "$(dirname "$0")/../gaudi_amd/csrc"
 mkdir -p ../../diag
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DGAUDI_STAMPS \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -shared -DGAUDI_STAMPS \
   -o ../../diag/libgaudi_hip_stamps.so gaudi_hip.hip kern_edm_192.hip kern_fused_192_208.hip kern8_edm_192.hip kern8_fused_192_208.hip kern8s_edm_192.hip kern8s_fused_192_208.hip kern8h_fused_192_208.hip \
   -DGAUDI_STAMP_STUBS

@@ -5,5 +5,5 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../gaudi_amd/csrc"
 mkdir -p ../../diag
-timeout 900 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DGAUDI_STAMP_STUBS "$@" \
+timeout 900 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -shared -DGAUDI_STAMP_STUBS "$@" \
   -o ../../diag/libgaudi_$name.so gaudi_hip.hip kern_edm_192.hip kern_fused_192_208.hip kern8_edm_192.hip kern8_fused_192_208.hip

@@ -3,7 +3,7 @@
 #   tools/resource_usage.sh > profiles/<tag>_resource_usage.txt
 cd "$(dirname "$0")/../gaudi_amd/csrc"
 for tu in kern8s_fused_192_208 kern8s_edm_192 kern8h_fused_192_208 kern8_fused_192_208 kern8_edm_192 kern_fused_192_208 kern_edm_192; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -S --cuda-device-only $tu.hip -o /tmp/ru_$tu.s 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -S --cuda-device-only $tu.hip -o /tmp/ru_$tu.s 2>/dev/null
   python3 - /tmp/ru_$tu.s $tu <<'PY'
 import re, sys
 txt = open(sys.argv[1]).read()
@@ -21,6 +21,6 @@ for f in re.split(r'\n(?=_ZN[^\n]*:\s*;? ?@?)', txt):
           f"scratch instructions {len(sc):4d} ({mid} outside prologue/epilogue)  MFMA {sum('v_mfma' in l for l in lines):5d}  "
           f"sgpr-spill lanes (v_writelane) {sum('v_writelane' in l for l in lines):4d}")
 PY
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $tu.hip -o /tmp/ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -c $tu.hip -o /tmp/ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | \
     grep -E "SGPRs Spill|VGPRs Spill|Occupancy" | sed 's/.*remark: *//; s/ \[-R.*//' | tr '\n' ';'; echo
 done
