@@ -313,7 +313,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                                         "w8": "8 waves per molecule (two per SIMD), fp32 matrix instructions",
                                         "w8s": "8 waves per molecule (two per SIMD); edge GEMMs: fp32 operands split exactly "
                                                "into 3 bf16 pieces, 6 piece products accumulated in fp32 on the bf16 matrix "
-                                               "pipe (error vs float64 <= the fp32 instruction's: tests/test_gpu_split.py); "
+                                               "pipe (error vs float64 at the level of the fp32 instruction's own: tests/test_gpu_split.py); "
                                                "node GEMMs: fp32 matrix instructions"}[variant],
                      "flops_basis": "issued matrix instructions counted from the kernel's loop structure (padding included): "
                                     "v_mfma_f32_16x16x4_f32 x 2048 FLOP at 157.3 TFLOP/s + v_mfma_f32_16x16x32_bf16 x 16384 FLOP "

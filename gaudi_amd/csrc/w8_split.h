@@ -5,7 +5,7 @@
 // |x|) and a product a.b is accumulated in fp32 from the six piece products of weight >= 2^-18:
 //     ah.bh + ah.bm + am.bh + am.bm + ah.bl + al.bh          (dropped: am.bl + al.bm + al.bl <= 2^-24.4 |a.b|)
 // Piece products are exact in fp32 (8 x 8 significant bits), so the only error beside the fp32 accumulation is the dropped
-// tail -- below the rounding error of ONE fp32 multiply (2^-24 |a.b|).  Measured against float64 the result is as close as
+// tail -- below the rounding error of ONE fp32 multiply (2^-24 |a.b|).  Measured against float64 the result is about as close as
 // the fp32-MFMA GEMM (tests/test_gpu_split.py, tools/split_gemm_microbench.hip).  Six 16-cycle instructions replace eight
 // 32-cycle ones per 32 inputs: 2.67x less matrix time, and vector-ALU work co-issues with bf16 MFMAs (it does not with
 // fp32 MFMAs).

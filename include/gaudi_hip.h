@@ -222,7 +222,7 @@ int gaudi_host_graph_meta8(int B, int N, const float* node_mask, const float* ed
 int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
 /* Arithmetic of the edge-level GEMMs (the W2 / Wc1 contractions and their transposes, edm/egnn/egnn_new.py:42-47 and
  * edm/egnn_predictor/gcl.py:225-231) on the 8-wave kernels: 1 = every fp32 operand split exactly into three bf16 pieces, six
- * piece products accumulated in fp32 on the bf16 matrix pipe (error against float64 not larger than the fp32 matrix
+ * piece products accumulated in fp32 on the bf16 matrix pipe (error against float64 at the level of the fp32 matrix
  * instruction's: tests/test_gpu_split.py); 0 = v_mfma_f32_16x16x4_f32 (environment GAUDI_EDGE_MATH=fp32 at gaudi_create,
  * the 4-wave kernels, and the per-call fallback when the LDS weight ring of the split form does not fit).  last_call: 1 =
  * split with the full ring (a 32-input chunk of all output tiles per trip), 2 = split with the half ring (two trips per
