@@ -1,9 +1,8 @@
 #!/bin/bash
 # Diagnostic build with in-kernel phase stamps (shares only; never used for reported timings).
-#   tools/build_stamped.sh && GAUDI_LIB=$PWD/diag/libgaudi_hip_stamps.so GAUDI_PRINT_STAMPS=1 python bench.py ...
+#   tools/build_stamped.sh && GAUDI_LIB=$PWD/gaudi_amd/libgaudi_hip_stamps.so GAUDI_PRINT_STAMPS=1 python bench.py ...
 set -e
 cd "$(dirname "$0")/../gaudi_amd/csrc"
-mkdir -p ../../diag
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -shared -DGAUDI_STAMPS \
-  -o ../../diag/libgaudi_hip_stamps.so gaudi_hip.hip kern_edm_192.hip kern_fused_192_208.hip kern8_edm_192.hip kern8_fused_192_208.hip kern8s_edm_192.hip kern8s_fused_192_208.hip kern8h_fused_192_208.hip \
+  -o ../libgaudi_hip_stamps.so gaudi_hip.hip kern_edm_192.hip kern_fused_192_208.hip kern8_edm_192.hip kern8_fused_192_208.hip kern8s_edm_192.hip kern8s_fused_192_208.hip kern8h_fused_192_208.hip \
   -DGAUDI_STAMP_STUBS
