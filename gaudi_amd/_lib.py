@@ -80,6 +80,7 @@ EXPORTS = {
                                         C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), FP, C.c_int32,
                                         C.POINTER(C.c_int32)]),
     "gaudi_host_pack_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, FP, FP]),
+    "gaudi_host_pack_matrix_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, FP, FP]),
     "gaudi_profile_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "gaudi_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "gaudi_set_steps_per_launch": (C.c_int, [C.c_void_p, C.c_int]),

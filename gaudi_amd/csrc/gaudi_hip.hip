@@ -1428,6 +1428,18 @@ int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, cons
   return GAUDI_OK;
 }
 
+int gaudi_host_pack_matrix_split(int H, int ldw, int col0, int HP, int transpose, int ktail, const float* W, float* packed_out) {
+  if (H < 1 || HP < H || HP % 16 || !W || !packed_out) return GAUDI_E_INVALID;
+  const int T = HP / 16;
+  std::memset(packed_out, 0, sizeof(float) * (size_t)((T + 1) / 2) * T * 3 * 256);
+  g_lane_linear = true;
+  g_ktail = ktail != 0 && has_ktail(H, HP);
+  pack_matrix_split(packed_out, W, H, ldw, col0, HP, transpose != 0);
+  g_lane_linear = false;
+  g_ktail = false;
+  return GAUDI_OK;
+}
+
 int gaudi_profile_reset(gaudi_handle* h, int enable) {
   if (!h) return GAUDI_E_INVALID;
   if (h->stream) (void)hipStreamSynchronize(h->stream);

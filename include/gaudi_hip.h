@@ -231,6 +231,12 @@ int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_ca
 /* Tile packing of a weight block W[o][col0+k] (o,k < H, row stride ldw) into [HP/16][HP/16][16][16]
  * (k-chunk major), optionally transposed: the layout every GEMM of the kernels streams. */
 int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, const float* W, float* packed_out);
+/* Split-bf16 image of the same block (what the default 8-wave edge GEMMs stream; csrc/w8_split.h): packed_out holds
+ * ceil(T/2) * T * 3 units of 1 KiB (T = HP/16), unit (m, t, p) = piece p (bf16, round to nearest; piece 0 + 1 + 2 == w exactly)
+ * of output tile t against the 32-input chunk m; lane L = (row L & 15, group g = L >> 4) holds 8 bf16: slots 0-3 = inputs
+ * 16(2m) + 4g .. +3, slots 4-7 = inputs 16(2m+1) + 4g .. +3.  ktail != 0 and H % 16 == 4 with an odd T >= 3: the last chunk
+ * holds the 4 tail inputs as T fp32 tiles instead (float4 index (k % 16) * 16 + o % 16 of tile t, element 0). */
+int gaudi_host_pack_matrix_split(int H, int ldw, int col0, int HP, int transpose, int ktail, const float* W, float* packed_out);
 
 /* Kernel timing with HIP events on the handle's own stream (bench.py roofline).
  * gaudi_profile_reset enables collection; gaudi_profile_get returns the number of step-kernel

@@ -148,3 +148,44 @@ def test_host_pack_matrix_layout():
         full[:H, :H] = blk
         got = p.transpose(1, 2, 0, 3).reshape(HP, HP)
         assert np.array_equal(got, full)
+
+
+def _bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_host_pack_matrix_split_is_exact_and_laid_out_as_documented():
+    """The split-bf16 image the default edge GEMMs stream (csrc/w8_split.h): three bf16 pieces per weight that sum to the
+    weight EXACTLY, in the documented unit / lane / slot positions; a K tail (H % 16 == 4, odd tile count) as fp32 tiles."""
+    lib, L = _lib()
+    rng = np.random.default_rng(1)
+    for H, HP, ktail in ((36, 48, 1), (36, 48, 0), (60, 64, 0), (20, 32, 1), (196, 208, 1)):
+        T, NC = HP // 16, (HP // 16 + 1) // 2
+        W = (rng.standard_normal((H, H + 3)) * rng.choice([1e-3, 1.0, 30.0], size=(H, H + 3))).astype(np.float32)
+        for tr in (0, 1):
+            out = np.empty(NC * T * 3 * 256, np.float32)
+            assert lib.gaudi_host_pack_matrix_split(H, H + 3, 2, HP, tr, ktail, L.fptr(W), L.fptr(out)) == 0
+            blk = W[:, 2:2 + H].T if tr else W[:, 2:2 + H]  # logical [o][k]
+            full = np.zeros((HP, HP), np.float32)
+            full[:H, :H] = blk
+            tail = bool(ktail) and HP - H == 12 and T % 2 == 1 and T >= 3
+            units16 = out.view(np.uint16).reshape(NC, T, 3, 64, 8)
+            units32 = out.reshape(NC, T, 3, 64, 4)
+            for m in range(NC):
+                for t in range(T):
+                    if tail and m == NC - 1:
+                        tile = units32.reshape(NC, T * 3, 64, 4)[m, t]  # fp32 tile t of the tail chunk: [L][4], element 0
+                        for kk in range(4):
+                            assert np.array_equal(tile[kk * 16:(kk + 1) * 16, 0], full[16 * t:16 * t + 16, 16 * (T - 1) + kk])
+                        continue
+                    pieces = [_bf16_to_f32(units16[m, t, p]) for p in range(3)]  # [64 lanes][8 slots]
+                    total = (pieces[0].astype(np.float64) + pieces[1] + pieces[2]).astype(np.float32)
+                    assert np.array_equal((pieces[0] + pieces[1]) + pieces[2], total)  # the fp32 sum is exact too
+                    for Ln in range(64):
+                        row, g = Ln & 15, Ln >> 4
+                        for e in range(8):
+                            k = 16 * (2 * m + (e >> 2)) + 4 * g + (e & 3)
+                            want = full[16 * t + row, k] if k < HP else np.float32(0)
+                            assert total[Ln, e] == want, (H, tr, m, t, Ln, e)
+                    assert np.all(np.abs(pieces[1]) <= np.abs(pieces[0]) * 2.0 ** -8 + 1e-45)
+                    assert np.all(np.abs(pieces[2]) <= np.abs(pieces[0]) * 2.0 ** -16 + 1e-45)
