@@ -607,7 +607,8 @@ static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pub
   if (base > cap) return false;
   if (!hpp) return true;
   const int T = hpp / 16;
-  const long long own = 2LL * N * (hpp + 4);  // b0 + b1 double as the head of the publish buffer
+  // b0 + b1 double as the head of the publish buffer; with the split edge GEMMs the (then idle) weight ring follows them
+  const long long own = 2LL * N * (hpp + 4) + (split ? w8::edge_ring_floats(hpp, split) : 0);
   pub_ch = w8::pub_chunk_tiles(S, own + (cap - base), T);
   if (pub_ch < 1) return false;
   // prefer the smallest chunk that gives the same number of chunks (less LDS, same barriers)
@@ -697,6 +698,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   if (!h->run_split && !plan_pub8(hpe, hpp, N, Dz, M.S, 0, pubx, pub_ch)) return 1;
   P.pubx = pubx;
   P.pub_ch = pub_ch;
+  if (getenv("GAUDI_DEBUG_PLAN")) fprintf(stderr, "[plan] N=%d S=%d split=%d pub_ch=%d pubx=%d lds=%zu\n", N, M.S, h->run_split, pub_ch, pubx, lds_bytes8(hpe, hpp, N, Dz, M.S, pubx, h->run_split));
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = d.reserve(bytes);
     if (e != hipSuccess) return e;

@@ -12,9 +12,10 @@ namespace w8 {
 
 template <int HP, int SP = 0>
 struct PredSmem {
-  float* ring;                    // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats)
   float *b2, *b3, *b4;            // [N][HP+4] node buffers (roles change per phase, see below)
-  float *b0, *b1;                 // [N][HP+4] ... these two sit right in front of `pub` and are part of it in the reverse pass
+  float *b0, *b1;                 // [N][HP+4] ... these two open the publish buffer of the reverse pass: [b0 | b1 | (ring) | pub]
+  float* ring;                    // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats); split form: idle while du is
+                                  // published (no group is prefetched across that phase), so it is part of the buffer too
   float* pub;                     // [pubx] extra floats of the publish buffer (reverse pass: du of every slot, CH tiles at a time)
   float *x, *x0, *dx;             // [N][4]
   f4* geo;                        // [S]
@@ -26,12 +27,13 @@ struct PredSmem {
   }
   __device__ void carve(float* base, int N, int S, int pubx) {
     constexpr int LD = HP + 4;
-    ring = base; base += EdgeRing<HP, SP>::kFloats;
+    if (SP == 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // fp32 form: the ring stays busy across the publish phase
     b2 = base; base += N * LD;
     b3 = base; base += N * LD;
     b4 = base; base += N * LD;
     b0 = base; base += N * LD;
     b1 = base; base += N * LD;
+    if (SP != 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // N * LD * 4 bytes is a multiple of 16: units stay aligned
     pub = base; base += pubx;
     x = base; base += 4 * N;
     x0 = base; base += 4 * N;
@@ -390,8 +392,10 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         }
         STAMP(ST_B_DV);
         // next edge GEMM of the chain: Wc1^T of layer l-1 (W2^T when that layer is ... never the last), none after layer 0
-        er_gemm_regs<HP>(du, de, ring, wbe, Lw.W2t, l > 0 ? lay.layer(l - 1) + 10 * HP * HP : -1, nullptr, nullptr, tc.active,
-                           wave, lane);  // dt1
+        // split form: nothing is prefetched across the publish phase (the ring is part of the publish buffer there); the
+        // next layer's first group is requested right after it instead
+        er_gemm_regs<HP>(du, de, ring, wbe, Lw.W2t, (SP == 0 && l > 0) ? lay.layer(l - 1) + 10 * HP * HP : -1, nullptr, nullptr,
+                         tc.active, wave, lane);  // dt1
         STAMP(ST_B_DT1);
       }
       if (tc.active) {
@@ -446,6 +450,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         }
         __syncthreads();
       }
+      if (SP != 0 && l > 0) er_start<HP>(ring, wbe, lay.layer(l - 1) + 10 * HP * HP /* Wc1^T of the layer below */, wave, lane);
       node_prefetch<HP>(pf, wb, Lw.At, wave, lane);
       STAMP(ST_BWD_COL);
     }
