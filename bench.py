@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--steps-per-launch", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 / C4 / C3-at-1024 passes after the headline")
+    ap.add_argument("--dist", action="store_true",
+                    help="N = 1 only: route the run through the SAME distributed code as N > 1 (init_process_group('nccl', "
+                         "world_size=1), the RCCL all_gather of every call, barrier + MAX all_reduce around the timed region)")
     return ap.parse_args()
 
 
@@ -159,7 +162,7 @@ def graph_meta8(nm, em):
     return ntiles, ncols
 
 
-def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, backend, T, K=5, edge_math=None):
+def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, backend, T, K=5, edge_math=None, use_dist=False):
     """Time `steps` complete sampling calls of one workload; returns the contract fields + roofline of its kernel.
     edge_math="fp32": a handle created with GAUDI_EDGE_MATH=fp32 (edge GEMMs on fp32 matrix instructions)."""
     import torch
@@ -217,13 +220,13 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
 
     def one_pass(it):
         x, h, diag = eng.sample(nm, em, seed=1234 + it, sample_offset=rank * B, std=1.0, target_w=tw, scale=0.6)
-        if world > 1:
+        if use_dist:
             x, h = gdist.gather_to_all(x, h, B * world, N, F, device=dev if backend == "nccl" else None)
         return x, h, diag
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -236,7 +239,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
         x, h, diag = one_pass(it)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -363,7 +366,11 @@ def main():
     gpu = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
-    if world > 1:
+    use_dist = world > 1 or a.dist
+    if use_dist:
+        if world == 1:  # --dist without a launcher: a one-rank group on this GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29534")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -374,8 +381,11 @@ def main():
     # (C5): 1024 guided samples per GPU, 8192 over 8 GPUs.
     B = a.batch or (1024 if (a.workload == "c4" or world > 1) else 256)
     engines = {}
-    out = run_workload(a, engines, a.workload, B, a.steps, a.warmup, rank, world, dev, backend, T)
+    out = run_workload(a, engines, a.workload, B, a.steps, a.warmup, rank, world, dev, backend, T, use_dist=use_dist)
     if rank == 0:
+        if use_dist:
+            out["config"]["collective"] = (f"{backend} all_gather per call (world {world}"
+                                           + (f", RCCL {'.'.join(map(str, torch.cuda.nccl.version()))}" if backend == "nccl" else "") + ")")
         if world == 1 and not a.no_secondary and a.workload == "c3":
             # the other single-GPU configurations, timed by the same harness (short: one or two calls each)
             sec = {}
@@ -399,7 +409,7 @@ def main():
         print(json.dumps(out), flush=True)
     for eng, _ in engines.values():
         eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

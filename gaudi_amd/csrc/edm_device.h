@@ -120,8 +120,8 @@ __device__ __forceinline__ void load_cols(const SM& sm, const MolGraph& mg, int 
 // x <- (x + sum_j trans_ij / normf) * mask     (egnn_new.py:132-155), fixed ascending-j order
 template <class SM>
 __device__ __forceinline__ void coord_update(const SM& sm, const MolGraph& mg, float normf, int tid) {
-  if (tid < mg.N * 3) {
-    const int n = tid / 3, d = tid % 3;
+  for (int idx = tid; idx < mg.N * 3; idx += kThreads) {  // strided: N * 3 may exceed the workgroup at small hidden sizes
+    const int n = idx / 3, d = idx % 3;
     const uint32_t sg = mg.seg[n];
     const int w = sg >> 30, st = (sg >> 15) & 0x7fff, len = sg & 0x7fff;
     float s = 0.f;

@@ -65,6 +65,12 @@ struct gaudi_handle {
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
   long long fix_key = 0;      // global sample index whose Philox stream is shared
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
+  // Plan hint (gaudi_set_plan_hint): the kernel family and the edge-GEMM arithmetic of a call follow from batch-wide maxima
+  // (edge slots, a node's live edges).  A shard of a larger logical batch plans with the WHOLE batch's figures, so that a
+  // molecule's rounding does not depend on where the batch was cut.  call_* = the same, set by gaudi_sample for its own
+  // sub-batches.
+  int plan_min_slots = 0, plan_force_waves = 0;
+  int call_min_slots = 0, call_force_waves = 0;
   // profiling: launches are bracketed by HIP events on the handle's stream.  A small window of pending pairs is kept;
   // older pairs are folded into running sums and their events recycled (a T = 1000 callback chain makes 2001 launches).
   bool prof = false;
@@ -117,7 +123,6 @@ struct gaudi_handle {
     }
   } prof_log, stab_log;
   long long prof_steps = 0;
-  std::map<const void*, int> lds_attr;  // largest dynamic-LDS size already granted to each kernel
 #ifdef GAUDI_STAMPS
   DevBuf d_stamps;
   unsigned long long stamp_acc[32] = {0};
@@ -206,30 +211,48 @@ struct Tensors {
   }
 };
 
-// W[o][col0 + k] (row stride ldw), o,k < H  ->  tile-packed [HP/16][HP/16][16][16]: dst[((k/16*T + o/16)*16 + o%16)*16 + k%16]
-// lane_linear (8-wave kernels): inside a tile float4 index L = (k%16/4)*16 + o%16 holds W[o][k .. k+3], i.e. lane L of a
-// wave reads the 16 bytes at offset 16 L whether the tile comes from L2 or from the LDS weight ring
-static bool g_lane_linear = false;
-// K tail (8-wave kernels, H % 16 == 4): the last K chunk carries its 4 valid inputs on element 0 of the four lane groups
-static bool g_ktail = false;
+// Packing context of one checkpoint load (a value passed down -- no file-scope state: two handles may load concurrently).
+//   lane_linear (8-wave kernels): inside a 16x16 tile float4 index L = (k%16/4)*16 + o%16 holds W[o][k .. k+3], i.e. lane L
+//     of a wave reads the 16 bytes at offset 16 L whether the tile comes from L2 or from the LDS weight ring; otherwise the
+//     tile is row-major (4-wave kernels)
+//   ktail (8-wave kernels, H % 16 == 4): the last K chunk carries its 4 valid inputs on element 0 of the four lane groups
+//   wbase / ws: when a split buffer is being filled, the fp32 buffer's base and the split image (w8_split.h) whose float
+//     offsets are twice the fp32 ones
+struct PackMode {
+  bool lane_linear = false;
+  bool ktail = false;
+  float* wbase = nullptr;
+  std::vector<float>* ws = nullptr;
+  PackMode with_ktail(bool kt) const {
+    PackMode m = *this;
+    m.ktail = kt;
+    return m;
+  }
+};
 static bool has_ktail(int H, int HP) { return HP - H == 12; }
-static void pack_matrix(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
+// W[o][col0 + k] (row stride ldw), o,k < H  ->  tile-packed [HP/16][HP/16][16][16]: dst[((k/16*T + o/16)*16 + o%16)*16 + k%16]
+static void pack_matrix(const PackMode& pm, float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
   const int T = HP / 16;
   for (int o = 0; o < H; ++o)
     for (int k = 0; k < H; ++k) {
       const float v = transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k];
       const size_t tile = ((size_t)(k / 16) * T + o / 16) * 256;
-      size_t in = g_lane_linear ? (size_t)(((k % 16) / 4) * 16 + o % 16) * 4 + k % 4 : (size_t)(o % 16) * 16 + k % 16;
-      if (g_lane_linear && g_ktail && k / 16 == T - 1) in = (size_t)((k % 16) * 16 + o % 16) * 4;  // k % 16 < 4 here
+      size_t in = pm.lane_linear ? (size_t)(((k % 16) / 4) * 16 + o % 16) * 4 + k % 4 : (size_t)(o % 16) * 16 + k % 16;
+      if (pm.lane_linear && pm.ktail && k / 16 == T - 1) in = (size_t)((k % 16) * 16 + o % 16) * 4;  // k % 16 < 4 here
       dst[tile + in] = v;
     }
 }
 // Split-bf16 image of an edge-GEMM matrix (w8_split.h): units of 1 KiB ordered [K chunk m][output tile t][piece p]; lane L
 // = (row L & 15, group g = L >> 4) holds 8 bf16: slots 0-3 = inputs 16(2m) + 4g .. +3, slots 4-7 = inputs 16(2m+1) + 4g .. +3.
-// Pieces by round-to-nearest-even: w = p0 + p1 + p2 exactly.
+// Pieces by round-to-nearest-even: w = p0 + p1 + p2 exactly.  NaN-safe: the integer rounding trick turns some NaN payloads
+// into 0 or infinity (MI355X_MICROARCH.md, correctness boundaries), so a NaN keeps a quiet-NaN pattern -- what the
+// device-side v_cvt_pk_bf16_f32 does -- and every piece of a NaN / infinite weight reproduces it (NaN - NaN = NaN; an
+// infinite weight gives inf, then inf - inf = NaN in the lower pieces: the product is non-finite either way, like the
+// fp32 product).
 static uint16_t bf16_rne(float x) {
   uint32_t u;
   std::memcpy(&u, &x, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // NaN stays NaN (quieted)
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
@@ -239,11 +262,11 @@ static float bf16_to_f(uint16_t b) {
   std::memcpy(&f, &u, 4);
   return f;
 }
-// K tail (g_ktail, odd tile count >= 3 = SplitGeo::kTailOK): the last chunk holds only the tail tile; it is stored as T fp32
+// K tail (pm.ktail, odd tile count >= 3 = SplitGeo::kTailOK): the last chunk holds only the tail tile; it is stored as T fp32
 // tiles in pack_matrix's K-tail form and issued as one fp32 k-step per tile.
-static void pack_matrix_split(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose) {
+static void pack_matrix_split(const PackMode& pm, float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose) {
   const int T = HP / 16;
-  const bool tail = g_ktail && (T & 1) && T >= 3;
+  const bool tail = pm.ktail && (T & 1) && T >= 3;
   uint16_t* d = (uint16_t*)dst;
   for (int o = 0; o < H; ++o)
     for (int k = 0; k < H; ++k) {
@@ -262,11 +285,9 @@ static void pack_matrix_split(float* dst, const float* W, int H, int ldw, int co
 }
 // An edge-GEMM matrix: the fp32 tiles (K tail included where the width has one) and, when a split buffer is being filled,
 // its split image at twice the float offset
-static float* g_wbase = nullptr;
-static std::vector<float>* g_ws = nullptr;
-static void pack_edge_matrix(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
-  pack_matrix(dst, W, H, ldw, col0, HP, transpose);
-  if (g_ws != nullptr) pack_matrix_split(g_ws->data() + 2 * (size_t)(dst - g_wbase), W, H, ldw, col0, HP, transpose);
+static void pack_edge_matrix(const PackMode& pm, float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
+  pack_matrix(pm, dst, W, H, ldw, col0, HP, transpose);
+  if (pm.ws != nullptr) pack_matrix_split(pm, pm.ws->data() + 2 * (size_t)(dst - pm.wbase), W, H, ldw, col0, HP, transpose);
 }
 static void pack_vec(float* dst, const float* v, int n) { std::memcpy(dst, v, sizeof(float) * n); }
 static void pack_col(float* dst, const float* W, int H, int ldw, int col) {
@@ -385,7 +406,8 @@ struct Meta8 {
   std::vector<uint16_t> soff, sidx;
 };
 
-static int build_meta8(int B, int N, const float* node_mask, const float* edge_mask, Meta8& M, std::string& err) {
+static int build_meta8(int B, int N, const float* node_mask, const float* edge_mask, Meta8& M, std::string& err,
+                       int min_slots = 0) {
   if (N > 255) {
     err = "N > 255 unsupported";
     return GAUDI_E_CAPACITY;
@@ -443,7 +465,7 @@ static int build_meta8(int B, int N, const float* node_mask, const float* edge_m
     M.ntiles[b] = (int)sl.size() / 16;
     max_tiles = std::max(max_tiles, M.ntiles[b]);
   }
-  M.S = 16 * max_tiles;
+  M.S = std::max(16 * max_tiles, (min_slots + 15) / 16 * 16);  // min_slots: plan hint (slot capacity of the whole logical batch)
   if (M.S > 0xffff) {
     err = "too many edge slots";
     return GAUDI_E_CAPACITY;
@@ -632,7 +654,12 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
   if (lds > 160 * 1024)
     return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
   {
-    int& granted = h->lds_attr[(const void*)fn];
+    // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function, not to a handle: one process-wide record per
+    // (device, kernel), only ever raised, so that no handle launches with more dynamic LDS than the attribute allows
+    static std::mutex attr_mu;
+    static std::map<std::pair<int, const void*>, int> granted_by_fn;
+    std::lock_guard<std::mutex> lock(attr_mu);
+    int& granted = granted_by_fn[{h->device, (const void*)fn}];
     if ((int)lds > granted) {
       HIPCHECK(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       granted = (int)lds;
@@ -681,9 +708,10 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
 // -> GAUDI_OK, or a positive value = "run this call on the 4-wave kernels" (graph outside the 8-wave kernels' limits)
 static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P, int hpe,
                         int hpp) {
+  if (std::max(h->plan_force_waves, h->call_force_waves) == 4) return 1;  // the whole logical batch runs on 4 waves
   Meta8 M;
   std::string err;
-  int rc = build_meta8(B, N, node_mask, edge_mask, M, err);
+  int rc = build_meta8(B, N, node_mask, edge_mask, M, err, std::max(h->plan_min_slots, h->call_min_slots));
   if (rc == GAUDI_E_CAPACITY) return 1;
   if (rc) return fail(h, rc, err);
   if (hpp && M.S > 16 * w8::kWaves) return 1;  // the 8-wave predictor handles one round of tiles
@@ -742,6 +770,9 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
     h->run_split = 0;
     P.pubx = P.pub_ch = 0;
   }
+  // the 4-wave reverse pass parks [4 waves][N * 3] partial coordinate gradients in its 4 x 16 x (HP + 4) transposition scratch
+  if (hpp && 4 * N * 3 > 4 * 16 * (hpp + 4))
+    return fail(h, GAUDI_E_CAPACITY, "N too large for the 4-wave predictor kernels at this hidden size");
   Meta M;
   std::string err;
   int rc = build_meta(B, N, node_mask, edge_mask, M, err);
@@ -851,20 +882,21 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   if (!HP) return fail(h, GAUDI_E_INVALID, "no kernel instantiated for this hidden size");
   Tensors T;
   for (int i = 0; i < n; ++i) T.m[names[i]] = {tensors[i], numel[i]};
-  static std::mutex pack_mu;
-  std::lock_guard<std::mutex> pack_lock(pack_mu);
   EdmLayout lay{HP, F1, L, S};
   const std::string p = "dynamics.egnn.";
   const int PK = HP * HP;
   // tile layout: lane-linear for the 8-wave kernels, row-major for the 4-wave ones (kept as the fallback of the 8-wave
   // variant for graphs that do not fit it)
   auto pack = [&](bool lane_linear, std::vector<float>& w, std::vector<float>* ws) {
-  g_lane_linear = lane_linear;
-  g_ktail = lane_linear && has_ktail(H, HP);
   w.assign((size_t)lay.total(), 0.f);
   if (ws) ws->assign(2 * (size_t)lay.total(), 0.f);
-  g_wbase = w.data();
-  g_ws = ws;
+  // only the matrices of the edge-level GEMMs carry the K tail: pe packs those, pn the node-level ones
+  PackMode pe;
+  pe.lane_linear = lane_linear;
+  pe.ktail = lane_linear && has_ktail(H, HP);
+  pe.wbase = w.data();
+  pe.ws = ws;
+  const PackMode pn = pe.with_ktail(false);
   {
     const float* ew = T.get(p + "embedding.weight", (int64_t)H * F1);
     const float* eb = T.get(p + "embedding.bias", H);
@@ -899,17 +931,12 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
         ba = T.get(q + "att_mlp.0.bias", 1);
       }
       if (!(W1 && b1 && W2 && b2 && Wn1 && bn1 && Wn2 && bn2) || (cfg->attention && !(wa && ba))) continue;
-      const bool kt = g_ktail;  // only the matrices of the edge-level GEMMs carry the K tail
-      g_ktail = false;
-      pack_matrix(G, W1, H, ld1, 0, HP);
-      pack_matrix(G + PK, W1, H, ld1, H, HP);
-      g_ktail = kt;
-      pack_edge_matrix(G + 2 * PK, W2, H, H, 0, HP);
-      g_ktail = false;
-      pack_matrix(G + 3 * PK, Wn1, H, 2 * H, 0, HP);
-      pack_matrix(G + 4 * PK, Wn1, H, 2 * H, H, HP);
-      pack_matrix(G + 5 * PK, Wn2, H, H, 0, HP);
-      g_ktail = kt;
+      pack_matrix(pn, G, W1, H, ld1, 0, HP);
+      pack_matrix(pn, G + PK, W1, H, ld1, H, HP);
+      pack_edge_matrix(pe, G + 2 * PK, W2, H, H, 0, HP);
+      pack_matrix(pn, G + 3 * PK, Wn1, H, 2 * H, 0, HP);
+      pack_matrix(pn, G + 4 * PK, Wn1, H, 2 * H, H, HP);
+      pack_matrix(pn, G + 5 * PK, Wn2, H, H, 0, HP);
       pack_col(V, W1, H, ld1, 2 * H);
       pack_col(V + HP, W1, H, ld1, 2 * H + 1);
       pack_vec(V + 2 * HP, b1, H);
@@ -928,19 +955,15 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
     const float* b2 = T.get(q + "coord_mlp.2.bias", H);
     const float* w3 = T.get(q + "coord_mlp.4.weight", H);
     if (!(W1 && b1 && W2 && b2 && w3)) continue;
-    const bool kt = g_ktail;
-    g_ktail = false;
-    pack_matrix(E, W1, H, ld1, 0, HP);
-    pack_matrix(E + PK, W1, H, ld1, H, HP);
-    g_ktail = kt;
-    pack_edge_matrix(E + 2 * PK, W2, H, H, 0, HP);
+    pack_matrix(pn, E, W1, H, ld1, 0, HP);
+    pack_matrix(pn, E + PK, W1, H, ld1, H, HP);
+    pack_edge_matrix(pe, E + 2 * PK, W2, H, H, 0, HP);
     pack_col(V, W1, H, ld1, 2 * H);
     pack_col(V + HP, W1, H, ld1, 2 * H + 1);
     pack_vec(V + 2 * HP, b1, H);
     pack_vec(V + 3 * HP, b2, H);
     pack_vec(V + 4 * HP, w3, H);
   }
-  g_ws = nullptr;
   };
   std::vector<float> w, ws;
   const bool want_split = h->variant == 8 && h->split;
@@ -1190,6 +1213,19 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
   HIPCHECK(h, hipSetDevice(h->device));
   const int T = h->ecfg.diffusion_steps, F = h->ecfg.in_node_nf, D = 3 + F;
   const int bmax = max_sub_batch(h, B, N, target_w != nullptr);
+  // sub-batches plan with the whole batch's graph figures (same kernel family and edge-GEMM arithmetic for every cut)
+  struct CallHint {
+    gaudi_handle* h;
+    ~CallHint() { h->call_min_slots = h->call_force_waves = 0; }
+  } call_hint{h};
+  if (bmax < B && h->variant == 8) {
+    Meta8 M;
+    std::string err;
+    const int rc = build_meta8(B, N, node_mask, edge_mask, M, err);
+    if (rc == GAUDI_E_CAPACITY) h->call_force_waves = 4;
+    else if (rc) return fail(h, rc, err);
+    else h->call_min_slots = M.S;
+  }
   int nanc = 0;
   std::vector<float> nz;
   for (int b0 = 0; b0 < B; b0 += bmax) {
@@ -1421,12 +1457,17 @@ int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_ca
   return GAUDI_OK;
 }
 
+int gaudi_set_plan_hint(gaudi_handle* h, int32_t min_slots, int32_t force_waves) {
+  if (!h || min_slots < 0 || (force_waves != 0 && force_waves != 4)) return GAUDI_E_INVALID;
+  h->plan_min_slots = min_slots;
+  h->plan_force_waves = force_waves;
+  return GAUDI_OK;
+}
+
 int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, const float* W, float* packed_out) {
   if (H < 1 || HP < H || HP % 16 || !W || !packed_out) return GAUDI_E_INVALID;
   std::memset(packed_out, 0, sizeof(float) * (size_t)HP * HP);
-  g_lane_linear = false;
-  g_ktail = false;
-  pack_matrix(packed_out, W, H, ldw, col0, HP, transpose != 0);
+  pack_matrix(PackMode{}, packed_out, W, H, ldw, col0, HP, transpose != 0);
   return GAUDI_OK;
 }
 
@@ -1434,11 +1475,10 @@ int gaudi_host_pack_matrix_split(int H, int ldw, int col0, int HP, int transpose
   if (H < 1 || HP < H || HP % 16 || !W || !packed_out) return GAUDI_E_INVALID;
   const int T = HP / 16;
   std::memset(packed_out, 0, sizeof(float) * (size_t)((T + 1) / 2) * T * 3 * 256);
-  g_lane_linear = true;
-  g_ktail = ktail != 0 && has_ktail(H, HP);
-  pack_matrix_split(packed_out, W, H, ldw, col0, HP, transpose != 0);
-  g_lane_linear = false;
-  g_ktail = false;
+  PackMode pm;
+  pm.lane_linear = true;
+  pm.ktail = ktail != 0 && has_ktail(H, HP);
+  pack_matrix_split(pm, packed_out, W, H, ldw, col0, HP, transpose != 0);
   return GAUDI_OK;
 }
 

@@ -573,11 +573,11 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       part[t] = acc;
     }
     __syncthreads();
-    if (tid < N * 3) {
-      const int n = tid / 3, d = tid % 3;
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
       float acc = sm.dx[4 * n + d];
 #pragma unroll
-      for (int w2 = 0; w2 < kWaves; ++w2) acc += part[w2 * N * 3 + tid];
+      for (int w2 = 0; w2 < kWaves; ++w2) acc += part[w2 * N * 3 + idx];
       sm.dx[4 * n + d] = acc;
     }
     __syncthreads();
@@ -593,8 +593,8 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   // embedding backward (time column dropped), d0 backward, input masking
   {
     const float* ew = w + lay.emb_w();
-    if (tid < N * 3) {
-      const int n = tid / 3, d = tid % 3;
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
       float acc = sm.dx[4 * n + d];
 #pragma unroll
       for (int w2 = 0; w2 < kWaves; ++w2)

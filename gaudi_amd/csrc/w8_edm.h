@@ -62,8 +62,8 @@ __device__ __forceinline__ void compute_geo(const SM& sm, const MolGraph& mg, fl
 // x <- (x + sum_j trans_ij / normf) * mask     (egnn_new.py:132-155), fixed ascending-j order
 template <class SM>
 __device__ __forceinline__ void coord_update(const SM& sm, const MolGraph& mg, float normf, int tid) {
-  if (tid < mg.N * 3) {
-    const int n = tid / 3, d = tid % 3;
+  for (int idx = tid; idx < mg.N * 3; idx += kThreads) {  // strided: small hidden sizes fit N > 170 nodes in LDS
+    const int n = idx / 3, d = idx % 3;
     const uint32_t sg = mg.seg[n];
     const int st = sg >> 16, len = sg & 0xffff;
     float s = 0.f;

@@ -455,8 +455,8 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       STAMP(ST_BWD_COL);
     }
     // dx <- dx*mask + sum_{e: i=n} ddiff_e - sum_{e: j=n} ddiff_e, in slot order
-    if (tid < N * 3) {
-      const int n = tid / 3, d = tid % 3;
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
       const uint32_t sg = mg.seg[n];
       const int rs = sg >> 16, rl = sg & 0xffff;
       float acc = sm.dx[4 * n + d];
@@ -477,8 +477,8 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   // embedding backward (time column dropped), d0 backward, input masking
   {
     const float* ew = w + lay.emb_w();
-    if (tid < N * 3) {
-      const int n = tid / 3, d = tid % 3;
+    for (int idx = tid; idx < N * 3; idx += kThreads) {
+      const int n = idx / 3, d = idx % 3;
       const uint32_t sg = mg.seg[n];
       const int rs = sg >> 16, rl = sg & 0xffff;
       float acc = sm.dx[4 * n + d];

@@ -1,8 +1,10 @@
 """Multi-GPU: independent samples are sharded over ranks (one process per GPU); no collective on the
 data path, ONE gather at the end (RCCL over xGMI when the backend is "nccl").  SURVEY.md section 8e.
 
-The noise stream is keyed by the GLOBAL sample index, and every shard pads to the batch-wide N, so the
-gathered result is identical to the unsharded run.
+The noise stream is keyed by the GLOBAL sample index, every shard pads to the batch-wide N, and every shard
+plans its kernels with the WHOLE batch's graph figures (Engine.plan_hint_for / gaudi_set_plan_hint: the
+kernel family and the edge-GEMM arithmetic follow from batch-wide maxima), so the gathered result is
+identical to the unsharded run.
 """
 from __future__ import annotations
 
@@ -16,11 +18,13 @@ def shard_bounds(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def sample_sharded(sample_fn, node_mask: np.ndarray, edge_mask: np.ndarray, rank: int, world: int):
+def sample_sharded(sample_fn, node_mask: np.ndarray, edge_mask: np.ndarray, rank: int, world: int, engine=None):
     """Run ``sample_fn(node_mask_shard, edge_mask_shard, sample_offset) -> (x, h)`` on this rank's block.
 
     node_mask [B,N(,1)], edge_mask reshapeable to [B,N,N] describe the WHOLE logical batch (already padded
-    to the batch-wide N, as sampling_edm.sample_guidance does, sampling_edm.py:177)."""
+    to the batch-wide N, as sampling_edm.sample_guidance does, sampling_edm.py:177).  ``engine``: the
+    gaudi_amd.engine.Engine that sample_fn runs on -- it is told the whole batch's plan figures for the
+    duration of the call, so a heterogeneous batch gives the same bits however it is cut."""
     nm = np.asarray(node_mask, np.float32)
     B, N = nm.shape[0], nm.shape[1]
     nm = nm.reshape(B, N)
@@ -28,8 +32,31 @@ def sample_sharded(sample_fn, node_mask: np.ndarray, edge_mask: np.ndarray, rank
     lo, hi = shard_bounds(B, rank, world)
     if hi == lo:
         return lo, hi, None, None
-    x, h = sample_fn(nm[lo:hi], em[lo:hi], lo)
+    if engine is not None:
+        engine.set_plan_hint(*engine.plan_hint_for(nm, em))
+    try:
+        x, h = sample_fn(nm[lo:hi], em[lo:hi], lo)
+    finally:
+        if engine is not None:
+            engine.set_plan_hint(0, 0)
     return lo, hi, x, h
+
+
+def check_same_plan(engine, device=None):
+    """All ranks must have run the same kernel family / edge-GEMM arithmetic (one small all_gather of two ints).
+    Raises if they differ: the gathered batch would then mix roundings (pass ``engine=`` to sample_sharded)."""
+    import torch
+    import torch.distributed as dist
+
+    mine = torch.tensor([engine.kernel_variant()[1], min(engine.edge_math()[1], 1)], dtype=torch.int32)
+    if device is not None:
+        mine = mine.to(device)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    plans = sorted({tuple(int(v) for v in t.cpu()) for t in out})
+    if len(plans) != 1:
+        raise RuntimeError(f"ranks ran different kernel plans (waves, split edge GEMMs): {plans}")
+    return plans[0]
 
 
 def gather_to_all(x_local, h_local, total: int, N: int, F: int, device=None):

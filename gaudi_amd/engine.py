@@ -321,5 +321,24 @@ class Engine:
         self._check(self.lib.gaudi_edge_math(self.h, C.byref(a), C.byref(b)), "gaudi_edge_math")
         return a.value, b.value
 
+    def set_plan_hint(self, min_slots: int = 0, force_waves: int = 0):
+        """Plan the following calls with the graph figures of a larger logical batch (see gaudi_set_plan_hint)."""
+        self._check(self.lib.gaudi_set_plan_hint(self.h, int(min_slots), int(force_waves)), "gaudi_set_plan_hint")
+
+    def plan_hint_for(self, node_mask, edge_mask):
+        """(min_slots, force_waves) of a WHOLE logical batch: what every shard of it passes to set_plan_hint so that all
+        shards run the same kernel family and edge-GEMM arithmetic (device-free: gaudi_host_graph_meta8)."""
+        nm = f32(node_mask)
+        B, N = nm.shape[0], nm.shape[1]
+        nm, em = self._masks(nm, edge_mask, B, N)
+        slots = C.c_int32()
+        rc = self.lib.gaudi_host_graph_meta8(B, N, fptr(nm), fptr(em), C.byref(slots), None, None, None, None, None, None,
+                                             None, 0, None)
+        if rc == -5:  # GAUDI_E_CAPACITY: a node with more than 32 live edges -> the 4-wave kernels for everybody
+            return 0, 4
+        if rc != 0:
+            raise GaudiError(f"gaudi_host_graph_meta8 failed ({rc})")
+        return int(slots.value), 0
+
     def set_steps_per_launch(self, k: int):
         self._check(self.lib.gaudi_set_steps_per_launch(self.h, int(k)), "gaudi_set_steps_per_launch")

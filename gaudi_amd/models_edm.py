@@ -140,13 +140,15 @@ class GaudiModel:
         self.n_dims = 3
         self.norm_values = list(checkpoint.normalize_factors(self.args))
         self.norm_biases = (None, 0.0, 0.0)
-        # Noise streams are keyed by (seed, global sample index, draw, element).  seed = None: torch's current seed
-        # (torch.initial_seed(), i.e. whatever torch.manual_seed last set -- read, never consumed, so the ring-count draws of
-        # DistributionRings see the same torch stream as in the reference); a new torch.manual_seed restarts the stream.
-        # Every sampling call consumes B fresh sample indices (sample_offset advances), as successive randn calls would.
+        # Noise streams are keyed by (seed, global sample index, draw, element).  seed = None (default): every call draws its
+        # 62-bit Philox key from torch's default generator, as the reference draws its noise from it (torch.randn,
+        # en_diffusion.py:937-956): consecutive calls get fresh noise, torch.manual_seed(s) reproduces a run -- also when it
+        # is called again with the SAME s between two calls (a stream position kept beside torch's seed
+        # missed that) -- and anything else the caller draws from torch in between moves the key as it would move the
+        # reference's noise.  An explicit seed (parity tests, sharded runs) keys the stream directly; then every call
+        # consumes B fresh sample indices (sample_offset advances).
         self.seed = None
         self.sample_offset = 0
-        self._torch_seed = None
         self.injected_noise = None  # [T+2,B,N,3+F] raw draws (parity tests); None -> on-device Philox
         self.last_diag = None
 
@@ -169,16 +171,12 @@ class GaudiModel:
 
     def next_stream(self, n_samples: int):
         """-> (seed, sample_offset) for a call that draws noise for ``n_samples`` molecules; advances the offset."""
-        seed = self.seed
-        if seed is None:
+        if self.seed is None:
             import torch
-            ts = int(torch.initial_seed())
-            if ts != self._torch_seed:  # first use, or torch.manual_seed was called since: restart the stream
-                self._torch_seed, self.sample_offset = ts, 0
-            seed = ts & (2 ** 62 - 1)
+            return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()), 0
         off = self.sample_offset
         self.sample_offset += int(n_samples)
-        return int(seed), off
+        return int(self.seed), off
 
     def _run(self, n_samples, node_mask, edge_mask, std, target, scale, fix_noise):
         nm = _to_numpy(node_mask).astype(np.float32)

@@ -228,6 +228,14 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
  * split with the full ring (a 32-input chunk of all output tiles per trip), 2 = split with the half ring (two trips per
  * chunk: molecules whose node buffers leave less LDS), 0 = fp32 instructions. */
 int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
+/* Plan hint for shards of a larger logical batch (gaudi_amd/dist.py; no reference counterpart: the reference runs one
+ * process).  The kernel family and the edge-GEMM arithmetic of a call are chosen from batch-wide maxima -- the largest
+ * number of 16-edge slots of a molecule (gaudi_host_graph_meta8: slots_out) and whether any node has more than 32 live edges
+ * (gaudi_host_graph_meta8 returns GAUDI_E_CAPACITY) -- so two shards of one batch could otherwise run different arithmetic
+ * and the gathered result would depend on the cut.  min_slots: plan every following call as if its batch held a molecule
+ * with that many slots (0 = no hint); force_waves: 4 = run every following call on the 4-wave kernels, 0 = automatic.
+ * gaudi_sample applies the same rule by itself to the sub-batches it cuts a large request into. */
+int gaudi_set_plan_hint(gaudi_handle* h, int32_t min_slots, int32_t force_waves);
 /* Tile packing of a weight block W[o][col0+k] (o,k < H, row stride ldw) into [HP/16][HP/16][16][16]
  * (k-chunk major), optionally transposed: the layout every GEMM of the kernels streams. */
 int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, const float* W, float* packed_out);

@@ -189,3 +189,77 @@ def test_host_pack_matrix_split_is_exact_and_laid_out_as_documented():
                             assert total[Ln, e] == want, (H, tr, m, t, Ln, e)
                     assert np.all(np.abs(pieces[1]) <= np.abs(pieces[0]) * 2.0 ** -8 + 1e-45)
                     assert np.all(np.abs(pieces[2]) <= np.abs(pieces[0]) * 2.0 ** -16 + 1e-45)
+
+
+def test_host_split_keeps_non_finite_weights_non_finite():
+    """A NaN (any payload, either sign) planted in an edge-GEMM matrix must stay a NaN in every bf16 piece of the split image
+    (the integer rounding trick alone turns 0xFFFFFFFF into +0 and 0x7F800001 into +inf); an infinite weight must give a
+    non-finite product as the fp32 weight would (inf in the high piece, NaN = inf - inf below it)."""
+    lib, L = _lib()
+    H, HP = 36, 48
+    T, NC = HP // 16, (HP // 16 + 1) // 2
+    W = np.random.default_rng(2).standard_normal((H, H)).astype(np.float32)
+    payloads = [0xFFFFFFFF, 0x7F800001, 0x7FC00000, 0xFFC00001, 0x7FFFFFFF, 0xFF800001]
+    spots = [(0, 0), (3, 17), (20, 5), (35, 31), (7, 7), (16, 16)]
+    Wv = W.view(np.uint32)
+    for (o, k), bits in zip(spots, payloads):
+        Wv[o, k] = bits
+    W[1, 2], W[9, 30] = np.inf, -np.inf
+    out = np.empty(NC * T * 3 * 256, np.float32)
+    assert lib.gaudi_host_pack_matrix_split(H, H, 0, HP, 0, 0, L.fptr(W), L.fptr(out)) == 0
+    units16 = out.view(np.uint16).reshape(NC, T, 3, 64, 8)
+
+    def pieces(o, k):
+        tile, g, e = k // 16, (k % 16) // 4, 4 * ((k // 16) & 1) + (k & 3)
+        return _bf16_to_f32(units16[tile // 2, o // 16, :, g * 16 + o % 16, e])
+
+    for o, k in spots:
+        assert np.isnan(pieces(o, k)).all(), (o, k, pieces(o, k))
+    for (o, k), sgn in (((1, 2), 1.0), ((9, 30), -1.0)):
+        p = pieces(o, k)
+        assert np.isinf(p[0]) and np.sign(p[0]) == sgn and not np.isfinite(p).any()
+    # everything else is still split exactly
+    fin = np.isfinite(W)
+    tot = np.zeros((HP, HP), np.float32)
+    for o in range(H):
+        for k in range(H):
+            if fin[o, k]:
+                p = pieces(o, k)
+                assert (p[0] + p[1]) + p[2] == W[o, k]
+
+
+def test_host_packers_are_reentrant():
+    """Packing state is a value passed down, not file-scope: concurrent calls with different layouts (K tail on / off, plain
+    tiles) give the same bytes as the same calls made one after the other (the globals could flip mid-pack)."""
+    import threading
+    lib, L = _lib()
+    rng = np.random.default_rng(3)
+    H, HP = 196, 208
+    T, NC = HP // 16, (HP // 16 + 1) // 2
+    W = rng.standard_normal((H, H)).astype(np.float32)
+
+    def split(ktail):
+        out = np.zeros(NC * T * 3 * 256, np.float32)
+        assert lib.gaudi_host_pack_matrix_split(H, H, 0, HP, 0, ktail, L.fptr(W), L.fptr(out)) == 0
+        return out
+
+    def plain(tr):
+        out = np.zeros(HP * HP, np.float32)
+        assert lib.gaudi_host_pack_matrix(H, H, 0, HP, tr, L.fptr(W), L.fptr(out)) == 0
+        return out
+
+    jobs = [(split, 1), (split, 0), (plain, 0), (plain, 1)] * 3
+    want = [f(a).tobytes() for f, a in jobs]
+    got = [None] * len(jobs)
+
+    def run(i):
+        f, a = jobs[i]
+        got[i] = f(a).tobytes()
+
+    for _ in range(3):
+        th = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert got == want

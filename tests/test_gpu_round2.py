@@ -115,6 +115,52 @@ def test_nan_scrubbing_vs_reference(golden):
         e.close()
 
 
+
+# ------------------------------------------------------------------------------------------------ g17: NaN in a split matrix
+def test_nan_in_edge_gemm_matrix_vs_reference(golden):
+    """A NaN planted in a matrix of the edge-level GEMMs (edge_mlp.2.weight, coord_mlp.0.weight): on the default path these
+    are streamed as three bf16 pieces made by the host (gaudi_hip.hip: bf16_rne, NaN-safe) -- the poisoned weight must act
+    exactly as it does in the reference: EDM h output NaN / velocity scrubbed / guided step finite; predictor: zeros."""
+    from gaudi_amd.engine import Engine
+    g = golden("g17_nan_edge_matrix")
+    cfg = json.loads(str(g["cfg"]))
+    base = dict(dataset=cfg["dataset"], amp=True)
+    eargs, esd = edm_from_cfg(dict(base, over=TINY, wseed=cfg["eseed"]), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(base, over=TINY_P, wseed=cfg["pseed"]))
+
+    def poisoned(src, name, bits=None):
+        d = {k: v.copy() for k, v in src.items()}
+        a = d[str(g[name + "_key"])]
+        if bits is None:
+            a[tuple(g[name + "_idx"])] = np.nan
+        else:  # a NaN payload the integer bf16 rounding trick would turn into +0 / +inf
+            a.view(np.uint32)[tuple(g[name + "_idx"])] = bits
+        return d
+
+    z, nm, em = g["z"], g["node_mask"], g["edge_mask"]
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    for bits in (None, 0xFFFFFFFF, 0x7F800001):
+        bad_edm = Engine(0)
+        bad_edm.load_edm(eargs, poisoned(esd, "edm", bits))
+        bad_edm.load_predictor(pargs, psd)
+        assert bad_edm.edge_math()[0] == 1  # the handle is configured for split edge GEMMs (default)
+        for s in (999, 500, 0):
+            eps = g[f"s{s}_eps"]
+            t = np.full(z.shape[0], np.float32(s + 1) / np.float32(cfg["T"]), np.float32)
+            e, want = bad_edm.phi(z, t, nm, em), g[f"s{s}_phi_edm_poisoned"]
+            assert bad_edm.edge_math()[1] in (1, 2)  # ... and the call really ran on them
+            assert np.array_equal(np.isnan(e), np.isnan(want)) and np.array_equal(np.nan_to_num(e), np.nan_to_num(want))
+            assert rel_err(bad_edm.step(s, z, nm, em, eps, target_w=w, scale=0.6), g[f"s{s}_zs_guided_edm_poisoned"]) < TOL
+        bad_edm.close()
+        for k in ("pred_w2", "pred_wc1"):
+            bad_pred = Engine(0)
+            bad_pred.load_edm(eargs, esd)
+            bad_pred.load_predictor(pargs, poisoned(psd, k, bits))
+            for s in (999, 500, 0):
+                zp = bad_pred.step(s, z, nm, em, g[f"s{s}_eps"], target_w=w, scale=0.6)
+                assert np.array_equal(zp, g[f"s{s}_zs_guided_{k}_poisoned"])  # the reference returns all zeros
+            bad_pred.close()
+
 # ------------------------------------------------------------------------------------------------ g16: fix_noise
 def test_fix_noise_vs_reference(golden):
     from gaudi_amd.models_edm import get_cond_predictor_model, get_model, target_function_max_gap
@@ -171,6 +217,18 @@ def test_consecutive_calls_draw_fresh_noise():
     assert np.array_equal(a, a2) and np.array_equal(b, b2)  # torch.manual_seed reproduces the run
     a3, _ = two_calls(124)
     assert not np.array_equal(a, a3)
+    # re-seeding with the SAME value between two calls of one model replays the first call, and anything
+    # else drawn from torch's generator in between moves the noise, as it would move the reference's torch.randn
+    torch.manual_seed(123)
+    model, _, _ = get_model(eargs, state_dict=esd)
+    c0, _ = model.sample(4, 6, nm, em)
+    torch.manual_seed(123)
+    c1, _ = model.sample(4, 6, nm, em)
+    torch.manual_seed(123)
+    torch.rand(1)
+    c2, _ = model.sample(4, 6, nm, em)
+    model.engine.close()
+    assert np.array_equal(c0.numpy(), a) and np.array_equal(c1.numpy(), a) and not np.array_equal(c2.numpy(), a)
     # analyze_and_save loops over batches: no molecule may repeat across batches
     torch.manual_seed(7)
     model, _, _ = get_model(eargs, state_dict=esd)

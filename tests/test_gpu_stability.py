@@ -166,8 +166,10 @@ def test_eval_validity_analyze_and_save():
     torch.manual_seed(3)
     d, mols, stable = eval_validity.analyze_and_save(args, model, nodes_dist, n_samples=20)
     assert len(mols) == 32  # rounded up to whole batches (eval_validity.py:29)
-    torch.manual_seed(3)
-    want_n = torch.cat([nodes_dist.sample(16), nodes_dist.sample(16)]).tolist()
+    torch.manual_seed(3)  # the torch stream of the run above: ring counts, one noise-key draw per sampling call, ring counts
+    first = nodes_dist.sample(16)
+    torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+    want_n = torch.cat([first, nodes_dist.sample(16)]).tolist()
     assert [len(x) for x, _ in mols] == want_n
     od, ostable = S.analyze_validity_for_molecules([(x.numpy(), t.numpy()) for x, t in mols], dataset="cata")
     assert d == od and len(stable) == len(ostable)

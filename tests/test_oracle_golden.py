@@ -216,6 +216,37 @@ def test_g15_nan_scrub(golden):
             assert np.array_equal(zp, g[f"s{s}_zs_guided_pred_poisoned"])  # all zeros
 
 
+def test_g17_nan_in_edge_gemm_matrix(golden):
+    """NaN planted in an edge-GEMM matrix (edge_mlp.2.weight / coord_mlp.0.weight): the oracle follows the reference --
+    EDM: h output NaN, velocity scrubbed, guided step finite (eps_hat zeroed); predictor: z_s scrubbed to zeros."""
+    g = golden("g17_nan_edge_matrix")
+    cfg = json.loads(str(g["cfg"]))
+    base = dict(dataset=cfg["dataset"], amp=True)
+    eargs, esd = edm_from_cfg(dict(base, over=TINY, wseed=cfg["eseed"]))
+    pargs, psd = pred_from_cfg(dict(base, over=TINY_P, wseed=cfg["pseed"]))
+
+    def poisoned(src, name):
+        d = {k: v.copy() for k, v in src.items()}
+        d[str(g[name + "_key"])][tuple(g[name + "_idx"])] = np.nan
+        return d
+
+    esd_bad = poisoned(esd, "edm")
+    gamma = O.gamma_table("polynomial_2", cfg["T"], 1e-5)
+    z, nm, em = g["z"], g["node_mask"], g["edge_mask"]
+    w = O.target_max_gap_weights(5)
+    with np.errstate(all="ignore"):
+        for s in (999, 500, 0):
+            eps = g[f"s{s}_eps"]
+            t = np.full(z.shape[0], np.float32(s + 1) / np.float32(cfg["T"]), np.float32)
+            e, want = O.edm_phi(esd_bad, eargs, z, t, nm, em), g[f"s{s}_phi_edm_poisoned"]
+            assert np.array_equal(np.isnan(e), np.isnan(want)) and np.array_equal(np.nan_to_num(e), np.nan_to_num(want))
+            assert rel_err(O.step_guided(esd_bad, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6),
+                           g[f"s{s}_zs_guided_edm_poisoned"]) < 1e-4
+            for k in ("pred_w2", "pred_wc1"):
+                zp = O.step_guided(esd, eargs, poisoned(psd, k), pargs, gamma, s, z, nm, em, eps, w, 0.6)
+                assert np.array_equal(zp, g[f"s{s}_zs_guided_{k}_poisoned"])  # all zeros
+
+
 def test_g14_steps_along_the_reference_trajectory(golden):
     """Teacher-forced guided steps at the DEFAULT architectures on points of the reference's own T = 1000 trajectory."""
     from tests.helpers import noise_from_fixture

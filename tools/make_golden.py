@@ -767,6 +767,63 @@ def g15_nan_scrub():
     save("g15_nan_scrub", **out)
 
 
+def g17_nan_in_edge_gemm_matrix():
+    """NaN planted in a matrix of the EDGE-level GEMMs (edge_mlp.2.weight of an EDM GCL; edge_mlp.2.weight and
+    coord_mlp.0.weight of a predictor layer) -- the matrices the default kernels stream as three bf16 pieces.  The EDM's
+    h output is NaN (only the velocity is scrubbed, edm/egnn/models.py:138-141), the guided step zeroes eps_hat
+    (en_diffusion.py:881) and stays finite; a poisoned predictor gives a NaN gradient and z_s is scrubbed to zeros (:933-934)."""
+    out = {}
+    T = 1000
+    ds, nodes = "cata", [4, 11, 7, 11]
+    F = 1
+    eargs = synth.edm_args(dataset=ds, **TINY)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=1700, amplify_coord=True)
+    pargs = synth.pred_args(dataset=ds, **TINY_P)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=1710, amplify_coord=True)
+    nm, em, z = case_inputs(ds, nodes, None, seed=1720, guidance_pad=True)
+    B, N, D = z.shape
+    tnm, tem = torch.from_numpy(nm), torch.from_numpy(em)
+    out["z"], out["node_mask"], out["edge_mask"] = z, nm, em
+    poison = dict(edm=("dynamics.egnn.e_block_1.gcl_0.edge_mlp.2.weight", [5, 17]),
+                  pred_w2=("egnn.gcl_1.edge_mlp.2.weight", [30, 2]),
+                  pred_wc1=("egnn.gcl_0.coord_mlp.0.weight", [7, 33]))
+    bad = {}
+    for name, (key, idx) in poison.items():
+        src = esd if name == "edm" else psd
+        d = {k: v.copy() for k, v in src.items()}
+        d[key][tuple(idx)] = np.nan
+        bad[name] = d
+        out[f"{name}_key"], out[f"{name}_idx"] = np.array(key), np.array(idx)
+    a, model_bad = build_ref_edm(ds, bad["edm"], **TINY)
+    a2, model_ok = build_ref_edm(ds, esd, **TINY)
+    pa, pred_ok = build_ref_pred(ds, psd, **TINY_P)
+    preds_bad = {k: build_ref_pred(ds, bad[k], **TINY_P)[1] for k in ("pred_w2", "pred_wc1")}
+    import contextlib, io
+    for s in (999, 500, 0):
+        eps = rng_noise(1730 + s % 7, (B, N, D))
+        st = torch.full((B, 1), s) / T
+        tt = (torch.full((B, 1), s) + 1) / T
+        out[f"s{s}_eps"] = eps
+        with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+            e = model_bad.phi(torch.from_numpy(z), tt, tnm, tem, None).numpy()
+            with InjectNoise([eps]):
+                zg = model_bad.sample_p_zs_given_zt_guidance(
+                    st, tt, torch.from_numpy(z), tnm, tem, lambda i, n, m, t: -pred_ok(i, n, m, t)[:, 1], 0.6).numpy()
+            zp = {}
+            for k, pb in preds_bad.items():
+                with InjectNoise([eps]):
+                    zp[k] = model_ok.sample_p_zs_given_zt_guidance(
+                        st, tt, torch.from_numpy(z), tnm, tem, lambda i, n, m, t, pb=pb: -pb(i, n, m, t)[:, 1], 0.6).numpy()
+        assert np.isfinite(e[:, :, :3]).all() and np.isnan(e[:, :, 3:][nm[:, :, 0] != 0]).all()
+        assert np.isfinite(zg).all() and all(np.isfinite(v).all() for v in zp.values())
+        out[f"s{s}_phi_edm_poisoned"] = e
+        out[f"s{s}_zs_guided_edm_poisoned"] = zg
+        for k, v in zp.items():
+            out[f"s{s}_zs_guided_{k}_poisoned"] = v
+    out["cfg"] = np.array(json.dumps(dict(dataset=ds, eseed=1700, pseed=1710, T=T, nodes=nodes)))
+    save("g17_nan_edge_matrix", **out)
+
+
 def g16_fix_noise():
     """fix_noise=True (en_diffusion.py:562-566,972-978,1022-1028): ONE raw draw [1,N,3+F] per call is broadcast over the
     batch and masked / mean-centred per molecule.  Tiny config, T = 50, unguided and guided."""
@@ -818,8 +875,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix)
     for w in which:
         fns[w]()
