@@ -44,6 +44,7 @@ struct MolGraph {
   const uint32_t* edge;   // LDS [4][EW]  i | j<<8
   const float* em;        // LDS [4][EW]  edge_mask value (0 for padding slots)
   const uint32_t* seg;    // LDS [N]      wave<<30 | start<<15 | len  (edge run of node n)
+  float* gnode = nullptr; // V4G kernels: this workgroup's global node-buffer scratch (NetSmem / PredSmem with GN)
   int npairs;             // 32-edge passes of THIS wave
   int npairs_all[kWaves]; // ... of every wave of the workgroup (lock-step loops of the reverse pass)
   // npairs_all[w] for a per-lane (non-uniform) w without dynamically indexing the array (which would spill it)
@@ -52,9 +53,14 @@ struct MolGraph {
   }
 };
 
-// LDS working set of one network evaluation
-template <int HP>
+// LDS working set of one network evaluation.  GN ("global node buffers"): the [N][HP+4] node buffers -- what outgrows 160 KiB
+// of LDS beyond ~22 graph nodes at the default widths -- live in a per-molecule global scratch instead (L2-resident; every
+// cross-wave hand-off of them already sits behind a workgroup barrier, which orders global memory inside a workgroup too).
+// The code is the same: the pointers carry their address space, hipcc emits global loads / stores for them.  Slower, but it
+// lifts the graph-size limit of the library to what the reference accepts (sampling_edm.py:172-209 has no cap).
+template <int HP, bool GN = false>
 struct NetSmem {
+  static constexpr bool kGlobalNodes = GN;
   float *h, *p, *q, *agg;  // [N][HP+4]
   float* scr;              // [4][16][HP+4]  per-wave transposition scratch
   float *x, *x0;           // [N][4]
@@ -63,14 +69,15 @@ struct NetSmem {
   float* trans;            // [4][EW][4]
   float* vec;              // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
   __device__ static int floats(int N, int EW) {
-    return 4 * N * (HP + 4) + kWaves * 16 * (HP + 4) + 8 * N + kWaves * EW * 9 + 8 * HP;
+    return (GN ? 0 : 4 * N * (HP + 4)) + kWaves * 16 * (HP + 4) + 8 * N + kWaves * EW * 9 + 8 * HP;
   }
-  __device__ void carve(float* base, int N, int EW) {
+  __device__ void carve(float* base, int N, int EW, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
-    h = base; base += N * LD;
-    p = base; base += N * LD;
-    q = base; base += N * LD;
-    agg = base; base += N * LD;
+    float*& nb = GN ? gnode : base;
+    h = nb; nb += N * LD;
+    p = nb; nb += N * LD;
+    q = nb; nb += N * LD;
+    agg = nb; nb += N * LD;
     scr = base; base += kWaves * 16 * LD;
     x = base; base += 4 * N;
     x0 = base; base += 4 * N;
@@ -131,8 +138,8 @@ __device__ __forceinline__ void coord_update(const SM& sm, const MolGraph& mg, f
 }
 
 // eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
-template <int HP>
-__device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP>& sm, const float* sZ, float* sEps,
+template <int HP, class SM = NetSmem<HP>>
+__device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const SM& sm, const float* sZ, float* sEps,
                             float* sMean /* [4] */, float t_val, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -200,7 +207,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           EdgeCol ec[2];
           float mk2[2];
           f4 geo2[2];
-          load_cols<NetSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
+          load_cols<SM, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
           f4 acc[2][T];
           edge_gemm_from_pq<HP, 2>(acc, wb, G + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
           STAMP(ST_EDGE);
@@ -261,7 +268,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         EdgeCol ec[2];
         float mk2[2];
         f4 geo2[2];
-        load_cols<NetSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
+        load_cols<SM, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
         f4 acc[2][T];
         edge_gemm_from_pq<HP, 2>(acc, wb, E + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
         STAMP(ST_EDGE);

@@ -56,12 +56,14 @@ struct gaudi_handle {
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
       d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols, d_soff,
-      d_sidx;
+      d_sidx, d_gnode;
   int steps_per_launch = 25;
   int variant = 8;            // 8 = two waves per SIMD (sampler_kernel8, default), 4 = one wave per SIMD (GAUDI_WAVES=4)
   int run_variant = 4;        // what the CURRENT call runs on (an 8-wave handle falls back to 4 waves for graphs that do not fit)
   bool split = true;          // 8-wave kernels: edge GEMMs on the bf16 matrix pipe with 3-way split operands (GAUDI_EDGE_MATH=fp32: off)
   int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
+  bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
+  bool force_gn = false;      // GAUDI_FORCE_GN=1 at gaudi_create: use them whenever they exist (test knob)
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
   long long fix_key = 0;      // global sample index whose Philox stream is shared
   int readout_n = 0;  // padded N the predictor readout divides by (0 = the call's N)
@@ -539,6 +541,21 @@ static kernel_fn pick_kernel(int hpe, int hpp) {
   return f;
 }
 
+// the 4-wave kernels with node buffers in global memory (kerng_*.hip): molecules beyond the LDS limit
+#ifdef GAUDI_STAMP_STUBS
+static kernel_fn pick_kernel_g(int, int) { return nullptr; }
+#else
+kernel_fn gaudi_kerng_edm(int hpe, int hpp);
+kernel_fn gaudi_kerng_pred(int hpe, int hpp);
+kernel_fn gaudi_kerng_fused(int hpe, int hpp);
+static kernel_fn pick_kernel_g(int hpe, int hpp) {
+  kernel_fn f = gaudi_kerng_edm(hpe, hpp);
+  if (!f) f = gaudi_kerng_pred(hpe, hpp);
+  if (!f) f = gaudi_kerng_fused(hpe, hpp);
+  return f;
+}
+#endif
+
 // the 8-wave instantiations (kern8_*.hip)
 #ifdef GAUDI_STAMP_STUBS
 #define GAUDI_KERNEL8_TUS(X) X(edm_192) X(fused_192_208)
@@ -606,11 +623,15 @@ static int round_hidden(int H) {
   return 0;
 }
 
-static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW) {
+// gn: node buffers in global memory (V4G kernels)
+static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW, bool gn = false) {
   size_t net = 0;
-  if (hpe) net = std::max(net, (size_t)(4 * N * (hpe + 4) + kWaves * 16 * (hpe + 4) + 8 * N + kWaves * EW * 9 + 8 * hpe));
-  if (hpp) net = std::max(net, (size_t)(5 * N * (hpp + 4) + kWaves * 16 * (hpp + 4) + 12 * N + kWaves * EW * 10 + 32 + 10 * hpp));
+  if (hpe) net = std::max(net, (size_t)((gn ? 0 : 4 * N * (hpe + 4)) + kWaves * 16 * (hpe + 4) + 8 * N + kWaves * EW * 9 + 8 * hpe));
+  if (hpp) net = std::max(net, (size_t)((gn ? 0 : 5 * N * (hpp + 4)) + kWaves * 16 * (hpp + 4) + 12 * N + kWaves * EW * 10 + 32 + 10 * hpp));
   return sizeof(float) * (common_floats(N, D, EW) + net);
+}
+static size_t gnode_floats(int hpe, int hpp, int N) {
+  return std::max((size_t)(hpe ? 4 * N * (hpe + 4) : 0), (size_t)(hpp ? 5 * N * (hpp + 4) : 0));
 }
 
 static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split) {
@@ -645,12 +666,12 @@ static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, int sp
 
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
   const bool v8 = h->run_variant == 8;
-  kernel_fn fn = v8 ? pick_kernel8_mode(hpe, hpp, h->run_split) : pick_kernel(hpe, hpp);
+  kernel_fn fn = v8 ? pick_kernel8_mode(hpe, hpp, h->run_split) : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
                     (v8 ? " in the 8-wave family" : ""));
-  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW);
+  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW, h->run_gn);
   if (lds > 160 * 1024)
     return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
   {
@@ -763,13 +784,15 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   if (B <= 0 || N <= 0) return fail(h, GAUDI_E_INVALID, "B and N must be positive");
   h->run_variant = h->variant;
   h->run_split = 0;
-  if (h->variant == 8) {
+  h->run_gn = false;
+  if (h->variant == 8 && !h->force_gn) {
     const int rc8 = stage_graph8(h, B, N, node_mask, edge_mask, P, hpe, hpp);
     if (rc8 <= 0) return rc8;
     h->run_variant = 4;  // fall back to the 4-wave kernels for this call
     h->run_split = 0;
     P.pubx = P.pub_ch = 0;
   }
+  h->run_variant = 4;
   // the 4-wave reverse pass parks [4 waves][N * 3] partial coordinate gradients in its 4 x 16 x (HP + 4) transposition scratch
   if (hpp && 4 * N * 3 > 4 * 16 * (hpp + 4))
     return fail(h, GAUDI_E_CAPACITY, "N too large for the 4-wave predictor kernels at this hidden size");
@@ -802,6 +825,19 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   P.npairs = h->d_npairs.as<int>();
   P.seginfo = h->d_seg.as<uint32_t>();
   P.ncols = h->d_ncols.as<int>();
+  // Molecules whose node buffers do not fit 160 KiB of LDS (beyond ~22 graph nodes at the default widths) run on the V4G
+  // kernels: same code, node buffers in a per-workgroup global scratch (L2-resident).  The reference has no size cap
+  // (sampling_edm.py:172-209); this one is N <= 255 (node indices are bytes in the edge words).
+  const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
+  if (h->force_gn || lds_bytes(hpe, hpp, N, Dz, M.EW) > 160 * 1024) {
+    if (pick_kernel_g(hpe, hpp) && lds_bytes(hpe, hpp, N, Dz, M.EW, true) <= 160 * 1024) {
+      h->run_gn = true;
+      const size_t stride = (gnode_floats(hpe, hpp, N) + 63) / 64 * 64;
+      HIPCHECK(h, h->d_gnode.reserve(sizeof(float) * stride * (size_t)B));
+      P.gnode = h->d_gnode.as<float>();
+      P.gnode_stride = (long long)stride;
+    }
+  }
   return GAUDI_OK;
 }
 
@@ -843,6 +879,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   h->device = device;
   if (const char* v = getenv("GAUDI_WAVES")) h->variant = atoi(v) == 4 ? 4 : 8;
   if (const char* v = getenv("GAUDI_EDGE_MATH")) h->split = std::string(v) != "fp32";
+  if (const char* v = getenv("GAUDI_FORCE_GN")) h->force_gn = atoi(v) != 0;
   h->run_variant = h->variant;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -861,7 +898,8 @@ void gaudi_destroy(gaudi_handle* h) {
   DevBuf* bufs[] = {&h->edm_w, &h->pred_w, &h->coef_d, &h->edm_w4, &h->pred_w4, &h->edm_ws, &h->pred_ws, &h->d_mask, &h->d_order, &h->d_edges, &h->d_emask, &h->d_npairs,
                     &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
                     &h->d_pred, &h->d_tw, &h->d_stash, &h->d_chain, &h->d_sx, &h->d_stype, &h->d_sn,
-                    &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as, &h->d_ncols, &h->d_soff, &h->d_sidx};
+                    &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as, &h->d_ncols, &h->d_soff, &h->d_sidx,
+                    &h->d_gnode};
   for (DevBuf* b : bufs) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

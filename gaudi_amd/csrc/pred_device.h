@@ -39,8 +39,9 @@ struct PredDev {
   unsigned ws_bytes;
 };
 
-template <int HP>
+template <int HP, bool GN = false>  // GN: node buffers in a per-molecule global scratch (edm_device.h: NetSmem)
 struct PredSmem {
+  static constexpr bool kGlobalNodes = GN;
   float *b0, *b1, *b2, *b3, *b4;  // [N][HP+4] node buffers (roles change per phase, see below)
   float* scr;                     // [4][16][HP+4]
   float *x, *x0, *dx;             // [N][4]
@@ -49,15 +50,16 @@ struct PredSmem {
   float* pred;                    // [16] pred | [16] dpred
   float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
   __host__ __device__ static int floats(int N, int EW) {
-    return 5 * N * (HP + 4) + kWaves * 16 * (HP + 4) + 12 * N + kWaves * EW * 10 + 32 + 10 * HP;
+    return (GN ? 0 : 5 * N * (HP + 4)) + kWaves * 16 * (HP + 4) + 12 * N + kWaves * EW * 10 + 32 + 10 * HP;
   }
-  __device__ void carve(float* base, int N, int EW) {
+  __device__ void carve(float* base, int N, int EW, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
-    b0 = base; base += N * LD;
-    b1 = base; base += N * LD;
-    b2 = base; base += N * LD;
-    b3 = base; base += N * LD;
-    b4 = base; base += N * LD;
+    float*& nb = GN ? gnode : base;
+    b0 = nb; nb += N * LD;
+    b1 = nb; nb += N * LD;
+    b2 = nb; nb += N * LD;
+    b3 = nb; nb += N * LD;
+    b4 = nb; nb += N * LD;
     scr = base; base += kWaves * 16 * LD;
     x = base; base += 4 * N;
     x0 = base; base += 4 * N;
@@ -120,8 +122,8 @@ __device__ __forceinline__ size_t edge_stash_off(int l, int wave, int tile, int 
 // forward: pred[K] -> sm.pred[0..K)
 // buffers: h = b0, P = b1, Q = b2, agg = b3
 // ---------------------------------------------------------------------------------------------
-template <int HP>
-__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* sZ, float t_val,
+template <int HP, class SM = PredSmem<HP>>
+__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const SM& sm, const float* sZ, float t_val,
                              float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -190,7 +192,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         EdgeCol ec[2];
         float mk2[2];
         f4 geo2[2];
-        load_cols<PredSmem<HP>, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
+        load_cols<SM, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
         f4 acc[2][T];
         edge_gemm_from_pq<HP, 2>(acc, wb, Lw.W2, Lw.b2, Lw.cr, Lw.cd, p, q, ec, lane);
         STAMP(ST_EDGE);
@@ -293,8 +295,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 //                          B2 = b2: P (stash) -> dP (in place, rows owned by the wave that reduces them)
 //                          B3 = b3: dh (running)     B4 = b4: npre (stash) -> dnpre -> dQ accumulator
 // ---------------------------------------------------------------------------------------------
-template <int HP>
-__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP>& sm, const float* stash,
+template <int HP, class SM = PredSmem<HP>>
+__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const SM& sm, const float* stash,
                               float* sGrad, float readout_div, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -398,7 +400,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           EdgeCol ec[NB];
           float mk[NB];
           f4 gg[NB];
-          load_cols<PredSmem<HP>, NB>(sm, mg, wave, tile0 * 16, c, ec, mk, gg);
+          load_cols<SM, NB>(sm, mg, wave, tile0 * 16, c, ec, mk, gg);
           // cpre, the attention gate and (after the first GEMM) v come back from the forward's stash: no recompute of W2 / Wc1
           // and only one NB x T quad array (the GEMM input) live in VGPRs across each GEMM.
           constexpr bool kKeepV = false;
@@ -618,13 +620,13 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 }
 
 // unit-test entry: pred (and optionally grad into sGrad) for z in sZ
-template <int HP>
+template <int HP, bool GN = false>
 __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                 float* sMean, float t_val, const float* dpred, bool want_grad, float* pred_out,
-                                float readout_div, float* stash, int tid STAMP_DECL) {
+                                float readout_div, float* stash, int tid STAMP_DECL, float* gnode = nullptr) {
   (void)sTmp; (void)sMean;
-  PredSmem<HP> sm;
-  sm.carve(net, mg.N, mg.EW);
+  PredSmem<HP, GN> sm;
+  sm.carve(net, mg.N, mg.EW, gnode);
   pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
     if (pred_out) pred_out[tid] = sm.pred[tid];
@@ -637,15 +639,15 @@ __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 // phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
 // (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
-template <int HP>
+template <int HP, bool GN = false>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                 float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                 float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase = 0,
-                                const float* dpred_ext = nullptr) {
+                                const float* dpred_ext = nullptr, float* gnode = nullptr) {
   (void)sTmp;
   const int N = mg.N, D = mg.D;
-  PredSmem<HP> sm;
-  sm.carve(net, N, mg.EW);
+  PredSmem<HP, GN> sm;
+  sm.carve(net, N, mg.EW, gnode);
   if (phase != 2) pred_forward<HP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
     if (pred_out && phase != 2) pred_out[tid] = sm.pred[tid];

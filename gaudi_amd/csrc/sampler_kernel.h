@@ -7,6 +7,10 @@
 #include "w8_edm.h"
 #include "w8_pred.h"
 
+#ifndef GAUDI_STATIC_PRIO
+#define GAUDI_STATIC_PRIO 0
+#endif
+
 namespace gaudi {
 
 enum Mode { MODE_PHI = 0, MODE_SAMPLE = 1, MODE_PRED_FWD = 2, MODE_PRED_GRAD = 3 };
@@ -60,6 +64,8 @@ struct KParams {
   float* chain_out;         // sample_chain: [keep_frames][B][N][D] un-normalised frames, or nullptr
   int keep_frames;
   unsigned long long* stamps;  // diagnostic builds only (-DGAUDI_STAMPS): [ST_N] cycle sums of block 0
+  float* gnode;                // V4G kernels: [B] x gnode_stride floats, the node buffers of large molecules (edm_device.h: NetSmem GN)
+  long long gnode_stride;
 };
 
 __host__ __device__ inline int common_floats(int N, int D, int EW) {
@@ -71,10 +77,12 @@ __host__ __device__ inline int common_floats8(int N, int D, int S) {
 
 // ---- kernel variants: what differs between the 4-wave kernels (one wave per SIMD, per-wave edge lists, weights streamed
 // per wave) and the 8-wave kernels (two waves per SIMD, flat 16-slot tiles, LDS-shared weight ring) behind one sampler body
-struct V4 {
+template <bool GN>
+struct V4T {
   static constexpr int kThreads = gaudi::kThreads;
+  static constexpr bool kGlobalNodes = GN;
   using Graph = gaudi::MolGraph;
-  template <int HP> using EdmSmem = gaudi::NetSmem<HP>;
+  template <int HP> using EdmSmem = gaudi::NetSmem<HP, GN>;
   __host__ __device__ static int graph_floats(int N, int EW) { return 2 * gaudi::kWaves * EW + align16(N); }
   __device__ __forceinline__ static float* load_graph(const KParams& P, int b, float* base, const float* sMask, Graph& mg, int tid, int wave) {
     const int N = P.N, EW = P.EW;
@@ -92,13 +100,14 @@ struct V4 {
     mg.npairs = P.npairs[b * gaudi::kWaves + wave];
 #pragma unroll
     for (int w = 0; w < gaudi::kWaves; ++w) mg.npairs_all[w] = P.npairs[b * gaudi::kWaves + w];
+    mg.gnode = GN ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr;  // one scratch slice per RESIDENT workgroup
     return base;
   }
   template <int HP>
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
                                              float* sMean, float t_val, int tid STAMP_DECL) {
-    gaudi::NetSmem<HP> sm;
-    sm.carve(net, mg.N, mg.EW);
+    gaudi::NetSmem<HP, GN> sm;
+    sm.carve(net, mg.N, mg.EW, mg.gnode);
     gaudi::edm_forward<HP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
   }
   // explicit by-value signatures: forwarding references (and a by-reference KParams) made hipcc keep the arguments in
@@ -108,17 +117,19 @@ struct V4 {
                                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
                                                const float* dpred_ext) {
-    gaudi::guidance_update<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
-                               tid STAMP_ARGS, phase, dpred_ext);
+    gaudi::guidance_update<HP, GN>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
+                                   tid STAMP_ARGS, phase, dpred_ext, mg.gnode);
   }
   template <int HP>
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
                                                     float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                     float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
-    gaudi::predictor_entry<HP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash,
-                               tid STAMP_ARGS);
+    gaudi::predictor_entry<HP, GN>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash,
+                                   tid STAMP_ARGS, mg.gnode);
   }
 };
+using V4 = V4T<false>;
+using V4G = V4T<true>;  // node buffers in global memory: molecules beyond the LDS limit (N up to 255)
 
 // ---- out-of-line phases of the 8-wave kernels.  Inlined into one 40k-instruction function, the denoiser, the predictor and
 // its reverse pass are register-allocated together and hipcc spills ~200 VGPRs whose reloads land next to the deep weight
@@ -312,6 +323,11 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
   constexpr int kThreads = V::kThreads;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if GAUDI_STATIC_PRIO
+  // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): the second-dispatched half of an 8-wave workgroup loses
+  // every issue arbitration by age; one static priority step for it, no per-phase flips
+  if (V::kThreads == 512 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int b = P.order[blockIdx.x];
   const int N = P.N, D = 3 + P.F;
 
@@ -523,6 +539,8 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
 typedef void (*sampler_fn)(const KParams);
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel = &sampler_kernel_v<V4, HPE, HPP>;
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel_g = &sampler_kernel_v<V4G, HPE, HPP>;
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8 = &sampler_kernel_v<V8, HPE, HPP>;
 template <int HPE, int HPP>

@@ -29,6 +29,14 @@ __device__ __forceinline__ float row_shr(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SH, 0xF, 0xF, true));
 }
 
+template <int N, class F>
+__device__ __forceinline__ void static_for_n(F f) {
+  if constexpr (N > 0) {
+    static_for_n<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 // Run bookkeeping of one 16-edge tile, per lane (column c = lane & 15): the edge list is sorted by receiving node, so the
 // edges of a node form a run of consecutive columns.  m1..m8 = 1 where the column 1/2/4/8 to the left belongs to the same
 // run (Hillis-Steele segmented scan); after seg_scan the LAST column of every run holds the run's sum.
@@ -246,24 +254,61 @@ struct NodePF {
   f4 a0[2], a1[2];  // first two K chunks of the wave's (up to) two tiles
 };
 
-template <int HP, int NTW>
+// The "tail tile" of a hidden size with H % 16 == 4 (196 -> 208, 36 -> 48): output tile T-1 holds 4 valid rows.  As a
+// 16x16x4 tile it costs as much matrix time as a full one and puts a fourth tile on one SIMD (13 tiles on 8 waves) while
+// the others carry three.  It is computed with v_mfma_f32_4x4x1_16B_f32 instead: 16 independent 4x4 outer products per
+// instruction, block (kk, cg) = lane >> 2 holding rows 0-3 x node columns 4 cg .. +3 for input 4 kk + q of the chunk --
+// four inputs per instruction like the 16x16x4 form, at a quarter of its cycles.  Lane (kk, cg, i) needs
+// W[16 (T-1) + i][16 m + 4 kk + q], q = 0..3: float4 index kk * 16 + i of the SAME lane-linear tile (so no second weight
+// layout), and the activation of node 4 cg + (lane & 3) = lane & 15 at inputs 16 m + 4 kk + q: exactly the float4 the
+// 16x16x4 form reads.  The four kk partial sums of an output sit in the four lane groups and are added at the end
+// (reduce_groups): accumulator register r of lane (c, any group) = feature 16 (T-1) + r of node c, the C layout of group 0.
+// Features 16 (T-1) + 4 .. +15 are padding and are written as zeros.
+__device__ __forceinline__ int tail_lane(int lane) { return (lane & 0x30) | (lane & 3); }
+// ... recomputed at every load (two vector instructions) instead of living in a register beside `lane` through the K loop:
+// the node GEMMs run at the register limit and a spilled value is reloaded through the same in-order vmcnt queue as the
+// weight prefetch
+__device__ __forceinline__ int tail_lane_fresh(int lane) {
+  asm volatile("" : "+v"(lane));
+  return tail_lane(lane);
+}
+__device__ __forceinline__ f4 mfma44(float w, float b, f4 acc) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(w, b, acc, 0, 0, 0);
+}
+#ifndef GAUDI_NODE_TAIL44
+#define GAUDI_NODE_TAIL44 1
+#endif
+// the wave (if any) whose LAST tile is the tail tile, for widths that have one
+template <int HP>
+__device__ __forceinline__ bool owns_tail(bool tail_width, int wave) {
+  constexpr int T = HP / 16;
+  // instantiated for the padded widths whose usual hidden size has a tail (196 -> 208; 36 -> 48 in the tests): every
+  // extra body costs registers in all of them
+  constexpr bool kHas = GAUDI_NODE_TAIL44 && (HP == 208 || HP == 48);
+  return kHas && tail_width && wave == (T - 1) % kWaves;
+}
+
+template <int HP, int NTW, bool TAIL = false>
 __device__ __forceinline__ void node_prefetch_n(NodePF<HP>& pf, const WBuf& wb, int W, int wave, int lane) {
   constexpr int T = HP / 16;
 #pragma unroll
   for (int u = 0; u < NTW; ++u) {
     const int toff = (wave + kWaves * u) * 256;
-    pf.a0[u] = ldw4n(wb, W + toff, lane);
-    pf.a1[u] = ldw4n(wb, W + (T > 1 ? T : 0) * 256 + toff, lane);
+    const int ln = TAIL && u == NTW - 1 ? tail_lane(lane) : lane;
+    pf.a0[u] = ldw4n(wb, W + toff, ln);
+    pf.a1[u] = ldw4n(wb, W + (T > 1 ? T : 0) * 256 + toff, ln);
   }
 }
 template <int HP>
-__device__ __forceinline__ void node_prefetch(NodePF<HP>& pf, const WBuf& wb, int W, int wave, int lane) {
+__device__ __forceinline__ void node_prefetch(NodePF<HP>& pf, const WBuf& wb, int W, int wave, int lane, bool tail_w) {
   constexpr int T = HP / 16;
-  if (wave + kWaves < T) node_prefetch_n<HP, 2>(pf, wb, W, wave, lane);
+  if (owns_tail<HP>(tail_w, wave)) {
+    node_prefetch_n<HP, (T - 1 >= kWaves ? 2 : 1), true>(pf, wb, W, wave, lane);  // the owner's tile count is a constant
+  } else if (wave + kWaves < T) node_prefetch_n<HP, 2>(pf, wb, W, wave, lane);
   else if (wave < T) node_prefetch_n<HP, 1>(pf, wb, W, wave, lane);
 }
 
-template <int HP, int EPI, bool PRE, int NT, int NTW>
+template <int HP, int EPI, bool PRE, int NT, int NTW, bool TAIL = false>
 __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
                                                const float* sBias, float* sY, const float* sRes, const float* sMask, int N,
                                                int wave, int lane, NodePF<HP>* pf, int nextW, float* gPre) {
@@ -274,6 +319,14 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
   int toff[NTW];
 #pragma unroll
   for (int u = 0; u < NTW; ++u) toff[u] = (wave + kWaves * u) * 256;
+  // the lane's float4 inside weight tile u (TAIL: the last tile is read in the 4x4 block arrangement)
+  auto wlane = [&](int u) { return TAIL && u == NTW - 1 ? tail_lane_fresh(lane) : lane; };
+  // one matrix instruction of tile u: 16x16x4, or 4x4x1 x 16 blocks for the tail tile
+  auto fma_u = [&](auto u_tag, float w, float x, f4 a) {
+    constexpr int u = decltype(u_tag)::value;
+    if constexpr (TAIL && u == NTW - 1) return mfma44(w, x, a);
+    else return mfma1(w, x, a);
+  };
   const int KT = Wb >= 0 ? 2 * T : T;  // two sources run as ONE K loop so the load pipeline never restarts
   auto chunk = [&](int cc) {  // float offset of K chunk cc (clamped past the end: surplus loads are unused)
     const int k = cc < KT ? cc : KT - 1;
@@ -298,7 +351,8 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
     f4 acc[NA][NT][NTW];
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
-      const f4 b = sBias != nullptr ? *(const f4*)(sBias + (toff[u] >> 4) + 4 * g) : splat(0.f);
+      // the tail tile's lane groups hold partial sums of the SAME outputs: its bias is added after they are folded
+      const f4 b = sBias != nullptr && !(TAIL && u == NTW - 1) ? *(const f4*)(sBias + (toff[u] >> 4) + 4 * g) : splat(0.f);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         acc[0][j][u] = b;
@@ -312,8 +366,8 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
     } else {
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {
-        a0[u] = ldw4n(wb, chunk(0) + toff[u], lane);
-        a1[u] = ldw4n(wb, chunk(1) + toff[u], lane);
+        a0[u] = ldw4n(wb, chunk(0) + toff[u], wlane(u));
+        a1[u] = ldw4n(wb, chunk(1) + toff[u], wlane(u));
       }
     }
     // two K chunks: k-step outermost over the independent accumulators
@@ -321,22 +375,26 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
       if (kSplit) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          acc[0][0][0] = mfma1(wE[0][q], xE[0][q], acc[0][0][0]);
-          acc[NA - 1][0][0] = mfma1(wO[0][q], xO[0][q], acc[NA - 1][0][0]);
+          acc[0][0][0] = fma_u(std::integral_constant<int, 0>{}, wE[0][q], xE[0][q], acc[0][0][0]);
+          acc[NA - 1][0][0] = fma_u(std::integral_constant<int, 0>{}, wO[0][q], xO[0][q], acc[NA - 1][0][0]);
         }
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int u = 0; u < NTW; ++u) acc[0][j][u] = mfma1(wE[u][q], xE[j][q], acc[0][j][u]);
+            static_for_n<NTW>([&](auto u_tag) {
+              constexpr int u = decltype(u_tag)::value;
+              acc[0][j][u] = fma_u(u_tag, wE[u][q], xE[j][q], acc[0][j][u]);
+            });
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int u = 0; u < NTW; ++u) acc[0][j][u] = mfma1(wO[u][q], xO[j][q], acc[0][j][u]);
+            static_for_n<NTW>([&](auto u_tag) {
+              constexpr int u = decltype(u_tag)::value;
+              acc[0][j][u] = fma_u(u_tag, wO[u][q], xO[j][q], acc[0][j][u]);
+            });
       }
     };
     auto mm1 = [&](const f4 (&w)[NTW], int cc) {
@@ -345,8 +403,10 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const f4 x = xin(j, cc);
-#pragma unroll
-          for (int u = 0; u < NTW; ++u) acc[0][j][u] = mfma1(w[u][q], x[q], acc[0][j][u]);
+          static_for_n<NTW>([&](auto u_tag) {
+            constexpr int u = decltype(u_tag)::value;
+            acc[0][j][u] = fma_u(u_tag, w[u][q], x[q], acc[0][j][u]);
+          });
         }
     };
     const int main_end = KT / 4 * 4;
@@ -362,16 +422,16 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
       }
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {
-        b0[u] = ldw4n(wb, chunk(cc + 2) + toff[u], lane);
-        b1[u] = ldw4n(wb, chunk(cc + 3) + toff[u], lane);
+        b0[u] = ldw4n(wb, chunk(cc + 2) + toff[u], wlane(u));
+        b1[u] = ldw4n(wb, chunk(cc + 3) + toff[u], wlane(u));
       }
       __builtin_amdgcn_sched_barrier(0);  // LDS reads + set B loads | MFMAs on set A | set A loads | MFMAs on set B
       mm2(a0, x0, a1, x1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {
-        a0[u] = ldw4n(wb, chunk(cc + 4) + toff[u], lane);
-        a1[u] = ldw4n(wb, chunk(cc + 5) + toff[u], lane);
+        a0[u] = ldw4n(wb, chunk(cc + 4) + toff[u], wlane(u));
+        a1[u] = ldw4n(wb, chunk(cc + 5) + toff[u], wlane(u));
       }
       __builtin_amdgcn_sched_barrier(0);
       mm2(b0, x2, b1, x3);
@@ -381,12 +441,12 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
     const int rem = KT - main_end;
     if (rem >= 3) {
 #pragma unroll
-      for (int u = 0; u < NTW; ++u) b0[u] = ldw4n(wb, chunk(main_end + 2) + toff[u], lane);
+      for (int u = 0; u < NTW; ++u) b0[u] = ldw4n(wb, chunk(main_end + 2) + toff[u], wlane(u));
     }
     if (rem >= 1) mm1(a0, main_end);
     if (rem >= 2) mm1(a1, main_end + 1);
     // software pipelining ACROSS calls: the next node GEMM's first tiles travel while this one drains
-    if (nextW >= 0 && nt0 + NT >= n_tiles) node_prefetch_n<HP, NTW>(*pf, wb, nextW, wave, lane);
+    if (nextW >= 0 && nt0 + NT >= n_tiles) node_prefetch_n<HP, NTW, TAIL>(*pf, wb, nextW, wave, lane);
     if (rem >= 3) mm1(b0, main_end + 2);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -394,9 +454,18 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
       for (int u = 0; u < NTW; ++u) {
         const int t = wave + kWaves * u;
         const int nd = node[j];
+        f4 y = kSplit ? acc[0][j][u] + acc[NA - 1][j][u] : acc[0][j][u];
+        if (TAIL && u == NTW - 1) {  // fold the four k partial sums (all lanes take part), then bias; padding rows = 0
+          y = (f4){reduce_groups(y[0]), reduce_groups(y[1]), reduce_groups(y[2]), reduce_groups(y[3])};
+          if (sBias != nullptr) y = y + *(const f4*)(sBias + 16 * t);
+        }
         if (nd < N) {
-          f4 y = kSplit ? acc[0][j][u] + acc[NA - 1][j][u] : acc[0][j][u];
           float* dst = sY + nd * LD + 16 * t + 4 * g;
+          if (TAIL && u == NTW - 1 && g > 0) {
+            if (gPre != nullptr) *(f4*)(gPre + nd * HP + 16 * t + 4 * g) = splat(0.f);
+            *(f4*)dst = splat(0.f);
+            continue;
+          }
           if (gPre != nullptr) *(f4*)(gPre + nd * HP + 16 * t + 4 * g) = y;
           if (EPI == EPI_SILU) y = silu4(y);
           if (EPI == EPI_RESIDUAL_MASK) {
@@ -417,10 +486,18 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
 template <int HP, int EPI, bool PRE = false>
 __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
                                           const float* sBias /* LDS [HP] or null */, float* sY, const float* sRes,
-                                          const float* sMask, int N, int wave, int lane, NodePF<HP>* pf = nullptr,
-                                          int nextW = -1, float* gPre = nullptr /* global [N][HP]: pre-epilogue value */) {
+                                          const float* sMask, int N, int wave, int lane,
+                                          bool tail_w /* H % 16 == 4: the last output tile holds 4 valid rows (tail_lane) */,
+                                          NodePF<HP>* pf = nullptr, int nextW = -1,
+                                          float* gPre = nullptr /* global [N][HP]: pre-epilogue value */) {
   constexpr int T = HP / 16;
-  if (wave + kWaves < T) {
+  if (owns_tail<HP>(tail_w, wave)) {
+    constexpr int NTW = T - 1 >= kWaves ? 2 : 1;
+    if (N <= 16)
+      node_gemm_body<HP, EPI, PRE, 1, NTW, true>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
+    else
+      node_gemm_body<HP, EPI, PRE, 2, NTW, true>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
+  } else if (wave + kWaves < T) {
     if (N <= 16)
       node_gemm_body<HP, EPI, PRE, 1, 2>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
     else

@@ -123,6 +123,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   const float* __restrict__ w = W.w;
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
   const WBuf wbe = SP ? make_wbuf(W.ws, W.ws_bytes) : wb;  // edge-GEMM matrices (w8_split.h)
+  const bool tw = W.ktail != 0;                            // H % 16 == 4: the node GEMMs' tail tile (w8_common.h: tail_lane)
 
   // ---- input split + masking (models.py:88-105): x = z[:, :3]*m ; h = [z[:, 3:]*m , t]
   for (int idx = tid; idx < N * 3; idx += kThreads) {
@@ -150,7 +151,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
   er_start<HP>(ring, wbe, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
   NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it
-  node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);
+  node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane, tw);
   constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next sub-layer's vectors (GCL: 7 HP + 16 floats, EquivariantUpdate: 5 HP), loaded a phase ahead
   vec_prefetch<NV, kThreads>(vpf, wb, lay.gcl(0, 0) + 6 * PK, 7 * HP + 16, tid);
@@ -173,8 +174,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
                   *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
       const float ba = sm.vec[7 * HP];
-      node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, G + PK);
-      node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf,
+      node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, G + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
                                     G + 3 * PK);  // node MLP weights travel across the edge phase
       STAMP(ST_NODE);
       __syncthreads();
@@ -212,14 +213,14 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       }
       __syncthreads();
       STAMP(ST_MISC);
-      node_gemm<HP, EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, mg.NC, wave, lane,
+      node_gemm<HP, EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw,
                                     &pf, G + 5 * PK);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
       vec_prefetch<NV, kThreads>(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK,
                                  s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
-      node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave, lane,
+      node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave, lane, tw,
                                              &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
       __syncthreads();
@@ -233,8 +234,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       __syncthreads();
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
-      node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, E + PK);
-      node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf,
+      node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, E + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
                                     l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
       STAMP(ST_NODE);
       __syncthreads();

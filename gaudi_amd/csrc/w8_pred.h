@@ -7,8 +7,28 @@
 #include "pred_device.h"
 #include "w8_edm.h"
 
+#ifndef GAUDI_STASH_NT
+#define GAUDI_STASH_NT 0  // experiment: 1 = non-temporal stores of the edge activation stash, 2 = non-temporal loads too
+#endif
+
 namespace gaudi {
 namespace w8 {
+
+// the edge activation stash is written once and read once, 2.9 MB per molecule-step: cache-policy knob for it
+__device__ __forceinline__ void stash_store(f4* p, f4 v) {
+#if GAUDI_STASH_NT >= 1
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ f4 stash_load(const f4* p) {
+#if GAUDI_STASH_NT >= 2
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 
 template <int HP, int SP = 0>
 struct PredSmem {
@@ -80,6 +100,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   const float* __restrict__ w = W.w;
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
   const WBuf wbe = SP ? make_wbuf(W.ws, W.ws_bytes) : wb;  // edge-GEMM matrices (w8_split.h)
+  const bool tw = W.ktail != 0;                            // H % 16 == 4: the node GEMMs' tail tile (w8_common.h: tail_lane)
   float *h = sm.b0, *p = sm.b1, *q = sm.b2, *agg = sm.b3, *agg1 = sm.b4;
   float* estash = stash + pred_stash_node_floats(N, HP, W.L);
   float* astash = estash + (size_t)W.L * S * HP * 2;
@@ -109,7 +130,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
   er_start<HP>(ring, wbe, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
   NodePF<HP> pf;
-  node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane);
+  node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane, tw);
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next layer's vectors, loaded one node GEMM ahead
   vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(0), HP), PredLayerW::vec_count(HP), tid);
@@ -127,8 +148,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     compute_geo(sm, mg, 1.0f, tid, false);  // gcl.py:308-316
     __syncthreads();
     STAMP(ST_STAGE);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Bm);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1h);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Bm);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1h);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
@@ -152,7 +173,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         {  // v (pre-activation of m) -> edge stash for the reverse pass
           f4* sv = (f4*)(estash + edge_stash_off8(l, tile, 0, S, HP)) + lane;
 #pragma unroll
-          for (int t = 0; t < T; ++t) sv[t * 64] = acc[t];
+          for (int t = 0; t < T; ++t) stash_store(sv + t * 64, acc[t]);
         }
         float sdot = 0.f;
 #pragma unroll
@@ -186,7 +207,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
               sl[q] = silu_dsilu_f(cp[t][q], d);
               ds[q] = d;
             }
-            sc[t * 64] = ds;
+            stash_store(sc + t * 64, ds);
             sdot += dot4(sl, *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
           }
           const float phi = reduce_groups(sdot);
@@ -205,13 +226,13 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     }
     __syncthreads();
     STAMP(ST_MISC);
-    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane, &pf, Lw.Wn2,
+    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn2,
                                   st + 2 * N * HP /* npre -> stash */);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
     vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), PredLayerW::vec_count(HP), tid);
-    node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, &pf,
+    node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, tw, &pf,
                                            l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
     STAMP(ST_NODE);
@@ -255,6 +276,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   const float* __restrict__ w = W.w;
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
   const WBuf wbe = SP ? make_wbuf(W.ws, W.ws_bytes) : wb;  // edge-GEMM matrices (w8_split.h)
+  const bool tw = W.ktail != 0;                            // H % 16 == 4: the node GEMMs' tail tile (w8_common.h: tail_lane)
   float *B0 = sm.b0, *B1 = sm.b1, *B2 = sm.b2, *dh = sm.b3, *B4 = sm.b4;
   float* pub = sm.b0;  // [slots][16 pub_ch + 4]
   const int PLD = 16 * pub_ch + 4;
@@ -297,7 +319,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     er_start<HP>(ring, wbe, L0 + 9 * HP * HP /* W2^T of the last layer (its coordinate branch is skipped) */, wave, lane);
   }
   NodePF<HP> pf;
-  node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane);
+  node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane, tw);
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;
   vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(W.L - 1), HP), PredLayerW::vec_count(HP), tid);
@@ -323,11 +345,11 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     compute_geo(sm, mg, 1.0f, tid, false);
     STAMP(ST_STASH);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
-    node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1ht);
+    node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1ht);
     __syncthreads();
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
-    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, &pf, Lw.Wn1at);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, &pf);
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1at);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, tw, &pf);
     __syncthreads();
     STAMP(ST_BWD_NODE);
     // (e) edge pass: MLP chain backward for the wave's tile, then du of all slots is published CH feature tiles at a time
@@ -353,7 +375,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           if (tc.active) {
             const f4* sc = (const f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
 #pragma unroll
-            for (int t = 0; t < T; ++t) cp[t] = sc[t * 64];  // silu'(cpre)
+            for (int t = 0; t < T; ++t) cp[t] = stash_load(sc + t * 64);  // silu'(cpre)
             const float phi = pstash[(size_t)l * S + tc.slot];
             const float th = tanhf(phi);
             tau = W.use_tanh ? th * W.coords_range_layer : phi;
@@ -379,7 +401,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           f4 ve[T];
           const f4* sv = (const f4*)(estash + edge_stash_off8(l, tile, 0, S, HP)) + lane;
 #pragma unroll
-          for (int t = 0; t < T; ++t) ve[t] = sv[t * 64];
+          for (int t = 0; t < T; ++t) ve[t] = stash_load(sv + t * 64);
           float dadot = 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) dadot += dot4(de[t], silu4(ve[t]));
@@ -451,7 +473,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         __syncthreads();
       }
       if (SP != 0 && l > 0) er_start<HP>(ring, wbe, lay.layer(l - 1) + 10 * HP * HP /* Wc1^T of the layer below */, wave, lane);
-      node_prefetch<HP>(pf, wb, Lw.At, wave, lane);
+      node_prefetch<HP>(pf, wb, Lw.At, wave, lane, tw);
       STAMP(ST_BWD_COL);
     }
     // dx <- dx*mask + sum_{e: i=n} ddiff_e - sum_{e: j=n} ddiff_e, in slot order
@@ -467,7 +489,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     }
     // (f) dh += A^T dP + Bm^T dQ
     vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l > 0 ? l - 1 : 0), HP), PredLayerW::vec_count(HP), tid);
-    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, &pf,
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf,
                                    l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
     STAMP(ST_BWD_NODE);

@@ -207,10 +207,24 @@ __device__ __forceinline__ void trip_barrier() {
 #ifndef GAUDI_SPLIT_PD
 #define GAUDI_SPLIT_PD 1  // A units are read this many output tiles ahead of their MFMAs
 #endif
-template <int HP, int MODE, int NT, class MID>
-__device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, const B3& b, bool active, MID mid) {  // NOLINT
+#ifndef GAUDI_SPLIT_SGB
+#define GAUDI_SPLIT_SGB 0  // > 0: sched_group_barrier pattern MFMA | this many vector instructions, per tile (experiment)
+#endif
+struct NoHook {
+  template <class TT>
+  __device__ __forceinline__ void operator()(TT) const {}
+};
+// `hook(tile tag)` runs next to the MFMAs of every output tile (inside the same scheduling region): vector work cut into
+// small slices co-issues with the bf16 matrix instructions of BOTH waves of the SIMD instead of stalling the wave's own
+// MFMA stream in one lump (GAUDI_SPLIT_GENSPREAD, edge_gemm_pq_s)
+template <int HP, int MODE, int NT, bool ACT, class MID, class HOOK>
+__device__ __forceinline__ void rings_mfma_act(f4* acc, const float* slot_lane, const B3& b, MID mid, HOOK hook) {  // NOLINT
   constexpr int U = SplitGeo<HP, MODE>::kUnit;
   constexpr int PD = GAUDI_SPLIT_PD, NB = PD + 1;
+  if constexpr (!ACT) {  // a wave without an edge tile in this round: its share of the ring traffic only
+    mid();
+    return;
+  }
   f4 a[NB][3];
 #pragma unroll
   for (int d = 0; d < PD; ++d)
@@ -218,9 +232,9 @@ __device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, cons
 #pragma unroll
       for (int p = 0; p < 3; ++p) a[d][p] = *(const f4*)(slot_lane + (d * 3 + p) * U);
     }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int cur = t % NB;
+  static_for<NT>([&](auto t_tag) {
+    constexpr int t = decltype(t_tag)::value;
+    constexpr int cur = t % NB;
     if (t == NT / 2) {
       mid();
       __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +244,7 @@ __device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, cons
       for (int p = 0; p < 3; ++p) a[(t + PD) % NB][p] = *(const f4*)(slot_lane + ((t + PD) * 3 + p) * U);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (active) {
+    {
       const u4 ah = __builtin_bit_cast(u4, a[cur][0]), am = __builtin_bit_cast(u4, a[cur][1]), al = __builtin_bit_cast(u4, a[cur][2]);
       f4 c = acc[t];
       c = mfma_bf(al, b.h, c);  // small terms first
@@ -241,8 +255,26 @@ __device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, cons
       c = mfma_bf(ah, b.h, c);
       acc[t] = c;
     }
+    hook(t_tag);
+#if GAUDI_SPLIT_SGB
+    // ask the scheduler for MFMA | 2 vector instructions | MFMA | ... inside this tile's region
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, GAUDI_SPLIT_SGB, 0);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
-  }
+  });
+}
+// `hook(tile tag)` runs next to the MFMAs of every output tile (inside the same scheduling region): vector work cut into
+// small slices co-issues with the bf16 matrix instructions instead of stalling the wave's MFMA stream in one lump
+// (GAUDI_SPLIT_GENSPREAD, edge_gemm_pq_s).  One wave-uniform branch per TRIP separates waves with and without a tile, so a
+// tile's MFMAs and its slice share a basic block.
+template <int HP, int MODE, int NT, class MID, class HOOK = NoHook>
+__device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, const B3& b, bool active, MID mid, HOOK hook = HOOK{}) {  // NOLINT
+  if (active) rings_mfma_act<HP, MODE, NT, true>(acc, slot_lane, b, mid, hook);
+  else rings_mfma_act<HP, MODE, NT, false>(acc, slot_lane, b, mid, hook);
 }
 
 // The K-tail trip: one fp32 k-step per output tile (A = element 0 of the tile's lane-linear float4, B = the lane group's input)
@@ -264,6 +296,47 @@ __device__ __forceinline__ void rings_mfma_tail(f4 (&acc)[HP / 16], const float*
   __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifndef GAUDI_SPLIT_GENSPREAD
+#define GAUDI_SPLIT_GENSPREAD 0  // 1: the next chunk's input generation runs in slices beside the tiles' MFMAs (measured: no gain -- the
+                                 // vector issue port is as busy as the matrix pipe either way); 0: one block mid-trip
+#endif
+// The input generation of one K chunk (silu(u) of 8 inputs per lane, split into 3 bf16 pieces each) as kGenStages slices
+// of ~10 vector instructions
+struct GenPipe {
+  static constexpr int kStages = 11;
+  f4 p, q, cr, cd;   // operands of the sub-tile being assembled
+  f4 ulo, uhi;       // u, then silu(u)
+  B3 out;            // the three bf16 pieces of the 8 inputs
+};
+template <int S>
+__device__ __forceinline__ void gen_stage(GenPipe& gp, const float* pp, const float* qq, const float* sCr, const float* sCd, int g,
+                                          int T, int m, float r, float d0) {
+  const int tl = 2 * m, th = 2 * m + 1 < T ? 2 * m + 1 : 0;  // an odd T leaves the upper half of the last chunk 0
+  const bool has_hi = 2 * m + 1 < T;
+  auto load = [&](int cc) {
+    gp.p = *(const f4*)(pp + 16 * cc);
+    gp.q = *(const f4*)(qq + 16 * cc);
+    gp.cr = *(const f4*)(sCr + 16 * cc + 4 * g);
+    gp.cd = *(const f4*)(sCd + 16 * cc + 4 * g);
+  };
+  auto u_of = [&] { return gp.p + gp.q + gp.cr * r + gp.cd * d0; };  // = edge_u (device_common.h), same operation order
+  if constexpr (S == 0) load(tl);
+  if constexpr (S == 1) { gp.ulo = u_of(); load(th); }
+  if constexpr (S == 2) gp.uhi = has_hi ? u_of() : splat(0.f);
+  if constexpr (S == 3) { gp.ulo[0] = silu_f(gp.ulo[0]); gp.ulo[1] = silu_f(gp.ulo[1]); }
+  if constexpr (S == 4) { gp.ulo[2] = silu_f(gp.ulo[2]); gp.ulo[3] = silu_f(gp.ulo[3]); }
+  if constexpr (S == 5) { gp.uhi[0] = silu_f(gp.uhi[0]); gp.uhi[1] = silu_f(gp.uhi[1]); }
+  if constexpr (S == 6) { gp.uhi[2] = silu_f(gp.uhi[2]); gp.uhi[3] = silu_f(gp.uhi[3]); }
+  if constexpr (S >= 7 && S <= 10) {
+    constexpr int k = S - 7;  // word k of the B operand: inputs 2k, 2k+1
+    const P3 t = k < 2 ? split2(gp.ulo[2 * (k & 1)], gp.ulo[2 * (k & 1) + 1]) : split2(gp.uhi[2 * (k & 1)], gp.uhi[2 * (k & 1) + 1]);
+    gp.out.h[k] = t.h;
+    gp.out.m[k] = t.m;
+    gp.out.l[k] = t.l;
+  }
+}
+__device__ __forceinline__ B3 gen_result(const GenPipe& gp) { return gp.out; }
+
 // acc = b2 + W2 . silu(u) (see edge_gemm_pq); weights in split format at float offset W of wb
 template <int HP, int MODE>
 __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MODE>& ring, const WBuf& wb, int W, int nextW,
@@ -283,16 +356,36 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
   static_assert(G::NH <= 3, "at most three trips per K chunk");
   const bool tail = G::kTailOK && ring.ktail;
   auto chunk = [&](int m) {
+    const int mn = m + 1 < G::NC ? m + 1 : m;  // the chunk generated during this one (clamped at the end: no branch)
     auto trip = [&](auto h_tag) {
       constexpr int h = decltype(h_tag)::value;
+      constexpr int NT = G::tiles_of(h);
       const int tr = m * G::NH + h;
       trip_barrier();
-      rings_mfma<HP, MODE, G::tiles_of(h)>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
+#if GAUDI_SPLIT_GENSPREAD
+      if constexpr (h == G::NH - 1) {
+        // stage s of the generation runs beside tile s * NT / kStages ... spread evenly over the trip's tiles
+        GenPipe gp;
+        rings_mfma<HP, MODE, NT>(
+            acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] { rings_stage(ring, wb, W, nextW, tr, wave, lane); },
+            [&](auto t_tag) {
+              constexpr int t = decltype(t_tag)::value;
+              constexpr int s0 = t * GenPipe::kStages / NT, s1 = (t + 1) * GenPipe::kStages / NT;
+              static_for<s1 - s0>([&](auto k_tag) { gen_stage<s0 + decltype(k_tag)::value>(gp, pp, qq, sCr, sCd, g, T, mn, r, d0); });
+            });
+        nb = gen_result(gp);
+      } else {
+        rings_mfma<HP, MODE, NT>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active,
+                                 [&] { rings_stage(ring, wb, W, nextW, tr, wave, lane); });
+      }
+#else
+      rings_mfma<HP, MODE, NT>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
         rings_stage(ring, wb, W, nextW, tr, wave, lane);
         // every wave generates the NEXT chunk in the middle of its block (vector work co-issues with bf16 MFMAs; the
         // staggered placement of the fp32 form is 2 % slower here, generation right after the barrier 7 %)
-        if (h == G::NH - 1) nb = gen(m + 1 < G::NC ? m + 1 : m);
+        if (h == G::NH - 1) nb = gen(mn);
       });
+#endif
       ring.par ^= 1;
     };
     trip(std::integral_constant<int, 0>{});

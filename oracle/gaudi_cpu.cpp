@@ -1,0 +1,731 @@
+// TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): C++/OpenMP restatement of the GaUDI sampler's hot path on the CPU --
+// EDM denoiser, conditional predictor with its hand-written input gradient, and the unguided / guided reverse step.
+// It is imported only by tests/ (as a second, independent checker next to oracle/gaudi_oracle.py) and by bench.py's
+// `cpu_baseline` leg (the CPU figure a GPU number is reported beside).  No product path may call it.
+//
+// The arithmetic is written as the reference writes it (concat -> Linear over the DENSE N x N edge set incl. self loops,
+// multiplied by the masks), one molecule per OpenMP thread:
+//   EGNN_dynamics._forward            edm/egnn/models.py:83-152
+//   EquivariantBlock / GCL / EquivariantUpdate   edm/egnn/egnn_new.py:42-89, 119-155, 203-236, 394-414
+//   EGNN_predictor.forward / E_GCL    edm/egnn_predictor/models.py:433-457,543-560; gcl.py:225-316
+//   the gradient torch.autograd.grad returns at edm/equivariant_diffusion/en_diffusion.py:900-903  (reverse pass below)
+//   sample_p_zs_given_zt(_guidance)   en_diffusion.py:807-935
+// Parity: pinned against the reference's own outputs (tests/golden/g3, g4, g5) in tests/test_cpu_port.py.
+//
+// Build: oracle/build_cpu.py (g++ -O3 -march=x86-64-v3 -fopenmp -shared -fPIC: AVX2 + FMA is the baseline, the AVX-512 GEMM
+// micro-kernel is picked at run time).
+#include <immintrin.h>
+#include <omp.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+inline int up16(int n) { return (n + 15) & ~15; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// C[M][ldc] (first Nc columns, Nc % 16 == 0) = A[M][lda] (first Kd columns) . Bm[Kd][ldb] + bias
+// ---------------------------------------------------------------------------------------------------------------
+__attribute__((target("avx512f"))) void gemm_avx512(int M, int Nc, int Kd, const float* A, int lda, const float* Bm, int ldb,
+                                                     float* C, int ldc, const float* bias) {
+  for (int n0 = 0; n0 < Nc; n0 += 16) {
+    const __m512 b0 = bias ? _mm512_loadu_ps(bias + n0) : _mm512_setzero_ps();
+    int m0 = 0;
+    for (; m0 + 12 <= M; m0 += 12) {
+      __m512 c[12];
+      for (int i = 0; i < 12; ++i) c[i] = b0;
+      const float* a = A + (size_t)m0 * lda;
+      for (int k = 0; k < Kd; ++k) {
+        const __m512 b = _mm512_loadu_ps(Bm + (size_t)k * ldb + n0);
+        for (int i = 0; i < 12; ++i) c[i] = _mm512_fmadd_ps(_mm512_set1_ps(a[(size_t)i * lda + k]), b, c[i]);
+      }
+      for (int i = 0; i < 12; ++i) _mm512_storeu_ps(C + (size_t)(m0 + i) * ldc + n0, c[i]);
+    }
+    for (; m0 < M; ++m0) {
+      __m512 c = b0;
+      const float* a = A + (size_t)m0 * lda;
+      for (int k = 0; k < Kd; ++k) c = _mm512_fmadd_ps(_mm512_set1_ps(a[k]), _mm512_loadu_ps(Bm + (size_t)k * ldb + n0), c);
+      _mm512_storeu_ps(C + (size_t)m0 * ldc + n0, c);
+    }
+  }
+}
+__attribute__((target("avx2,fma"))) void gemm_avx2(int M, int Nc, int Kd, const float* A, int lda, const float* Bm, int ldb, float* C,
+                                                  int ldc, const float* bias) {
+  for (int n0 = 0; n0 < Nc; n0 += 16) {
+    const __m256 bl = bias ? _mm256_loadu_ps(bias + n0) : _mm256_setzero_ps();
+    const __m256 bh = bias ? _mm256_loadu_ps(bias + n0 + 8) : _mm256_setzero_ps();
+    int m0 = 0;
+    for (; m0 + 6 <= M; m0 += 6) {
+      __m256 c[6][2];
+      for (int i = 0; i < 6; ++i) { c[i][0] = bl; c[i][1] = bh; }
+      const float* a = A + (size_t)m0 * lda;
+      for (int k = 0; k < Kd; ++k) {
+        const __m256 b0 = _mm256_loadu_ps(Bm + (size_t)k * ldb + n0), b1 = _mm256_loadu_ps(Bm + (size_t)k * ldb + n0 + 8);
+        for (int i = 0; i < 6; ++i) {
+          const __m256 av = _mm256_set1_ps(a[(size_t)i * lda + k]);
+          c[i][0] = _mm256_fmadd_ps(av, b0, c[i][0]);
+          c[i][1] = _mm256_fmadd_ps(av, b1, c[i][1]);
+        }
+      }
+      for (int i = 0; i < 6; ++i) {
+        _mm256_storeu_ps(C + (size_t)(m0 + i) * ldc + n0, c[i][0]);
+        _mm256_storeu_ps(C + (size_t)(m0 + i) * ldc + n0 + 8, c[i][1]);
+      }
+    }
+    for (; m0 < M; ++m0) {
+      __m256 c0 = bl, c1 = bh;
+      const float* a = A + (size_t)m0 * lda;
+      for (int k = 0; k < Kd; ++k) {
+        const __m256 av = _mm256_set1_ps(a[k]);
+        c0 = _mm256_fmadd_ps(av, _mm256_loadu_ps(Bm + (size_t)k * ldb + n0), c0);
+        c1 = _mm256_fmadd_ps(av, _mm256_loadu_ps(Bm + (size_t)k * ldb + n0 + 8), c1);
+      }
+      _mm256_storeu_ps(C + (size_t)m0 * ldc + n0, c0);
+      _mm256_storeu_ps(C + (size_t)m0 * ldc + n0 + 8, c1);
+    }
+  }
+}
+void gemm_plain(int M, int Nc, int Kd, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, const float* bias) {
+  for (int m = 0; m < M; ++m) {
+    float* c = C + (size_t)m * ldc;
+    for (int n = 0; n < Nc; ++n) c[n] = bias ? bias[n] : 0.f;
+    for (int k = 0; k < Kd; ++k) {
+      const float a = A[(size_t)m * lda + k];
+      const float* b = Bm + (size_t)k * ldb;
+      for (int n = 0; n < Nc; ++n) c[n] = fmaf(a, b[n], c[n]);
+    }
+  }
+}
+typedef void (*gemm_fn)(int, int, int, const float*, int, const float*, int, float*, int, const float*);
+gemm_fn pick_gemm() {
+  __builtin_cpu_init();
+  if (__builtin_cpu_supports("avx512f")) return gemm_avx512;
+  if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) return gemm_avx2;
+  return gemm_plain;
+}
+const gemm_fn gemm = pick_gemm();
+
+// exp(x), |relative error| < 2e-7 over the float range (Cody-Waite reduction + degree-6 polynomial): written with plain
+// arithmetic so that the loops around it vectorise (libm's expf does not without -ffast-math)
+inline float exp_f(float x) {
+  x = std::min(std::max(x, -87.3f), 88.7f);
+  const float k = (x * 1.4426950408889634f + 12582912.0f) - 12582912.0f;  // round to nearest (|x log2 e| < 2^22)
+  const float r = (x - k * 0.693145751953125f) - k * 1.42860682030941723212e-6f;
+  float p = 1.0f / 720.0f;
+  p = p * r + 1.0f / 120.0f;
+  p = p * r + 1.0f / 24.0f;
+  p = p * r + 1.0f / 6.0f;
+  p = p * r + 0.5f;
+  p = p * r + 1.0f;
+  p = p * r + 1.0f;
+  int32_t bits = ((int32_t)k + 127) << 23;
+  float s;
+  std::memcpy(&s, &bits, 4);
+  return p * s;
+}
+inline float sigmoid_f(float x) { return 1.0f / (1.0f + exp_f(-x)); }
+inline float silu_f(float x) { return x * sigmoid_f(x); }
+inline float dsilu_f(float x) {
+  const float s = sigmoid_f(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+inline void silu_rows(float* a, int rows, int ld, int n) {
+  for (int r = 0; r < rows; ++r) {
+    float* p = a + (size_t)r * ld;
+#pragma omp simd
+    for (int i = 0; i < n; ++i) p[i] = silu_f(p[i]);
+  }
+}
+
+// one Linear(in -> out): Wt = weight^T [in][up16(out)] for y = x W^T, W = weight [out][up16(in)] for dx = dy W
+struct Lin {
+  int in = 0, out = 0, outp = 0, inp = 0;
+  std::vector<float> Wt, W, b;
+  void set(const float* w, const float* bias, int out_, int in_) {
+    in = in_; out = out_; outp = up16(out); inp = up16(in);
+    Wt.assign((size_t)in * outp, 0.f);
+    W.assign((size_t)out * inp, 0.f);
+    b.assign(outp, 0.f);
+    for (int o = 0; o < out; ++o)
+      for (int k = 0; k < in; ++k) {
+        Wt[(size_t)k * outp + o] = w[(size_t)o * in + k];
+        W[(size_t)o * inp + k] = w[(size_t)o * in + k];
+      }
+    if (bias) std::memcpy(b.data(), bias, sizeof(float) * out);
+  }
+  // Y[M][ldy] = X[M][ldx] W^T + b
+  void fwd(int M, const float* X, int ldx, float* Y, int ldy) const { gemm(M, outp, in, X, ldx, Wt.data(), outp, Y, ldy, b.data()); }
+  // dX[M][ldx] (first inp columns) = dY[M][ldy] W
+  void bwd(int M, const float* dY, int ldy, float* dX, int ldx) const { gemm(M, inp, out, dY, ldy, W.data(), inp, dX, ldx, nullptr); }
+};
+
+struct Tensors {
+  std::map<std::string, std::pair<const float*, int64_t>> m;
+  bool ok = true;
+  const float* get(const std::string& k, int64_t numel) {
+    auto it = m.find(k);
+    if (it == m.end() || it->second.second != numel) {
+      ok = false;
+      return nullptr;
+    }
+    return it->second.first;
+  }
+};
+
+struct EdmCfg {
+  int32_t F, H, L, S, attention, use_tanh;
+  float coords_range, norm_constant, normf;
+};
+struct PredCfg {
+  int32_t F, K, H, L, attention, use_tanh;
+  float coords_range;
+};
+struct Gcl {
+  Lin e1, e2, n1, n2;
+  std::vector<float> wa;
+  float ba = 0.f;
+};
+struct Equ {
+  Lin c1, c2;
+  std::vector<float> w3;
+};
+struct PLayer {
+  Lin e1, e2, n1, n2, c1;
+  std::vector<float> wa, wc2;
+  float ba = 0.f;
+};
+struct Model {
+  bool has_edm = false, has_pred = false;
+  EdmCfg ec{};
+  PredCfg pc{};
+  Lin emb, emb_out, pemb, pemb_out;
+  std::vector<std::vector<Gcl>> gcl;  // [L][S]
+  std::vector<Equ> equ;               // [L]
+  std::vector<PLayer> pl;             // [L]
+};
+
+// radial = |x_i - x_j|^2, cdiff = (x_i - x_j) / (sqrt(radial + 1e-8) + norm_constant)   (egnn_new.py:394-400, gcl.py:308-316)
+void coord2diff(int N, const float* x, float norm_constant, float* radial, float* cdiff) {
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      float d[3], r = 0.f;
+      for (int k = 0; k < 3; ++k) {
+        d[k] = x[3 * i + k] - x[3 * j + k];
+        r += d[k] * d[k];
+      }
+      radial[i * N + j] = r;
+      if (cdiff) {
+        const float den = std::sqrt(r + 1e-8f) + norm_constant;
+        for (int k = 0; k < 3; ++k) cdiff[(i * N + j) * 3 + k] = d[k] / den;
+      }
+    }
+}
+// rows [h_i | h_j | radial | d0] of the dense edge set (egnn_new.py:42-47 / gcl.py:225-231: torch.cat then Linear)
+void edge_input(int N, int H, const float* h, int ldh, const float* radial, const float* d0, float* inp, int ldi) {
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      float* r = inp + (size_t)(i * N + j) * ldi;
+      std::memcpy(r, h + (size_t)i * ldh, sizeof(float) * H);
+      std::memcpy(r + H, h + (size_t)j * ldh, sizeof(float) * H);
+      r[2 * H] = radial[i * N + j];
+      r[2 * H + 1] = d0[i * N + j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// EGNN_dynamics._forward for one molecule: z [N][D] -> eps [N][D]
+// ---------------------------------------------------------------------------------------------------------------
+void edm_phi_one(const Model& M, int N, const float* z, float t, const float* nm, const float* em, float* eps) {
+  const EdmCfg& c = M.ec;
+  const int H = c.H, HP = up16(H), F = c.F, D = 3 + F, E = N * N, LI = up16(2 * H + 2), LN = up16(2 * H);
+  std::vector<float> x(3 * N), x_in, hin((size_t)N * (F + 1)), h((size_t)N * HP), d0(E), radial(E), cdiff((size_t)E * 3);
+  std::vector<float> inp((size_t)E * LI), u((size_t)E * HP), m((size_t)E * HP), nin((size_t)N * LN), n1((size_t)N * HP),
+      n2((size_t)N * HP);
+  for (int n = 0; n < N; ++n) {
+    for (int k = 0; k < 3; ++k) x[3 * n + k] = z[n * D + k] * nm[n];
+    for (int k = 0; k < F; ++k) hin[n * (F + 1) + k] = z[n * D + 3 + k] * nm[n];
+    hin[n * (F + 1) + F] = t;  // the time column is not masked (models.py:97-105)
+  }
+  x_in = x;
+  coord2diff(N, x.data(), 1.0f, d0.data(), nullptr);  // egnn_new.py:301
+  M.emb.fwd(N, hin.data(), F + 1, h.data(), HP);
+  for (int l = 0; l < c.L; ++l) {
+    coord2diff(N, x.data(), c.norm_constant, radial.data(), cdiff.data());  // egnn_new.py:216
+    for (int s = 0; s < c.S; ++s) {
+      const Gcl& g = M.gcl[l][s];
+      edge_input(N, H, h.data(), HP, radial.data(), d0.data(), inp.data(), LI);
+      g.e1.fwd(E, inp.data(), LI, u.data(), HP);
+      silu_rows(u.data(), E, HP, H);
+      g.e2.fwd(E, u.data(), HP, m.data(), HP);
+      silu_rows(m.data(), E, HP, H);
+      std::fill(nin.begin(), nin.end(), 0.f);
+      for (int i = 0; i < N; ++i) {
+        std::memcpy(&nin[(size_t)i * LN], &h[(size_t)i * HP], sizeof(float) * H);
+        float* agg = &nin[(size_t)i * LN + H];
+        for (int j = 0; j < N; ++j) {
+          const float* mij = &m[(size_t)(i * N + j) * HP];
+          float att = 1.f;
+          if (c.attention) {
+            float sd = g.ba;
+            for (int k = 0; k < H; ++k) sd += mij[k] * g.wa[k];
+            att = sigmoid_f(sd);
+          }
+          const float sc = att * em[i * N + j];
+#pragma omp simd
+          for (int k = 0; k < H; ++k) agg[k] += mij[k] * sc;
+        }
+        for (int k = 0; k < H; ++k) agg[k] /= c.normf;  // egnn_new.py:403-414
+      }
+      g.n1.fwd(N, nin.data(), LN, n1.data(), HP);
+      silu_rows(n1.data(), N, HP, H);
+      g.n2.fwd(N, n1.data(), HP, n2.data(), HP);
+      for (int i = 0; i < N; ++i)
+        for (int k = 0; k < H; ++k) h[(size_t)i * HP + k] = (h[(size_t)i * HP + k] + n2[(size_t)i * HP + k]) * nm[i];
+    }
+    const Equ& q = M.equ[l];
+    edge_input(N, H, h.data(), HP, radial.data(), d0.data(), inp.data(), LI);
+    q.c1.fwd(E, inp.data(), LI, u.data(), HP);
+    silu_rows(u.data(), E, HP, H);
+    q.c2.fwd(E, u.data(), HP, m.data(), HP);
+    silu_rows(m.data(), E, HP, H);
+    for (int i = 0; i < N; ++i) {
+      float acc[3] = {0.f, 0.f, 0.f};
+      for (int j = 0; j < N; ++j) {
+        const float* cij = &m[(size_t)(i * N + j) * HP];
+        float phi = 0.f;
+        for (int k = 0; k < H; ++k) phi += cij[k] * q.w3[k];
+        const float tau = (c.use_tanh ? std::tanh(phi) * c.coords_range : phi) * em[i * N + j];  // raw coords_range (:290)
+        for (int k = 0; k < 3; ++k) acc[k] += cdiff[(i * N + j) * 3 + k] * tau;
+      }
+      for (int k = 0; k < 3; ++k) x[3 * i + k] = (x[3 * i + k] + acc[k] / c.normf) * nm[i];
+    }
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < H; ++k) h[(size_t)i * HP + k] *= nm[i];
+  }
+  std::vector<float> ho((size_t)N * 16);
+  M.emb_out.fwd(N, h.data(), HP, ho.data(), 16);
+  bool bad = false;
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < 3; ++k) {
+      const float v = (x[3 * n + k] - x_in[3 * n + k]) * nm[n];
+      eps[n * D + k] = v;
+      bad |= v != v;
+    }
+  if (bad)  // models.py:138-141
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < 3; ++k) {
+        float& v = eps[n * D + k];
+        v = v != v ? 0.f : std::min(std::max(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+      }
+  float cnt = 0.f, mean[3] = {0.f, 0.f, 0.f};
+  for (int n = 0; n < N; ++n) {
+    cnt += nm[n];
+    for (int k = 0; k < 3; ++k) mean[k] += eps[n * D + k];
+  }
+  cnt = std::max(cnt, 1.f);
+  for (int n = 0; n < N; ++n) {
+    for (int k = 0; k < 3; ++k) eps[n * D + k] -= mean[k] / cnt * nm[n];
+    for (int k = 0; k < F; ++k) eps[n * D + 3 + k] = ho[n * 16 + k] * nm[n];  // time column dropped (models.py:132-134)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// EGNN_predictor: pred [K]; with dpred != nullptr also grad [N][D] = d(dpred . pred)/dz  (reverse pass by hand)
+// ---------------------------------------------------------------------------------------------------------------
+struct PCache {
+  std::vector<float> h, x, u, v, a, cpre, phi, cdiff, radial, npre;
+};
+void predictor_one(const Model& M, int N, const float* z, float t, const float* nm, const float* em, const float* dpred,
+                   float* pred, float* grad) {
+  const PredCfg& c = M.pc;
+  const int H = c.H, HP = up16(H), F = c.F, D = 3 + F, K = c.K, E = N * N, LI = up16(2 * H + 2), LN = up16(2 * H);
+  const float R = c.coords_range / (float)c.L;  // egnn_predictor/models.py:515
+  std::vector<float> x(3 * N), x0, hin((size_t)N * (F + 1)), h((size_t)N * HP), d0(E);
+  std::vector<float> inp((size_t)E * LI), su((size_t)E * HP), e((size_t)E * HP), nin((size_t)N * LN), n1((size_t)N * HP),
+      n2((size_t)N * HP), c1((size_t)E * HP);
+  std::vector<PCache> cache(c.L);
+  const bool want = dpred != nullptr;
+  for (int n = 0; n < N; ++n) {
+    for (int k = 0; k < 3; ++k) x[3 * n + k] = z[n * D + k] * nm[n];
+    for (int k = 0; k < F; ++k) hin[n * (F + 1) + k] = z[n * D + 3 + k] * nm[n];
+    hin[n * (F + 1) + F] = t;
+  }
+  x0 = x;
+  coord2diff(N, x.data(), 1.0f, d0.data(), nullptr);  // models.py:452
+  M.pemb.fwd(N, hin.data(), F + 1, h.data(), HP);
+  for (int l = 0; l < c.L; ++l) {
+    const PLayer& g = M.pl[l];
+    PCache& C = cache[l];
+    C.radial.resize(E); C.cdiff.resize((size_t)E * 3);
+    C.u.resize((size_t)E * HP); C.v.resize((size_t)E * HP); C.a.resize(E); C.cpre.resize((size_t)E * HP); C.phi.resize(E);
+    C.npre.resize((size_t)N * HP);
+    C.h = h; C.x = x;
+    coord2diff(N, x.data(), 1.0f, C.radial.data(), C.cdiff.data());
+    edge_input(N, H, h.data(), HP, C.radial.data(), d0.data(), inp.data(), LI);
+    g.e1.fwd(E, inp.data(), LI, C.u.data(), HP);
+    for (size_t i = 0; i < su.size(); ++i) su[i] = 0.f;
+    for (int r = 0; r < E; ++r) {
+      const float* ur = &C.u[(size_t)r * HP];
+      float* sr = &su[(size_t)r * HP];
+#pragma omp simd
+      for (int k = 0; k < H; ++k) sr[k] = silu_f(ur[k]);
+    }
+    g.e2.fwd(E, su.data(), HP, C.v.data(), HP);
+    for (int r = 0; r < E; ++r) {  // e = silu(v) * a * edge_mask   (gcl.py:231-237)
+      const float* vr = &C.v[(size_t)r * HP];
+      float* er = &e[(size_t)r * HP];
+      float sd = g.ba;
+#pragma omp simd reduction(+ : sd)
+      for (int k = 0; k < H; ++k) {
+        er[k] = silu_f(vr[k]);
+        sd += er[k] * g.wa[k];
+      }
+      const float a = c.attention ? sigmoid_f(sd) : 1.f;
+      C.a[r] = a;
+      const float sc = a * em[r];
+      for (int k = 0; k < H; ++k) er[k] *= sc;
+      for (int k = H; k < HP; ++k) er[k] = 0.f;
+    }
+    g.c1.fwd(E, e.data(), HP, C.cpre.data(), HP);  // coord_model (gcl.py:252-278)
+    std::vector<float> xn(3 * N);
+    for (int i = 0; i < N; ++i) {
+      float acc[3] = {0.f, 0.f, 0.f};
+      for (int j = 0; j < N; ++j) {
+        const int r = i * N + j;
+        const float* cp = &C.cpre[(size_t)r * HP];
+        float phi = 0.f;
+        for (int k = 0; k < H; ++k) phi += silu_f(cp[k]) * g.wc2[k];
+        C.phi[r] = phi;
+        const float tau = (c.use_tanh ? std::tanh(phi) * R : phi) * em[r];
+        for (int k = 0; k < 3; ++k) acc[k] += C.cdiff[(size_t)r * 3 + k] * tau;
+      }
+      for (int k = 0; k < 3; ++k) xn[3 * i + k] = (x[3 * i + k] + acc[k]) * nm[i];
+    }
+    std::fill(nin.begin(), nin.end(), 0.f);
+    for (int i = 0; i < N; ++i) {
+      std::memcpy(&nin[(size_t)i * LN], &h[(size_t)i * HP], sizeof(float) * H);
+      float* agg = &nin[(size_t)i * LN + H];
+      for (int j = 0; j < N; ++j) {
+        const float* er = &e[(size_t)(i * N + j) * HP];
+#pragma omp simd
+        for (int k = 0; k < H; ++k) agg[k] += er[k];
+      }
+    }
+    g.n1.fwd(N, nin.data(), LN, C.npre.data(), HP);
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < HP; ++k) n1[(size_t)i * HP + k] = k < H ? silu_f(C.npre[(size_t)i * HP + k]) : 0.f;
+    g.n2.fwd(N, n1.data(), HP, n2.data(), HP);
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < H; ++k) h[(size_t)i * HP + k] = (h[(size_t)i * HP + k] + n2[(size_t)i * HP + k]) * nm[i];
+    x = xn;
+  }
+  std::vector<float> ho((size_t)N * 16);
+  M.pemb_out.fwd(N, h.data(), HP, ho.data(), 16);
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += ho[n * 16 + k] * nm[n];
+    pred[k] = s / (float)N;  // mean over the PADDED node count (models.py:457)
+  }
+  if (!want) return;
+
+  // ---- reverse pass (the order of oracle/gaudi_oracle.py: predictor_grad)
+  std::vector<float> dh((size_t)N * HP, 0.f), dx(3 * N, 0.f), dd0(E, 0.f), dho((size_t)N * 16, 0.f);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) dho[n * 16 + k] = dpred[k] / (float)N * nm[n];
+  M.pemb_out.bwd(N, dho.data(), 16, dh.data(), HP);
+  std::vector<float> dn1((size_t)N * HP), dnin((size_t)N * LN), de((size_t)E * HP), dc((size_t)E * HP), dv((size_t)E * HP),
+      dt1((size_t)E * HP), dinp((size_t)E * LI), dhp((size_t)N * HP), dxp(3 * N), ddiff((size_t)E * 3);
+  for (int l = c.L - 1; l >= 0; --l) {
+    const PLayer& g = M.pl[l];
+    const PCache& C = cache[l];
+    for (int i = 0; i < N; ++i) {
+      for (int k = 0; k < HP; ++k) dh[(size_t)i * HP + k] *= nm[i];
+      for (int k = 0; k < 3; ++k) dx[3 * i + k] *= nm[i];
+    }
+    g.n2.bwd(N, dh.data(), HP, dn1.data(), HP);
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < HP; ++k) dn1[(size_t)i * HP + k] = k < H ? dn1[(size_t)i * HP + k] * dsilu_f(C.npre[(size_t)i * HP + k]) : 0.f;
+    g.n1.bwd(N, dn1.data(), HP, dnin.data(), LN);
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < HP; ++k) dhp[(size_t)i * HP + k] = k < H ? dh[(size_t)i * HP + k] + dnin[(size_t)i * LN + k] : 0.f;
+    // coordinate branch: dtau, dcdiff; dcpre = dphi * wc2 * silu'(cpre); de = dagg_i + dcpre Wc1
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        const int r = i * N + j;
+        const float phi = C.phi[r], th = std::tanh(phi);
+        const float tau = c.use_tanh ? th * R : phi;
+        float dtau = 0.f;
+        for (int k = 0; k < 3; ++k) dtau += dx[3 * i + k] * C.cdiff[(size_t)r * 3 + k];
+        dtau *= em[r];
+        const float dphi = c.use_tanh ? dtau * R * (1.0f - th * th) : dtau;
+        float* dcr = &dc[(size_t)r * HP];
+        const float* cp = &C.cpre[(size_t)r * HP];
+#pragma omp simd
+        for (int k = 0; k < H; ++k) dcr[k] = dphi * g.wc2[k] * dsilu_f(cp[k]);
+        for (int k = H; k < HP; ++k) dcr[k] = 0.f;
+        for (int k = 0; k < 3; ++k) ddiff[(size_t)r * 3 + k] = dx[3 * i + k] * tau * em[r];  // = dcdiff for now
+      }
+    g.c1.bwd(E, dc.data(), HP, de.data(), HP);
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        const int r = i * N + j;
+        float* der = &de[(size_t)r * HP];
+        const float* vr = &C.v[(size_t)r * HP];
+        const float* dagg = &dnin[(size_t)i * LN + H];
+        const float a = C.a[r], mk = em[r];
+        float dadot = 0.f;
+#pragma omp simd reduction(+ : dadot)
+        for (int k = 0; k < H; ++k) {
+          der[k] += dagg[k];
+          dadot += der[k] * silu_f(vr[k]);
+        }
+        const float da = dadot * mk;
+        const float ds = c.attention ? da * a * (1.0f - a) : 0.f;
+        float* dvr = &dv[(size_t)r * HP];
+#pragma omp simd
+        for (int k = 0; k < H; ++k) dvr[k] = (der[k] * a * mk + ds * g.wa[k]) * dsilu_f(vr[k]);
+        for (int k = H; k < HP; ++k) dvr[k] = 0.f;
+      }
+    g.e2.bwd(E, dv.data(), HP, dt1.data(), HP);
+    for (int r = 0; r < E; ++r) {
+      float* d = &dt1[(size_t)r * HP];
+      const float* ur = &C.u[(size_t)r * HP];
+#pragma omp simd
+      for (int k = 0; k < H; ++k) d[k] *= dsilu_f(ur[k]);
+      for (int k = H; k < HP; ++k) d[k] = 0.f;
+    }
+    g.e1.bwd(E, dt1.data(), HP, dinp.data(), LI);
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        const int r = i * N + j;
+        const float* di = &dinp[(size_t)r * LI];
+        float* hi = &dhp[(size_t)i * HP];
+        float* hj = &dhp[(size_t)j * HP];
+        for (int k = 0; k < H; ++k) hi[k] += di[k];
+        for (int k = 0; k < H; ++k) hj[k] += di[H + k];
+        const float dr = di[2 * H];
+        dd0[r] += di[2 * H + 1];
+        // radial / cdiff wrt x (gcl.py:308-316)
+        float diff[3], dot = 0.f;
+        for (int k = 0; k < 3; ++k) {
+          diff[k] = C.x[3 * i + k] - C.x[3 * j + k];
+          dot += ddiff[(size_t)r * 3 + k] * diff[k];
+        }
+        const float nrm = std::sqrt(C.radial[r] + 1e-8f), den = nrm + 1.0f;
+        for (int k = 0; k < 3; ++k)
+          ddiff[(size_t)r * 3 + k] = ddiff[(size_t)r * 3 + k] / den - diff[k] * (dot / (den * den * nrm)) + 2.0f * diff[k] * dr;
+      }
+    for (int i = 0; i < 3 * N; ++i) dxp[i] = dx[i];
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j)
+        for (int k = 0; k < 3; ++k) {
+          dxp[3 * i + k] += ddiff[(size_t)(i * N + j) * 3 + k];
+          dxp[3 * j + k] -= ddiff[(size_t)(i * N + j) * 3 + k];
+        }
+    dh = dhp;
+    dx = dxp;
+  }
+  std::vector<float> dh0((size_t)N * 16);
+  M.pemb.bwd(N, dh.data(), HP, dh0.data(), 16);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j)
+      for (int k = 0; k < 3; ++k) {
+        const float g0 = 2.0f * (x0[3 * i + k] - x0[3 * j + k]) * dd0[i * N + j];
+        dx[3 * i + k] += g0;
+        dx[3 * j + k] -= g0;
+      }
+  for (int n = 0; n < N; ++n) {
+    for (int k = 0; k < 3; ++k) grad[n * D + k] = dx[3 * n + k] * nm[n];
+    for (int k = 0; k < F; ++k) grad[n * D + 3 + k] = dh0[n * 16 + k] * nm[n];  // time column dropped
+  }
+}
+
+void remove_mean_x(int N, int D, float* a, const float* nm) {
+  float cnt = 0.f, mean[3] = {0.f, 0.f, 0.f};
+  for (int n = 0; n < N; ++n) {
+    cnt += nm[n];
+    for (int k = 0; k < 3; ++k) mean[k] += a[n * D + k];
+  }
+  cnt = std::max(cnt, 1.f);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < 3; ++k) a[n * D + k] -= mean[k] / cnt * nm[n];
+}
+
+}  // namespace
+
+extern "C" {
+
+void* gcpu_create() { return new Model(); }
+void gcpu_destroy(void* p) { delete (Model*)p; }
+const char* gcpu_isa() { return gemm == gemm_avx512 ? "avx512f" : gemm == gemm_avx2 ? "avx2+fma" : "scalar"; }
+int gcpu_threads() { return omp_get_max_threads(); }
+
+int gcpu_load_edm(void* p, const EdmCfg* cfg, int n, const char* const* names, const float* const* tensors, const int64_t* numel) {
+  Model& M = *(Model*)p;
+  M.ec = *cfg;
+  const int H = cfg->H, F1 = cfg->F + 1, ld1 = 2 * H + 2;
+  if (H < 1 || F1 > 16) return -1;
+  Tensors T;
+  for (int i = 0; i < n; ++i) T.m[names[i]] = {tensors[i], numel[i]};
+  const std::string q = "dynamics.egnn.";
+  const float *ew = T.get(q + "embedding.weight", (int64_t)H * F1), *eb = T.get(q + "embedding.bias", H);
+  const float *ow = T.get(q + "embedding_out.weight", (int64_t)F1 * H), *ob = T.get(q + "embedding_out.bias", F1);
+  if (!T.ok) return -4;
+  M.emb.set(ew, eb, H, F1);
+  M.emb_out.set(ow, ob, F1, H);
+  M.gcl.assign(cfg->L, std::vector<Gcl>(cfg->S));
+  M.equ.assign(cfg->L, Equ());
+  for (int l = 0; l < cfg->L; ++l) {
+    for (int s = 0; s < cfg->S; ++s) {
+      const std::string g = q + "e_block_" + std::to_string(l) + ".gcl_" + std::to_string(s) + ".";
+      Gcl& G = M.gcl[l][s];
+      const float *w1 = T.get(g + "edge_mlp.0.weight", (int64_t)H * ld1), *b1 = T.get(g + "edge_mlp.0.bias", H);
+      const float *w2 = T.get(g + "edge_mlp.2.weight", (int64_t)H * H), *b2 = T.get(g + "edge_mlp.2.bias", H);
+      const float *wn1 = T.get(g + "node_mlp.0.weight", (int64_t)H * 2 * H), *bn1 = T.get(g + "node_mlp.0.bias", H);
+      const float *wn2 = T.get(g + "node_mlp.2.weight", (int64_t)H * H), *bn2 = T.get(g + "node_mlp.2.bias", H);
+      if (!T.ok) return -4;
+      G.e1.set(w1, b1, H, ld1);
+      G.e2.set(w2, b2, H, H);
+      G.n1.set(wn1, bn1, H, 2 * H);
+      G.n2.set(wn2, bn2, H, H);
+      G.wa.assign(H, 0.f);
+      if (cfg->attention) {
+        const float *wa = T.get(g + "att_mlp.0.weight", H), *ba = T.get(g + "att_mlp.0.bias", 1);
+        if (!T.ok) return -4;
+        G.wa.assign(wa, wa + H);
+        G.ba = ba[0];
+      }
+    }
+    const std::string g = q + "e_block_" + std::to_string(l) + ".gcl_equiv.";
+    const float *w1 = T.get(g + "coord_mlp.0.weight", (int64_t)H * ld1), *b1 = T.get(g + "coord_mlp.0.bias", H);
+    const float *w2 = T.get(g + "coord_mlp.2.weight", (int64_t)H * H), *b2 = T.get(g + "coord_mlp.2.bias", H);
+    const float* w3 = T.get(g + "coord_mlp.4.weight", H);
+    if (!T.ok) return -4;
+    M.equ[l].c1.set(w1, b1, H, ld1);
+    M.equ[l].c2.set(w2, b2, H, H);
+    M.equ[l].w3.assign(w3, w3 + H);
+  }
+  M.has_edm = true;
+  return 0;
+}
+
+int gcpu_load_pred(void* p, const PredCfg* cfg, int n, const char* const* names, const float* const* tensors, const int64_t* numel) {
+  Model& M = *(Model*)p;
+  M.pc = *cfg;
+  const int H = cfg->H, F1 = cfg->F + 1, K = cfg->K, ld1 = 2 * H + 2;
+  if (H < 1 || F1 > 16 || K > 16) return -1;
+  Tensors T;
+  for (int i = 0; i < n; ++i) T.m[names[i]] = {tensors[i], numel[i]};
+  const std::string q = "egnn.";
+  const float *ew = T.get(q + "embedding.weight", (int64_t)H * F1), *eb = T.get(q + "embedding.bias", H);
+  const float *ow = T.get(q + "embedding_out.weight", (int64_t)K * H), *ob = T.get(q + "embedding_out.bias", K);
+  if (!T.ok) return -4;
+  M.pemb.set(ew, eb, H, F1);
+  M.pemb_out.set(ow, ob, K, H);
+  M.pl.assign(cfg->L, PLayer());
+  for (int l = 0; l < cfg->L; ++l) {
+    const std::string g = q + "gcl_" + std::to_string(l) + ".";
+    PLayer& G = M.pl[l];
+    const float *w1 = T.get(g + "edge_mlp.0.weight", (int64_t)H * ld1), *b1 = T.get(g + "edge_mlp.0.bias", H);
+    const float *w2 = T.get(g + "edge_mlp.2.weight", (int64_t)H * H), *b2 = T.get(g + "edge_mlp.2.bias", H);
+    const float *wn1 = T.get(g + "node_mlp.0.weight", (int64_t)H * 2 * H), *bn1 = T.get(g + "node_mlp.0.bias", H);
+    const float *wn2 = T.get(g + "node_mlp.2.weight", (int64_t)H * H), *bn2 = T.get(g + "node_mlp.2.bias", H);
+    const float *wc1 = T.get(g + "coord_mlp.0.weight", (int64_t)H * H), *bc1 = T.get(g + "coord_mlp.0.bias", H);
+    const float* wc2 = T.get(g + "coord_mlp.2.weight", H);
+    if (!T.ok) return -4;
+    G.e1.set(w1, b1, H, ld1);
+    G.e2.set(w2, b2, H, H);
+    G.n1.set(wn1, bn1, H, 2 * H);
+    G.n2.set(wn2, bn2, H, H);
+    G.c1.set(wc1, bc1, H, H);
+    G.wc2.assign(wc2, wc2 + H);
+    G.wa.assign(H, 0.f);
+    if (cfg->attention) {
+      const float *wa = T.get(g + "att_mlp.0.weight", H), *ba = T.get(g + "att_mlp.0.bias", 1);
+      if (!T.ok) return -4;
+      G.wa.assign(wa, wa + H);
+      G.ba = ba[0];
+    }
+  }
+  M.has_pred = true;
+  return 0;
+}
+
+// eps_out [B][N][D] = phi(z, t)
+int gcpu_phi(void* p, int B, int N, const float* z, const float* t, const float* nm, const float* em, float* eps_out) {
+  const Model& M = *(Model*)p;
+  if (!M.has_edm) return -3;
+  const int D = 3 + M.ec.F;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int b = 0; b < B; ++b)
+    edm_phi_one(M, N, z + (size_t)b * N * D, t[b], nm + (size_t)b * N, em + (size_t)b * N * N, eps_out + (size_t)b * N * D);
+  return 0;
+}
+
+// pred_out [B][K]; dpred [B][K] != null: grad_out [B][N][D] too
+int gcpu_predictor(void* p, int B, int N, const float* z, const float* t, const float* nm, const float* em, const float* dpred,
+                   float* pred_out, float* grad_out) {
+  const Model& M = *(Model*)p;
+  if (!M.has_pred) return -3;
+  const int D = 3 + M.pc.F, K = M.pc.K;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int b = 0; b < B; ++b)
+    predictor_one(M, N, z + (size_t)b * N * D, t[b], nm + (size_t)b * N, em + (size_t)b * N * N, dpred ? dpred + (size_t)b * K : nullptr,
+                  pred_out + (size_t)b * K, grad_out ? grad_out + (size_t)b * N * D : nullptr);
+  return 0;
+}
+
+// One reverse step (en_diffusion.py:807-935).  coef = {alpha_ts, eps_coef, sigma} of the step (oracle/gaudi_oracle.py:
+// step_coefficients), t_val = (s+1)/T, eps_raw [B][N][D] raw N(0,1) draws.  target_w == null: unguided.
+int gcpu_step(void* p, int B, int N, const float* coef, float t_val, const float* z_t, const float* nm, const float* em,
+              const float* eps_raw, const float* target_w, float scale, float* zs_out) {
+  const Model& M = *(Model*)p;
+  if (!M.has_edm || (target_w && !M.has_pred)) return -3;
+  const int D = 3 + M.ec.F, K = M.pc.K;
+  const float alpha_ts = coef[0], eps_coef = coef[1], sigma = coef[2];
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int b = 0; b < B; ++b) {
+    const float* z = z_t + (size_t)b * N * D;
+    const float* m = nm + (size_t)b * N;
+    const float* e = em + (size_t)b * N * N;
+    float* zs = zs_out + (size_t)b * N * D;
+    std::vector<float> eps((size_t)N * D), nz((size_t)N * D), grad((size_t)N * D), dp(16, 0.f), pred(16);
+    edm_phi_one(M, N, z, t_val, m, e, eps.data());
+    for (int i = 0; i < N * D; ++i) nz[i] = eps_raw[(size_t)b * N * D + i] * m[i / D];  // en_diffusion.py:937-956
+    remove_mean_x(N, D, nz.data(), m);
+    for (int i = 0; i < N * D; ++i) {
+      float ep = eps[i];
+      if (target_w) {  // eps_t.nan_to_num(0.)  (:881)
+        if (ep != ep) ep = 0.f;
+        ep = std::min(std::max(ep, -3.4028234663852886e38f), 3.4028234663852886e38f);
+      }
+      zs[i] = z[i] / alpha_ts - eps_coef * ep + sigma * nz[i];
+    }
+    if (target_w) {
+      for (int k = 0; k < K; ++k) dp[k] = target_w[k] * scale;
+      predictor_one(M, N, zs, t_val, m, e, dp.data(), pred.data(), grad.data());
+      double s = 0.0;
+      for (int i = 0; i < N * D; ++i) s += (double)grad[i] * grad[i];
+      const float clip = std::min(10.0f / ((float)std::sqrt(s) + 1e-6f), 1.0f);  // :905-909
+      for (int i = 0; i < N * D; ++i) grad[i] *= clip;
+      remove_mean_x(N, D, grad.data(), m);
+      for (int i = 0; i < N * D; ++i) zs[i] -= sigma * grad[i];
+    }
+    remove_mean_x(N, D, zs, m);
+    if (target_w) {  // :933-934
+      bool bad = false;
+      for (int i = 0; i < N * D; ++i) bad |= zs[i] != zs[i];
+      if (bad)
+        for (int i = 0; i < N * D; ++i) zs[i] = zs[i] != zs[i] ? 0.f : std::min(std::max(zs[i], -3.4028234663852886e38f), 3.4028234663852886e38f);
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from gaudi_amd import synth
+from tests.helpers import edm_from_cfg, pred_from_cfg, rel_err
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -72,4 +73,109 @@ def test_hetero_shards_run_one_plan_and_match_unsharded():
     sample_fn(nm[:4], em[:4], 0)
     hint_free = (eng.kernel_variant()[1], eng.edge_math()[1])
     print("plans: whole batch", plan_full, "first shard alone", hint_free)
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ large molecules (N up to 40)
+def _engine(eargs, esd, pargs=None, psd=None, **env):
+    from gaudi_amd.engine import Engine
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        eng = Engine(0)  # the knobs are read once, by gaudi_create
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    eng.load_edm(eargs, esd)
+    if pargs is not None:
+        eng.load_predictor(pargs, psd)
+    return eng
+
+
+@pytest.mark.parametrize("widths", ["tiny", "default"])
+def test_global_node_buffer_kernels_equal_the_lds_kernels_bit_for_bit(widths):
+    """The V4G kernels (node buffers in a global scratch: the path molecules beyond the LDS limit take) run the SAME code
+    as the 4-wave LDS kernels, only the address space of five buffers differs: forced on a small batch they must return
+    the same bits for phi, the predictor gradient and a guided chain."""
+    from oracle import gaudi_oracle as O
+    T = 6
+    if widths == "tiny":
+        eargs, pargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=T), synth.pred_args(nf=36, n_layers=3)
+    else:
+        eargs, pargs = synth.edm_args(diffusion_steps=T), synth.pred_args()
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=31, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=32, amplify_coord=True)
+    nm, em = O.build_masks([5, 11, 7, 3, 11], 11, False)
+    rng = np.random.default_rng(3)
+    z = O._combined_noise(rng.standard_normal((5, 11, 4)).astype(np.float32), nm)
+    t = np.full(5, 0.4, np.float32)
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    res = []
+    for env in (dict(GAUDI_WAVES=4), dict(GAUDI_FORCE_GN=1)):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        phi = eng.phi(z, t, nm, em)
+        pred, grad = eng.predictor_grad(z, t, nm, em, np.broadcast_to(w * np.float32(0.6), (5, 5)).copy())
+        x, h, _ = eng.sample(nm, em, seed=4, target_w=w, scale=0.6)
+        assert eng.kernel_variant()[1] == 4
+        res.append((phi, pred, grad, x, h))
+        eng.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("N", [24, 32, 40])
+def test_large_molecules_vs_oracle(N):
+    """Complete graphs of 24 / 32 / 40 nodes (and smaller molecules padded to the same N) at the DEFAULT widths: phi, the
+    predictor gradient and a guided step against the oracle at 1e-4.  These do not fit 160 KiB of LDS; the call must pick
+    the global-node-buffer kernels by itself."""
+    from oracle import gaudi_oracle as O
+    T = 1000
+    eargs, pargs = synth.edm_args(diffusion_steps=T), synth.pred_args()
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=41, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=42, amplify_coord=True)
+    nm, em = O.build_masks([N, N - 7, 5], N, False)
+    rng = np.random.default_rng(N)
+    z = O._combined_noise(rng.standard_normal((3, N, 4)).astype(np.float32), nm)
+    eps = rng.standard_normal((3, N, 4)).astype(np.float32)
+    s = 300
+    t = np.full(3, np.float32(s + 1) / np.float32(T), np.float32)
+    w = O.target_max_gap_weights(5)
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    eng = _engine(eargs, esd, pargs, psd)
+    assert rel_err(eng.phi(z, t, nm, em), O.edm_phi(esd, eargs, z, t, nm, em)) < 1e-4
+    assert eng.kernel_variant()[1] == 4
+    dp = np.broadcast_to(w * np.float32(0.6), (3, 5)).copy()
+    pred, grad = eng.predictor_grad(z, t, nm, em, dp)
+    opred, ograd = O.predictor_grad(psd, pargs, z, nm, em, t, dp)
+    assert rel_err(pred, opred) < 1e-4 and rel_err(grad, ograd) < 1e-4
+    assert np.abs(grad * (1 - nm)).max() == 0
+    zs = eng.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+    assert rel_err(zs, O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6)) < 1e-4
+    x, h, d = eng.sample(nm, em, seed=1, target_w=w, scale=0.6)  # a whole (short) chain runs too
+    eng.close()
+
+
+def test_n40_hetero_vs_reference(golden):
+    """Hetero 20 rings = 40 graph nodes, default architectures, against the REFERENCE's own outputs (g18): phi, predictor +
+    input gradient, unguided and guided teacher-forced step at 1e-4."""
+    import json as _json
+    g = golden("g18_large_molecules")
+    cfg = _json.loads(str(g["cfg"]))
+    T, s = cfg["T"], cfg["s"]
+    base = dict(dataset=cfg["dataset"], amp=True)
+    eargs, esd = edm_from_cfg(dict(base, wseed=cfg["eseed"]), diffusion_steps=T)
+    pargs, psd = pred_from_cfg(dict(base, wseed=cfg["pseed"]))
+    z, nm, em, eps = g["z"], g["node_mask"], g["edge_mask"], g["eps"]
+    t = np.full(z.shape[0], np.float32(s + 1) / np.float32(T), np.float32)
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    eng = _engine(eargs, esd, pargs, psd)
+    assert rel_err(eng.phi(z, t, nm, em), g["phi"]) < 1e-4
+    pred, grad = eng.predictor_grad(z, t, nm, em, np.broadcast_to(w * np.float32(0.6), (z.shape[0], 5)).copy())
+    assert rel_err(pred, g["pred"]) < 1e-4 and rel_err(grad, g["grad_gap"]) < 1e-4
+    assert rel_err(eng.step(s, z, nm, em, eps), g["zs_unguided"]) < 1e-4
+    assert rel_err(eng.step(s, z, nm, em, eps, target_w=w, scale=0.6), g["zs_guided"]) < 1e-4
+    assert eng.kernel_variant()[1] == 4
     eng.close()

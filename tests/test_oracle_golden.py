@@ -281,3 +281,32 @@ def test_g16_fix_noise(golden):
     assert rel_err(x, g["x_unguided"]) < 1e-4 and np.array_equal(h, g["h_unguided"])
     x, h, _ = O.sample(esd, eargs, nm, em, noise, std=1.0, pred_sd=psd, pcfg=pargs, target_w=O.target_max_gap_weights(5), scale=0.6)
     assert rel_err(x, g["x_guided"]) < 1e-4 and np.array_equal(h, g["h_guided"])
+
+
+def test_g18_large_molecules(golden):
+    """N = 40 graph nodes (hetero 20 rings + orientation nodes) at the default architectures: both CPU restatements follow
+    the reference there too (the GPU library runs these on its global-node-buffer kernels, tests/test_gpu_round3.py)."""
+    from oracle import build_cpu
+    g = golden("g18_large_molecules")
+    cfg = json.loads(str(g["cfg"]))
+    T, s = cfg["T"], cfg["s"]
+    base = dict(dataset=cfg["dataset"], amp=True)
+    eargs, esd = edm_from_cfg(dict(base, wseed=cfg["eseed"]), diffusion_steps=T)
+    pargs, psd = pred_from_cfg(dict(base, wseed=cfg["pseed"]))
+    z, nm, em, eps = g["z"], g["node_mask"], g["edge_mask"], g["eps"]
+    t = np.full(z.shape[0], np.float32(s + 1) / np.float32(T), np.float32)
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    w = O.target_max_gap_weights(5)
+    assert rel_err(O.edm_phi(esd, eargs, z, t, nm, em), g["phi"]) < 1e-4
+    pred, grad = O.predictor_grad(psd, pargs, z, nm, em, t, np.broadcast_to(w * np.float32(0.6), (z.shape[0], 5)))
+    assert rel_err(pred, g["pred"]) < 1e-5 and rel_err(grad, g["grad_gap"]) < 5e-5
+    assert rel_err(O.step_unguided(esd, eargs, gamma, s, z, nm, em, eps), g["zs_unguided"]) < 1e-5
+    assert rel_err(O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6), g["zs_guided"]) < 5e-5
+    if build_cpu.cpu_ok():
+        port = build_cpu.CpuPort()
+        port.load_edm(eargs, esd)
+        port.load_predictor(pargs, psd)
+        c = O.step_coefficients(gamma, s, s + 1)
+        assert rel_err(port.phi(z, t, nm, em), g["phi"]) < 1e-4
+        assert rel_err(port.step(c, t[0], z, nm, em, eps, target_w=w, scale=0.6), g["zs_guided"]) < 5e-5
+        port.close()

@@ -824,6 +824,45 @@ def g17_nan_in_edge_gemm_matrix():
     save("g17_nan_edge_matrix", **out)
 
 
+def g18_large_molecules():
+    """Molecules beyond the LDS limit of the library's resident kernels: hetero 20 rings (N = 40 graph nodes with the
+    orientation nodes: BASELINE config 4's "ring count 6-20" read literally; sampling_edm.py:172-209 has no cap) and a
+    14-ring one in the same batch, DEFAULT architectures: phi, predictor + input gradient, one teacher-forced guided step."""
+    out = {}
+    T = 1000
+    ds, nodes = "hetro", [20, 14]
+    F = synth.num_node_features(ds)
+    eargs = synth.edm_args(dataset=ds)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=1800, amplify_coord=True)
+    pargs = synth.pred_args(dataset=ds)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=1810, amplify_coord=True)
+    a, model = build_ref_edm(ds, esd)
+    pa, pred = build_ref_pred(ds, psd)
+    nm, em, z = case_inputs(ds, nodes, None, seed=1820, guidance_pad=True)
+    B, N, D = z.shape
+    assert N == 40
+    tnm, tem = torch.from_numpy(nm), torch.from_numpy(em)
+    out["z"], out["node_mask"], out["edge_mask"] = z, nm, em
+    s = 600
+    st = torch.full((B, 1), s) / T
+    tt = (torch.full((B, 1), s) + 1) / T
+    eps = rng_noise(1830, (B, N, D))
+    out["eps"] = eps
+    with torch.no_grad():
+        out["phi"] = model.phi(torch.from_numpy(z), tt, tnm, tem, None).numpy()
+    zt = torch.from_numpy(z).requires_grad_()
+    p = pred(zt, tnm, tem, tt)
+    out["pred"] = p.detach().numpy()
+    out["grad_gap"] = torch.autograd.grad((0.6 * -p[:, 1]).sum(), zt)[0].numpy()
+    with InjectNoise([eps]), torch.no_grad():
+        out["zs_unguided"] = model.sample_p_zs_given_zt(st, tt, torch.from_numpy(z), tnm, tem, None).numpy()
+    with InjectNoise([eps]), torch.no_grad():
+        out["zs_guided"] = model.sample_p_zs_given_zt_guidance(st, tt, torch.from_numpy(z), tnm, tem,
+                                                               lambda i, n, m, t: -pred(i, n, m, t)[:, 1], 0.6).numpy()
+    out["cfg"] = np.array(json.dumps(dict(dataset=ds, eseed=1800, pseed=1810, T=T, s=s, nodes=nodes)))
+    save("g18_large_molecules", **out)
+
+
 def g16_fix_noise():
     """fix_noise=True (en_diffusion.py:562-566,972-978,1022-1028): ONE raw draw [1,N,3+F] per call is broadcast over the
     batch and masked / mean-centred per molecule.  Tiny config, T = 50, unguided and guided."""
@@ -875,8 +914,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules)
     for w in which:
         fns[w]()
