@@ -200,7 +200,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         for (int e = 0; e < 2; ++e) {  // v (pre-activation of m) -> edge stash for the reverse pass
           f4* sv = (f4*)(estash + edge_stash_off(l, wave, tp * 2 + e, 0, mg.EW, HP)) + lane;
 #pragma unroll
-          for (int t = 0; t < T; ++t) sv[t * 64] = acc[e][t];
+          for (int t = 0; t < T; ++t) stash_store(sv + t * 64, acc[e][t]);
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -233,7 +233,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           for (int e = 0; e < 2; ++e) {  // cpre -> edge stash
             f4* sc = (f4*)(estash + edge_stash_off(l, wave, tp * 2 + e, 1, mg.EW, HP)) + lane;
 #pragma unroll
-            for (int t = 0; t < T; ++t) sc[t * 64] = cp[e][t];
+            for (int t = 0; t < T; ++t) stash_store(sc + t * 64, cp[e][t]);
           }
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
@@ -412,7 +412,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             const f4* sc = (const f4*)(estash + edge_stash_off(l, wave, tile0 + e, 1, EW, HP)) + lane;
             if (!last) {
 #pragma unroll
-              for (int t = 0; t < T; ++t) cp[e][t] = sc[t * 64];
+              for (int t = 0; t < T; ++t) cp[e][t] = stash_load(sc + t * 64);
             }
             my_i[e] = ec[e].i;
             a[e] = astash[((size_t)l * kWaves + wave) * EW + (tile0 + e) * 16 + c];
@@ -459,7 +459,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             if (!kKeepV) {
               const f4* sv = (const f4*)(estash + edge_stash_off(l, wave, tile0 + e, 0, EW, HP)) + lane;
 #pragma unroll
-              for (int t = 0; t < T; ++t) ve[t] = sv[t * 64];
+              for (int t = 0; t < T; ++t) ve[t] = stash_load(sv + t * 64);
             }
             float dadot = 0.f;
 #pragma unroll

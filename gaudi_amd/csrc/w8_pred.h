@@ -7,28 +7,8 @@
 #include "pred_device.h"
 #include "w8_edm.h"
 
-#ifndef GAUDI_STASH_NT
-#define GAUDI_STASH_NT 0  // experiment: 1 = non-temporal stores of the edge activation stash, 2 = non-temporal loads too
-#endif
-
 namespace gaudi {
 namespace w8 {
-
-// the edge activation stash is written once and read once, 2.9 MB per molecule-step: cache-policy knob for it
-__device__ __forceinline__ void stash_store(f4* p, f4 v) {
-#if GAUDI_STASH_NT >= 1
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-__device__ __forceinline__ f4 stash_load(const f4* p) {
-#if GAUDI_STASH_NT >= 2
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
 
 template <int HP, int SP = 0>
 struct PredSmem {
@@ -157,8 +137,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     // lane group -- measured 1.5 % slower on C3)
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
       const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
-      ((f4*)st)[idx] = *(const f4*)(p + n * LD + f);
-      ((f4*)(st + N * HP))[idx] = *(const f4*)(q + n * LD + f);
+      stash_store((f4*)st + idx, *(const f4*)(p + n * LD + f));
+      stash_store((f4*)(st + N * HP) + idx, *(const f4*)(q + n * LD + f));
     }
     {
       STAMP(ST_STASH);
@@ -331,7 +311,8 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     // (a) reload P -> B2, Q -> B1, npre -> B4, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
       const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
-      const f4 pv = ((const f4*)st)[idx], qv = ((const f4*)(st + N * HP))[idx], nv = ((const f4*)(st + 2 * N * HP))[idx];
+      const f4 pv = stash_load((const f4*)st + idx), qv = stash_load((const f4*)(st + N * HP) + idx),
+               nv = stash_load((const f4*)(st + 2 * N * HP) + idx);
       *(f4*)(B2 + n * LD + f) = pv;
       *(f4*)(B1 + n * LD + f) = qv;
       *(f4*)(B4 + n * LD + f) = nv;

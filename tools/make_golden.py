@@ -863,6 +863,45 @@ def g18_large_molecules():
     save("g18_large_molecules", **out)
 
 
+def g19_amplified_default_steps():
+    """Reference-held anchor for the ill-conditioned case: DEFAULT architectures with amplified coordinate heads (cata C3
+    shape and hetero C4 shape), teacher-forced unguided / guided steps at s = 999, 400, 0 -- run by the reference in fp32 AND
+    in float64 (model.double()), so that a kernel can be held to 1e-4 against the reference's own float64 result where
+    the two fp32 evaluations differ from each other by about that much."""
+    out = {}
+    T = 1000
+    for ci, (name, ds, nodes) in enumerate([("cata", "cata", [11, 11, 7, 11, 4, 9]), ("hetro", "hetro", [10, 3, 7, 5])]):
+        F = synth.num_node_features(ds)
+        eargs = synth.edm_args(dataset=ds)
+        esd = synth.synth_edm_state_dict(eargs, F, seed=1900 + ci, amplify_coord=True)
+        pargs = synth.pred_args(dataset=ds)
+        psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=1910 + ci, amplify_coord=True)
+        a, model = build_ref_edm(ds, esd)
+        pa, pred = build_ref_pred(ds, psd)
+        nm, em, z = case_inputs(ds, nodes, None, seed=1920 + ci, guidance_pad=True)
+        B, N, D = z.shape
+        tnm, tem = torch.from_numpy(nm), torch.from_numpy(em)
+        wv = torch.tensor([0., -1., 0., 0., 0.] if ds == "cata" else [3., 0., 1., 1., 0.])
+        out[f"{name}_z"], out[f"{name}_node_mask"], out[f"{name}_edge_mask"], out[f"{name}_w"] = z, nm, em, wv.numpy()
+        for dt, tag in ((torch.float32, "fp32"), (torch.float64, "fp64")):
+            if dt == torch.float64:
+                model.double()
+                pred.double()
+            zt_, nm_, em_ = torch.from_numpy(z).to(dt), tnm.to(dt), tem.to(dt)
+            tf = lambda i, n, m, t: (pred(i, n, m, t) * wv.to(dt)).sum(-1)
+            for s in (999, 400, 0):
+                eps = rng_noise(1930 + 10 * ci + s % 7, (B, N, D))
+                st = (torch.full((B, 1), s) / T).to(dt)
+                tt = ((torch.full((B, 1), s) + 1) / T).to(dt)
+                out[f"{name}_s{s}_eps"] = eps
+                with InjectNoise([eps], dt), torch.no_grad():
+                    out[f"{name}_s{s}_zs_unguided_{tag}"] = model.sample_p_zs_given_zt(st, tt, zt_, nm_, em_, None).numpy()
+                with InjectNoise([eps], dt), torch.no_grad():
+                    out[f"{name}_s{s}_zs_guided_{tag}"] = model.sample_p_zs_given_zt_guidance(st, tt, zt_, nm_, em_, tf, 0.6).numpy()
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, eseed=1900 + ci, pseed=1910 + ci, T=T, nodes=nodes)))
+    save("g19_amplified_default_steps", **out)
+
+
 def g16_fix_noise():
     """fix_noise=True (en_diffusion.py:562-566,972-978,1022-1028): ONE raw draw [1,N,3+F] per call is broadcast over the
     batch and masked / mean-centred per molecule.  Tiny config, T = 50, unguided and guided."""
@@ -914,8 +953,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps)
     for w in which:
         fns[w]()
