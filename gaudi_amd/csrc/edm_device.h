@@ -44,7 +44,6 @@ struct MolGraph {
   const uint32_t* edge;   // LDS [4][EW]  i | j<<8
   const float* em;        // LDS [4][EW]  edge_mask value (0 for padding slots)
   const uint32_t* seg;    // LDS [N]      wave<<30 | start<<15 | len  (edge run of node n)
-  float* gnode = nullptr; // V4G kernels: this workgroup's global node-buffer scratch (NetSmem / PredSmem with GN)
   int npairs;             // 32-edge passes of THIS wave
   int npairs_all[kWaves]; // ... of every wave of the workgroup (lock-step loops of the reverse pass)
   // npairs_all[w] for a per-lane (non-uniform) w without dynamically indexing the array (which would spill it)

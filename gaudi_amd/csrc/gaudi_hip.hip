@@ -544,15 +544,19 @@ static kernel_fn pick_kernel(int hpe, int hpp) {
 // the 4-wave kernels with node buffers in global memory (kerng_*.hip): molecules beyond the LDS limit
 #ifdef GAUDI_STAMP_STUBS
 static kernel_fn pick_kernel_g(int, int) { return nullptr; }
+static bool have_kernels_g(int, int) { return false; }
 #else
 kernel_fn gaudi_kerng_edm(int hpe, int hpp);
 kernel_fn gaudi_kerng_pred(int hpe, int hpp);
-kernel_fn gaudi_kerng_fused(int hpe, int hpp);
+// there is no fused (EDM + predictor) V4G instantiation: at the default widths it sits on the register cliff (512 registers,
+// 1120 spilled scalars) and faulted; a guided step of a large molecule is two launches, EDM-only then predictor-only
 static kernel_fn pick_kernel_g(int hpe, int hpp) {
   kernel_fn f = gaudi_kerng_edm(hpe, hpp);
   if (!f) f = gaudi_kerng_pred(hpe, hpp);
-  if (!f) f = gaudi_kerng_fused(hpe, hpp);
   return f;
+}
+static bool have_kernels_g(int hpe, int hpp) {
+  return (!hpe || pick_kernel_g(hpe, 0)) && (!hpp || pick_kernel_g(0, hpp));
 }
 #endif
 
@@ -830,7 +834,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   // (sampling_edm.py:172-209); this one is N <= 255 (node indices are bytes in the edge words).
   const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
   if (h->force_gn || lds_bytes(hpe, hpp, N, Dz, M.EW) > 160 * 1024) {
-    if (pick_kernel_g(hpe, hpp) && lds_bytes(hpe, hpp, N, Dz, M.EW, true) <= 160 * 1024) {
+    if (have_kernels_g(hpe, hpp) && lds_bytes(hpe, hpp, N, Dz, M.EW, true) <= 160 * 1024) {
       h->run_gn = true;
       const size_t stride = (gnode_floats(hpe, hpp, N) + 63) / 64 * 64;
       HIPCHECK(h, h->d_gnode.reserve(sizeof(float) * stride * (size_t)B));
@@ -1167,12 +1171,48 @@ static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, cons
     if (rc) return rc;
     hpp = h->HPP;
   }
+  float* zin = h->d_zin.as<float>();
+  float* zout = h->d_zout.as<float>();
+  if (h->run_gn && target_w) {
+    // Large molecules (V4G kernels), guided: every reverse step is two launches -- the EDM-only kernel runs the step up to
+    // z_s before guidance (split = 1: denoise, update with noise), the predictor-only kernel the guidance update, the
+    // projection and the NaN scrub (MODE_GUIDE) -- then one decode pass.
+    for (int s = s_hi; s >= s_lo; --s) {
+      P.mode = MODE_SAMPLE;
+      P.s_hi = P.s_lo = s;
+      P.do_init = (s == s_hi) && do_init;
+      P.do_decode = 0;
+      P.split = 1;
+      P.z_in = zin;
+      P.z_out = zout;
+      rc = launch(h, P, h->HPE, 0, 1);
+      if (rc) return rc;
+      P.mode = MODE_GUIDE;
+      P.do_init = 0;
+      P.split = 0;
+      P.z_in = zout;
+      P.z_out = zin;
+      rc = launch(h, P, 0, hpp, 0);
+      if (rc) return rc;
+    }
+    if (do_decode) {
+      P.mode = MODE_SAMPLE;
+      P.split = 0;
+      P.s_hi = -1;
+      P.s_lo = 0;
+      P.do_init = (s_hi < s_lo) && do_init;
+      P.do_decode = 1;
+      P.z_in = zin;
+      P.z_out = zout;
+      rc = launch(h, P, h->HPE, 0, 0);
+      if (rc) return rc;
+      std::swap(zin, zout);
+    }
+  } else {
   // chunk the chain into launches of steps_per_launch steps; z ping-pongs zout -> zin
   bool first = true;
   int s = s_hi;
   const bool any_steps = s_hi >= s_lo;
-  float* zin = h->d_zin.as<float>();
-  float* zout = h->d_zout.as<float>();
   do {
     const int lo = any_steps ? std::max(s_lo, s - h->steps_per_launch + 1) : s + 1;
     P.s_hi = s;
@@ -1187,6 +1227,7 @@ static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, cons
     first = false;
     s = lo - 1;
   } while (any_steps && s >= s_lo);
+  }
   // after the swap, `zin` holds the latest z
   if (z_out) HIPCHECK(h, hipMemcpyAsync(z_out, zin, zb, hipMemcpyDeviceToHost, h->stream));
   if (do_decode) {
@@ -1297,6 +1338,8 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
   KParams P{};
   int rc = stage_graph(h, B, N, node_mask, edge_mask, P, h->HPE, h->HPP);
   if (rc) return rc;
+  if (h->run_gn)
+    return fail(h, GAUDI_E_CAPACITY, "callback targets are not available for molecules beyond the LDS limit (use a linear target)");
   fill_edm(h, P);
   const int D = 3 + P.F, T = P.T, K = h->pcfg.out_nf;
   const size_t zb = sizeof(float) * B * N * D, pb = sizeof(float) * B * K;

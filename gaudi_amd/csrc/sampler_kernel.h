@@ -13,7 +13,7 @@
 
 namespace gaudi {
 
-enum Mode { MODE_PHI = 0, MODE_SAMPLE = 1, MODE_PRED_FWD = 2, MODE_PRED_GRAD = 3 };
+enum Mode { MODE_PHI = 0, MODE_SAMPLE = 1, MODE_PRED_FWD = 2, MODE_PRED_GRAD = 3, MODE_GUIDE = 4 };
 
 struct KParams {
   int mode, B, N, F, EW;
@@ -100,14 +100,15 @@ struct V4T {
     mg.npairs = P.npairs[b * gaudi::kWaves + wave];
 #pragma unroll
     for (int w = 0; w < gaudi::kWaves; ++w) mg.npairs_all[w] = P.npairs[b * gaudi::kWaves + w];
-    mg.gnode = GN ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr;  // one scratch slice per RESIDENT workgroup
     return base;
   }
+  // gnode: this workgroup's slice of the global node-buffer scratch (V4G), computed by the caller from the kernel arguments
+  // right at the call (kept out of MolGraph: one more long-lived pointer made the largest instantiation fault)
   template <int HP>
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
-                                             float* sMean, float t_val, int tid STAMP_DECL) {
+                                             float* sMean, float t_val, int tid STAMP_DECL, float* gnode) {
     gaudi::NetSmem<HP, GN> sm;
-    sm.carve(net, mg.N, mg.EW, mg.gnode);
+    sm.carve(net, mg.N, mg.EW, gnode);
     gaudi::edm_forward<HP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
   }
   // explicit by-value signatures: forwarding references (and a by-reference KParams) made hipcc keep the arguments in
@@ -116,16 +117,16 @@ struct V4T {
   __device__ __forceinline__ static void guide(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
-                                               const float* dpred_ext) {
+                                               const float* dpred_ext, float* gnode) {
     gaudi::guidance_update<HP, GN>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
-                                   tid STAMP_ARGS, phase, dpred_ext, mg.gnode);
+                                   tid STAMP_ARGS, phase, dpred_ext, gnode);
   }
   template <int HP>
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
                                                     float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
-                                                    float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
+                                                    float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, float* gnode) {
     gaudi::predictor_entry<HP, GN>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash,
-                                   tid STAMP_ARGS, mg.gnode);
+                                   tid STAMP_ARGS, gnode);
   }
 };
 using V4 = V4T<false>;
@@ -271,9 +272,10 @@ struct V8T {
   __device__ __forceinline__ static Graph8Args gargs(const Graph& mg) {
     return Graph8Args{mg.N, mg.D, mg.S, mg.NC, mg.ntiles, mg.pubx, mg.pub_ch};
   }
+  static constexpr bool kGlobalNodes = false;
   template <int HP>
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
-                                             float* sMean, float t_val, int tid STAMP_DECL) {
+                                             float* sMean, float t_val, int tid STAMP_DECL, float*) {
 #ifdef GAUDI_STAMPS
     w8::NetSmem<HP, SP> sm;
     sm.carve(net, mg.N, mg.S);
@@ -287,7 +289,7 @@ struct V8T {
   __device__ __forceinline__ static void guide(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
-                                               const float* dpred_ext) {
+                                               const float* dpred_ext, float*) {
 #ifdef GAUDI_STAMPS
     w8::guidance_update<HP, SP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
                             mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext);
@@ -305,7 +307,7 @@ struct V8T {
   template <int HP>
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
                                                     float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
-                                                    float* pred_out, float readout_div, float* stash, int tid STAMP_DECL) {
+                                                    float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, float*) {
     w8::predictor_entry<HP, SP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
                             mg.pub_ch, tid STAMP_ARGS);
   }
@@ -423,7 +425,9 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
         if (is_step == false && mode == MODE_SAMPLE)               // z_0 is final: publish it
           for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
         const int split = P.split;
-        if (split != 2) V::template edm<HPE>(edm, mg, net, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
+        if (split != 2)
+          V::template edm<HPE>(edm, mg, net, sZ, sEps, sMean, t_val, tid STAMP_ARGS,
+                               V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr);
         if (mode == MODE_PHI) {
           for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
         } else if (is_step) {
@@ -449,7 +453,8 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
               V::template guide<HPP>(P.pred, mg, net, sZ, sEps /* grad */, sNz /* scratch */, sMean, t_step, sigma_step,
                                    P.target_w, P.scale, split == 1 ? P.pred_out + (size_t)b * P.pred.K : nullptr,
                                    P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS, split,
-                                   split == 2 ? P.dpred_in + (size_t)b * P.pred.K : nullptr);
+                                   split == 2 ? P.dpred_in + (size_t)b * P.pred.K : nullptr,
+                                   V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr);
             }
           }
           if (split == 1) break;  // phase A ends before the projection: phase B resumes from this z_s
@@ -525,11 +530,40 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
       return;
     }
   }
-  if constexpr (HPP > 0 && HPE == 0) {  // unit-test modes live in the predictor-only kernels
+  if constexpr (HPP > 0 && HPE == 0) {
+    if (P.mode == MODE_GUIDE) {
+      // Second half of a guided reverse step as its own launch (the V4G path: its fused EDM + predictor instantiation at the
+      // default widths sits on the register cliff, so large molecules run "EDM-only kernel with split = 1, then this"):
+      // z_in = z_s before guidance (en_diffusion.py:897) -> guidance update, projection, NaN scrub (:899-934) -> z_out.
+      const f4 cf = *(const f4*)(P.coef + 4 * P.s_hi);
+      V::template guide<HPP>(P.pred, mg, net, sZ, sEps /* grad */, sNz /* scratch */, sMean, cf[3], cf[2], P.target_w, P.scale, nullptr,
+                             P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS, 0, nullptr,
+                             V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr);
+      col_means(sZ);
+      __syncthreads();
+      for (int e = tid; e < N * 3; e += kThreads) {
+        const int n = e / 3, d = e % 3;
+        sZ[n * D + d] = sZ[n * D + d] - sMean[d] * sMask[n];
+      }
+      __syncthreads();
+      int bad = 0;
+      for (int e = tid; e < N * D; e += kThreads) bad += sZ[e] != sZ[e];
+      if (__syncthreads_or(bad)) {
+        for (int e = tid; e < N * D; e += kThreads) {
+          float v = sZ[e];
+          sZ[e] = v != v ? 0.f : fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+        }
+        __syncthreads();
+      }
+      if (bad) atomicAdd(P.nan_count, bad);
+      for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
+    }
+    // unit-test modes live in the predictor-only kernels
     if (P.mode == MODE_PRED_FWD || P.mode == MODE_PRED_GRAD) {
       const float* dp = P.dpred_in ? P.dpred_in + (size_t)b * P.pred.K : nullptr;
       V::template pred_entry<HPP>(P.pred, mg, net, sZ, sEps, sNz, sMean, P.t_in[b], dp, P.mode == MODE_PRED_GRAD,
-                           P.pred_out + (size_t)b * P.pred.K, P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS);
+                           P.pred_out + (size_t)b * P.pred.K, P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS,
+                           V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr);
       if (P.mode == MODE_PRED_GRAD)
         for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
     }

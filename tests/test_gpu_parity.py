@@ -275,7 +275,10 @@ def test_error_paths():
     with pytest.raises(GaudiError, match="edge_mlp.2.weight"):
         eng.load_edm(eargs, broken)
     eng.load_edm(eargs, esd)
-    N = 40  # 40 nodes of a 192-wide net do not fit 160 KiB of LDS
+    N = 40  # 40 nodes of a 192-wide net do not fit 160 KiB of LDS: the call moves the node buffers to global memory (V4G)
+    out = eng.phi(np.zeros((1, N, 4), np.float32), 0.5, np.ones((1, N)), np.ones((1, N, N)) - np.eye(N))
+    assert out.shape == (1, N, 4) and np.isfinite(out).all() and eng.kernel_variant()[1] == 4
+    N = 100  # ... but the edge lists of a complete 100-node graph (9900 edges) do not fit either way
     with pytest.raises(GaudiError, match="LDS"):
         eng.phi(np.zeros((1, N, 4), np.float32), 0.5, np.ones((1, N)), np.ones((1, N, N)) - np.eye(N))
     with pytest.raises(GaudiError, match="predictor"):

@@ -150,10 +150,10 @@ def test_large_molecules_vs_oracle(N):
     w = O.target_max_gap_weights(5)
     gamma = O.gamma_table("polynomial_2", T, 1e-5)
     eng = _engine(eargs, esd, pargs, psd)
-    assert rel_err(eng.phi(z, t, nm, em), O.edm_phi(esd, eargs, z, t, nm, em)) < 1e-4
-    assert eng.kernel_variant()[1] == 4
+    assert rel_err(eng.phi(z, t, nm, em), O.edm_phi(esd, eargs, z, t, nm, em)) < 1e-4  # (N = 24 alone still fits an 8-wave EDM kernel)
     dp = np.broadcast_to(w * np.float32(0.6), (3, 5)).copy()
     pred, grad = eng.predictor_grad(z, t, nm, em, dp)
+    assert eng.kernel_variant()[1] == 4  # the predictor of a graph this size: 4 waves, node buffers in global memory
     opred, ograd = O.predictor_grad(psd, pargs, z, nm, em, t, dp)
     assert rel_err(pred, opred) < 1e-4 and rel_err(grad, ograd) < 1e-4
     assert np.abs(grad * (1 - nm)).max() == 0

@@ -17,6 +17,7 @@ for step in "$@"; do
     bench_exp) for v in $GAUDI_VARIANTS; do [ -f gaudi_amd/libgaudi_var_$v.so ] && GAUDI_LIB=$PWD/gaudi_amd/libgaudi_var_$v.so timeout 600 $B > $out/bench_$v.json 2> $out/bench_$v.err; done ;;
     tests_r3) timeout 2400 python3 -m pytest tests/test_gpu_round3.py -x -q -m gpu -s > $out/tests_r3.txt 2>&1
               timeout 600 python3 -m pytest tests/test_gpu_round2.py -x -q -m gpu -k "nan or fresh" >> $out/tests_r3.txt 2>&1 ;;
+    repro_gn) for w in tiny default; do for e in "GAUDI_WAVES=4" "GAUDI_FORCE_GN=1"; do echo "== $w $e" >> $out/repro_gn.txt; env $e timeout 300 python3 tools/repro_gn.py $w >> $out/repro_gn.txt 2>&1; done; done ;;
     bench) timeout 900 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench.json 2> $out/bench.err ;;
     bench_dist) timeout 600 $B --dist > $out/bench_dist.json 2> $out/bench_dist.err ;;
     *) echo "unknown step $step" ;;
