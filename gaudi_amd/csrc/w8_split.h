@@ -153,11 +153,29 @@ template <int HP, int MODE>
 __device__ __forceinline__ void rings_start(RingS<HP, MODE>& r, const WBuf&, int W, int wave, int lane) {
   rings_dma(r, r.slot(r.par), W, -1, 0, wave, lane);
 }
+#ifndef GAUDI_RING_PREFETCH
+#define GAUDI_RING_PREFETCH 0  // experiment: touch the group of trip tr + 2 (one dword per 128-byte line) so that its LDS-DMA hits L2
+#endif
 // trip tr has passed its opening barrier: nobody reads slot(par ^ 1) any more; the group of trip tr + 1 must have landed
 // at the next barrier (trip_barrier waits vmcnt(0))
 template <int HP, int MODE>
 __device__ __forceinline__ void rings_stage(RingS<HP, MODE>& r, const WBuf&, int W, int nextW, int tr, int wave, int lane) {
   rings_dma(r, r.slot(r.par ^ 1), W, nextW, tr + 1, wave, lane);
+#if GAUDI_RING_PREFETCH
+  // The weight set (58 MB) streams through a 4 MiB L2 once per step: the first CU of an XCD to ask for a line waits for the
+  // Infinity Cache.  Each wave touches 64 lines (8 KiB) of the group after next; the value is discarded.
+  {
+    int off, units;
+    if (trip_group(r, W, nextW, tr + 2, off, units)) {
+      const int line = wave * 64 + lane;  // 128-byte lines of the group
+      if (line < units * 8) {
+        float dummy;
+        const float* p = r.gbase + off + line * 32;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(p) : "memory");
+      }
+    }
+  }
+#endif
 }
 #else
 // register staging (kept for comparison: tools/split_gemm_microbench.hip): loads issued two trips ahead, stored mid-trip

@@ -151,6 +151,52 @@ class GaudiModel:
         self.sample_offset = 0
         self.injected_noise = None  # [T+2,B,N,3+F] raw draws (parity tests); None -> on-device Philox
         self.last_diag = None
+        import weakref
+        GaudiModel._latest = weakref.ref(self)
+
+    _latest = None
+
+    @classmethod
+    def latest(cls):
+        """The GaudiModel created last that is still alive (what get_cond_predictor_model(args, dataset) attaches to)."""
+        m = cls._latest() if cls._latest is not None else None
+        return m if m is not None and getattr(m.engine, "h", None) else None
+
+    def _trace_closure(self, target):
+        """An opaque target closure over (z, node_mask, edge_mask, t), as generation_guidance.py:198-211 writes them
+        (``lambda z, nm, em, t: -cond_predictor(z, nm, em, t)[:, 1]``), turned into a PredTarget: while the closure runs, the
+        predictor attached to this model returns a stand-in tensor, so torch.autograd yields dT/dpred for the GPU reverse
+        pass.  The closure may be ANY differentiable torch function of the predictor outputs and t; a direct dependence on
+        z (outside the predictor) cannot be followed on the GPU and is refused."""
+        cp = getattr(self, "cond_predictor", None)
+        if cp is None:
+            raise GaudiError("guidance with a target closure needs get_cond_predictor_model(...) on this model first")
+        model = self
+
+        def fn(pred, t):
+            import torch
+            B = pred.shape[0]
+            # stand-in z (deterministic, non-zero: a direct dependence must show up in its gradient; torch's default generator
+            # is not touched -- it keys the noise)
+            shape = (B, model._trace_N, 3 + model.in_node_nf)
+            probe = (0.25 + torch.linspace(0.0, 1.0, int(np.prod(shape))).reshape(shape)).requires_grad_(True)
+            nm = torch.from_numpy(model._trace_nm)
+            em = torch.from_numpy(model._trace_em)
+            cp._override, cp._override_used = pred, False
+            try:
+                val = target(probe, nm, em, torch.full((B, 1), float(t)))
+            finally:
+                cp._override = None
+            if not torch.is_tensor(val) or val.shape[0] != B:
+                raise GaudiError("the target function must return one value per molecule (a torch tensor [B])")
+            if val.requires_grad:
+                (gz,) = torch.autograd.grad(val.sum(), probe, allow_unused=True, retain_graph=True)
+                if gz is not None and bool((gz != 0).any()):
+                    raise GaudiError("the target function depends on z directly (outside cond_predictor): only functions of the "
+                                     "predictor outputs and t can be differentiated on the GPU")
+            return val
+
+        return PredTarget(cp, fn, name=getattr(target, "__name__", "closure"))
 
     def eval(self):
         return self
@@ -187,11 +233,11 @@ class GaudiModel:
         tw = None
         if target is not None:
             if not isinstance(target, (LinearTarget, PredTarget)):
-                raise GaudiError(
-                    "target_function must be a gaudi_amd.models_edm.LinearTarget (target_function_max_gap / "
-                    "target_function_opv: fused in-kernel guidance) or a PredTarget(cond_predictor, fn(pred, t)) for any "
-                    "other differentiable function of the predictor outputs; an opaque closure over (z, masks, t) "
-                    "cannot be differentiated on the GPU and there is no CPU fallback")
+                if not callable(target):
+                    raise GaudiError("target_function must be callable")
+                # the reference's own form: a closure over (z, node_mask, edge_mask, t) that calls cond_predictor
+                self._trace_N, self._trace_nm, self._trace_em = N, nm.reshape(B, N, 1), em.reshape(B * N * N, 1)
+                target = self._trace_closure(target)
             if target.cond_predictor.engine is not self.engine:
                 raise GaudiError("the target's predictor must be attached to this model (get_cond_predictor_model(..., model=model))")
         seed, off = self.next_stream(B)
@@ -247,7 +293,12 @@ class CondPredictor:
     def eval(self):
         return self
 
+    _override = None  # set while a target closure is being traced (GaudiModel._trace_closure): the stand-in prediction
+
     def __call__(self, xh, node_mask, edge_mask, t=0.0):
+        if self._override is not None:
+            self._override_used = True
+            return self._override
         z = _to_numpy(xh).astype(np.float32)
         B, N, _ = z.shape
         tt = np.broadcast_to(_to_numpy(t).astype(np.float32).reshape(-1), (B,)) if np.ndim(_to_numpy(t)) else float(t)
@@ -273,10 +324,14 @@ def get_model(args, dataloader_train=None, only_norm=True, device: int = 0, stat
 
 
 def get_cond_predictor_model(args, dataset=None, model: GaudiModel | None = None, state_dict=None) -> CondPredictor:
-    """cond_prediction/train_cond_predictor.py:183-203, attached to ``model``'s GPU handle so that guidance runs
-    inside the same kernel launch as the denoiser."""
+    """cond_prediction/train_cond_predictor.py:183-203 with the reference's own call shape ``(args, dataset)``: the predictor
+    is attached to a GaudiModel's GPU handle so that guidance runs inside the same kernel launch as the denoiser --
+    ``model`` if given, otherwise the model ``get_model`` created last (the order of generation_guidance.py:190-195)."""
     if model is None:
-        raise GaudiError("pass model=<GaudiModel>: the predictor shares the EDM's device handle")
+        model = GaudiModel.latest()
+        if model is None:
+            raise GaudiError("get_cond_predictor_model: call get_model first (the predictor shares the EDM's device handle) "
+                             "or pass model=<GaudiModel>")
     a = checkpoint.args_dict(args)
     if state_dict is None:
         state_dict = checkpoint.load_state_dict(a["exp_dir"])

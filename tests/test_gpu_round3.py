@@ -211,3 +211,49 @@ def test_amplified_default_architecture_steps_vs_reference(golden, name, math):
             assert rel_err(zu, g[f"{name}_s{s}_zs_unguided_{tag}"]) < 1e-4, (s, tag)
             assert rel_err(zg, g[f"{name}_s{s}_zs_guided_{tag}"]) < 1e-4, (s, tag)
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ the reference's closure targets
+def test_reference_style_closure_targets_and_call_shape(golden):
+    """generation_guidance.py:190-211 as written: get_model(...), then get_cond_predictor_model(args, dataset) with NO model
+    argument, then a target function that is a plain closure over (z, node_mask, edge_mask, t) calling cond_predictor --
+    the linear gap target and a nonlinear one (g10: the reference's own guided chain with that nonlinear closure)."""
+    import json as _json
+    import types
+
+    import torch
+
+    from gaudi_amd import sampling_edm
+    from gaudi_amd._lib import GaudiError
+    from gaudi_amd.models_edm import get_cond_predictor_model, get_model, target_function_max_gap
+    from tests.helpers import TINY, TINY_P
+    g = golden("g10_nonlinear_target")
+    cfg = _json.loads(str(g["chain_cfg"]))
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=TINY, wseed=cfg["eseed"], amp=False), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["pseed"], amp=False))
+    model, _, _ = get_model(eargs, state_dict=esd)
+    cond_predictor = get_cond_predictor_model(pargs, None, state_dict=psd)  # (args, dataset): attaches to the model made last
+    assert cond_predictor.engine is model.engine
+    model.injected_noise = g["chain_noise"]
+    args = types.SimpleNamespace(device="cuda", dataset="hetro", max_nodes=10)
+
+    def target_nonlinear(_input, _node_mask, _edge_mask, _t):  # the closure tools/make_golden.py gave the reference
+        p = cond_predictor(_input, _node_mask, _edge_mask, _t)
+        return 0.5 * torch.log1p(p[:, 1] ** 2) + 0.1 * torch.tanh(p[:, 0]) * p[:, 3] + _t[:, 0] * p[:, 2]
+
+    x, h, nm, em = sampling_edm.sample_guidance(args, model, target_nonlinear, cfg["nodes"], scale=0.6)
+    assert rel_err(x.numpy(), g["chain_x"]) < 1e-4 and np.array_equal(h.numpy(), g["chain_h"])
+
+    def target_function_max_gap_ref(_input, _node_mask, _edge_mask, _t):  # generation_guidance.py:200-203 verbatim shape
+        return -cond_predictor(_input, _node_mask, _edge_mask, _t)[:, 1]
+
+    xa, ha, _, _ = sampling_edm.sample_guidance(args, model, target_function_max_gap_ref, cfg["nodes"], scale=0.6)
+    xb, hb, _, _ = sampling_edm.sample_guidance(args, model, target_function_max_gap(cond_predictor), cfg["nodes"], scale=0.6)
+    assert rel_err(xa.numpy(), xb.numpy()) < 1e-4 and np.array_equal(ha.numpy(), hb.numpy())  # callback path vs fused path
+
+    def target_direct(_input, _node_mask, _edge_mask, _t):  # depends on z outside the predictor: refused loudly
+        return (_input[:, :, :3] ** 2).sum((1, 2)) - cond_predictor(_input, _node_mask, _edge_mask, _t)[:, 1]
+
+    with pytest.raises(GaudiError, match="depends on z directly"):
+        sampling_edm.sample_guidance(args, model, target_direct, cfg["nodes"], scale=0.6)
+    model.engine.close()
