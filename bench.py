@@ -316,7 +316,9 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                    "edm": "nf=192,n_layers=9", "predictor": "nf=196,n_layers=12" if guided else None,
                    "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
                    "steps_per_launch": a.steps_per_launch,
-                   "max_graph_nodes": "22 at these hidden sizes (one molecule's working set must fit 160 KiB of LDS)"},
+                   "max_graph_nodes": "resident kernels: 22 at these hidden sizes (one molecule's node buffers in 160 KiB of LDS); "
+                                      "beyond that the V4G kernels (node buffers in global memory): checked at N = 40, bounded "
+                                      "by the edge lists in LDS (a complete graph of about 60 nodes)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": frac, "traffic": traffic,
                      "kernel": "sampler_kernel_v<%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
@@ -326,11 +328,12 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                                         "w8s": "8 waves per molecule (two per SIMD); edge GEMMs: fp32 operands split exactly "
                                                "into 3 bf16 pieces, 6 piece products accumulated in fp32 on the bf16 matrix "
                                                "pipe (error vs float64 at the level of the fp32 instruction's own: tests/test_gpu_split.py); "
-                                               "node GEMMs: fp32 matrix instructions"}[variant],
+                                               "node GEMMs: fp32 matrix instructions (the 4-valid-row tail tile on 4x4x1 blocks); "
+                                               "activation stash written / read non-temporally"}[variant],
                      "flops_basis": "issued matrix instructions counted from the kernel's loop structure (padding included): "
-                                    "v_mfma_f32_16x16x4_f32 x 2048 FLOP at 157.3 TFLOP/s + v_mfma_f32_16x16x32_bf16 x 16384 FLOP "
-                                    "at 2516.6 TFLOP/s; frac = matrix-pipe time at peak / launch time; = SQ_INSTS_VALU_MFMA_MOPS_"
-                                    "F32 / 4 and _BF16 / 32 in profiles/",
+                                    "v_mfma_f32_16x16x4_f32 equivalents (a 4x4x1_16B instruction = 1/4) x 2048 FLOP at 157.3 TFLOP/s + "
+                                    "v_mfma_f32_16x16x32_bf16 x 16384 FLOP at 2516.6 TFLOP/s; frac = matrix-pipe time at peak / launch "
+                                    "time; = SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 and _BF16 / 32 in profiles/",
                      "issued_fp32_mfma_per_launch": per_launch[0], "issued_bf16_mfma_per_launch": per_launch[1],
                      "peak_fp32_matrix_tflops": flops.PEAK_F32_TFLOPS, "peak_bf16_matrix_tflops": flops.PEAK_BF16_TFLOPS,
                      "fp32_equivalent_tflops": equiv_launch / t_launch / 1e12,

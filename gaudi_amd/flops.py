@@ -74,6 +74,8 @@ def _has_ktail(nf, HP):
 def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4"):
     """(fp32, bf16) matrix instructions ONE molecule issues per reverse step, counted from the kernels' loop structure
     (validated against SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 and SQ_INSTS_VALU_MFMA_MOPS_BF16 / 32: profiles/*pmc_summary.csv).
+    fp32 = v_mfma_f32_16x16x4_f32 EQUIVALENTS (1 024 MACs, 32 matrix-pipe cycles on a SIMD): a 4x4x1_16B instruction of the
+    node GEMMs' tail tile counts 0.25.
 
     variant "w4"  (4 waves, 32-edge passes):  edge_units = list of 32-edge passes per wave [4]
     variant "w8"  (8 waves, 16-edge tiles, fp32 MFMAs):        edge_units = number of 16-edge tiles of the molecule
@@ -88,8 +90,13 @@ def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4"):
     else:
         waves, tiles16 = 8, int(edge_units)
 
-    def node(T, kt):  # K chunks x 4 k-steps x output tiles (the 4-wave kernels recompute a tile in idle tile slots)
-        return kt * 4 * ((-(-T // waves)) * waves if variant == "w4" else T) * nt
+    def node(T, kt, nf):  # K chunks x 4 k-steps x output tiles (the 4-wave kernels recompute a tile in idle tile slots)
+        if variant == "w4":
+            return kt * 4 * (-(-T // waves)) * waves * nt
+        # 8-wave kernels, widths with a tail tile (196 -> 208, 36 -> 48): that tile issues v_mfma_f32_4x4x1_16B_f32, a quarter of a
+        # 16x16x4 instruction each in MACs and in matrix-pipe cycles (w8_common.h: tail_lane) -> 0.25 instruction-equivalents
+        tail44 = _has_ktail(nf, 16 * T) and 16 * T in (208, 48)
+        return kt * 4 * (T - 0.75 if tail44 else T) * nt
 
     def edge(T, nf):  # one 16-edge tile through one T x T matrix -> (fp32, bf16)
         tail = variant != "w4" and _has_ktail(nf, 16 * T)
@@ -103,14 +110,14 @@ def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4"):
     Te = _pad_hidden_kernel(edm["nf"]) // 16
     L, S = edm["n_layers"], edm.get("inv_sublayers", 1)
     e32, ebf = edge(Te, edm["nf"])
-    f32 += L * (S * (node(Te, 5 * Te) + tiles16 * e32) + node(Te, 2 * Te) + tiles16 * e32)
+    f32 += L * (S * (node(Te, 5 * Te, edm["nf"]) + tiles16 * e32) + node(Te, 2 * Te, edm["nf"]) + tiles16 * e32)
     bf += L * (S + 1) * tiles16 * ebf
     if pred is not None:
         Tp = _pad_hidden_kernel(pred["nf"]) // 16
         Lp = pred["n_layers"]
         e32, ebf = edge(Tp, pred["nf"])
         n_edge = 2 * (2 * Lp - 1)  # W2 + Wc1 per layer (no Wc1 in the last), the same again transposed in the reverse pass
-        f32 += 2 * Lp * node(Tp, 5 * Tp) + n_edge * tiles16 * e32
+        f32 += 2 * Lp * node(Tp, 5 * Tp, pred["nf"]) + n_edge * tiles16 * e32
         bf += n_edge * tiles16 * ebf
     return f32, bf
 
