@@ -411,7 +411,7 @@ def main():
         if world == 1 and not a.no_secondary and a.workload == "c3":
             # the other single-GPU configurations, timed by the same harness (short: one or two calls each)
             sec = {}
-            for wl, b, st, wu, math in (("c2", 256, 2, 1, None), ("c4", 1024, 1, 0, None), ("c3_b1024", 1024, 1, 0, None),
+            for wl, b, st, wu, math in (("c2", 256, 2, 1, None), ("c4", 1024, 2, 1, None), ("c3_b1024", 1024, 2, 1, None),
                                         ("c3_fp32_mfma", 256, 2, 1, "fp32"), ("c2_fp32_mfma", 256, 2, 1, "fp32")):
                 r = run_workload(a, engines, wl.split("_")[0], b, st, wu, rank, world, dev, backend, T, edge_math=math)
                 sec[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": st,
