@@ -111,6 +111,15 @@ __device__ __forceinline__ float reduce_groups(float v) {
   return v;
 }
 
+// bitwise OR of `mask` (bits 0 .. nbits-1) over the workgroup.  __syncthreads_or returns a truth value, not the OR of the
+// arguments: one reduction tells whether anything is set (the common case: nothing), then one per bit.
+__device__ __forceinline__ int block_or_bits(int mask, int nbits) {
+  if (!__syncthreads_or(mask)) return 0;
+  int out = 0;
+  for (int k = 0; k < nbits; ++k)
+    if (__syncthreads_or(mask & (1 << k))) out |= 1 << k;
+  return out;
+}
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in order; this only stops the compiler from moving
   // LDS accesses across and drains the LDS queue.

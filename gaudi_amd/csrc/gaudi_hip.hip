@@ -56,13 +56,16 @@ struct gaudi_handle {
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
       d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols, d_soff,
-      d_sidx, d_gnode;
+      d_sidx, d_gnode, d_rowmap, d_compmol, d_ncomp;
   int steps_per_launch = 25;
   int variant = 8;            // 8 = two waves per SIMD (sampler_kernel8, default), 4 = one wave per SIMD (GAUDI_WAVES=4)
   int run_variant = 4;        // what the CURRENT call runs on (an 8-wave handle falls back to 4 waves for graphs that do not fit)
   bool split = true;          // 8-wave kernels: edge GEMMs on the bf16 matrix pipe with 3-way split operands (GAUDI_EDGE_MATH=fp32: off)
   int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
   bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
+  bool pack = true;           // several small molecules per workgroup in sampling calls (GAUDI_PACK=0: off)
+  bool pack_now = false;      // set by run_chain around stage_graph: this call may pack
+  int run_groups = 0;         // workgroups of the CURRENT call (= molecules unless packed)
   bool force_gn = false;      // GAUDI_FORCE_GN=1 at gaudi_create: use them whenever they exist (test knob)
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
   long long fix_key = 0;      // global sample index whose Philox stream is shared
@@ -408,8 +411,10 @@ struct Meta8 {
   std::vector<uint16_t> soff, sidx;
 };
 
+// align: [B][N] flags or nullptr -- a node whose flag is set starts its edge run at a tile boundary (packed launches: the
+// first node of every component, so that a molecule's tiles are the ones it has on its own)
 static int build_meta8(int B, int N, const float* node_mask, const float* edge_mask, Meta8& M, std::string& err,
-                       int min_slots = 0) {
+                       int min_slots = 0, const uint8_t* align = nullptr) {
   if (N > 255) {
     err = "N > 255 unsupported";
     return GAUDI_E_CAPACITY;
@@ -429,6 +434,7 @@ static int build_meta8(int B, int N, const float* node_mask, const float* edge_m
     std::vector<Slot>& sl = slots[b];
     runs[b].assign(N, {0, 0});
     int last = 0;
+    bool want_align = false;
     for (int i = 0; i < N; ++i) {
       const bool li = node_mask == nullptr || node_mask[(size_t)b * N + i] != 0.f;
       if (li) last = i;
@@ -442,6 +448,7 @@ static int build_meta8(int B, int N, const float* node_mask, const float* edge_m
         }
       }
       const int L = (int)run.size();
+      if (align != nullptr && align[(size_t)b * N + i]) want_align = true;  // (kept pending over nodes without a run)
       if (L == 0) {
         runs[b][i] = {(int)sl.size(), 0};
         continue;
@@ -450,6 +457,11 @@ static int build_meta8(int B, int N, const float* node_mask, const float* edge_m
         err = "a node with more than 32 live edges is not supported by the 8-wave kernels";
         return GAUDI_E_CAPACITY;
       }
+      if (want_align && !sl.empty()) {  // first run of a component: start a new tile
+        const int prev_i = sl.back().i;
+        while (sl.size() % 16) sl.push_back({prev_i, prev_i, 0.f, false});
+      }
+      want_align = false;
       const int o = (int)sl.size() % 16;
       if ((o + L + 15) / 16 > 2) {  // would straddle three tiles: start at the next tile boundary
         const int prev_i = sl.empty() ? i : sl.back().i;
@@ -729,6 +741,82 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
   return GAUDI_OK;
 }
 
+// Packed launches: groups of molecules, each group one graph of N node slots
+struct Pack {
+  int G = 0;
+  std::vector<float> umask, uemask;   // [G][N], [G][N][N]: the union graphs
+  std::vector<uint8_t> align;         // [G][N]: first slot of every component (tile alignment in build_meta8)
+  std::vector<int32_t> rowmap;        // [G][N]: slot -> molecule * N + node | component << 28, or -1
+  std::vector<int32_t> compmol;       // [G][kMaxComp]
+  std::vector<int32_t> ncomp;         // [G]
+};
+static void pack_groups(int B, int N, const float* node_mask, const float* edge_mask, const Meta8& M, Pack& pk) {
+  // nodes a molecule needs slots for: live ones and any node that touches a live edge, in their own order
+  std::vector<std::vector<int>> used(B);
+  for (int b = 0; b < B; ++b) {
+    std::vector<char> keep(N, 0);
+    for (int i = 0; i < N; ++i) {
+      const bool li = node_mask[(size_t)b * N + i] != 0.f;
+      if (li) keep[i] = 1;
+      for (int j = 0; j < N; ++j) {
+        const bool lj = node_mask[(size_t)b * N + j] != 0.f;
+        if (edge_mask[((size_t)b * N + i) * N + j] != 0.f && (li || lj)) keep[i] = keep[j] = 1;
+      }
+    }
+    for (int i = 0; i < N; ++i)
+      if (keep[i]) used[b].push_back(i);
+  }
+  struct Group {
+    std::vector<int> mols;
+    int nodes = 0, tiles = 0;
+  };
+  std::vector<Group> groups;
+  for (int b : M.order) {  // heaviest first
+    const int nn = (int)used[b].size(), nt = M.ntiles[b];
+    Group* fit = nullptr;
+    for (Group& g : groups)
+      if ((int)g.mols.size() < kMaxComp && g.nodes + nn <= N && g.tiles + nt <= w8::kWaves) {
+        fit = &g;
+        break;
+      }
+    if (!fit) {
+      groups.emplace_back();
+      fit = &groups.back();
+    }
+    fit->mols.push_back(b);
+    fit->nodes += nn;
+    fit->tiles += nt;
+  }
+  const int G = (int)groups.size();
+  pk.G = G;
+  pk.umask.assign((size_t)G * N, 0.f);
+  pk.uemask.assign((size_t)G * N * N, 0.f);
+  pk.align.assign((size_t)G * N, 0);
+  pk.rowmap.assign((size_t)G * N, -1);
+  pk.compmol.assign((size_t)G * kMaxComp, 0);
+  pk.ncomp.assign(G, 0);
+  std::vector<int> slot_of(N);
+  for (int g = 0; g < G; ++g) {
+    int base = 0;
+    for (size_t k = 0; k < groups[g].mols.size(); ++k) {
+      const int b = groups[g].mols[k];
+      pk.compmol[(size_t)g * kMaxComp + k] = b;
+      std::fill(slot_of.begin(), slot_of.end(), -1);
+      for (size_t r = 0; r < used[b].size(); ++r) slot_of[used[b][r]] = base + (int)r;
+      if (!used[b].empty()) pk.align[(size_t)g * N + base] = 1;
+      for (int i : used[b]) {
+        const int si = slot_of[i];
+        pk.umask[(size_t)g * N + si] = node_mask[(size_t)b * N + i];
+        pk.rowmap[(size_t)g * N + si] = (b * N + i) | ((int32_t)k << 28);
+        for (int j : used[b])
+          pk.uemask[((size_t)g * N + si) * N + slot_of[j]] = edge_mask[((size_t)b * N + i) * N + j];
+      }
+      base += (int)used[b].size();
+    }
+    pk.ncomp[g] = (int)groups[g].mols.size();
+  }
+}
+
 // upload masks + metadata, fill the graph part of KParams
 // -> GAUDI_OK, or a positive value = "run this call on the 4-wave kernels" (graph outside the 8-wave kernels' limits)
 static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P, int hpe,
@@ -740,6 +828,29 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   if (rc == GAUDI_E_CAPACITY) return 1;
   if (rc) return fail(h, rc, err);
   if (hpp && M.S > 16 * w8::kWaves) return 1;  // the 8-wave predictor handles one round of tiles
+  // ---- packing: small molecules share a workgroup as the components of one graph (sampling calls only).  First-fit in
+  // the heaviest-first order; a group holds at most kMaxComp molecules, N node slots and 8 edge tiles (one round on 8
+  // waves).  A molecule keeps its own tiles (component starts are tile-aligned), its nodes keep their relative order, its
+  // noise is keyed by its own sample and node indices, and every per-molecule reduction runs per component in the order
+  // the molecule's own workgroup would use: the result does not depend on the packing, bit for bit.
+  Pack pk;
+  const int B0 = B;
+  const float* nm_used = node_mask;
+  if (h->pack_now && h->pack && B > 1) {
+    pack_groups(B, N, node_mask, edge_mask, M, pk);
+    if (pk.G < B) {
+      Meta8 M2;
+      rc = build_meta8(pk.G, N, pk.umask.data(), pk.uemask.data(), M2, err, M.S, pk.align.data());
+      if (rc == GAUDI_OK && M2.S <= std::max(M.S, 16 * w8::kWaves)) {
+        M = std::move(M2);
+        B = pk.G;
+        nm_used = pk.umask.data();
+      } else {
+        pk.G = B0;  // (cannot happen by construction; keep the unpacked plan)
+      }
+    }
+  }
+  const bool packed = B != B0;
   if (!pick_kernel8(hpe, hpp)) return 1;
   int pubx = 0, pub_ch = 0;
   const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
@@ -758,7 +869,12 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
     return hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, h->stream);
   };
   HIPCHECK(h, up(h->d_ncols, M.ncols.data(), sizeof(int) * B));
-  HIPCHECK(h, up(h->d_mask, node_mask, sizeof(float) * B * N));
+  HIPCHECK(h, up(h->d_mask, nm_used, sizeof(float) * B * N));
+  if (packed) {
+    HIPCHECK(h, up(h->d_rowmap, pk.rowmap.data(), sizeof(int32_t) * pk.rowmap.size()));
+    HIPCHECK(h, up(h->d_compmol, pk.compmol.data(), sizeof(int32_t) * pk.compmol.size()));
+    HIPCHECK(h, up(h->d_ncomp, pk.ncomp.data(), sizeof(int32_t) * pk.ncomp.size()));
+  }
   HIPCHECK(h, up(h->d_order, M.order.data(), sizeof(int) * B));
   HIPCHECK(h, up(h->d_edges, M.edges.data(), sizeof(uint32_t) * M.edges.size()));
   HIPCHECK(h, up(h->d_emask, M.emask.data(), sizeof(float) * M.emask.size()));
@@ -779,6 +895,10 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   P.ncols = h->d_ncols.as<int>();
   P.soff = h->d_soff.as<uint16_t>();
   P.sidx = h->d_sidx.as<uint16_t>();
+  P.rowmap = packed ? h->d_rowmap.as<int32_t>() : nullptr;
+  P.compmol = packed ? h->d_compmol.as<int32_t>() : nullptr;
+  P.ncomp = packed ? h->d_ncomp.as<int32_t>() : nullptr;
+  h->run_groups = B;
   return GAUDI_OK;
 }
 
@@ -789,6 +909,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   h->run_variant = h->variant;
   h->run_split = 0;
   h->run_gn = false;
+  h->run_groups = B;
   if (h->variant == 8 && !h->force_gn) {
     const int rc8 = stage_graph8(h, B, N, node_mask, edge_mask, P, hpe, hpp);
     if (rc8 <= 0) return rc8;
@@ -884,6 +1005,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_WAVES")) h->variant = atoi(v) == 4 ? 4 : 8;
   if (const char* v = getenv("GAUDI_EDGE_MATH")) h->split = std::string(v) != "fp32";
   if (const char* v = getenv("GAUDI_FORCE_GN")) h->force_gn = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_PACK")) h->pack = atoi(v) != 0;
   h->run_variant = h->variant;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -903,7 +1025,7 @@ void gaudi_destroy(gaudi_handle* h) {
                     &h->d_seg, &h->d_zin, &h->d_zout, &h->d_t, &h->d_x, &h->d_h, &h->d_noise, &h->d_nan, &h->d_dpred,
                     &h->d_pred, &h->d_tw, &h->d_stash, &h->d_chain, &h->d_sx, &h->d_stype, &h->d_sn,
                     &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as, &h->d_ncols, &h->d_soff, &h->d_sidx,
-                    &h->d_gnode};
+                    &h->d_gnode, &h->d_rowmap, &h->d_compmol, &h->d_ncomp};
   for (DevBuf* b : bufs) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1126,7 +1248,9 @@ static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, cons
   if (target_w && !h->has_pred) return fail(h, GAUDI_E_STATE, "guided sampling needs predictor weights");
   HIPCHECK(h, hipSetDevice(h->device));
   KParams P{};
+  h->pack_now = chain_out == nullptr;  // sampling calls may pack small molecules into one workgroup (stage_graph8)
   int rc = stage_graph(h, B, N, node_mask, edge_mask, P, h->HPE, target_w ? h->HPP : 0);
+  h->pack_now = false;
   if (rc) return rc;
   fill_edm(h, P);
   const int D = 3 + P.F, T = P.T;
@@ -1138,6 +1262,12 @@ static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, cons
   HIPCHECK(h, h->d_h.reserve(sizeof(float) * B * N * P.F));
   HIPCHECK(h, h->d_nan.reserve(sizeof(int)));
   HIPCHECK(h, hipMemsetAsync(h->d_nan.p, 0, sizeof(int), h->stream));
+  if (P.rowmap != nullptr) {  // packed: masked nodes have no slot in any workgroup -- their rows stay zero
+    HIPCHECK(h, hipMemsetAsync(h->d_zin.p, 0, zb, h->stream));
+    HIPCHECK(h, hipMemsetAsync(h->d_zout.p, 0, zb, h->stream));
+    HIPCHECK(h, hipMemsetAsync(h->d_x.p, 0, sizeof(float) * B * N * 3, h->stream));
+    HIPCHECK(h, hipMemsetAsync(h->d_h.p, 0, sizeof(float) * B * N * P.F, h->stream));
+  }
   if (z_in) HIPCHECK(h, hipMemcpyAsync(h->d_zin.p, z_in, zb, hipMemcpyHostToDevice, h->stream));
   const bool fixn = h->fix_noise && do_init;  // whole-chain calls only (gaudi_step / gaudi_decode inject per-molecule draws)
   const size_t nzb = fixn ? sizeof(float) * N * D : zb;  // bytes of one raw draw
@@ -1520,6 +1650,28 @@ int gaudi_host_graph_meta8(int B, int N, const float* node_mask, const float* ed
     if (edges_out) std::memcpy(edges_out, M.edges.data(), sizeof(uint32_t) * M.edges.size());
     if (emask_out) std::memcpy(emask_out, M.emask.data(), sizeof(float) * M.emask.size());
     if (sidx_out) std::memcpy(sidx_out, M.sidx.data(), sizeof(uint16_t) * M.sidx.size());
+  }
+  return GAUDI_OK;
+}
+
+int gaudi_host_pack_plan(int B, int N, const float* node_mask, const float* edge_mask, int32_t* groups_out, int32_t* group_of_out,
+                         int32_t* ntiles_out, int32_t* ncols_out) {
+  if (B <= 0 || N <= 0 || !node_mask || !edge_mask || !groups_out) return GAUDI_E_INVALID;
+  Meta8 M;
+  std::string err;
+  int rc = build_meta8(B, N, node_mask, edge_mask, M, err);
+  if (rc) return rc;
+  Pack pk;
+  pack_groups(B, N, node_mask, edge_mask, M, pk);
+  Meta8 M2;
+  rc = build_meta8(pk.G, N, pk.umask.data(), pk.uemask.data(), M2, err, M.S, pk.align.data());
+  if (rc) return rc;
+  *groups_out = pk.G;
+  for (int g = 0; g < pk.G; ++g) {
+    if (ntiles_out) ntiles_out[g] = M2.ntiles[g];
+    if (ncols_out) ncols_out[g] = M2.ncols[g];
+    if (group_of_out)
+      for (int k = 0; k < pk.ncomp[g]; ++k) group_of_out[pk.compmol[(size_t)g * kMaxComp + k]] = g;
   }
   return GAUDI_OK;
 }

@@ -66,14 +66,23 @@ struct KParams {
   unsigned long long* stamps;  // diagnostic builds only (-DGAUDI_STAMPS): [ST_N] cycle sums of block 0
   float* gnode;                // V4G kernels: [B] x gnode_stride floats, the node buffers of large molecules (edm_device.h: NetSmem GN)
   long long gnode_stride;
+  // Packed launches (gaudi_hip.hip: pack_groups): a workgroup holds up to kMaxComp small molecules as ONE graph with
+  // disconnected components; B = groups, every per-graph array above (node_mask, edges, ...) is per group.
+  const int32_t* rowmap;       // [B][N] node slot -> global row (molecule * N + its node) | component << 28, or -1; nullptr = not packed
+  const int32_t* compmol;      // [B][kMaxComp] molecule index of each component
+  const int32_t* ncomp;        // [B]
 };
+constexpr int kMaxComp = 4;
 
 __host__ __device__ inline int common_floats(int N, int D, int EW) {
-  return 3 * align16(N * D) + align16(N) + 16 + 2 * kWaves * EW + align16(N);
+  return 3 * align16(N * D) + align16(N) + 16 + align16(N) + 16 + 2 * kWaves * EW + align16(N);
 }
 __host__ __device__ inline int common_floats8(int N, int D, int S) {
-  return 3 * align16(N * D) + align16(N) + 16 + 2 * S + align16(N) + align16((N + 1 + S + 1) / 2);
+  return 3 * align16(N * D) + align16(N) + 16 + align16(N) + 16 + 2 * S + align16(N) + align16((N + 1 + S + 1) / 2);
 }
+// node slot -> row word (sRow): global row in bits 0-27, component in bits 28-30; -1 = empty slot (component 7)
+__device__ __forceinline__ int row_of(int w) { return w & 0x0fffffff; }
+__device__ __forceinline__ int comp_of(int w) { return (w >> 28) & 7; }
 
 // ---- kernel variants: what differs between the 4-wave kernels (one wave per SIMD, per-wave edge lists, weights streamed
 // per wave) and the 8-wave kernels (two waves per SIMD, flat 16-slot tiles, LDS-shared weight ring) behind one sampler body
@@ -83,6 +92,7 @@ struct V4T {
   static constexpr bool kGlobalNodes = GN;
   using Graph = gaudi::MolGraph;
   template <int HP> using EdmSmem = gaudi::NetSmem<HP, GN>;
+  __device__ __forceinline__ static void set_rows(Graph&, const int*, int) {}  // the 4-wave kernels are never packed
   __host__ __device__ static int graph_floats(int N, int EW) { return 2 * gaudi::kWaves * EW + align16(N); }
   __device__ __forceinline__ static float* load_graph(const KParams& P, int b, float* base, const float* sMask, Graph& mg, int tid, int wave) {
     const int N = P.N, EW = P.EW;
@@ -139,6 +149,7 @@ using V4G = V4T<true>;  // node buffers in global memory: molecules beyond the L
 // dynamic-LDS symbol itself, so LDS accesses keep their address space (ds_* instructions, not flat_*).
 struct Lds8 {
   float *sZ, *sEps, *sNz, *sMask, *sMean, *net;
+  int *sRow, *sCmol;  // node slot -> row word; [0..3] molecule of component k, [4] = number of components
   uint32_t *sEdge, *sSeg;
   float* sEm;
   uint16_t *sOff, *sIdx;
@@ -151,6 +162,8 @@ __device__ __forceinline__ Lds8 carve_lds8(float* smem, int N, int D, int S) {
   L.sNz = base; base += align16(N * D);
   L.sMask = base; base += align16(N);
   L.sMean = base; base += 16;
+  L.sRow = (int*)base; base += align16(N);
+  L.sCmol = (int*)base; base += 16;
   L.sEdge = (uint32_t*)base; base += S;
   L.sEm = base; base += S;
   L.sSeg = (uint32_t*)base; base += align16(N);
@@ -170,6 +183,8 @@ __device__ __forceinline__ w8::MolGraph graph8(const Lds8& L, const Graph8Args& 
   mg.rounds = (a.ntiles + w8::kWaves - 1) / w8::kWaves;
   mg.pubx = a.pubx; mg.pub_ch = a.pub_ch;
   mg.mask = L.sMask; mg.edge = L.sEdge; mg.em = L.sEm; mg.seg = L.sSeg; mg.soff = L.sOff; mg.sidx = L.sIdx;
+  mg.row = L.sRow;
+  mg.ncomp = __builtin_amdgcn_readfirstlane(L.sCmol[4]);
   return mg;
 }
 // Function arguments arrive in VGPRs: without these the callee treats every size, offset and buffer descriptor as
@@ -269,6 +284,7 @@ struct V8T {
     mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg; mg.soff = sOff; mg.sidx = sIdx;
     return base;
   }
+  __device__ __forceinline__ static void set_rows(Graph& mg, const int* row, int ncomp) { mg.row = row; mg.ncomp = ncomp; }
   __device__ __forceinline__ static Graph8Args gargs(const Graph& mg) {
     return Graph8Args{mg.N, mg.D, mg.S, mg.NC, mg.ntiles, mg.pubx, mg.pub_ch};
   }
@@ -339,42 +355,63 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
   float* sEps = base; base += align16(N * D);
   float* sNz = base; base += align16(N * D);
   float* sMask = base; base += align16(N);
-  float* sMean = base; base += 16;
-  for (int i = tid; i < N; i += kThreads) sMask[i] = P.node_mask[b * N + i];
+  float* sMean = base; base += 16;          // [component k][4]: masked means of the x columns (d < 3), clip coefficient (3)
+  int* sRow = (int*)base; base += align16(N);
+  int* sCmol = (int*)base; base += 16;
+  for (int i = tid; i < N; i += kThreads) {
+    sMask[i] = P.node_mask[b * N + i];
+    sRow[i] = P.rowmap != nullptr ? P.rowmap[(size_t)b * N + i] : b * N + i;  // not packed: slot i = node i of molecule b
+  }
+  if (tid < kMaxComp) sCmol[tid] = P.rowmap != nullptr ? P.compmol[(size_t)b * kMaxComp + tid] : b;
+  if (tid == kMaxComp) sCmol[kMaxComp] = P.rowmap != nullptr ? P.ncomp[b] : 1;
   typename V::Graph mg;
   float* net = V::load_graph(P, b, base, sMask, mg, tid, wave);
+  __syncthreads();
+  const int ncomp = __builtin_amdgcn_readfirstlane(sCmol[kMaxComp]);
+  V::set_rows(mg, sRow, ncomp);
 
-  const uint64_t gsample = (uint64_t)(P.fix_noise ? P.fix_key : P.sample_offset + b);
   // locals (not references into the kernarg struct) so nothing forces P onto the stack
-  const float* const noise_p = P.noise ? P.noise + (P.fix_noise ? (size_t)0 : (size_t)b * N * D) : nullptr;
-  const long long draw_stride = P.draw_stride;
-  const int draw_base = P.draw_base;
+  const float* const noise_p = P.noise;
+  const long long draw_stride = P.draw_stride, sample_offset = P.sample_offset, fix_key = P.fix_key;
+  const int draw_base = P.draw_base, fix_noise = P.fix_noise;
   const unsigned long long seed = P.seed;
-  auto raw_noise = [=](int draw, int e) -> float {
-    if (noise_p != nullptr) return noise_p[(size_t)(draw - draw_base) * draw_stride + e];
-    const f4 v = philox_normal4(seed, gsample, (uint32_t)draw, (uint32_t)(e >> 2));
-    return v[e & 3];
+  // raw N(0,1) draw `draw`, element (slot n, column d): keyed by the molecule's GLOBAL sample index and the node's index
+  // inside its own molecule, so a molecule's noise does not depend on which workgroup (or which slot) holds it
+  auto raw_noise = [=](int draw, int n, int d) -> float {
+    const int w = sRow[n];
+    if (w < 0) return 0.f;
+    const int row = row_of(w), local = (row % N) * D + d;
+    if (noise_p != nullptr)
+      return noise_p[(size_t)(draw - draw_base) * draw_stride + (fix_noise ? (size_t)local : (size_t)row * D + d)];
+    const uint64_t gsample = (uint64_t)(fix_noise ? fix_key : sample_offset + sCmol[comp_of(w)]);
+    const f4 v = philox_normal4(seed, gsample, (uint32_t)draw, (uint32_t)(local >> 2));
+    return v[local & 3];
   };
-  // masked mean over nodes of column d (<3) of an LDS [N][D] array -> sMean[d]
+  // masked mean over the nodes of component k of column d (<3) of an LDS [N][D] array -> sMean[4 k + d]
   auto col_means = [=](const float* a) {
-    if (tid < 3) {
+    if (tid < 3 * ncomp) {
+      const int k = tid / 3, d = tid % 3;
       float s = 0.f, cnt = 0.f;
-      for (int n = 0; n < N; ++n) { s += a[n * D + tid]; cnt += sMask[n]; }
-      sMean[tid] = s / fmaxf(cnt, 1.0f);
+      for (int n = 0; n < N; ++n)
+        if (comp_of(sRow[n]) == k) { s += a[n * D + d]; cnt += sMask[n]; }
+      sMean[4 * k + d] = s / fmaxf(cnt, 1.0f);
     }
   };
+  auto mean_of = [=](int n, int d) { return sRow[n] < 0 ? 0.f : sMean[4 * comp_of(sRow[n]) + d]; };
   // sNz <- sample_combined_position_feature_noise (en_diffusion.py:937-956) from raw draw `draw`
   auto combined_noise = [=](int draw, float std) {
-    for (int e = tid; e < N * D; e += kThreads) sNz[e] = raw_noise(draw, e) * std * sMask[e / D];
+    for (int e = tid; e < N * D; e += kThreads) sNz[e] = raw_noise(draw, e / D, e % D) * std * sMask[e / D];
     __syncthreads();
     col_means(sNz);
     __syncthreads();
     for (int e = tid; e < N * 3; e += kThreads) {
       const int n = e / 3, d = e % 3;
-      sNz[n * D + d] = sNz[n * D + d] - sMean[d] * sMask[n];
+      sNz[n * D + d] = sNz[n * D + d] - mean_of(n, d) * sMask[n];
     }
     __syncthreads();
   };
+  // global element of (slot n, column d) in a [rows][W] array, or -1 for an empty slot
+  auto gidx = [=](int n, int d, int W) -> long long { return sRow[n] < 0 ? -1LL : (long long)row_of(sRow[n]) * W + d; };
 
   const int mode = P.mode;
 #ifdef GAUDI_STAMPS
@@ -391,22 +428,37 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
     // sample_edm_t (cond_prediction/train_cond_predictor.py:47-61): z_t = alpha_t * normalize([x | h]) + sigma_t * eps
     __syncthreads();
     combined_noise(draw_base, 1.0f);
-    const float a_t = P.alpha_sigma[2 * b], s_t = P.alpha_sigma[2 * b + 1];
     const float nv0 = P.nv0, nv1 = P.nv1;
     for (int e = tid; e < N * D; e += kThreads) {
       const int n = e / D, d = e % D;
-      const float raw = P.z_in[(size_t)b * N * D + e];
+      const long long gi = gidx(n, d, D);
+      const int mol = gi < 0 ? 0 : (int)(gi / ((long long)N * D));
+      const float a_t = P.alpha_sigma[2 * mol], s_t = P.alpha_sigma[2 * mol + 1];
+      const float raw = gi < 0 ? 0.f : P.z_in[gi];
       const float xh = d < 3 ? raw / nv0 : (raw - 0.0f) / nv1 * sMask[n];  // en_diffusion.py:384-392
-      sZ[e] = a_t * xh + s_t * sNz[e];
+      sZ[e] = gi < 0 ? 0.f : a_t * xh + s_t * sNz[e];
     }
     if (P.zt_out != nullptr) {
       __syncthreads();
-      for (int e = tid; e < N * D; e += kThreads) P.zt_out[(size_t)b * N * D + e] = sZ[e];
+      for (int e = tid; e < N * D; e += kThreads) {
+        const long long gi = gidx(e / D, e % D, D);
+        if (gi >= 0) P.zt_out[gi] = sZ[e];
+      }
     }
   } else {
-    for (int e = tid; e < N * D; e += kThreads) sZ[e] = P.z_in[(size_t)b * N * D + e];
+    for (int e = tid; e < N * D; e += kThreads) {
+      const long long gi = gidx(e / D, e % D, D);
+      sZ[e] = gi < 0 ? 0.f : P.z_in[gi];
+    }
   }
   __syncthreads();
+  // z of every mapped node -> z_out
+  auto store_z = [=](const float* src) {
+    for (int e = tid; e < N * D; e += kThreads) {
+      const long long gi = gidx(e / D, e % D, D);
+      if (gi >= 0) P.z_out[gi] = src[e];
+    }
+  };
 
   if constexpr (HPE > 0) {
     if (mode == MODE_PHI || mode == MODE_SAMPLE) {
@@ -422,14 +474,13 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
         f4 cf = splat(0.f);
         if (is_step) cf = *(const f4*)(P.coef + 4 * s);
         const float t_val = mode == MODE_PHI ? P.t_in[b] : cf[3];  // decode: t = 0
-        if (is_step == false && mode == MODE_SAMPLE)               // z_0 is final: publish it
-          for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
+        if (is_step == false && mode == MODE_SAMPLE) store_z(sZ);  // z_0 is final: publish it
         const int split = P.split;
         if (split != 2)
           V::template edm<HPE>(edm, mg, net, sZ, sEps, sMean, t_val, tid STAMP_ARGS,
                                V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr);
         if (mode == MODE_PHI) {
-          for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
+          store_z(sEps);
         } else if (is_step) {
           if (split != 2) {
             // ---- z_s = z_t/alpha_ts - c*eps + sigma*noise ; x part mean-removed (en_diffusion.py:831-852)
@@ -462,21 +513,26 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
           __syncthreads();
           for (int e = tid; e < N * 3; e += kThreads) {
             const int n = e / 3, d = e % 3;
-            sZ[n * D + d] = sZ[n * D + d] - sMean[d] * sMask[n];
+            sZ[n * D + d] = sZ[n * D + d] - mean_of(n, d) * sMask[n];
           }
           __syncthreads();
           if (guided) {
             // `if torch.isnan(zs).any(): zs = zs.nan_to_num(0.)` (en_diffusion.py:933-934): NaN -> 0 and +-inf -> +-FLT_MAX.
-            // The reference tests the whole batch; a workgroup sees one molecule, so the trigger here is "a NaN in THIS
-            // molecule" (differs only for a molecule that holds an inf but no NaN while another molecule holds a NaN).
-            int bad = 0;
-            for (int e = tid; e < N * D; e += kThreads) bad += sZ[e] != sZ[e];
+            // The reference tests the whole batch; a workgroup sees one molecule (or a few, as components), so the trigger
+            // here is "a NaN in THIS molecule" (differs only for a molecule that holds an inf but no NaN while another
+            // molecule holds a NaN).
+            int bad = 0, badmask = 0;
+            for (int e = tid; e < N * D; e += kThreads)
+              if (sZ[e] != sZ[e]) { ++bad; badmask |= 1 << comp_of(sRow[e / D]); }
             nan_local += bad;
-            if (__syncthreads_or(bad)) {
+            badmask = block_or_bits(badmask & ((1 << kMaxComp) - 1), ncomp);
+            if (badmask) {
               for (int e = tid; e < N * D; e += kThreads) {
                 float v = sZ[e];
-                v = v != v ? 0.f : fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
-                sZ[e] = v;
+                if ((badmask >> comp_of(sRow[e / D])) & 1) {
+                  v = v != v ? 0.f : fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+                  sZ[e] = v;
+                }
               }
               __syncthreads();
             }
@@ -488,10 +544,11 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
             const int K = P.keep_frames;
             const int idx = (int)(((long long)s * K) / T);
             if (s == 0 || (int)(((long long)(s - 1) * K) / T) != idx) {
-              float* dst = P.chain_out + ((size_t)idx * P.B + b) * N * D;
+              float* dst = P.chain_out + (size_t)idx * P.B * N * D;  // (never packed: B = molecules)
               for (int e = tid; e < N * D; e += kThreads) {
                 const int n = e / D, d = e % D;
-                dst[e] = d < 3 ? sZ[e] * P.nv0 : (sZ[e] * P.nv1 + 0.0f) * sMask[n];
+                const long long gi = gidx(n, d, D);
+                if (gi >= 0) dst[gi] = d < 3 ? sZ[e] * P.nv0 : (sZ[e] * P.nv1 + 0.0f) * sMask[n];
               }
             }
           }
@@ -504,21 +561,22 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
           for (int e = tid; e < N * 3; e += kThreads) {
             const int n = e / 3, d = e % 3;
             const float mu = inv_a * (sZ[n * D + d] - sigma0 * sEps[n * D + d]);
-            P.x_out[(size_t)b * N * 3 + e] = (mu + sigma_x * sNz[n * D + d]) * nv0;
+            const long long gi = gidx(n, d, 3);
+            if (gi >= 0) P.x_out[gi] = (mu + sigma_x * sNz[n * D + d]) * nv0;
           }
           for (int n = tid; n < N; n += kThreads) {
+            if (sRow[n] < 0) continue;
             int best = 0;
             float bv = (sZ[n * D + 3] * nv1 + 0.0f) * sMask[n];
             for (int k = 1; k < F; ++k) {
               const float v = (sZ[n * D + 3 + k] * nv1 + 0.0f) * sMask[n];
               if (v > bv) { bv = v; best = k; }
             }
-            for (int k = 0; k < F; ++k) P.h_out[((size_t)b * N + n) * F + k] = (k == best ? 1.0f : 0.0f) * sMask[n];
+            for (int k = 0; k < F; ++k) P.h_out[(size_t)row_of(sRow[n]) * F + k] = (k == best ? 1.0f : 0.0f) * sMask[n];
           }
         }
       }
-      if (mode == MODE_SAMPLE && !P.do_decode)
-        for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
+      if (mode == MODE_SAMPLE && !P.do_decode) store_z(sZ);
 #ifdef GAUDI_STAMPS
       if (stamps_on) {
         for (int i = 0; i < ST_N; ++i) P.stamps[i] = g_stamps.acc[i];
@@ -543,7 +601,7 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
       __syncthreads();
       for (int e = tid; e < N * 3; e += kThreads) {
         const int n = e / 3, d = e % 3;
-        sZ[n * D + d] = sZ[n * D + d] - sMean[d] * sMask[n];
+        sZ[n * D + d] = sZ[n * D + d] - mean_of(n, d) * sMask[n];
       }
       __syncthreads();
       int bad = 0;
@@ -556,7 +614,7 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
         __syncthreads();
       }
       if (bad) atomicAdd(P.nan_count, bad);
-      for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sZ[e];
+      store_z(sZ);
     }
     // unit-test modes live in the predictor-only kernels
     if (P.mode == MODE_PRED_FWD || P.mode == MODE_PRED_GRAD) {
@@ -564,8 +622,7 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
       V::template pred_entry<HPP>(P.pred, mg, net, sZ, sEps, sNz, sMean, P.t_in[b], dp, P.mode == MODE_PRED_GRAD,
                            P.pred_out + (size_t)b * P.pred.K, P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS,
                            V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr);
-      if (P.mode == MODE_PRED_GRAD)
-        for (int e = tid; e < N * D; e += kThreads) P.z_out[(size_t)b * N * D + e] = sEps[e];
+      if (P.mode == MODE_PRED_GRAD) store_z(sEps);
     }
   }
 }

@@ -346,7 +346,9 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
     auto xin = [&](int j, int cc) { return *(const f4*)((cc < T ? xa[j] : xb[j]) + 16 * cc); };
     // One accumulator per (column tile, output tile); a wave that owns a single output tile of a single column tile gets a
     // second one for the odd K chunks (a dependent accumulate needs 40 cycles, issue is every 32).
-    constexpr bool kSplit = NT * NTW == 1;
+    // (a wave with one output tile: even K chunks go to one accumulator, odd ones to a second -- for BOTH column-tile counts,
+    // so that a node's result does not depend on how many other nodes share the workgroup: packed launches)
+    constexpr bool kSplit = NTW == 1;
     constexpr int NA = kSplit ? 2 : 1;
     f4 acc[NA][NT][NTW];
 #pragma unroll
@@ -374,10 +376,12 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
     auto mm2 = [&](const f4 (&wE)[NTW], const f4 (&xE)[NT], const f4 (&wO)[NTW], const f4 (&xO)[NT]) {
       if (kSplit) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[0][0][0] = fma_u(std::integral_constant<int, 0>{}, wE[0][q], xE[0][q], acc[0][0][0]);
-          acc[NA - 1][0][0] = fma_u(std::integral_constant<int, 0>{}, wO[0][q], xO[0][q], acc[NA - 1][0][0]);
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            acc[0][j][0] = fma_u(std::integral_constant<int, 0>{}, wE[0][q], xE[j][q], acc[0][j][0]);
+            acc[NA - 1][j][0] = fma_u(std::integral_constant<int, 0>{}, wO[0][q], xO[j][q], acc[NA - 1][j][0]);
+          }
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -524,7 +528,12 @@ struct MolGraph {
   const uint32_t* seg;    // LDS [N]  start << 16 | len : slots whose RECEIVING node is n
   const uint16_t* soff;   // LDS [N+1] CSR offsets into sidx: slots whose SENDING node is n ...
   const uint16_t* sidx;   // LDS [S]   ... ascending (= ascending receiving node)
+  // packed launches: the graph is a disjoint union of up to 4 molecules (components); per-molecule reductions (centre of
+  // gravity, gradient clip, NaN scrub) run per component.  row[n] = global row | component << 28, -1 = empty slot
+  const int* row;         // LDS [N]
+  int ncomp;
 };
+__device__ __forceinline__ int mg_comp(const MolGraph& mg, int n) { return (mg.row[n] >> 28) & 7; }
 
 }  // namespace w8
 }  // namespace gaudi

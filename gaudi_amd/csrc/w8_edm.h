@@ -289,26 +289,38 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         [=](int p, int k) { return hh[(p / F) * LD + k]; },
         [=](int p, float acc) { sEps[(p / F) * D + 3 + p % F] = (acc + ob[p % F]) * msk[p / F]; });
     // `if torch.any(torch.isnan(vel)): vel = torch.nan_to_num(vel, 0.0)` (models.py:138-141), triggered per molecule
-    if (__syncthreads_or(bad)) {
+    // (= per component of a packed graph)
+    int badmask = 0;
+    if (bad)
+      for (int idx = tid; idx < N * 3; idx += kThreads) {
+        const float v = sEps[(idx / 3) * D + idx % 3];
+        if (v != v) badmask |= 1 << mg_comp(mg, idx / 3);
+      }
+    badmask = block_or_bits(badmask & 15, mg.ncomp);
+    if (badmask) {
       for (int idx = tid; idx < N * 3; idx += kThreads) {
         const int n = idx / 3, d = idx % 3;
         const float v = sEps[n * D + d];
-        sEps[n * D + d] = v != v ? 0.f : fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+        if ((badmask >> mg_comp(mg, n)) & 1)
+          sEps[n * D + d] = v != v ? 0.f : fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
       }
       __syncthreads();
     }
-    if (tid < 3) {
+    if (tid < 3 * mg.ncomp) {
+      const int k = tid / 3, d = tid % 3;
       float s = 0.f, cnt = 0.f;
-      for (int n = 0; n < N; ++n) {
-        s += sEps[n * D + tid];
-        cnt += mg.mask[n];
-      }
-      sMean[tid] = s / fmaxf(cnt, 1.0f);
+      for (int n = 0; n < N; ++n)
+        if (mg_comp(mg, n) == k) {
+          s += sEps[n * D + d];
+          cnt += mg.mask[n];
+        }
+      sMean[4 * k + d] = s / fmaxf(cnt, 1.0f);
     }
     __syncthreads();
     for (int idx = tid; idx < N * 3; idx += kThreads) {
       const int n = idx / 3, d = idx % 3;
-      sEps[n * D + d] = sEps[n * D + d] - sMean[d] * mg.mask[n];
+      const int k = mg_comp(mg, n);
+      sEps[n * D + d] = sEps[n * D + d] - (k < mg.ncomp ? sMean[4 * k + d] : 0.f) * mg.mask[n];
     }
     __syncthreads();
   }

@@ -557,30 +557,42 @@ __device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<H
   __syncthreads();
 }
 
-// clip, project, apply (en_diffusion.py:905-920)
+// clip, project, apply (en_diffusion.py:905-920), per molecule = per component of a packed graph.  A component's sums
+// visit its elements in the order (and on the lanes) the molecule's own workgroup would: element index = (node inside the
+// molecule) * D + column, so the result does not depend on which slots of which workgroup hold the molecule.
 __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, float* sGrad, float* sMean, float sigma, int tid) {
   const int N = mg.N, D = mg.D;
   // clip_coef = min(1, 10 / (||g||_2 + 1e-6)) over all N*(3+F) entries   (en_diffusion.py:905-909)
-  if (tid < 64) {
+  if (tid < 64 * mg.ncomp) {
+    const int k = tid >> 6, lane = tid & 63;
     float s = 0.f;
-    for (int e = tid; e < N * D; e += 64) s += sGrad[e] * sGrad[e];
+    for (int n = 0; n < N; ++n) {
+      if (mg_comp(mg, n) != k) continue;
+      const int local = ((mg.row[n] & 0x0fffffff) % N) * D;
+      for (int d = 0; d < D; ++d)
+        if (((local + d) & 63) == lane) s += sGrad[n * D + d] * sGrad[n * D + d];
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (tid == 0) sMean[4] = fminf(10.0f / (sqrtf(s) + 1e-6f), 1.0f);
-  }
-  __syncthreads();
-  const float coef = sMean[4];
-  for (int e = tid; e < N * D; e += kThreads) sGrad[e] *= coef;
-  __syncthreads();
-  if (tid < 3) {  // masked mean of the x part of the gradient (en_diffusion.py:911-919)
-    float s = 0.f, cnt = 0.f;
-    for (int n = 0; n < N; ++n) { s += sGrad[n * D + tid]; cnt += mg.mask[n]; }
-    sMean[tid] = s / fmaxf(cnt, 1.0f);
+    if (lane == 0) sMean[4 * k + 3] = fminf(10.0f / (sqrtf(s) + 1e-6f), 1.0f);
   }
   __syncthreads();
   for (int e = tid; e < N * D; e += kThreads) {
-    const int n = e / D, d = e % D;
+    const int k = mg_comp(mg, e / D);
+    sGrad[e] *= k < mg.ncomp ? sMean[4 * k + 3] : 0.f;
+  }
+  __syncthreads();
+  if (tid < 3 * mg.ncomp) {  // masked mean of the x part of the gradient (en_diffusion.py:911-919)
+    const int k = tid / 3, d = tid % 3;
+    float s = 0.f, cnt = 0.f;
+    for (int n = 0; n < N; ++n)
+      if (mg_comp(mg, n) == k) { s += sGrad[n * D + d]; cnt += mg.mask[n]; }
+    sMean[4 * k + d] = s / fmaxf(cnt, 1.0f);
+  }
+  __syncthreads();
+  for (int e = tid; e < N * D; e += kThreads) {
+    const int n = e / D, d = e % D, k = mg_comp(mg, n);
     float gv = sGrad[e];
-    if (d < 3) gv = gv - sMean[d] * mg.mask[n];
+    if (d < 3 && k < mg.ncomp) gv = gv - sMean[4 * k + d] * mg.mask[n];
     sZ[e] = sZ[e] - sigma * gv;
   }
   __syncthreads();

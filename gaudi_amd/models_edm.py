@@ -187,8 +187,9 @@ class GaudiModel:
                 val = target(probe, nm, em, torch.full((B, 1), float(t)))
             finally:
                 cp._override = None
-            if not torch.is_tensor(val) or val.shape[0] != B:
-                raise GaudiError("the target function must return one value per molecule (a torch tensor [B])")
+            if not torch.is_tensor(val) or val.dim() == 0 or val.shape[0] != B:
+                raise GaudiError("the target function must return one value per molecule (a torch tensor [B]); use a "
+                                 "LinearTarget / PredTarget or a closure over cond_predictor (generation_guidance.py:198-211)")
             if val.requires_grad:
                 (gz,) = torch.autograd.grad(val.sum(), probe, allow_unused=True, retain_graph=True)
                 if gz is not None and bool((gz != 0).any()):

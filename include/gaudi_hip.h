@@ -228,6 +228,14 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
  * split with the full ring (a 32-input chunk of all output tiles per trip), 2 = split with the half ring (two trips per
  * chunk: molecules whose node buffers leave less LDS), 0 = fp32 instructions. */
 int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
+/* How a sampling call of the 8-wave kernels packs a batch (device-free): small molecules share a workgroup as the components
+ * of one disjoint graph -- at most 4 molecules, N node slots and 8 edge tiles of 16 slots per group; a molecule keeps its own
+ * tiles, node order, noise stream and per-molecule reductions, so its result does not depend on the packing (tested bit for
+ * bit; GAUDI_PACK=0 at gaudi_create turns it off).  groups_out = G; group_of_out[B] = group of every molecule; ntiles_out /
+ * ncols_out [>= G] = edge tiles and node columns of each group (what bench.py counts the issued matrix instructions from).
+ * No reference counterpart (the reference batches dense N x N tensors, sampling_edm.py:172-209). */
+int gaudi_host_pack_plan(int B, int N, const float* node_mask, const float* edge_mask, int32_t* groups_out, int32_t* group_of_out,
+                         int32_t* ntiles_out, int32_t* ncols_out);
 /* Plan hint for shards of a larger logical batch (gaudi_amd/dist.py; no reference counterpart: the reference runs one
  * process).  The kernel family and the edge-GEMM arithmetic of a call are chosen from batch-wide maxima -- the largest
  * number of 16-edge slots of a molecule (gaudi_host_graph_meta8: slots_out) and whether any node has more than 32 live edges

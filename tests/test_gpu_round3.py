@@ -257,3 +257,76 @@ def test_reference_style_closure_targets_and_call_shape(golden):
     with pytest.raises(GaudiError, match="depends on z directly"):
         sampling_edm.sample_guidance(args, model, target_direct, cfg["nodes"], scale=0.6)
     model.engine.close()
+
+
+# ------------------------------------------------------------------------------------------------ packed workgroups
+@pytest.mark.parametrize("dataset,rings", [("hetro", [3, 10, 4, 3, 5, 7, 3, 6, 4, 9, 3, 4, 8, 5, 3, 3]),
+                                           ("cata", [4, 11, 3, 5, 2, 6, 3, 4, 1, 7, 5, 2])])
+def test_packed_workgroups_equal_unpacked_bit_for_bit(dataset, rings):
+    """Sampling calls pack small molecules into one workgroup as components of a disjoint graph (gaudi_hip.hip:
+    pack_groups).  A molecule keeps its own tiles, node order, noise stream and per-molecule reductions, so guided and
+    unguided chains, injected noise, fix_noise and teacher-forced steps give the SAME BITS with GAUDI_PACK=0 -- at the
+    default widths (where the LDS plan decides) and at the test widths."""
+    from gaudi_amd.sampling_edm import build_masks
+    hetero = dataset == "hetro"
+    F = synth.num_node_features(dataset)
+    nm3, em_flat, N = build_masks(np.asarray(rings), max(rings), hetero)
+    B = len(rings)
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    w = np.array([3, 0, 1, 1, 0] if hetero else [0, -1, 0, 0, 0], np.float32)
+    for widths in ("tiny", "default"):
+        T = 9 if widths == "tiny" else 5
+        if widths == "tiny":
+            eargs, pargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=T, dataset=dataset), synth.pred_args(nf=36, n_layers=3, dataset=dataset)
+        else:
+            eargs, pargs = synth.edm_args(diffusion_steps=T, dataset=dataset), synth.pred_args(dataset=dataset)
+        esd = synth.synth_edm_state_dict(eargs, F, seed=51, amplify_coord=True)
+        psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=52, amplify_coord=True)
+        rng = np.random.default_rng(8)
+        noise = rng.standard_normal((T + 2, B, N, 3 + F)).astype(np.float32)
+        z = rng.standard_normal((B, N, 3 + F)).astype(np.float32) * nm[:, :, None]
+        z[:, :, :3] -= z[:, :, :3].sum(1, keepdims=True) / np.maximum(nm.sum(1)[:, None, None], 1) * nm[:, :, None]
+        eps = rng.standard_normal(z.shape).astype(np.float32)
+        outs = []
+        for pack in (1, 0):
+            eng = _engine(eargs, esd, pargs, psd, GAUDI_PACK=pack)
+            o = [eng.sample(nm, em, seed=3, sample_offset=5, target_w=w, scale=0.6, return_z0=True),
+                 eng.sample(nm, em, seed=3, sample_offset=5, return_z0=True),
+                 eng.sample(nm, em, noise=noise, target_w=w, scale=0.6, return_z0=True)]
+            assert eng.kernel_variant()[1] == 8
+            o.append((eng.step(T - 2, z, nm, em, eps, target_w=w, scale=0.6), eng.step(2, z, nm, em, eps), None))
+            eng.set_fix_noise(True)
+            o.append(eng.sample(nm, em, seed=3, sample_offset=5, target_w=w, scale=0.6, return_z0=True))
+            eng.close()
+            outs.append(o)
+        for a, b in zip(*outs):
+            for u, v in zip(a, b):
+                if isinstance(u, np.ndarray):
+                    assert np.array_equal(u, v), (widths, dataset)
+                elif isinstance(u, dict):
+                    assert u["nan_count"] == v["nan_count"] and u["max_masked_leak"] == v["max_masked_leak"] == 0
+        x = outs[0][0][0]
+        assert np.isfinite(x).all() and len({x[i].tobytes() for i in range(B)}) == B  # every molecule its own noise
+        if widths == "tiny":
+            # NaN scrubbing is per molecule = per component: a NaN planted in the last coordinate head (every molecule's
+            # velocity becomes NaN and is scrubbed) and one in the predictor readout (z_s scrubbed to zeros)
+            res = []
+            for pack in (1, 0):
+                esd_bad = {k: v.copy() for k, v in esd.items()}
+                esd_bad[f"dynamics.egnn.e_block_{eargs['n_layers'] - 1}.gcl_equiv.coord_mlp.4.weight"][0, 3] = np.nan
+                psd_bad = {k: v.copy() for k, v in psd.items()}
+                psd_bad["egnn.embedding_out.weight"][1, 5] = np.nan
+                e1, e2 = _engine(eargs, esd_bad, pargs, psd, GAUDI_PACK=pack), _engine(eargs, esd, pargs, psd_bad, GAUDI_PACK=pack)
+                a = e1.sample(nm, em, seed=3, target_w=w, scale=0.6)
+                b = e2.sample(nm, em, seed=3, target_w=w, scale=0.6)
+                c = e1.step(T - 2, z, nm, em, eps)
+                res.append((a[0], a[1], b[0], b[1], c, a[2]["nan_count"], b[2]["nan_count"]))
+                e1.close(); e2.close()
+            live = nm != 0
+            for i, (u, v) in enumerate(zip(*res)):
+                if isinstance(u, np.ndarray):
+                    assert np.array_equal(u[live], v[live]), i      # every live node: the same bits
+                    assert np.all(u[~live] == 0), i                  # masked nodes have no slot in a packed workgroup: zeros
+                elif i == 6:
+                    assert u > 0 and v > 0, i  # poisoned predictor: z_s scrubbed (the count itself includes masked rows when unpacked)
+            assert np.isfinite(res[0][0]).all() and np.isfinite(res[0][4]).all()

@@ -84,3 +84,40 @@ def test_random_masks_including_long_runs_and_empty_molecules():
         em *= 1 - np.eye(N, dtype=np.float32)
         em[1] = 0  # a molecule without edges
         check(nm[:, :, None], em)
+
+
+def test_pack_plan_groups_small_molecules():
+    """gaudi_host_pack_plan: every molecule lands in exactly one group; a group holds at most 4 molecules, N node slots and 8
+    edge tiles; big molecules stay alone; the groups' tile counts are the sums of their members' own tile counts (component
+    starts are tile-aligned, so a molecule keeps the tiles it has on its own)."""
+    import ctypes as C
+
+    from gaudi_amd import _lib
+    from gaudi_amd.sampling_edm import build_masks
+    lib = _lib.load_library()
+    i32 = C.POINTER(C.c_int32)
+    rings = np.random.default_rng(1).integers(3, 11, size=64)
+    nm3, em_flat, N = build_masks(rings, 10, True)
+    B = len(rings)
+    nm, em = np.ascontiguousarray(nm3.reshape(B, N)), np.ascontiguousarray(em_flat.reshape(B, N, N))
+    G = C.c_int32()
+    group_of, ntiles, ncols = np.full(B, -1, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+    assert lib.gaudi_host_pack_plan(B, N, _lib.fptr(nm), _lib.fptr(em), C.byref(G), group_of.ctypes.data_as(i32),
+                                    ntiles.ctypes.data_as(i32), ncols.ctypes.data_as(i32)) == 0
+    G = G.value
+    assert 0 < G < B and (group_of >= 0).all() and group_of.max() == G - 1
+    slots = C.c_int32()
+    own_tiles = np.zeros(B, np.int32)
+    assert lib.gaudi_host_graph_meta8(B, N, _lib.fptr(nm), _lib.fptr(em), C.byref(slots), None, own_tiles.ctypes.data_as(i32),
+                                      None, None, None, None, None, 0, None) == 0
+    live = (nm != 0).sum(1)
+    for g in range(G):
+        members = np.nonzero(group_of == g)[0]
+        assert 1 <= len(members) <= 4
+        assert ntiles[g] == own_tiles[members].sum() <= 8
+        assert live[members].sum() <= N and ncols[g] <= N
+    # cata 11-ring molecules (the C3 shape) fill N = 11 on their own: nothing packs
+    nm3, em_flat, N = build_masks([11] * 8, 11, False)
+    nm, em = np.ascontiguousarray(nm3.reshape(8, N)), np.ascontiguousarray(em_flat.reshape(8, N, N))
+    G = C.c_int32()
+    assert lib.gaudi_host_pack_plan(8, N, _lib.fptr(nm), _lib.fptr(em), C.byref(G), None, None, None) == 0 and G.value == 8
