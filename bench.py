@@ -154,6 +154,23 @@ def graph_meta(nm, em):
     return npairs, ncols
 
 
+def graph_meta8_packed(nm, em):
+    """16-slot tiles and node columns per WORKGROUP of a sampling call of the 8-wave kernels: small molecules are packed
+    into one workgroup as components of a disjoint graph (gaudi_host_pack_plan); G = B when nothing packs."""
+    import ctypes as C
+    from gaudi_amd import _lib
+    lib = _lib.load_library()
+    B, N = nm.shape
+    G = C.c_int32()
+    ntiles = np.zeros(B, np.int32)
+    ncols = np.zeros(B, np.int32)
+    i32 = C.POINTER(C.c_int32)
+    rc = lib.gaudi_host_pack_plan(B, N, _lib.fptr(np.ascontiguousarray(nm, np.float32)), _lib.fptr(np.ascontiguousarray(em, np.float32)),
+                                  C.byref(G), None, ntiles.ctypes.data_as(i32), ncols.ctypes.data_as(i32))
+    assert rc == 0, rc
+    return ntiles[:G.value], ncols[:G.value]
+
+
 def graph_meta8(nm, em):
     """16-slot tiles per molecule and node columns of the 8-wave kernels."""
     import ctypes as C
@@ -270,14 +287,16 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     wv = eng.kernel_variant()[1]
     em_mode = eng.edge_math()[1]  # 0 fp32 instructions, 1 split operands (full LDS weight ring), 2 split (half ring)
     variant = "w4" if wv == 4 else ("w8s" if em_mode else "w8")
-    units, ncols = graph_meta(nm, em) if variant == "w4" else graph_meta8(nm, em)
+    packed = variant != "w4" and os.environ.get("GAUDI_PACK", "1") != "0"
+    units, ncols = graph_meta(nm, em) if variant == "w4" else (graph_meta8_packed(nm, em) if packed else graph_meta8(nm, em))
     npairs = units
+    G = len(ncols)  # workgroups per call: molecules, or groups of molecules when the call packs
     pa = pargs if guided else None
-    cnt = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, pa, variant) for b in range(B)], dtype=np.float64).sum(0)
-    cnt_edm = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, None, variant) for b in range(B)], dtype=np.float64).sum(0)
+    cnt = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, pa, variant) for b in range(G)], dtype=np.float64).sum(0)
+    cnt_edm = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, None, variant) for b in range(G)], dtype=np.float64).sum(0)
     equiv_variant = "w8" if variant == "w8s" else variant  # the same work issued as fp32 matrix instructions
-    mfma_step = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, pa, equiv_variant) for b in range(B))
-    edm_only = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, None, equiv_variant) for b in range(B))
+    mfma_step = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, pa, equiv_variant) for b in range(G))
+    edm_only = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, None, equiv_variant) for b in range(G))
     useful_step = B * flops.step_flops_useful(live_edges, live_nodes, F, eargs, pa, K)
     written_step = B * flops.step_flops_as_written(N, F, eargs, pa, K)
     # per launch: `steps_done` reverse steps + one decode pass (= one EDM evaluation) per call, over n_launch launches
@@ -313,6 +332,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
         "dtype": "f32", "edge_gemm_math": "bf16x3 split operands, f32 accumulate" if variant == "w8s" else "f32",
         "data": "synthetic (seeded default-init weights, on-device Philox noise)",
         "config": {"workload": label, "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
+                   "workgroups_per_call": G,
                    "edm": "nf=192,n_layers=9", "predictor": "nf=196,n_layers=12" if guided else None,
                    "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
                    "steps_per_launch": a.steps_per_launch,
