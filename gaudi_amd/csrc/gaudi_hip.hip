@@ -640,6 +640,10 @@ static int round_hidden(int H) {
 }
 
 // gn: node buffers in global memory (V4G kernels)
+// edge slots per wave of the 4-wave kernels for the fully connected graph of N nodes (build_meta: whole receiving nodes are
+// dealt to the waves, the longest list rounded up to 32)
+static int dense_ew4(int N) { return std::max(32, ((N + kWaves - 1) / kWaves * (N - 1) + 31) / 32 * 32); }
+
 static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW, bool gn = false) {
   size_t net = 0;
   if (hpe) net = std::max(net, (size_t)((gn ? 0 : 4 * N * (hpe + 4)) + kWaves * 16 * (hpe + 4) + 8 * N + kWaves * EW * 9 + 8 * hpe));
@@ -833,33 +837,41 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   // waves).  A molecule keeps its own tiles (component starts are tile-aligned), its nodes keep their relative order, its
   // noise is keyed by its own sample and node indices, and every per-molecule reduction runs per component in the order
   // the molecule's own workgroup would use: the result does not depend on the packing, bit for bit.
+  if (!pick_kernel8(hpe, hpp)) return 1;
+  const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
+  int pubx = 0, pub_ch = 0;
+  // the arithmetic of the edge GEMMs for S edge slots: split-bf16 when the kernel exists and its larger weight ring fits
+  // (1 = full ring, 2 = half ring); else fp32 MFMAs (0); else -1 = this call runs on 4 waves
+  auto plan_for = [&](int S) -> int {
+    if (h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes))
+      for (int mode = 1; mode <= 2; ++mode)
+        if (pick_kernel8_mode(hpe, hpp, mode) && plan_pub8(hpe, hpp, N, Dz, S, mode, pubx, pub_ch)) return mode;
+    return plan_pub8(hpe, hpp, N, Dz, S, 0, pubx, pub_ch) ? 0 : -1;
+  };
+  const int mode_u = plan_for(M.S);
+  if (mode_u < 0) return 1;
   Pack pk;
   const int B0 = B;
   const float* nm_used = node_mask;
-  if (h->pack_now && h->pack && B > 1) {
+  // (a row of the map holds molecule * N + node in 28 bits)
+  if (h->pack_now && h->pack && B > 1 && (int64_t)B * N < (1 << 28)) {
     pack_groups(B, N, node_mask, edge_mask, M, pk);
     if (pk.G < B) {
       Meta8 M2;
       rc = build_meta8(pk.G, N, pk.umask.data(), pk.uemask.data(), M2, err, M.S, pk.align.data());
-      if (rc == GAUDI_OK && M2.S <= std::max(M.S, 16 * w8::kWaves)) {
+      // a packed launch has more edge slots per workgroup; it must keep the arithmetic the unpacked plan has (the plan of a
+      // sharded batch is the same on every rank, gaudi_set_plan_hint, and packing must not move a rank off it)
+      if (rc == GAUDI_OK && M2.S <= 16 * w8::kWaves && plan_for(M2.S) == mode_u) {
         M = std::move(M2);
         B = pk.G;
         nm_used = pk.umask.data();
       } else {
-        pk.G = B0;  // (cannot happen by construction; keep the unpacked plan)
+        plan_for(M.S);  // keep the unpacked plan
       }
     }
   }
   const bool packed = B != B0;
-  if (!pick_kernel8(hpe, hpp)) return 1;
-  int pubx = 0, pub_ch = 0;
-  const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
-  // split-bf16 edge GEMMs when the kernel exists and its larger weight ring fits; else fp32 MFMAs; else 4 waves
-  h->run_split = 0;
-  if (h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes))
-    for (int mode = 1; mode <= 2 && !h->run_split; ++mode)
-      if (pick_kernel8_mode(hpe, hpp, mode) && plan_pub8(hpe, hpp, N, Dz, M.S, mode, pubx, pub_ch)) h->run_split = mode;
-  if (!h->run_split && !plan_pub8(hpe, hpp, N, Dz, M.S, 0, pubx, pub_ch)) return 1;
+  h->run_split = mode_u;
   P.pubx = pubx;
   P.pub_ch = pub_ch;
   if (getenv("GAUDI_DEBUG_PLAN")) fprintf(stderr, "[plan] N=%d S=%d split=%d pub_ch=%d pubx=%d lds=%zu\n", N, M.S, h->run_split, pub_ch, pubx, lds_bytes8(hpe, hpp, N, Dz, M.S, pubx, h->run_split));
@@ -953,8 +965,10 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   // Molecules whose node buffers do not fit 160 KiB of LDS (beyond ~22 graph nodes at the default widths) run on the V4G
   // kernels: same code, node buffers in a per-workgroup global scratch (L2-resident).  The reference has no size cap
   // (sampling_edm.py:172-209); this one is N <= 255 (node indices are bytes in the edge words).
+  // The choice is made for the DENSE graph of N nodes, not for this batch's edges: shards of one logical batch must not
+  // land on different kernels because one of them happens to be sparser.
   const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
-  if (h->force_gn || lds_bytes(hpe, hpp, N, Dz, M.EW) > 160 * 1024) {
+  if (h->force_gn || lds_bytes(hpe, hpp, N, Dz, std::max(M.EW, dense_ew4(N))) > 160 * 1024) {
     if (have_kernels_g(hpe, hpp) && lds_bytes(hpe, hpp, N, Dz, M.EW, true) <= 160 * 1024) {
       h->run_gn = true;
       const size_t stride = (gnode_floats(hpe, hpp, N) + 63) / 64 * 64;
@@ -1396,8 +1410,7 @@ int gaudi_decode(gaudi_handle* h, int B, int N, const float* z0, const float* no
 // CU) that fit `budget` bytes.  Noise is keyed by the global sample index, so the result does not depend on the cut.
 static int max_sub_batch(gaudi_handle* h, int B, int N, bool guided) {
   if (!guided) return B;
-  const long long dense_ew = ((((long long)N * (N - 1) + kWaves - 1) / kWaves) + 31) / 32 * 32;
-  const long long per_mol = 4LL * pred_stash_floats(N, h->HPP, h->pcfg.n_layers, (int)std::max(32LL, dense_ew));
+  const long long per_mol = 4LL * pred_stash_floats(N, h->HPP, h->pcfg.n_layers, dense_ew4(N));
   long long budget = 0;
   if (const char* e = getenv("GAUDI_MAX_WORKSPACE_MB")) budget = atoll(e) * (1LL << 20);
   const bool forced = budget > 0;

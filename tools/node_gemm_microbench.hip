@@ -159,7 +159,11 @@ void run_num(int H, int N, int tail, int two) {
   hipFree(dw); hipFree(dx); hipFree(db); hipFree(dy);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {  // one timing configuration (for counter passes): N
+    run<208>(atoi(argv[1]), 256, 120, 1);
+    return 0;
+  }
   for (int tail = 0; tail < 2; ++tail) {
     run_num<208>(196, 11, tail, 0);
     run_num<208>(196, 11, tail, 1);
@@ -173,5 +177,9 @@ int main() {
     run<208>(11, 1, 120, tail);
     run<208>(20, 256, 120, tail);
   }
+  // the same with the weights resident in L2 (one matrix, 173 KB): what is left is not the Infinity Cache's latency
+  run<208>(11, 256, 1, 1);
+  run<208>(11, 1, 1, 1);
+  run<208>(20, 256, 1, 1);
   return 0;
 }
