@@ -340,5 +340,21 @@ class Engine:
             raise GaudiError(f"gaudi_host_graph_meta8 failed ({rc})")
         return int(slots.value), 0
 
+    def pack_plan(self, node_mask, edge_mask):
+        """-> (G, group_of[B], ntiles[G], ncols[G]): the workgroups a sampling call of the 8-wave kernels launches for this
+        batch -- small molecules share a workgroup as components of one disjoint graph (device-free: gaudi_host_pack_plan;
+        G = B when nothing packs)."""
+        nm = f32(node_mask)
+        B, N = nm.shape[0], nm.shape[1]
+        nm, em = self._masks(nm, edge_mask, B, N)
+        G = C.c_int32()
+        group_of, ntiles, ncols = (np.zeros(B, np.int32) for _ in range(3))
+        i32 = C.POINTER(C.c_int32)
+        rc = self.lib.gaudi_host_pack_plan(B, N, fptr(nm), fptr(em), C.byref(G), group_of.ctypes.data_as(i32),
+                                           ntiles.ctypes.data_as(i32), ncols.ctypes.data_as(i32))
+        if rc != 0:
+            raise GaudiError(f"gaudi_host_pack_plan failed ({rc})")
+        return G.value, group_of, ntiles[:G.value], ncols[:G.value]
+
     def set_steps_per_launch(self, k: int):
         self._check(self.lib.gaudi_set_steps_per_launch(self.h, int(k)), "gaudi_set_steps_per_launch")

@@ -330,3 +330,40 @@ def test_packed_workgroups_equal_unpacked_bit_for_bit(dataset, rings):
                 elif i == 6:
                     assert u > 0 and v > 0, i  # poisoned predictor: z_s scrubbed (the count itself includes masked rows when unpacked)
             assert np.isfinite(res[0][0]).all() and np.isfinite(res[0][4]).all()
+
+
+def test_packed_workgroups_fuzz():
+    """Random hetero batches (ring counts 1..10, 2..40 molecules, test widths): the packed launch, the unpacked launch and
+    every molecule sampled ALONE (same padded N, its own sample index) give the same bits -- a molecule's result depends on
+    nothing but its own graph, its sample index and the weights."""
+    from gaudi_amd.sampling_edm import build_masks
+    dataset, F, T = "hetro", synth.num_node_features("hetro"), 6
+    eargs, pargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=T, dataset=dataset), synth.pred_args(nf=36, n_layers=3, dataset=dataset)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=61, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=62, amplify_coord=True)
+    w = np.array([1, -2, 0.5, 0, 1], np.float32)
+    packed, plain = _engine(eargs, esd, pargs, psd, GAUDI_PACK=1), _engine(eargs, esd, pargs, psd, GAUDI_PACK=0)
+    rng = np.random.default_rng(2024)
+    groups_seen = 0
+    for case in range(12):
+        B = int(rng.integers(2, 41))
+        rings = rng.integers(1, 11, size=B)
+        nm3, em_flat, N = build_masks(rings, int(rings.max()), True)
+        nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+        off = int(rng.integers(0, 1000))
+        guided = case % 3 != 2
+        kw = dict(target_w=w, scale=0.7) if guided else {}
+        a = packed.sample(nm, em, seed=17, sample_offset=off, return_z0=True, **kw)
+        b = plain.sample(nm, em, seed=17, sample_offset=off, return_z0=True, **kw)
+        assert packed.kernel_variant()[1] == 8
+        for u, v in zip(a, b):
+            if isinstance(u, np.ndarray):
+                assert np.array_equal(u, v), case
+        assert np.isfinite(a[0]).all()
+        G = packed.pack_plan(nm, em)[0]
+        groups_seen += int(G < B)
+        for i in rng.choice(B, size=min(3, B), replace=False):
+            alone = plain.sample(nm[i:i + 1], em[i:i + 1], seed=17, sample_offset=off + int(i), return_z0=True, **kw)
+            assert np.array_equal(alone[0][0], a[0][i]) and np.array_equal(alone[1][0], a[1][i]), (case, int(i))
+    assert groups_seen >= 10  # the batches really were packed
+    packed.close(); plain.close()
