@@ -37,8 +37,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=None,
                     help="molecules per GPU (default: 256 = C3/C2 at one GPU; 1024 for c4 and for --gpus > 1 = C5's per-GPU shard)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "stability"],
-                    help="c2 = unguided cata, c3 = gap-guided cata (headline), c4 = hetero mixed 3-10 rings, multi-objective; "
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c4x", "stability"],
+                    help="c2 = unguided cata, c3 = gap-guided cata (headline), c4 = hetero mixed 3-10 rings, multi-objective; c4x = the same at 6-20 rings (12-40 graph nodes: BASELINE config 4 read literally; V4G kernels, not in the default run); "
                          "stability = the graph-of-rings stability kernel that follows sampling (SURVEY 8f rank 1)")
     ap.add_argument("--molecules", type=int, default=262144, help="stability workload: molecules per call")
     ap.add_argument("--dataset", default="cata", choices=["cata", "hetro"], help="stability workload: geometry tables")
@@ -197,9 +197,10 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     from gaudi_amd import flops, synth
     from gaudi_amd.engine import Engine
 
-    guided = workload in ("c3", "c4")
-    hetero = workload == "c4"
-    N, F = (20, 12) if hetero else (11, 1)
+    guided = workload in ("c3", "c4", "c4x")
+    hetero = workload in ("c4", "c4x")
+    max_rings = 20 if workload == "c4x" else 10
+    N, F = (2 * max_rings, 12) if hetero else (11, 1)
     ds = "hetro" if hetero else "cata"
     eargs = synth.edm_args(diffusion_steps=T, dataset=ds)
     pargs = synth.pred_args(dataset=ds)
@@ -229,8 +230,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     if hetero:
         # PASs-like batch: 3..10 rings drawn uniformly (seed 1), orientation nodes -> 6..20 graph nodes, N = 20
         from gaudi_amd.sampling_edm import build_masks
-        rings = np.random.default_rng(1 + rank).integers(3, 11, size=B)
-        nm3, em_flat, _ = build_masks(rings, 10, True)
+        rings = np.random.default_rng(1 + rank).integers(6 if workload == "c4x" else 3, max_rings + 1, size=B)
+        nm3, em_flat, _ = build_masks(rings, max_rings, True)
         nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
     else:
         nm = np.ones((B, N), np.float32)  # 11-ring cata molecules: every node live (sampling_edm.py:176-186)
@@ -322,7 +323,9 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     label = {"c3": f"C3: cc-PBH 11-ring, batch={B}/GPU, {T} steps, HOMO-LUMO-gap guidance (scale 0.6)",
              "c2": f"C2: cc-PBH 11-ring, batch={B}/GPU, {T} steps, unconditional EDM",
              "c4": f"C4: PASs-like hetero, 3-10 rings (6-20 graph nodes, N=20: the reference's own cap, "
-                   f"data/aromatic_dataloader.py:285), batch={B}/GPU, {T} steps, multi-objective (OPV) guidance"}[workload]
+                   f"data/aromatic_dataloader.py:285), batch={B}/GPU, {T} steps, multi-objective (OPV) guidance",
+             "c4x": f"C4 read literally: PASs-like hetero, 6-20 rings (12-40 graph nodes, N=40; beyond the reference dataset's cap), "
+                    f"batch={B}/GPU, {T} steps, multi-objective (OPV) guidance"}[workload]
     if world > 1 and workload == "c3":
         label = f"C5: {B * world} guided cc-PBH 11-ring samples sharded over {world} GPUs ({B}/GPU), {T} steps, one RCCL all_gather at the end"
     return {
@@ -341,8 +344,10 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                                       "by the edge lists in LDS (a complete graph of about 60 nodes)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": frac, "traffic": traffic,
-                     "kernel": "sampler_kernel_v<%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
-                                                                 "208" if guided else "0"),
+                     "kernel": ("sampler_kernel_v<%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
+                                                                  "208" if guided else "0")) if not (variant == "w4" and N > 22) else
+                               "sampler_kernel_g<V4G,192,0> + sampler_kernel_g<V4G,0,208> (node buffers in global memory; two launches "
+                               "per guided step, averaged together)",
                      "kernel_variant": {"w4": "4 waves per molecule, fp32 matrix instructions",
                                         "w8": "8 waves per molecule (two per SIMD), fp32 matrix instructions",
                                         "w8s": "8 waves per molecule (two per SIMD); edge GEMMs: fp32 operands split exactly "
@@ -421,7 +426,7 @@ def main():
     T, K = a.diffusion_steps, 5
     # N = 1: BASELINE configs[2] (C3, 256 molecules) -- or configs[1] / configs[3] with --workload.  N > 1: configs[4]
     # (C5): 1024 guided samples per GPU, 8192 over 8 GPUs.
-    B = a.batch or (1024 if (a.workload == "c4" or world > 1) else 256)
+    B = a.batch or (1024 if (a.workload in ("c4", "c4x") or world > 1) else 256)
     engines = {}
     out = run_workload(a, engines, a.workload, B, a.steps, a.warmup, rank, world, dev, backend, T, use_dist=use_dist)
     if rank == 0:
@@ -442,7 +447,7 @@ def main():
                            "edge_gemm_math": r["edge_gemm_math"]}
             out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline:
-            guided = a.workload in ("c3", "c4")
+            guided = a.workload in ("c3", "c4", "c4x")
             out["cpu_baseline"] = cpu_baseline(synth.edm_args(diffusion_steps=T), synth.pred_args(),
                                                 synth.synth_edm_state_dict(synth.edm_args(diffusion_steps=T), 1, seed=0),
                                                 synth.synth_predictor_state_dict(synth.pred_args(), 1, K, seed=1), guided, T,
