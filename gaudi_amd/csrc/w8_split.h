@@ -26,8 +26,35 @@
 #define GAUDI_RING_AUX 0  // cache-policy bits of the LDS-DMA ring loads (experiment knob: 2 = nt)
 #endif
 
+#ifndef GAUDI_TRIP_FLAGS
+#define GAUDI_TRIP_FLAGS 0  // 1: trips are opened by per-slot FULL / FREE counters in LDS instead of a workgroup barrier (experiment)
+#endif
+
 namespace gaudi {
 namespace w8 {
+
+#if GAUDI_TRIP_FLAGS
+// Split barrier of the weight ring.  Four counters in LDS: F[s] = waves whose share of a fill of slot s has landed,
+// D[s] = waves that finished reading a fill of slot s.  They only grow; every wave keeps use[s] = completed uses of slot s
+// (the control flow is workgroup-uniform), so the k-th fill of slot s is complete at F[s] = 8 k and free again at D[s] = 8 k.
+// A wave SIGNALS as early as it can (its LDS-DMA retired: before the last tile of the trip) and WAITS as late as it must
+// (FULL when it opens the next trip, FREE in the middle of a trip before it overwrites the other slot): waves may drift
+// apart by that much instead of meeting at a barrier every trip.  LDS operations of a wave execute in order, so a
+// counter update follows the wave's earlier reads and a read after a successful poll sees the other waves' data.
+typedef __attribute__((address_space(3))) int lds_int;  // LDS address space: ds_read / ds_add, not flat instructions (a flat
+                                                        // load would also wait for the wave's LDS-DMA loads in flight)
+__device__ __forceinline__ void flag_wait(const lds_int* f, int target) {
+  int v;
+  do {
+    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  } while (v < target);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void flag_add(lds_int* f, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
@@ -108,6 +135,12 @@ struct RingS {
 #else
   f4 st[G::UT];
 #endif
+#if GAUDI_TRIP_FLAGS
+  lds_int* fl;   // LDS: F[0], F[1], D[0], D[1]
+  int use0, use1;  // completed uses of each slot (two scalars: a dynamically indexed array would live in scratch)
+  bool pend;     // this wave issued a fill of slot par ^ 1 (or, before the first trip, of slot par) and has not signalled it
+  int pend_slot;
+#endif
   __device__ __forceinline__ float* slot(int p) const { return base + p * G::kSlotFloats; }
 };
 
@@ -137,10 +170,10 @@ __device__ __forceinline__ bool trip_group(const RingS<HP, MODE>& r, int W, int 
 #if GAUDI_SPLIT_GLDS
 // LDS-DMA: unit un of the group goes straight to slot + un KiB (wave-uniform LDS base + 16 B per lane)
 template <int HP, int MODE>
-__device__ __forceinline__ void rings_dma(const RingS<HP, MODE>& r, float* slot, int W, int nextW, int tr, int wave, int lane) {
+__device__ __forceinline__ bool rings_dma(const RingS<HP, MODE>& r, float* slot, int W, int nextW, int tr, int wave, int lane) {
   using G = SplitGeo<HP, MODE>;
   int off, units;
-  if (!trip_group(r, W, nextW, tr, off, units)) return;
+  if (!trip_group(r, W, nextW, tr, off, units)) return false;
 #pragma unroll
   for (int u = 0; u < G::UT; ++u) {
     const int un = wave + kWaves * u;
@@ -148,10 +181,37 @@ __device__ __forceinline__ void rings_dma(const RingS<HP, MODE>& r, float* slot,
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r.gbase + off + un * G::kUnit + lane * 4),
                                        (__attribute__((address_space(3))) void*)(slot + un * G::kUnit), 16, 0, GAUDI_RING_AUX);
   }
+  return true;
 }
+#if GAUDI_TRIP_FLAGS
+// fill slot s for its next use: wait until every wave has finished reading its previous contents, then issue this wave's share
+template <int HP, int MODE>
+__device__ __forceinline__ void rings_fill(RingS<HP, MODE>& r, int s, int W, int nextW, int tr, int wave, int lane) {
+  using G = SplitGeo<HP, MODE>;
+  int off, units;
+  if (!trip_group(r, W, nextW, tr, off, units)) return;
+  flag_wait(r.fl + 2 + s, kWaves * (s ? r.use1 : r.use0));
+  rings_dma(r, r.slot(s), W, nextW, tr, wave, lane);
+  r.pend = true;
+  r.pend_slot = s;
+}
+// this wave's share of the pending fill has landed: tell the others
+template <int HP, int MODE>
+__device__ __forceinline__ void rings_signal(RingS<HP, MODE>& r, int lane) {
+  if (r.pend) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag_add(r.fl + r.pend_slot, lane);
+    r.pend = false;
+  }
+}
+#endif
 template <int HP, int MODE>
 __device__ __forceinline__ void rings_start(RingS<HP, MODE>& r, const WBuf&, int W, int wave, int lane) {
+#if GAUDI_TRIP_FLAGS
+  rings_fill(r, r.par, W, -1, 0, wave, lane);
+#else
   rings_dma(r, r.slot(r.par), W, -1, 0, wave, lane);
+#endif
 }
 #ifndef GAUDI_RING_PREFETCH
 #define GAUDI_RING_PREFETCH 0  // experiment: touch the group of trip tr + 2 (one dword per 128-byte line) so that its LDS-DMA hits L2
@@ -160,7 +220,11 @@ __device__ __forceinline__ void rings_start(RingS<HP, MODE>& r, const WBuf&, int
 // at the next barrier (trip_barrier waits vmcnt(0))
 template <int HP, int MODE>
 __device__ __forceinline__ void rings_stage(RingS<HP, MODE>& r, const WBuf&, int W, int nextW, int tr, int wave, int lane) {
+#if GAUDI_TRIP_FLAGS
+  rings_fill(r, r.par ^ 1, W, nextW, tr + 1, wave, lane);
+#else
   rings_dma(r, r.slot(r.par ^ 1), W, nextW, tr + 1, wave, lane);
+#endif
 #if GAUDI_RING_PREFETCH
   // The weight set (58 MB) streams through a 4 MiB L2 once per step: the first CU of an XCD to ask for a line waits for the
   // Infinity Cache.  Each wave touches 64 lines (8 KiB) of the group after next; the value is discarded.
@@ -224,6 +288,29 @@ __device__ __forceinline__ void trip_barrier() {
 #endif
   __syncthreads();
 }
+// open a trip on slot par / close it (the slot is free for this wave)
+template <int HP, int MODE>
+__device__ __forceinline__ void trip_open(RingS<HP, MODE>& r, int lane) {
+#if GAUDI_TRIP_FLAGS
+  rings_signal(r, lane);
+  flag_wait(r.fl + r.par, kWaves * ((r.par ? r.use1 : r.use0) + 1));
+#else
+  (void)r;
+  (void)lane;
+  trip_barrier();
+#endif
+}
+template <int HP, int MODE>
+__device__ __forceinline__ void trip_close(RingS<HP, MODE>& r, int lane) {
+#if GAUDI_TRIP_FLAGS
+  flag_add(r.fl + 2 + r.par, lane);
+  r.use0 += r.par ^ 1;
+  r.use1 += r.par;
+#else
+  (void)lane;
+#endif
+  r.par ^= 1;
+}
 
 // One trip: NT output tiles (acc[t0 .. t0+NT)) against the K chunk in `b`; A units one tile ahead in registers.
 #ifndef GAUDI_SPLIT_PD
@@ -239,12 +326,16 @@ struct NoHook {
 // `hook(tile tag)` runs next to the MFMAs of every output tile (inside the same scheduling region): vector work cut into
 // small slices co-issues with the bf16 matrix instructions of BOTH waves of the SIMD instead of stalling the wave's own
 // MFMA stream in one lump (GAUDI_SPLIT_GENSPREAD, edge_gemm_pq_s)
-template <int HP, int MODE, int NT, bool ACT, class MID, class HOOK>
-__device__ __forceinline__ void rings_mfma_act(f4* acc, const float* slot_lane, const B3& b, MID mid, HOOK hook) {  // NOLINT
+#ifndef GAUDI_TRIP_LATE
+#define GAUDI_TRIP_LATE 2  // the FULL signal of the fill issued mid-trip is given this many tiles before the end of the trip
+#endif
+template <int HP, int MODE, int NT, bool ACT, class MID, class HOOK, class LATE>
+__device__ __forceinline__ void rings_mfma_act(f4* acc, const float* slot_lane, const B3& b, MID mid, HOOK hook, LATE late) {  // NOLINT
   constexpr int U = SplitGeo<HP, MODE>::kUnit;
   constexpr int PD = GAUDI_SPLIT_PD, NB = PD + 1;
   if constexpr (!ACT) {  // a wave without an edge tile in this round: its share of the ring traffic only
     mid();
+    late();
     return;
   }
   f4 a[NB][3];
@@ -259,6 +350,10 @@ __device__ __forceinline__ void rings_mfma_act(f4* acc, const float* slot_lane, 
     constexpr int cur = t % NB;
     if (t == NT / 2) {
       mid();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t == (NT - GAUDI_TRIP_LATE > NT / 2 ? NT - GAUDI_TRIP_LATE : NT - 1)) {
+      late();
       __builtin_amdgcn_sched_barrier(0);
     }
     if (t + PD < NT) {
@@ -293,10 +388,14 @@ __device__ __forceinline__ void rings_mfma_act(f4* acc, const float* slot_lane, 
 // small slices co-issues with the bf16 matrix instructions instead of stalling the wave's MFMA stream in one lump
 // (GAUDI_SPLIT_GENSPREAD, edge_gemm_pq_s).  One wave-uniform branch per TRIP separates waves with and without a tile, so a
 // tile's MFMAs and its slice share a basic block.
-template <int HP, int MODE, int NT, class MID, class HOOK = NoHook>
-__device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, const B3& b, bool active, MID mid, HOOK hook = HOOK{}) {  // NOLINT
-  if (active) rings_mfma_act<HP, MODE, NT, true>(acc, slot_lane, b, mid, hook);
-  else rings_mfma_act<HP, MODE, NT, false>(acc, slot_lane, b, mid, hook);
+struct NoLate {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int HP, int MODE, int NT, class MID, class HOOK = NoHook, class LATE = NoLate>
+__device__ __forceinline__ void rings_mfma(f4* acc, const float* slot_lane, const B3& b, bool active, MID mid, HOOK hook = HOOK{},
+                                           LATE late = LATE{}) {  // NOLINT
+  if (active) rings_mfma_act<HP, MODE, NT, true>(acc, slot_lane, b, mid, hook, late);
+  else rings_mfma_act<HP, MODE, NT, false>(acc, slot_lane, b, mid, hook, late);
 }
 
 // The K-tail trip: one fp32 k-step per output tile (A = element 0 of the tile's lane-linear float4, B = the lane group's input)
@@ -383,7 +482,7 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
       constexpr int h = decltype(h_tag)::value;
       constexpr int NT = G::tiles_of(h);
       const int tr = m * G::NH + h;
-      trip_barrier();
+      trip_open(ring, lane);
 #if GAUDI_SPLIT_GENSPREAD
       if constexpr (h == G::NH - 1) {
         // stage s of the generation runs beside tile s * NT / kStages ... spread evenly over the trip's tiles
@@ -406,9 +505,13 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
         // every wave generates the NEXT chunk in the middle of its block (vector work co-issues with bf16 MFMAs; the
         // staggered placement of the fp32 form is 2 % slower here, generation right after the barrier 7 %)
         if (h == G::NH - 1) nb = gen(mn);
+      }, NoHook{}, [&] {
+#if GAUDI_TRIP_FLAGS
+        rings_signal(ring, lane);
+#endif
       });
 #endif
-      ring.par ^= 1;
+      trip_close(ring, lane);
     };
     trip(std::integral_constant<int, 0>{});
     if constexpr (G::NH > 1) trip(std::integral_constant<int, 1>{});
@@ -420,11 +523,11 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
   for (int m = 0; m < full; ++m) chunk(m);
   if constexpr (G::kTailOK) {
     if (tail) {
-      trip_barrier();
+      trip_open(ring, lane);
       const float bt = silu_f(edge_u_tail(pp, qq, sCr, sCd, g, T, r, d0)[0]);
       rings_mfma_tail<HP, MODE>(acc, ring.slot(ring.par) + lane * 4, bt, active,
                           [&] { rings_stage(ring, wb, W, nextW, G::kTripsTail - 1, wave, lane); });
-      ring.par ^= 1;
+      trip_close(ring, lane);
     }
   }
 }
@@ -451,10 +554,14 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
     auto trip = [&](auto h_tag) {
       constexpr int h = decltype(h_tag)::value;
       constexpr int tr = m * G::NH + h;
-      trip_barrier();
+      trip_open(ring, lane);
       rings_mfma<HP, MODE, G::tiles_of(h)>(out + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active,
-                                           [&] { rings_stage(ring, wb, W, nextW, tr, wave, lane); });
-      ring.par ^= 1;
+                                           [&] { rings_stage(ring, wb, W, nextW, tr, wave, lane); }, NoHook{}, [&] {
+#if GAUDI_TRIP_FLAGS
+                                             rings_signal(ring, lane);
+#endif
+                                           });
+      trip_close(ring, lane);
     };
     trip(std::integral_constant<int, 0>{});
     if constexpr (G::NH > 1) trip(std::integral_constant<int, 1>{});
@@ -463,10 +570,10 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
   static_for<G::NC - 1>([&](auto m_tag) { chunk(m_tag); });
   if constexpr (G::kTailOK) {
     if (ring.ktail) {
-      trip_barrier();
+      trip_open(ring, lane);
       rings_mfma_tail<HP, MODE>(out, ring.slot(ring.par) + lane * 4, tail_to_b(in[T - 1], c, g)[0], active,
                           [&] { rings_stage(ring, wb, W, nextW, G::kTripsTail - 1, wave, lane); });
-      ring.par ^= 1;
+      trip_close(ring, lane);
       return;
     }
   }
@@ -481,7 +588,7 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
 template <int HP, int SP>  // SP: 0 = fp32 matrix instructions, 1 / 2 = split operands with the full / half ring (SplitGeo)
 struct EdgeRing {
   using type = RingS<HP, SP>;
-  static constexpr int kFloats = 2 * SplitGeo<HP, SP>::kSlotFloats;
+  static constexpr int kFloats = 2 * SplitGeo<HP, SP>::kSlotFloats + (GAUDI_TRIP_FLAGS ? 4 : 0);
 };
 template <int HP>
 struct EdgeRing<HP, 0> {
@@ -491,10 +598,10 @@ struct EdgeRing<HP, 0> {
 __host__ __device__ constexpr int edge_ring_floats(int HP, int mode) {
   const int T = HP / 16;
   const int CH = (mode == 2 || (T + 1) / 2 == 1) && T > 1 ? (T + 1) / 2 : T;  // = SplitGeo<HP, mode>::CH
-  return mode ? 2 * CH * 3 * 256 : 2 * T * 256;
+  return mode ? 2 * CH * 3 * 256 + (GAUDI_TRIP_FLAGS ? 4 : 0) : 2 * T * 256;
 }
-static_assert(edge_ring_floats(32, 1) == 2 * SplitGeo<32, 1>::kSlotFloats && edge_ring_floats(208, 1) == 2 * SplitGeo<208, 1>::kSlotFloats &&
-                  edge_ring_floats(48, 2) == 2 * SplitGeo<48, 2>::kSlotFloats && edge_ring_floats(208, 2) == 2 * SplitGeo<208, 2>::kSlotFloats,
+static_assert(edge_ring_floats(32, 1) == EdgeRing<32, 1>::kFloats && edge_ring_floats(208, 1) == EdgeRing<208, 1>::kFloats &&
+                  edge_ring_floats(48, 2) == EdgeRing<48, 2>::kFloats && edge_ring_floats(208, 2) == EdgeRing<208, 2>::kFloats,
               "host LDS planning and SplitGeo disagree");
 __device__ __forceinline__ int split_off(int W) { return W < 0 ? -1 : 2 * W; }
 
@@ -509,6 +616,16 @@ __device__ __forceinline__ void er_init(RingS<HP, MODE>& r, float* base, bool kt
   r.base = base;
   r.par = 0;
   r.ktail = ktail;
+#if GAUDI_TRIP_FLAGS
+  // the counters live behind the two slots (EdgeRing::kFloats counts them); every phase starts from zero behind a barrier
+  r.fl = (lds_int*)(base + 2 * SplitGeo<HP, MODE>::kSlotFloats);
+  r.use0 = r.use1 = 0;
+  r.pend = false;
+  r.pend_slot = 0;
+  __syncthreads();
+  if (threadIdx.x < 4) r.fl[threadIdx.x] = 0;
+  __syncthreads();
+#endif
 #if GAUDI_SPLIT_GLDS
   r.gbase = ws;
 #else

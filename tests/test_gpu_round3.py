@@ -367,3 +367,24 @@ def test_packed_workgroups_fuzz():
             assert np.array_equal(alone[0][0], a[0][i]) and np.array_equal(alone[1][0], a[1][i]), (case, int(i))
     assert groups_seen >= 10  # the batches really were packed
     packed.close(); plain.close()
+
+
+def test_default_fused_kernel_200_repeats_are_bit_identical():
+    """The LDS-DMA weight ring's loads are not tracked by the compiler's barrier fence (every wave retires its
+    own with vmcnt(0) before the trip barrier).  A lost wait shows as run-to-run differences under load: 200 guided
+    launches of the default fused kernel (sampler_kernel_v<V8S,192,208>, C3 shape: 11-node cata molecules, one per CU on
+    all 256 CUs, 3 reverse steps + decode each) must return the same bits."""
+    F, N, B, T = 1, 11, 256, 3
+    eargs, pargs = synth.edm_args(diffusion_steps=T), synth.pred_args()
+    esd = synth.synth_edm_state_dict(eargs, F, seed=81, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=82, amplify_coord=True)
+    eng = _engine(eargs, esd, pargs, psd)
+    nm = np.ones((B, N), np.float32)
+    em = np.broadcast_to(1.0 - np.eye(N, dtype=np.float32), (B, N, N)).copy()
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    ref = eng.sample(nm, em, seed=5, target_w=w, scale=0.6, return_z0=True)
+    assert eng.kernel_variant()[1] == 8 and eng.edge_math()[1] == 1 and np.isfinite(ref[0]).all()
+    for rep in range(200):
+        out = eng.sample(nm, em, seed=5, target_w=w, scale=0.6, return_z0=True)
+        assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]) and np.array_equal(out[-1], ref[-1]), rep
+    eng.close()

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, i
   constexpr int T = HP / 16, LD = HP + 4, N = 11;
   using G = w8::SplitGeo<HP, SPLIT_MODE>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int ring_floats = SPLIT ? 2 * G::kSlotFloats : 2 * T * 256;
+  constexpr int ring_floats = SPLIT ? w8::EdgeRing<HP, SPLIT_MODE>::kFloats : 2 * T * 256;
   float* sP = smem + ring_floats;
   float* sQ = sP + N * LD;
   float* vec = sQ + N * LD;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, co
 
 template <int HP, bool SPLIT>
 static size_t ring_bytes() {
-  return (SPLIT ? 2 * w8::SplitGeo<HP, SPLIT_MODE>::kSlotFloats : 2 * (HP / 16) * 256) * 4;
+  return (SPLIT ? w8::EdgeRing<HP, SPLIT_MODE>::kFloats : 2 * (HP / 16) * 256) * 4;
 }
 
 template <int HP, bool SPLIT>
@@ -181,6 +181,17 @@ void run_time(int nactive, int blocks, int nmat) {
   unsigned long long hc[2];
   hipMemcpy(&hc[0], cyc, 8, hipMemcpyDeviceToHost);
   hipMemcpy(&hc[1], cyc + blocks * 8, 8, hipMemcpyDeviceToHost);
+  {  // checksum of every thread's accumulated outputs: equal between the barrier and the flag form, and from run to run
+    std::vector<float> ho((size_t)blocks * 512);
+    hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost);
+    uint64_t hsh = 1469598103934665603ull;
+    for (float v : ho) {
+      uint32_t u;
+      memcpy(&u, &v, 4);
+      hsh = (hsh ^ u) * 1099511628211ull;
+    }
+    printf("[out hash %016llx] ", (unsigned long long)hsh);
+  }
   printf("[memtime %llu ticks, wall %llu ticks of 100 MHz => memtime runs at %.0f MHz] ", hc[0], hc[1], 100.0 * hc[0] / hc[1]);
   printf("%s edge_gemm_pq HP=%d CH=%d active=%d blocks=%d matrices=%d (%.1f MB) LDS %zu B: %.2f us per GEMM (K=%d)\n",
          SPLIT ? "split-bf16" : "fp32-mfma ", HP, SPLIT ? G::CH : 0, nactive, blocks, nmat, wfloats * 4 / 1e6, lds, ms * 1e3 / gemms, HP);
