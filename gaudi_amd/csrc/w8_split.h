@@ -26,6 +26,9 @@
 #define GAUDI_RING_AUX 0  // cache-policy bits of the LDS-DMA ring loads (experiment knob: 2 = nt)
 #endif
 
+#ifndef GAUDI_RING_OPAQUE_UNITS
+#define GAUDI_RING_OPAQUE_UNITS 1
+#endif
 #ifndef GAUDI_TRIP_FLAGS
 #define GAUDI_TRIP_FLAGS 0  // 1: trips are opened by per-slot FULL / FREE counters in LDS instead of a workgroup barrier (experiment)
 #endif
@@ -165,6 +168,11 @@ __device__ __forceinline__ bool trip_group(const RingS<HP, MODE>& r, int W, int 
   }
   off = __builtin_amdgcn_readfirstlane(off);
   units = __builtin_amdgcn_readfirstlane(units);
+#if GAUDI_RING_OPAQUE_UNITS
+  // `units` is the same for every trip of a matrix: left visible, hipcc computes the "unit < units" tests of all the ring loads
+  // once per GEMM chain, keeps them as lane masks across the chain and spills them (two v_readlane per ring load and trip)
+  asm volatile("" : "+s"(units));
+#endif
   return !(nxt && nextW < 0);
 }
 #if GAUDI_SPLIT_GLDS
