@@ -304,6 +304,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     per_launch = (cnt * steps_done + cnt_edm * steps) / max(n_launch, 1)
     f32_flop, bf_flop = per_launch[0] * flops.FLOP_MFMA_F32, per_launch[1] * flops.FLOP_MFMA_BF16
     evals = steps_done + steps * (edm_only / max(mfma_step, 1))
+    wstream = flops.step_weight_stream_bytes(eargs, pa, equiv_variant if variant != "w8s" else "w8s")
     avg_launch_ms = kern_ms / max(n_launch, 1)
     t_launch = avg_launch_ms * 1e-3
     achieved = (f32_flop + bf_flop) / t_launch / 1e12
@@ -359,6 +360,12 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                                     "v_mfma_f32_16x16x4_f32 equivalents (a 4x4x1_16B instruction = 1/4) x 2048 FLOP at 157.3 TFLOP/s + "
                                     "v_mfma_f32_16x16x32_bf16 x 16384 FLOP at 2516.6 TFLOP/s; frac = matrix-pipe time at peak / launch "
                                     "time; = SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 and _BF16 / 32 in profiles/",
+                     "l2_weight_stream": {
+                         "bytes_per_workgroup_step": wstream,
+                         "achieved_TBps": G * wstream * evals / max(n_launch, 1) / t_launch / 1e12,
+                         "note": "packed weights every workgroup streams from L2 per network evaluation (no reuse across workgroups "
+                                 "of a CU: one molecule or packed group per workgroup); MI355X_MICROARCH.md: 16.8-18.8 TB/s chip-wide "
+                                 "for rows gathered from L2 hits, 34.5 TB/s L2 peak -- the second ceiling of this design beside the matrix pipe"},
                      "issued_fp32_mfma_per_launch": per_launch[0], "issued_bf16_mfma_per_launch": per_launch[1],
                      "peak_fp32_matrix_tflops": flops.PEAK_F32_TFLOPS, "peak_bf16_matrix_tflops": flops.PEAK_BF16_TFLOPS,
                      "fp32_equivalent_tflops": equiv_launch / t_launch / 1e12,

@@ -127,6 +127,32 @@ def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
     return step_mfma_counts(edge_units, ncols, edm, pred, variant)[0]
 
 
+def step_weight_stream_bytes(edm, pred=None, variant="w8s"):
+    """Bytes of packed weights ONE workgroup streams from L2 per reverse step: every node-level matrix as (16 T)^2 fp32
+    (lane-linear tiles), every edge-level matrix as fp32 tiles or, for "w8s", as its split image (units of 1 KiB: K chunks x
+    output tiles x 3 bf16 pieces; a K tail as T fp32 tiles).  Same matrix counts as step_mfma_counts.  No reuse across
+    workgroups inside a CU -- one molecule (or packed group) per workgroup -- so a launch of G workgroups moves G times this
+    through the L2 -> CU fabric per step."""
+    def node_b(T):
+        return (16 * T) ** 2 * 4
+
+    def edge_b(T, nf):
+        if variant != "w8s":
+            return (16 * T) ** 2 * 4
+        tail = _has_ktail(nf, 16 * T) and T % 2 == 1 and T >= 3
+        nc = (T + 1) // 2 - (1 if tail else 0)
+        return nc * T * 3 * 1024 + (T * 1024 if tail else 0)
+
+    Te = _pad_hidden_kernel(edm["nf"]) // 16
+    L, S = edm["n_layers"], edm.get("inv_sublayers", 1)
+    total = L * ((S * 5 + 2) * node_b(Te) + (S + 1) * edge_b(Te, edm["nf"]))
+    if pred is not None:
+        Tp = _pad_hidden_kernel(pred["nf"]) // 16
+        Lp = pred["n_layers"]
+        total += 2 * Lp * 5 * node_b(Tp) + 2 * (2 * Lp - 1) * edge_b(Tp, pred["nf"])
+    return total
+
+
 def step_bytes_fused(B, N, F, weight_bytes, stash_bytes_per_mol=0):
     """HBM bytes a fully fused per-timestep launch must touch: state in/out + weights once
     (+ the predictor's per-layer node stash, written and read once)."""
