@@ -30,7 +30,8 @@
 #define GAUDI_RING_OPAQUE_UNITS 1
 #endif
 #ifndef GAUDI_TRIP_FLAGS
-#define GAUDI_TRIP_FLAGS 0  // 1: trips are opened by per-slot FULL / FREE counters in LDS instead of a workgroup barrier (experiment)
+#define GAUDI_TRIP_FLAGS 0  // 1: trips are opened by per-slot FULL / FREE counters in LDS instead of a workgroup barrier (experiment:
+                            // correct and slower; exercised by tools/split_gemm_microbench.hip only)
 #endif
 
 namespace gaudi {
