@@ -335,6 +335,9 @@ struct NoHook {
 // `hook(tile tag)` runs next to the MFMAs of every output tile (inside the same scheduling region): vector work cut into
 // small slices co-issues with the bf16 matrix instructions of BOTH waves of the SIMD instead of stalling the wave's own
 // MFMA stream in one lump (GAUDI_SPLIT_GENSPREAD, edge_gemm_pq_s)
+#ifndef GAUDI_SPLIT_PQ_UNROLL2
+#define GAUDI_SPLIT_PQ_UNROLL2 1
+#endif
 #ifndef GAUDI_TRIP_LATE
 #define GAUDI_TRIP_LATE 2  // the FULL signal of the fill issued mid-trip is given this many tiles before the end of the trip
 #endif
@@ -485,7 +488,7 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
   B3 bin = gen(0), nb = bin;
   static_assert(G::NH <= 3, "at most three trips per K chunk");
   const bool tail = G::kTailOK && ring.ktail;
-  auto chunk = [&](int m) {
+  auto chunk = [&](int m, const B3& bin, B3& nb) {  // consumes `bin`, generates the next chunk into `nb`
     const int mn = m + 1 < G::NC ? m + 1 : m;  // the chunk generated during this one (clamped at the end: no branch)
     auto trip = [&](auto h_tag) {
       constexpr int h = decltype(h_tag)::value;
@@ -525,11 +528,24 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
     trip(std::integral_constant<int, 0>{});
     if constexpr (G::NH > 1) trip(std::integral_constant<int, 1>{});
     if constexpr (G::NH > 2) trip(std::integral_constant<int, 2>{});
-    bin = nb;
   };
   const int full = tail ? G::NC - 1 : G::NC;  // one copy of the chunk body: the tail only shortens the rolled loop
+#if GAUDI_SPLIT_PQ_UNROLL2
+  // two chunks per iteration with the roles of the two operand sets swapped: no copy of the generated pieces per trip
+  int m = 0;
 #pragma unroll 1
-  for (int m = 0; m < full; ++m) chunk(m);
+  for (; m + 1 < full; m += 2) {
+    chunk(m, bin, nb);
+    chunk(m + 1, nb, bin);
+  }
+  if (m < full) chunk(m, bin, nb);
+#else
+#pragma unroll 1
+  for (int m = 0; m < full; ++m) {
+    chunk(m, bin, nb);
+    bin = nb;
+  }
+#endif
   if constexpr (G::kTailOK) {
     if (tail) {
       trip_open(ring, lane);

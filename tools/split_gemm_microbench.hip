@@ -190,7 +190,9 @@ void run_time(int nactive, int blocks, int nmat) {
       memcpy(&u, &v, 4);
       hsh = (hsh ^ u) * 1099511628211ull;
     }
-    printf("[out hash %016llx] ", (unsigned long long)hsh);
+    double sum = 0, asum = 0;
+    for (float v : ho) { sum += v; asum += std::fabs(v); }
+    printf("[out hash %016llx sum %.9e abs %.9e] ", (unsigned long long)hsh, sum, asum);
   }
   printf("[memtime %llu ticks, wall %llu ticks of 100 MHz => memtime runs at %.0f MHz] ", hc[0], hc[1], 100.0 * hc[0] / hc[1]);
   printf("%s edge_gemm_pq HP=%d CH=%d active=%d blocks=%d matrices=%d (%.1f MB) LDS %zu B: %.2f us per GEMM (K=%d)\n",
