@@ -42,6 +42,7 @@ def parse():
                          "stability = the graph-of-rings stability kernel that follows sampling (SURVEY 8f rank 1)")
     ap.add_argument("--molecules", type=int, default=262144, help="stability workload: molecules per call")
     ap.add_argument("--dataset", default="cata", choices=["cata", "hetro"], help="stability workload: geometry tables")
+    ap.add_argument("--nodes", type=int, default=11, help="c2 / c3: rings of the cata molecules (BASELINE: 11; fully connected graphs)")
     ap.add_argument("--diffusion-steps", type=int, default=1000)
     ap.add_argument("--steps-per-launch", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -200,7 +201,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     guided = workload in ("c3", "c4", "c4x")
     hetero = workload in ("c4", "c4x")
     max_rings = 20 if workload == "c4x" else 10
-    N, F = (2 * max_rings, 12) if hetero else (11, 1)
+    N, F = (2 * max_rings, 12) if hetero else (a.nodes, 1)
     ds = "hetro" if hetero else "cata"
     eargs = synth.edm_args(diffusion_steps=T, dataset=ds)
     pargs = synth.pred_args(dataset=ds)
@@ -321,8 +322,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
             traffic = json.load(open(pmc)).get(f"{workload}_bytes_per_launch")
         except Exception:
             traffic = None
-    label = {"c3": f"C3: cc-PBH 11-ring, batch={B}/GPU, {T} steps, HOMO-LUMO-gap guidance (scale 0.6)",
-             "c2": f"C2: cc-PBH 11-ring, batch={B}/GPU, {T} steps, unconditional EDM",
+    label = {"c3": f"C3: cc-PBH {N}-ring, batch={B}/GPU, {T} steps, HOMO-LUMO-gap guidance (scale 0.6)",
+             "c2": f"C2: cc-PBH {N}-ring, batch={B}/GPU, {T} steps, unconditional EDM",
              "c4": f"C4: PASs-like hetero, 3-10 rings (6-20 graph nodes, N=20: the reference's own cap, "
                    f"data/aromatic_dataloader.py:285), batch={B}/GPU, {T} steps, multi-objective (OPV) guidance",
              "c4x": f"C4 read literally: PASs-like hetero, 6-20 rings (12-40 graph nodes, N=40; beyond the reference dataset's cap), "

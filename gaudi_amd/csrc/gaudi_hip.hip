@@ -64,8 +64,10 @@ struct gaudi_handle {
   int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
   bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
   bool pack = true;           // several small molecules per workgroup in sampling calls (GAUDI_PACK=0: off)
+  bool pred_rounds = true;    // GAUDI_PRED_ROUNDS=0: guided calls with more than 128 edge slots go to the 4-wave kernels
   bool pack_now = false;      // set by run_chain around stage_graph: this call may pack
   int run_groups = 0;         // workgroups of the CURRENT call (= molecules unless packed)
+  bool run_mr = false;        // the current call runs the 8-wave kernels whose predictor takes several rounds of edge tiles
   bool force_gn = false;      // GAUDI_FORCE_GN=1 at gaudi_create: use them whenever they exist (test knob)
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
   long long fix_key = 0;      // global sample index whose Philox stream is shared
@@ -627,7 +629,27 @@ static kernel_fn pick_kernel8h(int hpe, int hpp) {
 #undef X
   return f;
 }
-static kernel_fn pick_kernel8_mode(int hpe, int hpp, int mode) {
+// ... and the kernels whose predictor runs several rounds of edge tiles (kern8m_*.hip: graphs of more than 128 slots)
+#ifdef GAUDI_STAMP_STUBS
+static kernel_fn pick_kernel8m(int, int, int) { return nullptr; }
+#else
+#define GAUDI_KERNEL8M_TUS(X) \
+  X(fused_192_208_s) X(fused_192_208_h) X(fused_192_208_f) X(pred_208_s) X(pred_208_h) X(pred_208_f) X(fused_tiny) X(pred_small)
+#define X(name) kernel_fn gaudi_kern8m_##name(int hpe, int hpp, int mode);
+GAUDI_KERNEL8M_TUS(X)
+#undef X
+static kernel_fn pick_kernel8m(int hpe, int hpp, int mode) {
+  kernel_fn f = nullptr;
+#define X(name) \
+  if (!f) f = gaudi_kern8m_##name(hpe, hpp, mode);
+  GAUDI_KERNEL8M_TUS(X)
+#undef X
+  return f;
+}
+#endif
+// mr: the call holds a graph of more than one round of edge tiles AND runs the predictor
+static kernel_fn pick_kernel8_mode(int hpe, int hpp, int mode, bool mr = false) {
+  if (mr) return pick_kernel8m(hpe, hpp, mode);
   return mode == 1 ? pick_kernel8s(hpe, hpp) : mode == 2 ? pick_kernel8h(hpe, hpp) : pick_kernel8(hpe, hpp);
 }
 
@@ -686,7 +708,7 @@ static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, int sp
 
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
   const bool v8 = h->run_variant == 8;
-  kernel_fn fn = v8 ? pick_kernel8_mode(hpe, hpp, h->run_split) : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
+  kernel_fn fn = v8 ? pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp) : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
@@ -831,13 +853,17 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   int rc = build_meta8(B, N, node_mask, edge_mask, M, err, std::max(h->plan_min_slots, h->call_min_slots));
   if (rc == GAUDI_E_CAPACITY) return 1;
   if (rc) return fail(h, rc, err);
-  if (hpp && M.S > 16 * w8::kWaves) return 1;  // the 8-wave predictor handles one round of tiles
+  // more than one round of eight edge tiles (a graph of more than 128 live-edge slots, e.g. a fully connected molecule of
+  // 12+ nodes): the 8-wave kernels run the rounds one after the other (GAUDI_PRED_ROUNDS=0: the round-2 behaviour, such calls
+  // go to the 4-wave kernels); the LDS plan below decides whether the larger per-slot arrays and publish buffer still fit
+  const bool mr = hpp && M.S > 16 * w8::kWaves;
+  if (mr && !h->pred_rounds) return 1;
   // ---- packing: small molecules share a workgroup as the components of one graph (sampling calls only).  First-fit in
   // the heaviest-first order; a group holds at most kMaxComp molecules, N node slots and 8 edge tiles (one round on 8
   // waves).  A molecule keeps its own tiles (component starts are tile-aligned), its nodes keep their relative order, its
   // noise is keyed by its own sample and node indices, and every per-molecule reduction runs per component in the order
   // the molecule's own workgroup would use: the result does not depend on the packing, bit for bit.
-  if (!pick_kernel8(hpe, hpp)) return 1;
+  if (!pick_kernel8_mode(hpe, hpp, 0, mr) && !pick_kernel8_mode(hpe, hpp, 1, mr) && !pick_kernel8_mode(hpe, hpp, 2, mr)) return 1;
   const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
   int pubx = 0, pub_ch = 0;
   // the arithmetic of the edge GEMMs for S edge slots: split-bf16 when the kernel exists and its larger weight ring fits
@@ -845,8 +871,8 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   auto plan_for = [&](int S) -> int {
     if (h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes))
       for (int mode = 1; mode <= 2; ++mode)
-        if (pick_kernel8_mode(hpe, hpp, mode) && plan_pub8(hpe, hpp, N, Dz, S, mode, pubx, pub_ch)) return mode;
-    return plan_pub8(hpe, hpp, N, Dz, S, 0, pubx, pub_ch) ? 0 : -1;
+        if (pick_kernel8_mode(hpe, hpp, mode, mr) && plan_pub8(hpe, hpp, N, Dz, S, mode, pubx, pub_ch)) return mode;
+    return pick_kernel8_mode(hpe, hpp, 0, mr) && plan_pub8(hpe, hpp, N, Dz, S, 0, pubx, pub_ch) ? 0 : -1;
   };
   const int mode_u = plan_for(M.S);
   if (mode_u < 0) return 1;
@@ -911,6 +937,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   P.compmol = packed ? h->d_compmol.as<int32_t>() : nullptr;
   P.ncomp = packed ? h->d_ncomp.as<int32_t>() : nullptr;
   h->run_groups = B;
+  h->run_mr = mr;
   return GAUDI_OK;
 }
 
@@ -921,6 +948,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   h->run_variant = h->variant;
   h->run_split = 0;
   h->run_gn = false;
+  h->run_mr = false;
   h->run_groups = B;
   if (h->variant == 8 && !h->force_gn) {
     const int rc8 = stage_graph8(h, B, N, node_mask, edge_mask, P, hpe, hpp);
@@ -1020,6 +1048,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_EDGE_MATH")) h->split = std::string(v) != "fp32";
   if (const char* v = getenv("GAUDI_FORCE_GN")) h->force_gn = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PACK")) h->pack = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_PRED_ROUNDS")) h->pred_rounds = atoi(v) != 0;
   h->run_variant = h->variant;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;

@@ -227,7 +227,7 @@ __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, f
 }
 // the predictor's forward and reverse passes are separate functions too (the reverse pass holds three 52-register
 // operand sets at its peak; allocated together with the forward it spilled twice as much)
-template <int HP, int SP>
+template <int HP, int SP, bool MR>
 __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args ga_, float t_val_, float* stash_, float readout_div_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PredDev W = uni(W_);
@@ -236,9 +236,9 @@ __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args 
   const w8::MolGraph mg = graph8(L, ga);
   w8::PredSmem<HP, SP> sm;
   sm.carve(L.net, ga.N, ga.S, ga.pubx);
-  w8::pred_forward<HP, SP>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
+  w8::pred_forward<HP, SP, MR>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
 }
-template <int HP, int SP>
+template <int HP, int SP, bool MR>
 __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args ga_, float* stash_, float readout_div_, int resume_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PredDev W = uni(W_);
@@ -247,13 +247,14 @@ __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args 
   const w8::MolGraph mg = graph8(L, ga);
   w8::PredSmem<HP, SP> sm;
   sm.carve(L.net, ga.N, ga.S, ga.pubx);
-  w8::pred_backward<HP, SP>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
+  w8::pred_backward<HP, SP, MR>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
                         uni(resume_) ? L.sZ : nullptr);
 }
 #endif
 
 // SP: edge GEMMs on the bf16 matrix pipe with three-way split operands (w8_split.h); otherwise fp32 MFMAs
-template <int SP>
+// MR: the predictor takes graphs of more than one round of eight edge tiles (w8_pred.h); the denoiser always does
+template <int SP, bool MR = false>
 struct V8T {
   static constexpr int kThreads = w8::kThreads;
   static constexpr int kSplit = SP;
@@ -307,16 +308,16 @@ struct V8T {
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
                                                const float* dpred_ext, float*) {
 #ifdef GAUDI_STAMPS
-    w8::guidance_update<HP, SP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
+    w8::guidance_update<HP, SP, MR>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
                             mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext);
 #else
     (void)sTmp;
     w8::PredSmem<HP, SP> sm;
     sm.carve(net, mg.N, mg.S, mg.pubx);
-    if (phase != 2) pred_fwd8_call<HP, SP>(W, gargs(mg), t_val, stash, readout_div);
+    if (phase != 2) pred_fwd8_call<HP, SP, MR>(W, gargs(mg), t_val, stash, readout_div);
     w8::guidance_seed<HP, SP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
     if (phase == 1) return;
-    pred_bwd8_call<HP, SP>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0);
+    pred_bwd8_call<HP, SP, MR>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0);
     w8::guidance_apply(mg, sZ, sGrad, sMean, sigma, tid);
 #endif
   }
@@ -324,7 +325,7 @@ struct V8T {
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
                                                     float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                     float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, float*) {
-    w8::predictor_entry<HP, SP>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
+    w8::predictor_entry<HP, SP, MR>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
                             mg.pub_ch, tid STAMP_ARGS);
   }
 };
@@ -638,5 +639,8 @@ template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8s = &sampler_kernel_v<V8S, HPE, HPP>;
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8h = &sampler_kernel_v<V8H, HPE, HPP>;
+// ... whose predictor runs several rounds of edge tiles (kern8m_*.hip): SP = 0 / 1 / 2 as above
+template <int SP, int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel8m = &sampler_kernel_v<V8T<SP, true>, HPE, HPP>;
 
 }  // namespace gaudi

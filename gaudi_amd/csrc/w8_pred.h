@@ -1,7 +1,7 @@
 // w8_pred.h -- EGNN_predictor (edm/egnn_predictor/models.py:433-457,543-560; gcl.py:225-316) on the 8-wave kernels: forward
 // with the per-layer activation stash, the hand-written reverse pass that replaces torch.autograd.grad at
-// en_diffusion.py:900-903, and the guidance epilogue (:905-920).  One workgroup (8 waves) = one molecule whose live edges fit
-// ONE round of 16-slot tiles (<= 128 slots; larger graphs run on the 4-wave kernels).  Weight layout = PredLayout
+// en_diffusion.py:900-903, and the guidance epilogue (:905-920).  One workgroup (8 waves) = one molecule; its live edges run in
+// rounds of eight 16-slot tiles (one round for every molecule of the reference's datasets).  Weight layout = PredLayout
 // (pred_device.h), matrices packed lane-linear.
 #pragma once
 #include "pred_device.h"
@@ -52,8 +52,10 @@ struct PredSmem {
 //                     gate part  L x S floats (attention gate a_ij of every slot) | L x S floats (phi_ij = wc2 . silu(cpre))
 // The coordinate branch stashes what the reverse pass consumes -- silu'(cpre) and the scalar phi, both by-products of the
 // forward's own sigmoid -- instead of cpre: the reverse pass then needs no transcendental on those 208 features per edge.
+//                     du part    (S/16 tiles) x [HP/16][64 lanes] float4, graphs of more than one round (S > 128) only: the reverse
+//                                pass parks every tile's du there between its chain and the publish phase
 __host__ __device__ inline long long pred_stash_floats8(int N, int HP, int L, int S) {
-  return pred_stash_node_floats(N, HP, L) + (long long)L * S * HP * 2 + 2LL * L * S;
+  return pred_stash_node_floats(N, HP, L) + (long long)L * S * HP * 2 + 2LL * L * S + (S > 16 * kWaves ? (long long)S * HP : 0);
 }
 __device__ __forceinline__ size_t edge_stash_off8(int l, int tile, int arr, int S, int HP) {
   return (((size_t)l * (S / 16) + tile) * 2 + arr) * (size_t)(16 * HP);
@@ -69,7 +71,10 @@ __host__ __device__ inline int pub_chunk_tiles(int S, long long avail_floats, in
 // forward: pred[K] -> sm.pred[0..K)
 // buffers: h = b0, P = b1, Q = b2, agg = b3, second agg partial = b4
 // ---------------------------------------------------------------------------------------------
-template <int HP, int SP = 0>
+// MR: the kernel takes graphs of more than one round of eight edge tiles (more than 128 slots).  A separate instantiation: the
+// round loops (and the second copy of the reverse chain that parks du in the stash) cost the single-round kernels 2-4 % when
+// they live in the same function (hipcc's register allocation of the out-of-line phases changes), measured on C3.
+template <int HP, int SP = 0, bool MR = false>
 __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP>& sm, const float* sZ,
                                              float t_val, float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
@@ -140,12 +145,18 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       stash_store((f4*)st + idx, *(const f4*)(p + n * LD + f));
       stash_store((f4*)(st + N * HP) + idx, *(const f4*)(q + n * LD + f));
     }
+    STAMP(ST_STASH);
+    // Rounds of eight 16-slot tiles.  The kernels that are not MR run exactly one and must compile to what they were before
+    // rounds existed (a loop that folds away, or a lambda called once, cost C3 1-4 % through hipcc's register allocation):
+    // the round is a plain block, and only an MR kernel has the backward jump that repeats it.
+    int rd = 0;
     {
-      STAMP(ST_STASH);
-      const TileCols tc = load_tile(mg, 0, wave, c);
+    pred_fwd_round:
+      const bool more = MR && rd + 1 < mg.rounds;
+      const TileCols tc = load_tile(mg, MR ? rd : 0, wave, c);
       const f4 gg = sm.geo[tc.slot];
       f4 acc[T];
-      er_gemm_pq<HP>(acc, ring, wbe, Lw.W2, last ? -1 : Lw.Wc1, Lw.b2, Lw.cr, Lw.cd, p + tc.i * LD + 4 * g,
+      er_gemm_pq<HP>(acc, ring, wbe, Lw.W2, last ? (more ? Lw.W2 : -1) : Lw.Wc1, Lw.b2, Lw.cr, Lw.cd, p + tc.i * LD + 4 * g,
                        q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
       STAMP(ST_EDGE);
       const int tile = tc.slot >> 4;
@@ -173,7 +184,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       STAMP(ST_EDGE_EPI);
       if (!last) {  // coord_model (gcl.py:252-278): trans = dhat * tanh(wc2 . silu(Wc1 e + bc1)) * R * mask
         f4 cp[T];
-        er_gemm_regs<HP>(cp, acc, ring, wbe, Lw.Wc1, lay.layer(l + 1) + 2 * HP * HP, Lw.bc1, nullptr, tc.active, wave, lane);
+        er_gemm_regs<HP>(cp, acc, ring, wbe, Lw.Wc1, more ? Lw.W2 : lay.layer(l + 1) + 2 * HP * HP, Lw.bc1, nullptr, tc.active, wave,
+                         lane);
         STAMP(ST_EDGE);
         if (tc.active) {
           f4* sc = (f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
@@ -196,6 +208,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           if (g == 0) *(f4*)(sm.trans + 4 * tc.slot) = (f4){gg[1] * tau, gg[2] * tau, gg[3] * tau, 0.f};
         }
         STAMP(ST_EDGE_EPI);
+      }
+      if constexpr (MR) {
+        if (++rd < mg.rounds) goto pred_fwd_round;
       }
     }
     __syncthreads();
@@ -245,7 +260,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 //                          B4 = b4: npre (stash) -> dnpre -> dQ
 // pub_ch = 16-feature tiles of du published per chunk into [b0 | b1 | pub] (row = 16 pub_ch + 4 floats per slot)
 // ---------------------------------------------------------------------------------------------
-template <int HP, int SP = 0>
+template <int HP, int SP = 0, bool MR = false>
 __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP>& sm, const float* stash,
                                               float* sGrad, float readout_div, int pub_ch, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
@@ -265,6 +280,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   const float* pstash = astash + (size_t)W.L * S;
   const float* dpred = sm.pred + 16;
   const int nslots = mg.ntiles * 16;
+  f4* dus = (f4*)const_cast<float*>(pstash + (size_t)W.L * S);  // [S / 16 tiles][T][64] float4: du of every tile (more than one round only)
 
   if (sZin != nullptr) {
     // split-step mode: the forward ran in an earlier launch; rebuild the two input-geometry tensors it left in LDS
@@ -337,7 +353,15 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     //     and every thread sums one (node, 4 features) of dP_i = sum_j du_ij (receiver runs) and dQ_j = sum_i du_ij
     //     (sender lists) in slot order -- no atomics, fixed order
     {
-      const TileCols tc = load_tile(mg, 0, wave, c);
+      // One round of eight tiles (every molecule of the reference's datasets; the kernels that are not MR): du stays in
+      // registers until it is published.  More rounds (MR kernels): a wave's registers hold one tile, and the publish buffer
+      // overwrites dagg / Q, which the later rounds' chains still read -- so every round parks its du in the stash and the
+      // publish phase reads it back.
+      constexpr bool mr = MR;  // (an MR kernel parks du in the stash for one-round graphs too: they are not its business)
+      int rd = 0;
+    pred_bwd_round:  // (only an MR kernel jumps back here: see pred_forward)
+      const bool more = MR && rd + 1 < mg.rounds;
+      const TileCols tc = load_tile(mg, MR ? rd : 0, wave, c);
       const int tile = tc.slot >> 4;
       const f4 gg = sm.geo[tc.slot];
       const float d0v = sm.d0[tc.slot];
@@ -397,7 +421,8 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         // next edge GEMM of the chain: Wc1^T of layer l-1 (W2^T when that layer is ... never the last), none after layer 0
         // split form: nothing is prefetched across the publish phase (the ring is part of the publish buffer there); the
         // next layer's first group is requested right after it instead
-        er_gemm_regs<HP>(du, de, ring, wbe, Lw.W2t, (SP == 0 && l > 0) ? lay.layer(l - 1) + 10 * HP * HP : -1, nullptr, nullptr,
+        er_gemm_regs<HP>(du, de, ring, wbe, Lw.W2t,
+                         more ? (last ? Lw.W2t : Lw.Wc1t) : ((SP == 0 && l > 0) ? lay.layer(l - 1) + 10 * HP * HP : -1), nullptr, nullptr,
                          tc.active, wave, lane);  // dt1
         STAMP(ST_B_DT1);
       }
@@ -428,15 +453,36 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           sm.dd0[tc.slot] += dd0v;
         }
       }
+      if constexpr (MR) {
+        if (tc.active) {
+          f4* sd = dus + (size_t)tile * (T * 64) + lane;
+#pragma unroll
+          for (int t = 0; t < T; ++t) stash_store(sd + t * 64, du[t]);
+        }
+        if (++rd < mg.rounds) goto pred_bwd_round;
+      }
       STAMP(ST_B_DU);
       __syncthreads();  // every wave is done with P (B2), Q (B1) and dagg (B0): the publish buffer may overwrite B0 / B1
       for (int t0 = 0; t0 < T; t0 += pub_ch) {
         const int t1 = t0 + pub_ch < T ? t0 + pub_ch : T;
-        if (tc.active) {
-          float* row = pub + tc.slot * PLD + 4 * g - 16 * t0;
+        if constexpr (!mr) {
+          if (tc.active) {
+            float* row = pub + tc.slot * PLD + 4 * g - 16 * t0;
 #pragma unroll
-          for (int t = 0; t < T; ++t)
-            if (t >= t0 && t < t1) *(f4*)(row + 16 * t) = du[t];
+            for (int t = 0; t < T; ++t)
+              if (t >= t0 && t < t1) *(f4*)(row + 16 * t) = du[t];
+          }
+        } else {
+          for (int r2 = 0; r2 < mg.rounds; ++r2) {
+            const TileCols tp = load_tile(mg, r2, wave, c);
+            if (tp.active) {
+              float* row = pub + tp.slot * PLD + 4 * g - 16 * t0;
+              const f4* sd = dus + (size_t)(tp.slot >> 4) * (T * 64) + lane;
+#pragma unroll
+              for (int t = 0; t < T; ++t)
+                if (t >= t0 && t < t1) *(f4*)(row + 16 * t) = stash_load(sd + t * 64);
+            }
+          }
         }
         __syncthreads();
         const int nf4 = (t1 - t0) * 4;  // float4 per slot in this chunk
@@ -506,20 +552,20 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 }
 
 // unit-test entry: pred (and optionally grad into sGrad) for z in sZ
-template <int HP, int SP = 0>
+template <int HP, int SP = 0, bool MR = false>
 __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                 float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid STAMP_DECL) {
   (void)sTmp; (void)sMean;
   PredSmem<HP, SP> sm;
   sm.carve(net, mg.N, mg.S, pubx);
-  pred_forward<HP, SP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
+  pred_forward<HP, SP, MR>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
     if (pred_out) pred_out[tid] = sm.pred[tid];
     sm.pred[16 + tid] = dpred ? dpred[tid] : 0.f;
   }
   __syncthreads();
-  if (want_grad) pred_backward<HP, SP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS);
+  if (want_grad) pred_backward<HP, SP, MR>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS);
 }
 
 template <int HP, int SP = 0>
@@ -530,7 +576,7 @@ __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, fl
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 // phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
 // (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
-template <int HP, int SP = 0>
+template <int HP, int SP = 0, bool MR = false>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, float sigma, const float* target_w,
                                                 float scale, float* pred_out, float readout_div, float* stash, int pubx,
@@ -539,10 +585,10 @@ __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph
   const int N = mg.N, D = mg.D;
   PredSmem<HP, SP> sm;
   sm.carve(net, N, mg.S, pubx);
-  if (phase != 2) pred_forward<HP, SP>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
+  if (phase != 2) pred_forward<HP, SP, MR>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   guidance_seed<HP, SP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
   if (phase == 1) return;
-  pred_backward<HP, SP>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
+  pred_backward<HP, SP, MR>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
   guidance_apply(mg, sZ, sGrad, sMean, sigma, tid);
 }
 

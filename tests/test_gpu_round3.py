@@ -388,3 +388,55 @@ def test_default_fused_kernel_200_repeats_are_bit_identical():
         out = eng.sample(nm, em, seed=5, target_w=w, scale=0.6, return_z0=True)
         assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]) and np.array_equal(out[-1], ref[-1]), rep
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ more than one round of edge tiles
+@pytest.mark.parametrize("widths", ["tiny", "default"])
+@pytest.mark.parametrize("N", [12, 14, 16, 19])
+def test_dense_molecules_beyond_128_edge_slots_stay_on_8_waves(widths, N):
+    """A fully connected molecule of 12+ nodes has more than 128 live edges = more than one round of eight 16-slot tiles.
+    The guided path used to drop such calls to the 4-wave kernels; the 8-wave predictor now runs the
+    rounds one after the other (the reverse pass parks du of every tile in the stash between its chains and the publish
+    phase).  Predictor + input gradient and a guided step against the oracle at 1e-4, agreement with the 4-wave kernels
+    (GAUDI_PRED_ROUNDS=0), bitwise repeatability, and a mixed batch (one big, two small molecules) through a whole chain."""
+    from oracle import gaudi_oracle as O
+    T = 1000 if widths == "default" else 12
+    if widths == "tiny":
+        eargs, pargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=T), synth.pred_args(nf=36, n_layers=3)
+    else:
+        eargs, pargs = synth.edm_args(diffusion_steps=T), synth.pred_args()
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=91, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=92, amplify_coord=True)
+    nm, em = O.build_masks([N, N - 3, 5], N, False)
+    em = np.asarray(em, np.float32).reshape(3, N, N)
+    rng = np.random.default_rng(100 + N)
+    z = O._combined_noise(rng.standard_normal((3, N, 4)).astype(np.float32), nm)
+    eps = rng.standard_normal((3, N, 4)).astype(np.float32)
+    s = T // 3
+    t = np.full(3, np.float32(s + 1) / np.float32(T), np.float32)
+    w = O.target_max_gap_weights(5)
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    dp = np.broadcast_to(w * np.float32(0.6), (3, 5)).copy()
+    eng = _engine(eargs, esd, pargs, psd)
+    pred, grad = eng.predictor_grad(z, t, nm, em, dp)
+    assert eng.kernel_variant()[1] == 8, "the 8-wave predictor must take a graph of more than 128 edge slots"
+    opred, ograd = O.predictor_grad(psd, pargs, z, nm, em, t, dp)
+    assert rel_err(pred, opred) < 1e-4 and rel_err(grad, ograd) < 1e-4
+    assert np.abs(grad * (1 - nm)).max() == 0
+    zs = eng.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+    assert eng.kernel_variant()[1] == 8
+    assert rel_err(zs, O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6)) < 1e-4
+    for _ in range(3):
+        assert np.array_equal(eng.step(s, z, nm, em, eps, target_w=w, scale=0.6), zs)
+    one = eng.step(s, z[:1], nm[:1], em[:1], eps[:1], target_w=w, scale=0.6)  # the big molecule alone: the same bits
+    assert np.array_equal(one[0], zs[0])
+    x, h, d = eng.sample(nm, em, seed=1, target_w=w, scale=0.6) if widths == "tiny" else (None, None, None)
+    eng.close()
+    old = _engine(eargs, esd, pargs, psd, GAUDI_PRED_ROUNDS=0)
+    pred4, grad4 = old.predictor_grad(z, t, nm, em, dp)
+    assert old.kernel_variant()[1] == 4
+    assert rel_err(pred4, pred) < 1e-5 and rel_err(grad4, grad) < 2e-5
+    if widths == "tiny":
+        x4, h4, _ = old.sample(nm, em, seed=1, target_w=w, scale=0.6)
+        assert np.isfinite(x).all() and rel_err(x, x4) < 1e-3 and np.array_equal(h, h4)
+    old.close()

@@ -68,14 +68,34 @@ def test_four_wave_chain_and_entry_points(waves4, golden):
 
 
 def test_eight_wave_handle_falls_back_for_large_graphs(monkeypatch, O):
-    """More than 128 edge slots with guidance (a dense 14-node graph has 182 edges) is outside the 8-wave predictor's single
-    round of tiles: the call runs on the 4-wave kernels of the same handle and still matches the oracle."""
+    """Graphs outside the 8-wave kernels' limits run on the 4-wave kernels of the same handle and still match the oracle.
+    Round 2: more than 128 edge slots with guidance (a dense 14-node graph has 182 edges).  Since round 3 the 8-wave
+    predictor runs several rounds of eight tiles, so that graph stays on 8 waves (GAUDI_PRED_ROUNDS=0 restores the fallback,
+    checked here too); what still falls back is a node with more than 32 live edges (a dense 34-node graph)."""
     monkeypatch.delenv("GAUDI_WAVES", raising=False)
     from gaudi_amd.engine import Engine
     eargs = synth.edm_args(nf=64, n_layers=2, diffusion_steps=20)
     pargs = synth.pred_args(nf=60, n_layers=2)
     esd = synth.synth_edm_state_dict(eargs, 1, seed=5, amplify_coord=True)
     psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=6, amplify_coord=True)
+    gamma = O.gamma_table("polynomial_2", 20, 1e-5)
+    w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
+    for rounds, N, sizes, want in (("1", 14, [14, 9, 14], (8, 8)), ("0", 14, [14, 9, 14], (8, 4)), ("1", 34, [34, 9], (8, 4))):
+        monkeypatch.setenv("GAUDI_PRED_ROUNDS", rounds)
+        eng = Engine(0)
+        eng.load_edm(eargs, esd)
+        eng.load_predictor(pargs, psd)
+        nm, em = O.build_masks(sizes, N, False)
+        B = len(sizes)
+        rng = np.random.default_rng(1)
+        z = rng.standard_normal((B, N, 4)).astype(np.float32) * nm
+        z[:, :, :3] -= z[:, :, :3].sum(1, keepdims=True) / nm.sum(1, keepdims=True) * nm
+        eps = rng.standard_normal(z.shape).astype(np.float32)
+        got = eng.step(11, z, nm, em, eps, target_w=w, scale=0.7)
+        assert eng.kernel_variant() == want, (rounds, N, eng.kernel_variant())
+        assert rel_err(got, O.step_guided(esd, eargs, psd, pargs, gamma, 11, z, nm, em, eps, w, 0.7)) < 1e-4
+        eng.close()
+    monkeypatch.delenv("GAUDI_PRED_ROUNDS")
     eng = Engine(0)
     eng.load_edm(eargs, esd)
     eng.load_predictor(pargs, psd)
@@ -85,11 +105,6 @@ def test_eight_wave_handle_falls_back_for_large_graphs(monkeypatch, O):
     z = rng.standard_normal((3, N, 4)).astype(np.float32) * nm
     z[:, :, :3] -= z[:, :, :3].sum(1, keepdims=True) / nm.sum(1, keepdims=True) * nm
     eps = rng.standard_normal(z.shape).astype(np.float32)
-    gamma = O.gamma_table("polynomial_2", 20, 1e-5)
-    w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
-    got = eng.step(11, z, nm, em, eps, target_w=w, scale=0.7)
-    assert eng.kernel_variant() == (8, 4)
-    assert rel_err(got, O.step_guided(esd, eargs, psd, pargs, gamma, 11, z, nm, em, eps, w, 0.7)) < 1e-4
     # the unguided step of the same graph runs on the 8-wave denoiser (several rounds of tiles)
     got_u = eng.step(11, z, nm, em, eps)
     assert eng.kernel_variant() == (8, 8)
