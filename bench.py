@@ -346,8 +346,9 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                                       "by the edge lists in LDS (a complete graph of about 60 nodes)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": frac, "traffic": traffic,
-                     "kernel": ("sampler_kernel_v<%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
-                                                                  "208" if guided else "0")) if not (variant == "w4" and N > 22) else
+                     "kernel": ("sampler_kernel_v<%s%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
+                                                                    " (MR: several rounds of edge tiles)" if guided and variant != "w4" and int(np.max(units)) > 8 else "",
+                                                                    "208" if guided else "0")) if not (variant == "w4" and N > 22) else
                                "sampler_kernel_g<V4G,192,0> + sampler_kernel_g<V4G,0,208> (node buffers in global memory; two launches "
                                "per guided step, averaged together)",
                      "kernel_variant": {"w4": "4 waves per molecule, fp32 matrix instructions",
