@@ -887,7 +887,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
       rc = build_meta8(pk.G, N, pk.umask.data(), pk.uemask.data(), M2, err, M.S, pk.align.data());
       // a packed launch has more edge slots per workgroup; it must keep the arithmetic the unpacked plan has (the plan of a
       // sharded batch is the same on every rank, gaudi_set_plan_hint, and packing must not move a rank off it)
-      if (rc == GAUDI_OK && M2.S <= 16 * w8::kWaves && plan_for(M2.S) == mode_u) {
+      if (rc == GAUDI_OK && M2.S <= std::max(M.S, 16 * w8::kWaves) && plan_for(M2.S) == mode_u) {  // (a group holds <= 8 tiles)
         M = std::move(M2);
         B = pk.G;
         nm_used = pk.umask.data();

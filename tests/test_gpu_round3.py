@@ -440,3 +440,30 @@ def test_dense_molecules_beyond_128_edge_slots_stay_on_8_waves(widths, N):
         x4, h4, _ = old.sample(nm, em, seed=1, target_w=w, scale=0.6)
         assert np.isfinite(x).all() and rel_err(x, x4) < 1e-3 and np.array_equal(h, h4)
     old.close()
+
+
+def test_mixed_batch_big_and_small_molecules_packs_and_matches_unpacked():
+    """One fully connected 13-node molecule (10 edge tiles: two rounds, MR kernels) among small hetero-like ones: the small
+    ones still share workgroups, and the result equals the unpacked run bit for bit."""
+    from oracle import gaudi_oracle as O
+    T = 6
+    eargs, pargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=T), synth.pred_args(nf=36, n_layers=3)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=71, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=72, amplify_coord=True)
+    N = 13
+    sizes = [13, 3, 4, 2, 5, 3, 13, 4]
+    nm, em = O.build_masks(sizes, N, False)
+    em = np.asarray(em, np.float32).reshape(len(sizes), N, N)
+    w = np.array([0, -1, 0.5, 0, 0], np.float32)
+    outs = []
+    for pack in (1, 0):
+        eng = _engine(eargs, esd, pargs, psd, GAUDI_PACK=pack)
+        outs.append(eng.sample(nm, em, seed=9, sample_offset=3, target_w=w, scale=0.6, return_z0=True))
+        assert eng.kernel_variant()[1] == 8
+        if pack:
+            assert eng.pack_plan(nm, em)[0] < len(sizes)
+        eng.close()
+    for u, v in zip(*outs):
+        if isinstance(u, np.ndarray):
+            assert np.array_equal(u, v)
+    assert np.isfinite(outs[0][0]).all()
