@@ -467,3 +467,52 @@ def test_mixed_batch_big_and_small_molecules_packs_and_matches_unpacked():
         if isinstance(u, np.ndarray):
             assert np.array_equal(u, v)
     assert np.isfinite(outs[0][0]).all()
+
+
+@pytest.mark.parametrize("shape", ["c3", "c4"])
+def test_full_batch_guided_step_vs_cpp_port(shape):
+    """BASELINE's full batch shapes through ONE teacher-forced guided step at the default architectures against the C++/OpenMP
+    restatement (oracle/gaudi_cpu.cpp, itself pinned to the reference's goldens): C3 = 256 cata molecules of 11 nodes (one
+    workgroup per CU), C4 = 1024 hetero molecules of 3-10 rings, packed into ~700 workgroups.  Every molecule of the batch is
+    compared -- block -> molecule order, packing maps and noise rows included -- at 1e-4."""
+    from oracle import build_cpu
+    from oracle import gaudi_oracle as O
+    if not build_cpu.cpu_ok():
+        pytest.skip("host CPU lacks the ISA the C++ port is built for")
+    from gaudi_amd.sampling_edm import build_masks
+    T = 1000
+    hetero = shape == "c4"
+    ds = "hetro" if hetero else "cata"
+    F = synth.num_node_features(ds)
+    eargs, pargs = synth.edm_args(diffusion_steps=T, dataset=ds), synth.pred_args(dataset=ds)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=0, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=1, amplify_coord=True)
+    if hetero:
+        B = 1024
+        rings = np.random.default_rng(1).integers(3, 11, size=B)
+        nm3, em_flat, N = build_masks(rings, 10, True)
+        nm, em = nm3.reshape(B, N).astype(np.float32), em_flat.reshape(B, N, N).astype(np.float32)
+        w = np.array([3, 0, 1, 1, 0], np.float32)
+    else:
+        B, N = 256, 11
+        nm = np.ones((B, N), np.float32)
+        em = np.broadcast_to(1.0 - np.eye(N, dtype=np.float32), (B, N, N)).copy()
+        w = np.array([0, -1, 0, 0, 0], np.float32)
+    rng = np.random.default_rng(77)
+    z = O._combined_noise(rng.standard_normal((B, N, 3 + F)).astype(np.float32), nm[:, :, None])
+    eps = rng.standard_normal((B, N, 3 + F)).astype(np.float32)
+    s = 500
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    port = build_cpu.CpuPort()
+    port.load_edm(eargs, esd)
+    port.load_predictor(pargs, psd)
+    want = port.step(O.step_coefficients(gamma, s, s + 1), np.float32(np.float32(s + 1) / np.float32(T)), z, nm, em, eps,
+                     target_w=w, scale=0.6)
+    port.close()
+    eng = _engine(eargs, esd, pargs, psd)
+    got = eng.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+    assert eng.kernel_variant()[1] == 8
+    eng.close()
+    per_mol = np.abs(got - want).reshape(B, -1).max(1) / np.abs(want).reshape(B, -1).max(1)
+    assert per_mol.max() < 1e-4, (int(per_mol.argmax()), float(per_mol.max()))
+    assert np.all(got[nm == 0] == 0)
