@@ -8,7 +8,7 @@ B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary"
 for step in "$@"; do
   case $step in
     mb_node) timeout 300 gaudi_amd/ngemm_mb > $out/ngemm_mb.txt 2>&1 ;;
-    mb_split) for v in ${GAUDI_MB:-gs0 gs1 gs1sgb1 gs1sgb2}; do [ -x gaudi_amd/split_mb_$v ] && timeout 300 gaudi_amd/split_mb_$v t > $out/split_mb_$v.txt 2>&1; done ;;
+    mb_split) for v in ${GAUDI_MB:-base}; do [ -x gaudi_amd/split_mb_$v ] && timeout 300 gaudi_amd/split_mb_$v t > $out/split_mb_$v.txt 2>&1; done ;;
     tests_new) timeout 1500 python3 -m pytest tests/test_gpu_round3.py -x -q -m gpu -s > $out/tests_new.txt 2>&1
                timeout 1500 python3 -m pytest tests/test_gpu_round2.py tests/test_gpu_parity.py tests/test_gpu_stability.py -x -q -m gpu -k "nan or fresh or main_from_checkpoint or analyze or phi_vs_reference or predictor_forward_and_gradient or reproducible" >> $out/tests_new.txt 2>&1 ;;
     tests_all) timeout 3000 python3 -m pytest tests -x -q -m gpu > $out/tests_all.txt 2>&1 ;;
