@@ -564,3 +564,32 @@ def test_random_masks_fuzz_vs_oracle():
             worst = max(worst, err)
             assert err < 1e-4, (case, guided, B, N, n_live.tolist(), err)
     eng.close()
+
+
+def test_callback_target_on_a_graph_of_several_rounds():
+    """An arbitrary (nonlinear) target through gaudi_sample_cb on a fully connected 13-node molecule: the two device phases
+    per step (predictor forward | reverse pass + update) run on the MR 8-wave kernels; with a LINEAR target given as a
+    callback the chain equals the fused linear-target chain bit for bit, and a nonlinear one agrees with the 4-wave kernels."""
+    from oracle import gaudi_oracle as O
+    T = 8
+    eargs, pargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=T), synth.pred_args(nf=36, n_layers=3)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=61, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=62, amplify_coord=True)
+    N = 13
+    nm, em = O.build_masks([13, 6, 13], N, False)
+    em = np.asarray(em, np.float32).reshape(3, N, N)
+    w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
+    lin = lambda pred, t: np.broadcast_to(w, pred.shape)
+    nonlin = lambda pred, t: (2.0 * pred * w + np.cos(pred[:, :1]) * 0.1).astype(np.float32)
+    eng = _engine(eargs, esd, pargs, psd)
+    a = eng.sample(nm, em, seed=4, target_w=w, scale=0.5)
+    b = eng.sample_callback(nm, em, lin, seed=4, scale=0.5)
+    assert eng.kernel_variant()[1] == 8
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    c = eng.sample_callback(nm, em, nonlin, seed=4, scale=0.5)
+    eng.close()
+    old = _engine(eargs, esd, pargs, psd, GAUDI_PRED_ROUNDS=0)
+    c4 = old.sample_callback(nm, em, nonlin, seed=4, scale=0.5)
+    assert old.kernel_variant()[1] == 4
+    old.close()
+    assert np.isfinite(c[0]).all() and rel_err(c[0], c4[0]) < 1e-3 and np.array_equal(c[1], c4[1])
