@@ -593,3 +593,43 @@ def test_callback_target_on_a_graph_of_several_rounds():
     assert old.kernel_variant()[1] == 4
     old.close()
     assert np.isfinite(c[0]).all() and rel_err(c[0], c4[0]) < 1e-3 and np.array_equal(c[1], c4[1])
+
+
+def test_two_handles_sample_concurrently_from_two_threads():
+    """The C ABI is re-entrant across handles (include/gaudi_hip.h): two engines with DIFFERENT weights and widths load and
+    sample at the same time from two host threads (ctypes drops the GIL in the calls; each handle has its own stream) and
+    return exactly what they return one after the other."""
+    import threading
+    from gaudi_amd.sampling_edm import build_masks
+    cfgs = []
+    for k, (nf_e, nf_p, ds) in enumerate(((32, 36, "hetro"), (64, 60, "cata"))):
+        F = synth.num_node_features(ds)
+        eargs = synth.edm_args(nf=nf_e, n_layers=2, diffusion_steps=12, dataset=ds)
+        pargs = synth.pred_args(nf=nf_p, n_layers=2, dataset=ds)
+        esd = synth.synth_edm_state_dict(eargs, F, seed=10 + k, amplify_coord=True)
+        psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=20 + k, amplify_coord=True)
+        rings = np.random.default_rng(k).integers(2, 9, size=40)
+        nm3, em_flat, N = build_masks(rings, int(rings.max()), ds == "hetro")
+        cfgs.append((eargs, esd, pargs, psd, nm3.reshape(40, N), em_flat.reshape(40, N, N)))
+    w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
+
+    def run(cfg, out, reps):
+        eargs, esd, pargs, psd, nm, em = cfg
+        for r in range(reps):
+            eng = _engine(eargs, esd, pargs, psd)  # loading (= weight packing) inside the thread too
+            out.append(eng.sample(nm, em, seed=3 + r, target_w=w, scale=0.6))
+            eng.close()
+
+    serial = [[], []]
+    for k in range(2):
+        run(cfgs[k], serial[k], 3)
+    both = [[], []]
+    threads = [threading.Thread(target=run, args=(cfgs[k], both[k], 3)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(2):
+        assert len(both[k]) == 3
+        for a, b in zip(serial[k], both[k]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
