@@ -76,6 +76,19 @@ def cpu_baseline(eargs, pargs, esd, psd, guided, T, B):
                          target_w=w if guided else None, scale=0.6)
 
     one(T - 1)  # warm-up
+    # One molecule per thread streams the whole weight set through the core's caches: on a many-core host the memory system,
+    # not the core count, sets the rate, and fewer threads than hardware threads can be faster.  Probe a few thread counts
+    # (one step each) and time the sample with the best; `cores` reports the threads actually used.
+    hw = port.threads
+    best_n, best_t = hw, None
+    for n_thr in sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8)}, reverse=True):
+        port.set_threads(n_thr)
+        t1 = time.time()
+        one(T - 1)
+        dt1 = time.time() - t1
+        if best_t is None or dt1 < best_t:
+            best_n, best_t = n_thr, dt1
+    port.set_threads(best_n)
     n_steps, t0 = 0, time.time()
     while n_steps < 5 or (time.time() - t0 < 20.0 and n_steps < 100):
         one(T - 2 - n_steps)
@@ -83,11 +96,11 @@ def cpu_baseline(eargs, pargs, esd, psd, guided, T, B):
     per_step = (time.time() - t0) / n_steps
     total = per_step * T * (1.0 + (1.0 / T) * (0.3 if guided else 1.0))  # + decode = one EDM evaluation
     ref = 0.058 if guided else 0.175
-    threads, isa = port.threads, port.isa
+    threads, isa = best_n, port.isa
     port.close()
     return dict(value=B / total, unit="molecules/s", cores=threads, kind="port",
-                sample=f"C++/OpenMP restatement oracle/gaudi_cpu.cpp ({isa} GEMM micro-kernel, {threads} threads, one molecule per "
-                       f"thread), B={B} x {n_steps} {'guided' if guided else 'unguided'} reverse steps at N=11 after 1 warm-up, "
+                sample=f"C++/OpenMP restatement oracle/gaudi_cpu.cpp ({isa} GEMM micro-kernel, {threads} threads = the fastest of "
+                       f"{hw} / {hw // 2} / {hw // 4} / {hw // 8} on this host, one molecule per thread), B={B} x {n_steps} {'guided' if guided else 'unguided'} reverse steps at N=11 after 1 warm-up, "
                        f"extrapolated x{T} + decode; {per_step * 1e3:.0f} ms/step.  Cross-check (BASELINE.md section 2): the "
                        f"reference's own PyTorch-CPU path measured {ref} molecules/s on the 8-core build container for this "
                        f"workload, where this port measures 0.141 guided / 0.333 unguided; speedup_vs_cpu_baseline divides by the "

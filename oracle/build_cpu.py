@@ -80,6 +80,10 @@ class CpuPort:
     def threads(self):
         return int(self.lib.gcpu_threads())
 
+    def set_threads(self, n: int):
+        """OpenMP threads of the following calls (one molecule per thread)."""
+        self.lib.gcpu_set_threads(int(n))
+
     def _load(self, fn, cfg, sd, prefix):
         sd = {k: _f32(v) for k, v in sd.items() if k.startswith(prefix)}
         names = list(sd)

@@ -565,6 +565,8 @@ void* gcpu_create() { return new Model(); }
 void gcpu_destroy(void* p) { delete (Model*)p; }
 const char* gcpu_isa() { return gemm == gemm_avx512 ? "avx512f" : gemm == gemm_avx2 ? "avx2+fma" : "scalar"; }
 int gcpu_threads() { return omp_get_max_threads(); }
+// one molecule per thread streams the whole weight set: on a many-core host fewer threads than hardware threads can be faster
+void gcpu_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 int gcpu_load_edm(void* p, const EdmCfg* cfg, int n, const char* const* names, const float* const* tensors, const int64_t* numel) {
   Model& M = *(Model*)p;
