@@ -1,5 +1,5 @@
 // Microbenchmark + numerics probe of the split-bf16 edge GEMM (w8_split.h) next to the fp32-MFMA one (w8_common.h).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gaudi_amd/csrc tools/split_gemm_microbench.hip -o split_mb && ./split_mb
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I gaudi_amd/csrc -I tools/experiments tools/split_gemm_microbench.hip -o split_mb && ./split_mb
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
@@ -7,7 +7,7 @@
 #include <cstring>
 #include <random>
 #include <vector>
-#include "w8_split.h"
+#include "w8_split_variants.h"  // tools/experiments: the production header without the rejected knobs is gaudi_amd/csrc/w8_split.h
 using namespace gaudi;
 #ifndef SPLIT_MODE
 #define SPLIT_MODE 1  // 2: half ring
