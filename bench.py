@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--diffusion-steps", type=int, default=1000)
     ap.add_argument("--steps-per-launch", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the untimed full-batch step against the CPU restatement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 / C4 / C3-at-1024 passes after the headline")
     ap.add_argument("--dist", action="store_true",
                     help="N = 1 only: route the run through the SAME distributed code as N > 1 (init_process_group('nccl', "
@@ -106,6 +107,50 @@ def cpu_baseline(eargs, pargs, esd, psd, guided, T, B):
                        f"workload, where this port measures 0.141 guided / 0.333 unguided; speedup_vs_cpu_baseline divides by the "
                        f"larger of the port's figure on this host and the reference's 8-core figure",
                 per_core=B / total / max(threads, 1), reference_torch_cpu_8core=ref, reference_torch_cpu_per_core=ref / 8)
+
+
+def parity_gate(eng, eargs, pargs, esd, psd, nm, em, tw, T, tol=1e-4):
+    """One teacher-forced reverse step (s = T/2) of the FULL batch on the engine the timed loop is about to use, checked
+    molecule by molecule against the CPU restatement (oracle/: the C++ port, itself pinned to the reference's goldens; the
+    numpy oracle on the first 8 molecules when the port cannot be built here).  Untimed; a failing gate exits non-zero --
+    a fast kernel with wrong results must not print a bench line."""
+    from oracle import gaudi_oracle as O  # checker only
+    B, N = nm.shape
+    D = 3 + (np.asarray(esd["dynamics.egnn.embedding.weight"]).shape[1] - 1)
+    rng = np.random.default_rng(77)
+    z = O._combined_noise(rng.standard_normal((B, N, D)).astype(np.float32), nm[:, :, None])
+    eps = rng.standard_normal((B, N, D)).astype(np.float32)
+    s = T // 2
+    gamma = O.gamma_table(eargs["diffusion_noise_schedule"], T, eargs["diffusion_noise_precision"])
+    got = eng.step(s, z, nm, em, eps, target_w=tw, scale=0.6)
+    checker, rows = "oracle/gaudi_cpu.cpp (C++ port)", slice(0, B)
+    try:
+        from oracle import build_cpu
+        if not build_cpu.cpu_ok():
+            raise RuntimeError("host CPU lacks AVX2/FMA")
+        port = build_cpu.CpuPort()
+        port.load_edm(eargs, esd)
+        if tw is not None:
+            port.load_predictor(pargs, psd)
+        want = port.step(O.step_coefficients(gamma, s, s + 1), np.float32(np.float32(s + 1) / np.float32(T)), z, nm, em, eps,
+                         target_w=tw, scale=0.6)
+        port.close()
+    except Exception as exc:  # no g++ / no AVX2 on this host: the numpy oracle on a few molecules
+        rows = slice(0, min(B, 8))
+        checker = f"oracle/gaudi_oracle.py (numpy, first {rows.stop} molecules; C++ port unavailable: {exc})"
+        if tw is None:
+            want = O.step_unguided(esd, eargs, gamma, s, z[rows], nm[rows][:, :, None], em[rows], eps[rows])
+        else:
+            want = O.step_guided(esd, eargs, psd, pargs, gamma, s, z[rows], nm[rows][:, :, None], em[rows], eps[rows], tw, 0.6)
+    g, w = got[rows].reshape(want.shape[0], -1), np.asarray(want).reshape(want.shape[0], -1)
+    per_mol = np.abs(g - w).max(1) / np.maximum(np.abs(w).max(1), 1e-30)
+    rel = float(per_mol.max())
+    leak = bool(np.any(got[nm == 0] != 0))
+    gate = {"rel_err": rel, "tol": tol, "passed": bool(rel < tol and not leak and np.isfinite(got).all()),
+            "what": f"one teacher-forced {'guided' if tw is not None else 'unguided'} reverse step (s = {s}) of the full batch "
+                    f"({B} molecules) on the timed engine, max over molecules of max|HIP - CPU| / max|CPU|",
+            "checker": checker, "kernel_waves": eng.kernel_variant()[1], "edge_math": eng.edge_math()[1]}
+    return gate
 
 
 def bench_stability(a, emit):
@@ -202,7 +247,8 @@ def graph_meta8(nm, em):
     return ntiles, ncols
 
 
-def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, backend, T, K=5, edge_math=None, use_dist=False):
+def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, backend, T, K=5, edge_math=None, use_dist=False,
+                 gate=False, closure=None):
     """Time `steps` complete sampling calls of one workload; returns the contract fields + roofline of its kernel.
     edge_math="fp32": a handle created with GAUDI_EDGE_MATH=fp32 (edge GEMMs on fp32 matrix instructions)."""
     import torch
@@ -238,8 +284,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
             psd = synth.synth_predictor_state_dict(pargs, F, K, seed=1)
             eng.load_predictor(pargs, psd)
             wfloats += 2 * sum(v.size for v in psd.values())  # + the transposed copies the reverse pass streams
-        eng_cache[key] = (eng, 4 * wfloats)
-    eng, wbytes = eng_cache[key]
+        eng_cache[key] = (eng, 4 * wfloats, esd, psd if guided else None)
+    eng, wbytes, esd_k, psd_k = eng_cache[key]
     eng.set_steps_per_launch(a.steps_per_launch)
     if hetero:
         # PASs-like batch: 3..10 rings drawn uniformly (seed 1), orientation nodes -> 6..20 graph nodes, N = 20
@@ -259,11 +305,48 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
         else:
             tw[1] = -1.0  # target_function_max_gap: -pred[:,1]  (generation_guidance.py:200-203)
 
+    gate_out = None
+    if gate and rank == 0:
+        gate_out = parity_gate(eng, eargs, pargs, esd_k, psd_k, nm, em, tw, T)
+    closure_target = None
+    if closure is not None:
+        # The reference-form call: sampling_edm.sample_guidance(args, model, <closure over cond_predictor>, nodesxsample, scale)
+        # (generation_guidance.py:198-211, sampling_edm.py:172-224) through the Python mirror, on this engine.
+        import types
+        from gaudi_amd import sampling_edm as gs
+        from gaudi_amd.models_edm import CondPredictor, GaudiModel
+        model = GaudiModel.from_engine(eng, eargs)
+        cp = CondPredictor.from_engine(model, pargs)
+        if closure == "linear":
+            def closure_target(_input, _node_mask, _edge_mask, _t):  # generation_guidance.py:200-203, verbatim
+                pred = cp(_input, _node_mask, _edge_mask, _t)
+                gap = pred[:, 1]
+                return -gap
+        else:
+            def closure_target(_input, _node_mask, _edge_mask, _t):  # a target that is NOT affine in pred (README: "any target")
+                import torch as _t_
+                pred = cp(_input, _node_mask, _edge_mask, _t)
+                return -_t_.tanh(0.05 * pred[:, 1]) * 20.0 + 0.01 * pred[:, 0] ** 2
+        cl_args = types.SimpleNamespace(device="cuda", dataset=ds, max_nodes=N)
+        nodesxsample = np.full(B, N, np.int64)
+
     def one_pass(it):
-        x, h, diag = eng.sample(nm, em, seed=1234 + it, sample_offset=rank * B, std=1.0, target_w=tw, scale=0.6)
+        if closure_target is not None:
+            model.sample_offset = rank * B  # same global sample indices every pass (the seed changes)
+            model.seed = 1234 + it
+            x, h, _, _ = gs.sample_guidance(cl_args, model, closure_target, nodesxsample, scale=0.6, std=1.0)
+            x, h, diag = x.numpy(), h.numpy(), model.last_diag
+        else:
+            x, h, diag = eng.sample(nm, em, seed=1234 + it, sample_offset=rank * B, std=1.0, target_w=tw, scale=0.6)
+        t_g = 0.0
         if use_dist:
+            tg0 = time.perf_counter()
             x, h = gdist.gather_to_all(x, h, B * world, N, F, device=dev if backend == "nccl" else None)
+            t_g = time.perf_counter() - tg0
+        gather_s[0] += t_g
         return x, h, diag
+
+    gather_s = [0.0]
 
     def sync():
         torch.cuda.synchronize()
@@ -274,16 +357,25 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     for it in range(warmup):
         one_pass(-1 - it)
     eng.profile_reset(True)
+    gather_s[0] = 0.0
     sync()
     t0 = time.perf_counter()
     for it in range(steps):
         x, h, diag = one_pass(it)
+    dt_own = time.perf_counter() - t0  # this rank's own time, before it waits for the others
     sync()
     dt = time.perf_counter() - t0
+    per_rank_ms = None
     if use_dist:
-        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        tdev = dev if backend == "nccl" else "cpu"
+        tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # the curve must be decomposable: every rank's own time per call and its share spent in the gather
+        mine = torch.tensor([dt_own / steps * 1e3, gather_s[0] / steps * 1e3], device=tdev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [[float(v) for v in t_.cpu()] for t_ in allr]
     n_launch, kern_ms, steps_done = eng.profile_get()
     eng.profile_reset(False)
     assert x.shape[0] == B * world and np.isfinite(x).all()
@@ -302,8 +394,13 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     wv = eng.kernel_variant()[1]
     em_mode = eng.edge_math()[1]  # 0 fp32 instructions, 1 split operands (full LDS weight ring), 2 split (half ring)
     variant = "w4" if wv == 4 else ("w8s" if em_mode else "w8")
-    packed = variant != "w4" and os.environ.get("GAUDI_PACK", "1") != "0"
-    units, ncols = graph_meta(nm, em) if variant == "w4" else (graph_meta8_packed(nm, em) if packed else graph_meta8(nm, em))
+    # workgroups of the launches that actually ran (molecules, or the groups the call packed them into): the issued-instruction
+    # model below must describe THAT launch, so the host-side plan is only used when it agrees with it
+    run_groups = eng.last_workgroups()
+    units, ncols = graph_meta(nm, em) if variant == "w4" else graph_meta8(nm, em)
+    if variant != "w4" and run_groups != B:
+        units, ncols = graph_meta8_packed(nm, em)
+        assert len(ncols) == run_groups, f"the launch ran {run_groups} workgroups, the host pack plan says {len(ncols)}"
     npairs = units
     G = len(ncols)  # workgroups per call: molecules, or groups of molecules when the call packs
     pa = pargs if guided else None
@@ -396,6 +493,10 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                      "hbm_algorithmic_gbps": hbm_bytes_launch / (avg_launch_ms * 1e-3) / 1e9,
                      "hbm_frac": hbm_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS},
         "diag": diag,
+        **({"parity_gate": gate_out} if gate_out is not None else {}),
+        **({"rccl_ranks": world, "per_rank_ms": [r[0] for r in per_rank_ms], "gather_ms": [r[1] for r in per_rank_ms],
+            "per_rank_note": "per call: each rank's own wall time before the closing barrier, and the part of it spent in the "
+                             "all_gather (host staging + collective)"} if per_rank_ms is not None else {}),
     }
 
 
@@ -450,7 +551,12 @@ def main():
     # (C5): 1024 guided samples per GPU, 8192 over 8 GPUs.
     B = a.batch or (1024 if (a.workload in ("c4", "c4x") or world > 1) else 256)
     engines = {}
-    out = run_workload(a, engines, a.workload, B, a.steps, a.warmup, rank, world, dev, backend, T, use_dist=use_dist)
+    out = run_workload(a, engines, a.workload, B, a.steps, a.warmup, rank, world, dev, backend, T, use_dist=use_dist,
+                       gate=not a.no_parity_gate)
+    if rank == 0 and "parity_gate" in out and not out["parity_gate"]["passed"]:
+        sys.stderr.write("bench.py: PARITY GATE FAILED: " + json.dumps(out["parity_gate"]) + "\n")
+        emit({"error": "parity gate failed", "parity_gate": out["parity_gate"]})
+        os._exit(3)
     if rank == 0:
         if use_dist:
             out["config"]["collective"] = (f"{backend} all_gather per call (world {world}"
@@ -467,17 +573,40 @@ def main():
                            "fp32_equivalent_frac_of_fp32_peak": r["roofline"]["fp32_equivalent_frac_of_fp32_peak"],
                            "avg_launch_ms": r["roofline"]["avg_launch_ms"], "kernel": r["roofline"]["kernel"],
                            "edge_gemm_math": r["edge_gemm_math"]}
+            # the reference-form call: C3 through sampling_edm.sample_guidance with the closure the
+            # reference ships (affine in pred: recognised and run on the fused kernel) and with one that is not (callback path:
+            # two launches per step around torch.autograd on the [B,K] leaf)
+            for wl, cl, st, wu in (("c3_closure_linear", "linear", 2, 1), ("c3_closure_nonlinear", "nonlinear", 1, 0)):
+                try:
+                    r = run_workload(a, engines, "c3", 256, st, wu, rank, world, dev, backend, T, closure=cl)
+                    sec[wl] = {"workload": r["config"]["workload"] + f"; reference-form closure ({cl}) through "
+                               "gaudi_amd.sampling_edm.sample_guidance", "value": r["value"], "unit": r["unit"], "steps": st,
+                               "warmup": wu, "ms_per_step": r["ms_per_step"], "launches": r["roofline"]["launches"],
+                               "ratio_to_fused_headline": r["value"] / out["value"]}
+                except Exception as exc:  # a secondary line must not cost the headline
+                    sec[wl] = {"error": repr(exc)}
             out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline:
             guided = a.workload in ("c3", "c4", "c4x")
-            out["cpu_baseline"] = cpu_baseline(synth.edm_args(diffusion_steps=T), synth.pred_args(),
-                                                synth.synth_edm_state_dict(synth.edm_args(diffusion_steps=T), 1, seed=0),
-                                                synth.synth_predictor_state_dict(synth.pred_args(), 1, K, seed=1), guided, T,
-                                                256)
-            out["speedup_vs_cpu_baseline"] = out["value"] / max(out["cpu_baseline"]["value"],
-                                                                 out["cpu_baseline"]["reference_torch_cpu_8core"])
+            ref8 = 0.058 if guided else 0.175  # the reference's own PyTorch-CPU path on the 8-core build container
+            try:  # the baseline leg must never cost the measured line (no g++ / no AVX2 / a stale build on this host)
+                from oracle import build_cpu
+                if not build_cpu.cpu_ok():
+                    raise RuntimeError("host CPU lacks AVX2/FMA: the C++ port cannot run here")
+                out["cpu_baseline"] = cpu_baseline(synth.edm_args(diffusion_steps=T), synth.pred_args(),
+                                                    synth.synth_edm_state_dict(synth.edm_args(diffusion_steps=T), 1, seed=0),
+                                                    synth.synth_predictor_state_dict(synth.pred_args(), 1, K, seed=1), guided, T,
+                                                    256)
+                out["speedup_vs_cpu_baseline"] = out["value"] / max(out["cpu_baseline"]["value"],
+                                                                     out["cpu_baseline"]["reference_torch_cpu_8core"])
+            except Exception as exc:
+                out["cpu_baseline"] = {"error": repr(exc), "reference_torch_cpu_8core": ref8, "unit": "molecules/s",
+                                       "kind": "reference", "cores": 8,
+                                       "sample": "C++ port unavailable on this host; the figure is the reference's PyTorch-CPU "
+                                                 "path measured on the 8-core build container (BASELINE.md section 2)", "value": ref8}
+                out["speedup_vs_cpu_baseline"] = out["value"] / ref8
         emit(out)
-    for eng, _ in engines.values():
+    for eng, *_ in engines.values():
         eng.close()
     if use_dist:
         dist.destroy_process_group()

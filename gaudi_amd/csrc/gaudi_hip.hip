@@ -41,6 +41,28 @@ struct DevBuf {
   T* as() const { return (T*)p; }
 };
 
+// pinned host memory (the per-step [B,K] exchange of gaudi_sample_cb: a pageable hipMemcpyAsync is staged and blocks)
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return (T*)p; }
+};
+
 struct gaudi_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -57,6 +79,8 @@ struct gaudi_handle {
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
       d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols, d_soff,
       d_sidx, d_gnode, d_rowmap, d_compmol, d_ncomp;
+  PinBuf p_pred, p_dpred;     // gaudi_sample_cb: pred [B,K] device -> host, dT/dpred [B,K] host -> device, once per step
+  hipEvent_t cb_event = nullptr;
   int steps_per_launch = 25;
   int variant = 8;            // 8 = two waves per SIMD (sampler_kernel8, default), 4 = one wave per SIMD (GAUDI_WAVES=4)
   int run_variant = 4;        // what the CURRENT call runs on (an 8-wave handle falls back to 4 waves for graphs that do not fit)
@@ -78,6 +102,7 @@ struct gaudi_handle {
   // sub-batches.
   int plan_min_slots = 0, plan_force_waves = 0;
   int call_min_slots = 0, call_force_waves = 0;
+  bool call_cut = false;      // gaudi_sample cut this request into sub-batches
   // profiling: launches are bracketed by HIP events on the handle's stream.  A small window of pending pairs is kept;
   // older pairs are folded into running sums and their events recycled (a T = 1000 callback chain makes 2001 launches).
   bool prof = false;
@@ -945,6 +970,8 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
 static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, KParams& P, int hpe,
                        int hpp) {
   if (B <= 0 || N <= 0) return fail(h, GAUDI_E_INVALID, "B and N must be positive");
+  // a node slot's row word holds molecule * N + node in 28 bits (sampler_kernel.h: row_of / comp_of)
+  if ((int64_t)B * N >= (1 << 28)) return fail(h, GAUDI_E_CAPACITY, "B * N must stay below 2^28 per call: cut the request into several calls");
   h->run_variant = h->variant;
   h->run_split = 0;
   h->run_gn = false;
@@ -993,10 +1020,13 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   // Molecules whose node buffers do not fit 160 KiB of LDS (beyond ~22 graph nodes at the default widths) run on the V4G
   // kernels: same code, node buffers in a per-workgroup global scratch (L2-resident).  The reference has no size cap
   // (sampling_edm.py:172-209); this one is N <= 255 (node indices are bytes in the edge words).
-  // The choice is made for the DENSE graph of N nodes, not for this batch's edges: shards of one logical batch must not
-  // land on different kernels because one of them happens to be sparser.
+  // While the call is a shard of a larger logical batch (plan hint) or one of gaudi_sample's sub-batches, the choice is made
+  // for the DENSE graph of N nodes, not for this batch's edges: the cuts of one logical batch must not land on different
+  // kernels because one of them happens to be sparser.  A call that stands alone decides from its own edge lists (a sparse
+  // hetero batch of 18-20 nodes fits the resident kernels where the dense graph would not).
   const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
-  if (h->force_gn || lds_bytes(hpe, hpp, N, Dz, std::max(M.EW, dense_ew4(N))) > 160 * 1024) {
+  const bool part_of_batch = h->plan_min_slots || h->plan_force_waves || h->call_min_slots || h->call_force_waves || h->call_cut;
+  if (h->force_gn || lds_bytes(hpe, hpp, N, Dz, part_of_batch ? std::max(M.EW, dense_ew4(N)) : M.EW) > 160 * 1024) {
     if (have_kernels_g(hpe, hpp) && lds_bytes(hpe, hpp, N, Dz, M.EW, true) <= 160 * 1024) {
       h->run_gn = true;
       const size_t stride = (gnode_floats(hpe, hpp, N) + 63) / 64 * 64;
@@ -1070,6 +1100,9 @@ void gaudi_destroy(gaudi_handle* h) {
                     &h->d_sflags, &h->d_sdist, &h->d_sadj, &h->d_saux, &h->d_stab, &h->d_as, &h->d_ncols, &h->d_soff, &h->d_sidx,
                     &h->d_gnode, &h->d_rowmap, &h->d_compmol, &h->d_ncomp};
   for (DevBuf* b : bufs) b->release();
+  h->p_pred.release();
+  h->p_dpred.release();
+  if (h->cb_event) (void)hipEventDestroy(h->cb_event);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1467,8 +1500,12 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
   // sub-batches plan with the whole batch's graph figures (same kernel family and edge-GEMM arithmetic for every cut)
   struct CallHint {
     gaudi_handle* h;
-    ~CallHint() { h->call_min_slots = h->call_force_waves = 0; }
+    ~CallHint() {
+      h->call_min_slots = h->call_force_waves = 0;
+      h->call_cut = false;
+    }
   } call_hint{h};
+  h->call_cut = bmax < B;
   if (bmax < B && h->variant == 8) {
     Meta8 M;
     std::string err;
@@ -1510,8 +1547,6 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
   KParams P{};
   int rc = stage_graph(h, B, N, node_mask, edge_mask, P, h->HPE, h->HPP);
   if (rc) return rc;
-  if (h->run_gn)
-    return fail(h, GAUDI_E_CAPACITY, "callback targets are not available for molecules beyond the LDS limit (use a linear target)");
   fill_edm(h, P);
   const int D = 3 + P.F, T = P.T, K = h->pcfg.out_nf;
   const size_t zb = sizeof(float) * B * N * D, pb = sizeof(float) * B * K;
@@ -1522,6 +1557,9 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
   HIPCHECK(h, h->d_nan.reserve(sizeof(int)));
   HIPCHECK(h, h->d_pred.reserve(pb));
   HIPCHECK(h, h->d_dpred.reserve(pb));
+  HIPCHECK(h, h->p_pred.reserve(pb));
+  HIPCHECK(h, h->p_dpred.reserve(pb));
+  if (!h->cb_event) HIPCHECK(h, hipEventCreateWithFlags(&h->cb_event, hipEventDisableTiming));
   HIPCHECK(h, hipMemsetAsync(h->d_nan.p, 0, sizeof(int), h->stream));
   const size_t nzb = h->fix_noise ? sizeof(float) * N * D : zb;
   if (noise) {
@@ -1547,33 +1585,50 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
   if (rc) return rc;
   P.pred_out = h->d_pred.as<float>();
   P.dpred_in = h->d_dpred.as<float>();
-  std::vector<float> pred((size_t)B * K), dT((size_t)B * K);
+  float* pred = h->p_pred.as<float>();
+  float* dT = h->p_dpred.as<float>();
   float* zin = h->d_zin.as<float>();
   float* zout = h->d_zout.as<float>();
+  // Large molecules (V4G kernels: node buffers in global memory) have no fused EDM + predictor instantiation (DESIGN.md
+  // 7.12): phase A is the EDM-only kernel (split = 1: z_t -> z_s before guidance) followed by the predictor-only kernel's
+  // forward half (MODE_GUIDE, split = 1), phase B the predictor-only kernel's second half (MODE_GUIDE, split = 2).
+  const bool gn = h->run_gn;
   for (int s = T - 1; s >= 0; --s) {
     // phase A: z_t -> z_s (before guidance) and pred = predictor(z_s, t); the activation stash stays on the device
+    P.mode = MODE_SAMPLE;
     P.s_hi = P.s_lo = s;
     P.do_init = s == T - 1;
     P.do_decode = 0;
     P.split = 1;
     P.z_in = zin;
     P.z_out = zout;
-    rc = launch(h, P, h->HPE, h->HPP, 1);
+    rc = launch(h, P, h->HPE, gn ? 0 : h->HPP, 1);
     if (rc) return rc;
-    HIPCHECK(h, hipMemcpyAsync(pred.data(), h->d_pred.p, pb, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
-    std::fill(dT.begin(), dT.end(), 0.f);
-    target_grad(user, B, K, pred.data(), (float)(s + 1) / (float)T, dT.data());
-    HIPCHECK(h, hipMemcpyAsync(h->d_dpred.p, dT.data(), pb, hipMemcpyHostToDevice, h->stream));
+    if (gn) {
+      P.mode = MODE_GUIDE;
+      P.do_init = 0;
+      P.z_in = zout;
+      P.z_out = zin;
+      rc = launch(h, P, 0, h->HPP, 0);
+      if (rc) return rc;
+    }
+    HIPCHECK(h, hipMemcpyAsync(pred, h->d_pred.p, pb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipEventRecord(h->cb_event, h->stream));
+    HIPCHECK(h, hipEventSynchronize(h->cb_event));
+    std::memset(dT, 0, pb);
+    target_grad(user, B, K, pred, (float)(s + 1) / (float)T, dT);
+    HIPCHECK(h, hipMemcpyAsync(h->d_dpred.p, dT, pb, hipMemcpyHostToDevice, h->stream));
     // phase B: reverse pass with the caller's dT/dpred, clip / project / apply, CoG removal
+    P.mode = gn ? MODE_GUIDE : MODE_SAMPLE;
     P.do_init = 0;
     P.split = 2;
     P.z_in = zout;
     P.z_out = zin;
-    rc = launch(h, P, h->HPE, h->HPP, 0);
+    rc = launch(h, P, gn ? 0 : h->HPE, h->HPP, 0);
     if (rc) return rc;
   }
   // decode pass
+  P.mode = MODE_SAMPLE;
   P.split = 0;
   P.s_hi = -1;
   P.s_lo = 0;
@@ -1581,7 +1636,7 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
   P.do_decode = 1;
   P.z_in = zin;
   P.z_out = zout;
-  rc = launch(h, P, h->HPE, h->HPP, 0);
+  rc = launch(h, P, h->HPE, gn ? 0 : h->HPP, 0);
   if (rc) return rc;
   if (z0_out) HIPCHECK(h, hipMemcpyAsync(z0_out, zout, zb, hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(h, hipMemcpyAsync(x_out, h->d_x.p, sizeof(float) * B * N * 3, hipMemcpyDeviceToHost, h->stream));
@@ -1722,6 +1777,12 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
   if (!h) return GAUDI_E_INVALID;
   if (configured) *configured = h->variant;
   if (last_call) *last_call = h->run_variant;
+  return GAUDI_OK;
+}
+
+int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups) {
+  if (!h || !workgroups) return GAUDI_E_INVALID;
+  *workgroups = h->run_groups;
   return GAUDI_OK;
 }
 

@@ -594,10 +594,16 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
       // Second half of a guided reverse step as its own launch (the V4G path: its fused EDM + predictor instantiation at the
       // default widths sits on the register cliff, so large molecules run "EDM-only kernel with split = 1, then this"):
       // z_in = z_s before guidance (en_diffusion.py:897) -> guidance update, projection, NaN scrub (:899-934) -> z_out.
+      // P.split = 1 / 2: the two halves of this launch around a host callback (gaudi_sample_cb on large molecules): 1 = predictor
+      // forward only, pred -> pred_out, z untouched; 2 = reverse pass with dT/dpred = dpred_in, then the update below.
       const f4 cf = *(const f4*)(P.coef + 4 * P.s_hi);
-      V::template guide<HPP>(P.pred, mg, net, sZ, sEps /* grad */, sNz /* scratch */, sMean, cf[3], cf[2], P.target_w, P.scale, nullptr,
-                             P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS, 0, nullptr,
+      const int gsplit = P.split;
+      V::template guide<HPP>(P.pred, mg, net, sZ, sEps /* grad */, sNz /* scratch */, sMean, cf[3], cf[2], P.target_w, P.scale,
+                             gsplit == 1 ? P.pred_out + (size_t)b * P.pred.K : nullptr,
+                             P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS, gsplit,
+                             gsplit == 2 ? P.dpred_in + (size_t)b * P.pred.K : nullptr,
                              V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr);
+      if (gsplit == 1) return;
       col_means(sZ);
       __syncthreads();
       for (int e = tid; e < N * 3; e += kThreads) {

@@ -32,13 +32,15 @@ def sample_sharded(sample_fn, node_mask: np.ndarray, edge_mask: np.ndarray, rank
     lo, hi = shard_bounds(B, rank, world)
     if hi == lo:
         return lo, hi, None, None
+    prev = None
     if engine is not None:
+        prev = getattr(engine, "_plan_hint", (0, 0))  # a hint the caller had set is restored afterwards
         engine.set_plan_hint(*engine.plan_hint_for(nm, em))
     try:
         x, h = sample_fn(nm[lo:hi], em[lo:hi], lo)
     finally:
         if engine is not None:
-            engine.set_plan_hint(0, 0)
+            engine.set_plan_hint(*prev)
     return lo, hi, x, h
 
 

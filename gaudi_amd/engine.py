@@ -321,9 +321,16 @@ class Engine:
         self._check(self.lib.gaudi_edge_math(self.h, C.byref(a), C.byref(b)), "gaudi_edge_math")
         return a.value, b.value
 
+    def last_workgroups(self) -> int:
+        """Workgroups of the most recent launch (molecules, or the groups they were packed into)."""
+        n = C.c_int32()
+        self._check(self.lib.gaudi_last_workgroups(self.h, C.byref(n)), "gaudi_last_workgroups")
+        return n.value
+
     def set_plan_hint(self, min_slots: int = 0, force_waves: int = 0):
         """Plan the following calls with the graph figures of a larger logical batch (see gaudi_set_plan_hint)."""
         self._check(self.lib.gaudi_set_plan_hint(self.h, int(min_slots), int(force_waves)), "gaudi_set_plan_hint")
+        self._plan_hint = (int(min_slots), int(force_waves))
 
     def plan_hint_for(self, node_mask, edge_mask):
         """(min_slots, force_waves) of a WHOLE logical batch: what every shard of it passes to set_plan_hint so that all

@@ -112,6 +112,40 @@ class PredTarget:
         return self.fn(pred, t)
 
 
+def affine_target_weights(fn, K: int, T: int, B: int = 3):
+    """-> w [K] if fn(pred [B,K], t) -> [B] is  w . pred + c  with the same w for every molecule and every t, else None.
+    Checked on the autograd graph (dT/dpred must not depend on pred: asked for a differentiable gradient, it carries no
+    grad_fn -- all Hessian-vector products vanish identically) and numerically: bit-equal gradients at four random
+    predictions of very different magnitude, at the first reverse step's t = 1, the last step's t = 1/T and one in between,
+    and in every row of the batch.  Anything the probe cannot digest is 'not affine' (the general callback path)."""
+    import torch
+    gen = torch.Generator().manual_seed(1234)  # (torch's default generator keys the noise: not touched)
+    ref = None
+    try:
+        for scale_p in (1.0, 1e-2, 30.0, 1e3):
+            for t in (1.0, 0.5, 1.0 / max(int(T), 1)):
+                p = (torch.randn(B, K, generator=gen) * scale_p).requires_grad_(True)
+                with torch.enable_grad():
+                    val = fn(p, t)
+                    if not torch.is_tensor(val) or not val.requires_grad:
+                        return None
+                    (g,) = torch.autograd.grad(val.sum(), p, create_graph=True, allow_unused=True)
+                if g is None or g.requires_grad:
+                    return None  # no dependence on pred at all / the gradient depends on pred: not affine
+                g = g.detach()
+                if not bool(torch.isfinite(g).all()):
+                    return None
+                if ref is None:
+                    ref = g[0].clone()
+                if not bool((g == ref[None]).all()):
+                    return None
+    except GaudiError:
+        raise
+    except Exception:
+        return None
+    return ref.numpy().astype(np.float32)
+
+
 def target_function_max_gap(cond_predictor) -> LinearTarget:
     """-pred[:,1]  (generation_guidance.py:200-203)."""
     w = np.zeros(cond_predictor.K, np.float32)
@@ -157,6 +191,20 @@ class GaudiModel:
     _latest = None
 
     @classmethod
+    def from_engine(cls, engine: Engine, args) -> "GaudiModel":
+        """A model object over an Engine whose EDM weights are already loaded (bench.py: one handle serves several drivers)."""
+        m = cls.__new__(cls)
+        m.args = checkpoint.args_dict(args)
+        m.engine = engine
+        m.T = int(m.args["diffusion_steps"])
+        m.in_node_nf = engine.F
+        m.n_dims = 3
+        m.norm_values = list(checkpoint.normalize_factors(m.args))
+        m.norm_biases = (None, 0.0, 0.0)
+        m.seed, m.sample_offset, m.injected_noise, m.last_diag = None, 0, None, None
+        return m
+
+    @classmethod
     def latest(cls):
         """The GaudiModel created last that is still alive (what get_cond_predictor_model(args, dataset) attaches to)."""
         m = cls._latest() if cls._latest is not None else None
@@ -180,8 +228,10 @@ class GaudiModel:
             # is not touched -- it keys the noise)
             shape = (B, model._trace_N, 3 + model.in_node_nf)
             probe = (0.25 + torch.linspace(0.0, 1.0, int(np.prod(shape))).reshape(shape)).requires_grad_(True)
-            nm = torch.from_numpy(model._trace_nm)
-            em = torch.from_numpy(model._trace_em)
+            nm_all, em_all = model._trace_nm, model._trace_em.reshape(model._trace_nm.shape[0], -1, 1)
+            rows = np.arange(B) % nm_all.shape[0]  # (the affine probe runs on a few rows only)
+            nm = torch.from_numpy(np.ascontiguousarray(nm_all[rows]))
+            em = torch.from_numpy(np.ascontiguousarray(em_all[rows]).reshape(-1, 1))
             cp._override, cp._override_used = pred, False
             try:
                 val = target(probe, nm, em, torch.full((B, 1), float(t)))
@@ -190,6 +240,12 @@ class GaudiModel:
             if not torch.is_tensor(val) or val.dim() == 0 or val.shape[0] != B:
                 raise GaudiError("the target function must return one value per molecule (a torch tensor [B]); use a "
                                  "LinearTarget / PredTarget or a closure over cond_predictor (generation_guidance.py:198-211)")
+            # The closure must route through the predictor attached to THIS model: one that closes over another predictor (or a
+            # torch module, or uses t only) would give dT/dpred = 0 here and the chain would run unguided without a word.
+            if not cp._override_used or (pred.requires_grad and not val.requires_grad):
+                raise GaudiError("the target function does not use the predictor attached to this model (it must call the "
+                                 "cond_predictor returned by get_cond_predictor_model(..., model=<this model>)): its value does "
+                                 "not depend on the prediction, guidance would be a no-op")
             if val.requires_grad:
                 (gz,) = torch.autograd.grad(val.sum(), probe, allow_unused=True, retain_graph=True)
                 if gz is not None and bool((gz != 0).any()):
@@ -197,7 +253,15 @@ class GaudiModel:
                                      "predictor outputs and t can be differentiated on the GPU")
             return val
 
-        return PredTarget(cp, fn, name=getattr(target, "__name__", "closure"))
+        pt = PredTarget(cp, fn, name=getattr(target, "__name__", "closure"))
+        lin = affine_target_weights(pt.fn, cp.K, self.T)
+        if lin is not None:
+            # affine in pred and independent of t (both closures the reference ships are, generation_guidance.py:200-211): the
+            # declarative form, whose guidance is fused into the step kernel (one launch per 25 steps, no host round trip)
+            lt = LinearTarget(cp, lin, name=pt.name + " (affine: fused)")
+            lt._closure_fn = pt.fn  # _run re-checks the closure's gradient at the predictions the chain ends on
+            return lt
+        return pt
 
     def eval(self):
         return self
@@ -250,8 +314,22 @@ class GaudiModel:
                                                          noise=self.injected_noise, std=std, scale=scale)
             else:
                 tw = None if target is None else target.weights
-                x, h, diag = self.engine.sample(nm.reshape(B, N), em, seed=seed, sample_offset=off,
-                                                noise=self.injected_noise, std=std, target_w=tw, scale=scale)
+                fn = getattr(target, "_closure_fn", None)
+                out = self.engine.sample(nm.reshape(B, N), em, seed=seed, sample_offset=off, noise=self.injected_noise, std=std,
+                                         target_w=tw, scale=scale, return_z0=fn is not None)
+                x, h, diag = out[0], out[1], out[2]
+                if fn is not None:
+                    # the closure was recognised as affine on probe predictions; hold it to that at the predictions the chain
+                    # actually ended on (a piecewise-linear closure whose kink the probes missed must not pass silently)
+                    import torch
+                    t_last = 1.0 / self.T
+                    p0 = torch.from_numpy(self.engine.predictor_fwd(out[3], t_last, nm.reshape(B, N), em)).requires_grad_(True)
+                    with torch.enable_grad():
+                        (g0,) = torch.autograd.grad(fn(p0, t_last).sum(), p0, allow_unused=True)
+                    if g0 is None or not bool((g0 == torch.from_numpy(tw)[None]).all()):
+                        raise GaudiError("the target closure was run as an affine function of the predictor outputs, but its "
+                                         "gradient at the final predictions differs from the probed one: wrap it in "
+                                         "PredTarget(cond_predictor, fn) to force the general path")
         finally:
             self.engine.set_fix_noise(False, 0)
         self.last_diag = diag
@@ -290,6 +368,16 @@ class CondPredictor:
         self.engine = model.engine
         self.engine.load_predictor(self.args, state_dict)
         self.K = self.engine.K
+
+    @classmethod
+    def from_engine(cls, model: GaudiModel, args) -> "CondPredictor":
+        """Over a model whose engine already holds the predictor weights; attaches itself to the model."""
+        cp = cls.__new__(cls)
+        cp.args = checkpoint.args_dict(args)
+        cp.engine = model.engine
+        cp.K = model.engine.K
+        model.cond_predictor = cp
+        return cp
 
     def eval(self):
         return self

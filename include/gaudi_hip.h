@@ -139,8 +139,10 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
  * predictor, generation_guidance.py:187-205).  Each reverse step runs in two launches: (A) denoise + predictor forward,
  * (B) predictor reverse pass + guidance update; in between, target_grad receives pred [B,K] and t and must write
  * dT/dpred [B,K] (the energy is scale * sum_b T(pred_b), en_diffusion.py:899).  Both networks stay on the device;
- * only the K-vector per molecule crosses the boundary.  With target_grad returning a constant w this equals
- * gaudi_sample(target_w = w) bit for bit. */
+ * only the K-vector per molecule crosses the boundary (pinned host buffers, one event wait per step).  With target_grad
+ * returning a constant w this equals gaudi_sample(target_w = w) bit for bit.  Molecules beyond the LDS limit (the V4G
+ * kernels: node buffers in global memory) run phase A as two launches -- the reference has no size cap,
+ * sampling_edm.py:172-209 -- so a step there is three launches. */
 typedef void (*gaudi_target_cb)(void* user, int B, int K, const float* pred, float t, float* dT_dpred_out);
 int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
                     int64_t sample_offset, const float* noise, float std, gaudi_target_cb target_grad, void* user,
@@ -228,6 +230,9 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
  * split with the full ring (a 32-input chunk of all output tiles per trip), 2 = split with the half ring (two trips per
  * chunk: molecules whose node buffers leave less LDS), 0 = fp32 instructions. */
 int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
+/* Workgroups the most recent kernel launch of the handle ran: the molecules of the call (or of its last sub-batch), or the
+ * groups they were packed into.  bench.py prices its roofline with this figure, not with the host-side plan. */
+int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups);
 /* How a sampling call of the 8-wave kernels packs a batch (device-free): small molecules share a workgroup as the components
  * of one disjoint graph -- at most 4 molecules, N node slots and 8 edge tiles of 16 slots per group; a molecule keeps its own
  * tiles, node order, noise stream and per-molecule reductions, so its result does not depend on the packing (tested bit for

@@ -1,0 +1,178 @@
+"""GPU evidence added in round 4: the reference-form closure path -- callback targets on molecules beyond
+the LDS limit, affine closures recognised and fused, closures that bypass the attached predictor refused -- and the 4-wave
+callback case ADVICE r3 named."""
+import os
+
+import numpy as np
+import pytest
+
+from gaudi_amd import synth
+from tests.helpers import TINY, TINY_P, cfg_of, edm_from_cfg, nonlinear_target_grad, pred_from_cfg, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(eargs, esd, pargs=None, psd=None, **env):
+    from gaudi_amd.engine import Engine
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        eng = Engine(0)  # the knobs are read once, by gaudi_create
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    eng.load_edm(eargs, esd)
+    if pargs is not None:
+        eng.load_predictor(pargs, psd)
+    return eng
+
+
+@pytest.mark.parametrize("N", [24, 40])
+def test_callback_targets_on_large_molecules_vs_oracle(N):
+    """sample_guidance with an arbitrary closure has no size cap in the reference (sampling_edm.py:172-209,
+    en_diffusion.py:899-903).  Complete graphs of 24 / 40 nodes at the DEFAULT widths do not fit LDS: gaudi_sample_cb runs them
+    on the V4G kernels (three launches per step).  A nonlinear target against the numpy oracle at 1e-4; a constant-gradient
+    callback equals the fused linear chain of the same kernels bit for bit."""
+    from oracle import gaudi_oracle as O
+    T = 3
+    eargs, pargs = synth.edm_args(diffusion_steps=T), synth.pred_args()
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=41, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=42, amplify_coord=True)
+    nm, em = O.build_masks([N, N - 9], N, False)
+    B = 2
+    em = np.asarray(em, np.float32).reshape(B, N, N)
+    noise = np.random.default_rng(N).standard_normal((T + 2, B, N, 4)).astype(np.float32)
+    eng = _engine(eargs, esd, pargs, psd)
+    x, h, d, z0 = eng.sample_callback(nm.reshape(B, N), em, nonlinear_target_grad, noise=noise, scale=0.6, return_z0=True)
+    assert eng.kernel_variant()[1] == 4
+    xo, ho, zo = O.sample(esd, eargs, nm, em, noise, std=1.0, pred_sd=psd, pcfg=pargs, target_w=nonlinear_target_grad, scale=0.6)
+    assert rel_err(z0, zo) < 1e-4 and rel_err(x, xo) < 1e-4 and np.array_equal(h, ho)
+    w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
+    a = eng.sample(nm.reshape(B, N), em, noise=noise, target_w=w, scale=0.6)
+    b = eng.sample_callback(nm.reshape(B, N), em, lambda pred, t: np.broadcast_to(w, pred.shape), noise=noise, scale=0.6)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    eng.close()
+
+
+def test_affine_closures_run_on_the_fused_kernel(golden):
+    """The two closures the reference ships (generation_guidance.py:200-211) are affine in the predictor outputs and do not
+    depend on t: sample_guidance recognises that and runs them as a LinearTarget -- one launch per 25 steps -- with the result
+    of the declarative form, bit for bit.  A closure that is not affine keeps the callback path (two launches per step)."""
+    import types
+
+    import torch
+
+    from gaudi_amd import sampling_edm
+    from gaudi_amd.models_edm import (PropertyNorm, get_cond_predictor_model, get_model, target_function_max_gap,
+                                      target_function_opv)
+    g = golden("g7_end_to_end")
+    cfg = cfg_of(g, "hetro_tiny")
+    base = dict(dataset=cfg["dataset"], amp=cfg["amp"])
+    eargs, esd = edm_from_cfg(dict(base, over=TINY, wseed=cfg["eseed"]), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(base, over=TINY_P, wseed=cfg["pseed"]))
+    model, _, _ = get_model(eargs, state_dict=esd)
+    cond_predictor = get_cond_predictor_model(pargs, None, state_dict=psd)
+    prop_dist = PropertyNorm(np.array([0.1, -0.2, 0.3, 0.4, 0.5]), np.array([1.5, 0.5, 2.0, 0.7, 1.0]))
+    nodes = [3, 5, 4, 2]
+    args = types.SimpleNamespace(device="cuda", dataset=cfg["dataset"], max_nodes=10)
+    T = cfg["T"]
+
+    def max_gap(_input, _node_mask, _edge_mask, _t):  # generation_guidance.py:200-203
+        pred = cond_predictor(_input, _node_mask, _edge_mask, _t)
+        gap = pred[:, 1]
+        return -gap
+
+    def opv(_input, _node_mask, _edge_mask, _t):  # generation_guidance.py:205-211
+        pred = cond_predictor(_input, _node_mask, _edge_mask, _t)
+        pred = pred * torch.from_numpy(prop_dist.std) + torch.from_numpy(prop_dist.mean)  # prop_dist.unnormalize (models_edm.py:186-188)
+        gap, ea, ip = pred[:, 0], pred[:, 2], pred[:, 3]
+        return ip + ea + 3 * gap
+
+    def not_affine(_input, _node_mask, _edge_mask, _t):
+        pred = cond_predictor(_input, _node_mask, _edge_mask, _t)
+        return torch.tanh(pred[:, 1]) + 0.1 * pred[:, 0] ** 2
+
+    def run(target):
+        model.seed, model.sample_offset = 7, 0
+        model.engine.profile_reset(True)
+        x, h, _, _ = sampling_edm.sample_guidance(args, model, target, nodes, scale=0.6)
+        n_launch = model.engine.profile_get()[0]
+        model.engine.profile_reset(False)
+        return x.numpy(), h.numpy(), n_launch
+
+    fused_launches = -(-T // 25)
+    for closure, declarative in ((max_gap, target_function_max_gap(cond_predictor)), (opv, target_function_opv(cond_predictor, prop_dist))):
+        xa, ha, na = run(closure)
+        xb, hb, nb = run(declarative)
+        assert na == nb == fused_launches, (na, nb)
+        if closure is max_gap:
+            assert np.array_equal(xa, xb) and np.array_equal(ha, hb)
+        else:  # w = 3 std0 etc.: the traced gradient and the declarative weights may differ in the last bit
+            assert rel_err(xa, xb) < 1e-5 and np.array_equal(ha, hb)
+    xc, hc, nc = run(not_affine)
+    assert nc == 2 * T + 1 and np.isfinite(xc).all()
+    model.engine.close()
+
+
+def test_closure_over_a_foreign_predictor_is_refused():
+    """a closure that never calls the predictor attached to the sampling model would be differentiated to zero and
+    the chain would run unguided without a word.  It is refused."""
+    import types
+
+    import torch
+
+    from gaudi_amd import sampling_edm
+    from gaudi_amd._lib import GaudiError
+    from gaudi_amd.models_edm import get_cond_predictor_model, get_model
+    eargs = synth.edm_args(diffusion_steps=4, **TINY)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=1)
+    pargs = synth.pred_args(**TINY_P)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=2)
+    other, _, _ = get_model(eargs, state_dict=esd)
+    foreign = get_cond_predictor_model(pargs, model=other, state_dict=psd)
+    model, _, _ = get_model(eargs, state_dict=esd)
+    get_cond_predictor_model(pargs, model=model, state_dict=psd)
+    args = types.SimpleNamespace(device="cuda", dataset="cata", max_nodes=5)
+
+    def uses_foreign(_input, _node_mask, _edge_mask, _t):
+        return -foreign(_input, _node_mask, _edge_mask, _t)[:, 1]
+
+    def uses_t_only(_input, _node_mask, _edge_mask, _t):
+        return torch.as_tensor(_t).reshape(-1) * 2.0
+
+    for bad in (uses_foreign, uses_t_only):
+        with pytest.raises(GaudiError, match="does not use the predictor"):
+            sampling_edm.sample_guidance(args, model, bad, [3, 5], scale=0.6)
+    other.engine.close()
+    model.engine.close()
+
+
+@pytest.mark.parametrize("rings", [[9, 10, 9], [10, 10]])
+def test_four_wave_callbacks_on_sparse_hetero_graphs_of_18_to_20_nodes(rings):
+    """at the default widths a guided hetero call of 18-20 graph nodes (sparse: every ring has its ring
+    neighbours + one orientation node) fits the resident 4-wave kernels, and must keep running there when it stands alone --
+    the dense-graph LDS estimate applies only to the cuts of a larger logical batch.  Callback and fused chains agree bit for
+    bit on a GAUDI_WAVES=4 handle; the 8-wave default agrees with it at 1e-4."""
+    from gaudi_amd.sampling_edm import build_masks
+    T = 3
+    F = synth.num_node_features("hetro")
+    eargs, pargs = synth.edm_args(dataset="hetro", diffusion_steps=T), synth.pred_args(dataset="hetro")
+    esd = synth.synth_edm_state_dict(eargs, F, seed=5, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=6, amplify_coord=True)
+    nm3, em_flat, N = build_masks(rings, 10, True)
+    B = len(rings)
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    w = np.array([3, 0, 1, 1, 0], np.float32)
+    eng4 = _engine(eargs, esd, pargs, psd, GAUDI_WAVES=4)
+    a = eng4.sample(nm, em, seed=3, target_w=w, scale=0.6)
+    b = eng4.sample_callback(nm, em, lambda pred, t: np.broadcast_to(w, pred.shape), seed=3, scale=0.6)
+    assert eng4.kernel_variant()[1] == 4
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    eng4.close()
+    eng8 = _engine(eargs, esd, pargs, psd)
+    c = eng8.sample_callback(nm, em, lambda pred, t: np.broadcast_to(w, pred.shape), seed=3, scale=0.6)
+    eng8.close()
+    assert rel_err(c[0], a[0]) < 1e-4 and np.array_equal(c[1], a[1])

@@ -114,3 +114,21 @@ def test_ring_count_sampler_matches_reference(golden):
         s = d.sample(2000)
         assert np.array_equal(s.numpy(), g[f"{ds}_sample"])
         assert np.array_equal(d.log_prob(s[:64]).numpy(), g[f"{ds}_log_prob"])
+
+
+def test_affine_target_probe():
+    """GaudiModel turns a reference-form closure into the fused LinearTarget only when it is affine in the predictor outputs
+    with ONE weight vector for every molecule and every t (models_edm.affine_target_weights); anything else keeps the
+    callback path.  Device-free: the probe works on fn(pred, t)."""
+    import torch
+    from gaudi_amd.models_edm import affine_target_weights as A
+    std, mean = torch.tensor([1.0, 2, 3, 4, 5]), torch.tensor([0.1, 0.2, 0.3, 0.4, 0.5])
+    np.testing.assert_array_equal(A(lambda p, t: -p[:, 1], 5, 1000), [0, -1, 0, 0, 0])  # generation_guidance.py:200-203
+    u = lambda p: p * std + mean
+    np.testing.assert_array_equal(A(lambda p, t: u(p)[:, 3] + u(p)[:, 2] + 3 * u(p)[:, 0], 5, 1000), [3, 0, 3, 4, 0])  # :205-211
+    assert A(lambda p, t: 0.5 * torch.log1p(p[:, 1] ** 2), 5, 1000) is None        # not affine
+    assert A(lambda p, t: t * p[:, 2], 5, 1000) is None                            # depends on t
+    assert A(lambda p, t: p[:, 2] * torch.arange(3.0), 5, 1000) is None            # a different weight per molecule
+    assert A(lambda p, t: torch.zeros(3), 5, 1000) is None                         # does not depend on pred
+    assert A(lambda p, t: p[:, 0].abs(), 5, 1000) is None                          # piecewise linear
+    assert A(lambda p, t: (p[:, 0] / 0.0), 5, 1000) is None                        # non-finite gradient
