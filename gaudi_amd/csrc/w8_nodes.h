@@ -12,12 +12,14 @@
 //     bytes through an L2 -> CU path that is the co-limit of these GEMMs, so a weight tile pair
 //     (16 outputs x 32 inputs) is split after it has landed in registers -- 44 vector instructions for 6 matrix instructions
 //     per node-column tile;
-//   * the work is done by FOUR waves, one per SIMD (waves 0-3; tiles t = wave, wave + 4, ...): alone on its SIMD a wave issues
-//     vector instructions in the shadow of its own matrix instructions (an MFMA holds the issue port for 8 of its 16 cycles,
-//     MI355X_MICROARCH.md), while two waves per SIMD pay 4.3 cycles per vector instruction on top of 16.5 per MFMA
+//   * the work is done by FOUR waves, one per SIMD (waves 0-3; tiles t = wave, wave + 4, wave + 8): alone on its SIMD a wave
+//     issues vector instructions in the shadow of its own matrix instructions (an MFMA holds the issue port for 8 of its 16
+//     cycles, MI355X_MICROARCH.md), while two waves per SIMD pay 4.3 cycles per vector instruction on top of 16.5 per MFMA
 //     (profiles/r03c_coissue_microbench.txt) and would split every activation chunk twice as often.  Waves 4-7 go straight to
-//     the barrier that follows every node GEMM;
-//   * the 4-valid-row tail tile of H % 16 == 4 widths keeps its v_mfma_f32_4x4x1_16B_f32 form (w8_common.h).
+//     the barrier that follows every node GEMM -- except for tiles 12-15 of the widest matrices (one per wave 4-7), so that no
+//     wave holds more than three tiles' weights in flight (the register budget of the phase functions);
+//   * the 4-valid-row tail tile of H % 16 == 4 widths keeps its v_mfma_f32_4x4x1_16B_f32 form (w8_common.h); at the default
+//     predictor width (196 -> 13 tiles) it is tile 12 = wave 4's only work, so waves 0-3 carry three full tiles each.
 // Accumulation order per output element: K chunks of 32 in order, six piece products smallest first -- independent of the
 // number of node columns, so a molecule's result does not depend on what shares its workgroup (packed launches).
 #pragma once
@@ -26,22 +28,26 @@
 namespace gaudi {
 namespace w8 {
 
-constexpr int kNodeWaves = 4;
-constexpr int kNodeMaxTiles = 4;  // output tiles per wave: HP <= 256
+constexpr int kNodeWaves = 4;     // waves 0-3 carry tiles 0-11 (t -> wave t & 3); tiles 12-15 go to waves 4-7, one each
+constexpr int kNodeMaxTiles = 3;  // output tiles per wave (HP <= 256)
 
 template <int HP>
 struct NodePF4 {
   f4 a0[kNodeMaxTiles], a1[kNodeMaxTiles];  // first two 16-input chunks of the wave's tiles
 };
 
-// tiles of wave w (< 4): t = w + 4 u, u < ng_ntw(T, w)
-__host__ __device__ constexpr int ng_ntw(int T, int w) { return w < kNodeWaves ? (T - w + kNodeWaves - 1) / kNodeWaves : 0; }
+// tiles of wave w: t = ng_tile(w, u), u < ng_ntw(T, w)
+__host__ __device__ constexpr int ng_ntw(int T, int w) {
+  return w < kNodeWaves ? ((T < 12 ? T : 12) - w + kNodeWaves - 1) / kNodeWaves : (w + 8 < T ? 1 : 0);
+}
+__host__ __device__ constexpr int ng_tile(int w, int u) { return w < kNodeWaves ? w + kNodeWaves * u : w + 8; }
+__host__ __device__ constexpr int ng_wave_of(int t) { return t < 12 ? t % kNodeWaves : t - 8; }
 // the wave whose LAST tile is the tail tile of a width that has one
 template <int HP>
 __device__ __forceinline__ bool ng_owns_tail(bool tail_width, int wave) {
   constexpr int T = HP / 16;
   constexpr bool kHas = GAUDI_NODE_TAIL44 && (HP == 208 || HP == 48);
-  return kHas && tail_width && wave == (T - 1) % kNodeWaves;
+  return kHas && tail_width && wave == ng_wave_of(T - 1);
 }
 
 template <int HP, int NTW, bool TAIL>
@@ -49,24 +55,37 @@ __device__ __forceinline__ void node_prefetch4_n(NodePF4<HP>& pf, const WBuf& wb
   constexpr int T = HP / 16;
 #pragma unroll
   for (int u = 0; u < NTW; ++u) {
-    const int toff = (wave + kNodeWaves * u) * 256;
+    const int toff = ng_tile(wave, u) * 256;
     const int ln = TAIL && u == NTW - 1 ? tail_lane(lane) : lane;
     pf.a0[u] = ldw4n(wb, W + toff, ln);
     pf.a1[u] = ldw4n(wb, W + (T > 1 ? T : 0) * 256 + toff, ln);
   }
 }
+// wave-uniform dispatch on the wave's tile count (only the counts this width can produce are instantiated)
+template <int HP, class F>
+__device__ __forceinline__ void ng_dispatch(int wave, bool tail_w, F f) {
+  constexpr int T = HP / 16;
+  const int ntw = ng_ntw(T, wave);
+  if (ntw == 0) return;
+  if (ng_owns_tail<HP>(tail_w, wave)) {
+    f(std::integral_constant<int, ng_ntw(T, ng_wave_of(T - 1))>{}, std::integral_constant<bool, true>{});
+    return;
+  }
+  if constexpr (ng_ntw(T, 0) >= 3) {
+    if (ntw == 3) { f(std::integral_constant<int, 3>{}, std::integral_constant<bool, false>{}); return; }
+  }
+  if constexpr (ng_ntw(T, 0) >= 2 && ng_ntw(T, 3) <= 2) {
+    if (ntw == 2) { f(std::integral_constant<int, 2>{}, std::integral_constant<bool, false>{}); return; }
+  }
+  if constexpr (ng_ntw(T, 3) <= 1) {
+    if (ntw == 1) { f(std::integral_constant<int, 1>{}, std::integral_constant<bool, false>{}); return; }
+  }
+}
 template <int HP>
 __device__ __forceinline__ void node_prefetch4(NodePF4<HP>& pf, const WBuf& wb, int W, int wave, int lane, bool tail_w) {
-  constexpr int T = HP / 16;
-  constexpr int HI = ng_ntw(T, 0), LO = ng_ntw(T, kNodeWaves - 1);
-  if (wave >= kNodeWaves) return;
-  if (ng_owns_tail<HP>(tail_w, wave)) {
-    node_prefetch4_n<HP, ng_ntw(T, (T - 1) % kNodeWaves), true>(pf, wb, W, wave, lane);
-  } else if (wave < T % kNodeWaves || HI == LO) {
-    node_prefetch4_n<HP, HI, false>(pf, wb, W, wave, lane);
-  } else if (LO > 0) {
-    node_prefetch4_n<HP, (LO > 0 ? LO : 1), false>(pf, wb, W, wave, lane);
-  }
+  ng_dispatch<HP>(wave, tail_w, [&](auto ntw_tag, auto tail_tag) {
+    node_prefetch4_n<HP, decltype(ntw_tag)::value, decltype(tail_tag)::value>(pf, wb, W, wave, lane);
+  });
 }
 
 // six piece products of a (weights: A operand) x b (activations: B operand), smallest first (w8_split.h: rings_mfma_act)
@@ -90,7 +109,7 @@ __device__ __forceinline__ void node_gemm4_body(const WBuf& wb, int Wa, const fl
   const int n_tiles = (N + 15) >> 4;
   int toff[NTW];
 #pragma unroll
-  for (int u = 0; u < NTW; ++u) toff[u] = (wave + kNodeWaves * u) * 256;
+  for (int u = 0; u < NTW; ++u) toff[u] = ng_tile(wave, u) * 256;
   auto wlane = [&](int u) { return TAIL && u == NTW - 1 ? tail_lane_fresh(lane) : lane; };
   const int KT = Wb >= 0 ? 2 * T : T;  // 16-input chunks; two sources run as ONE K loop so the load pipeline never restarts
   auto chunk = [&](int cc) {           // float offset of chunk cc (clamped past the end: surplus loads are unused)
@@ -131,28 +150,38 @@ __device__ __forceinline__ void node_gemm4_body(const WBuf& wb, int Wa, const fl
     // one 32-input chunk: inputs 16 cc .. +15 (wE, xE) and 16 (cc + 1) .. +15 (wO, xO; ODD = false: absent)
     auto mm = [&](auto odd_tag, const f4 (&wE)[NTW], const f4 (&xE)[NT], const f4 (&wO)[NTW], const f4 (&xO)[NT]) {
       constexpr bool ODD = decltype(odd_tag)::value;
+      constexpr int NS = TAIL ? NTW - 1 : NTW;  // tiles on split operands (the tail tile, if any, is the wave's last)
       B3 xs[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) xs[j] = split8(xE[j], ODD ? xO[j] : splat(0.f));
-      static_for_n<NTW>([&](auto u_tag) {
-        constexpr int u = decltype(u_tag)::value;
-        if constexpr (TAIL && u == NTW - 1) {  // the 4-valid-row tile: fp32 4x4x1 blocks (w8_common.h)
+      if constexpr (TAIL) {  // the 4-valid-row tile first: fp32 4x4x1 blocks (w8_common.h), no split needed
+        constexpr int u = NTW - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j][u] = mfma44(wE[u][q], xE[j][q], acc[j][u]);
+        if (ODD) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][u] = mfma44(wE[u][q], xE[j][q], acc[j][u]);
-          if (ODD) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int j = 0; j < NT; ++j) acc[j][u] = mfma44(wO[u][q], xO[j][q], acc[j][u]);
-          }
-        } else {
-          const B3 ws = split8(wE[u], ODD ? wO[u] : splat(0.f));
+            for (int j = 0; j < NT; ++j) acc[j][u] = mfma44(wO[u][q], xO[j][q], acc[j][u]);
+        }
+      }
+      // software pipeline over the wave's tiles: the split of tile u + 1 (44 vector instructions) is issued beside the six
+      // matrix instructions per node column of tile u; one scheduling region per tile keeps hipcc from splitting all tiles
+      // up front (12 more live registers per tile)
+      if constexpr (NS > 0) {
+        B3 ws = split8(wE[0], ODD ? wO[0] : splat(0.f));
+        static_for_n<NS>([&](auto u_tag) {
+          constexpr int u = decltype(u_tag)::value;
+          B3 wn = ws;
+          if constexpr (u + 1 < NS) wn = split8(wE[u + 1], ODD ? wO[u + 1] : splat(0.f));
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[j][u] = mfma6(ws, xs[j], acc[j][u]);
-        }
-      });
+          __builtin_amdgcn_sched_barrier(0);
+          ws = wn;
+        });
+      }
     };
     using Odd = std::integral_constant<bool, true>;
     using Even = std::integral_constant<bool, false>;
@@ -213,7 +242,7 @@ __device__ __forceinline__ void node_gemm4_body(const WBuf& wb, int Wa, const fl
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {
-        const int t = wave + kNodeWaves * u;
+        const int t = ng_tile(wave, u);
         const int nd = node[j];
         f4 y = acc[j][u];
         if (TAIL && u == NTW - 1) {  // fold the four k partial sums (all lanes take part), then bias; padding rows = 0
@@ -252,23 +281,59 @@ __device__ __forceinline__ void node_gemm4_cols(const WBuf& wb, int Wa, const fl
   else node_gemm4_body<HP, EPI, PRE, 2, NTW, TAIL>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
 }
 
-// same interface as w8_common.h: node_gemm (pf: NodePF4).  Waves 4-7 return at once: the caller's barrier collects them.
+// same interface as w8_common.h: node_gemm (pf: NodePF4).  Waves without a tile return at once: the caller's barrier collects them.
 template <int HP, int EPI, bool PRE = false>
 __device__ __forceinline__ void node_gemm4(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb,
                                            const float* sBias /* LDS [HP] or null */, float* sY, const float* sRes,
                                            const float* sMask, int N, int wave, int lane, bool tail_w,
                                            NodePF4<HP>* pf = nullptr, int nextW = -1, float* gPre = nullptr) {
-  constexpr int T = HP / 16;
-  constexpr int HI = ng_ntw(T, 0), LO = ng_ntw(T, kNodeWaves - 1);
-  if (wave >= kNodeWaves) return;
-  if (ng_owns_tail<HP>(tail_w, wave)) {
-    node_gemm4_cols<HP, EPI, PRE, ng_ntw(T, (T - 1) % kNodeWaves), true>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
-  } else if (wave < T % kNodeWaves || HI == LO) {
-    node_gemm4_cols<HP, EPI, PRE, HI, false>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
-  } else if (LO > 0) {
-    node_gemm4_cols<HP, EPI, PRE, (LO > 0 ? LO : 1), false>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
-  }
+  ng_dispatch<HP>(wave, tail_w, [&](auto ntw_tag, auto tail_tag) {
+    node_gemm4_cols<HP, EPI, PRE, decltype(ntw_tag)::value, decltype(tail_tag)::value>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave,
+                                                                                       lane, pf, nextW, gPre);
+  });
 }
+
+// ---------------------------------------------------------------------------------------------
+// One interface over both node-GEMM engines: the kernels whose edge GEMMs run on split operands (SP != 0) run their node GEMMs
+// on split operands too; the fp32-instruction kernels (GAUDI_EDGE_MATH=fp32) keep v_mfma_f32_16x16x4_f32 throughout.
+// -DGAUDI_NODE_SPLIT=0 builds the round-3 arrangement (split edge GEMMs, fp32-instruction node GEMMs) for A/B runs.
+// ---------------------------------------------------------------------------------------------
+#ifndef GAUDI_NODE_SPLIT
+#define GAUDI_NODE_SPLIT 0  // measured (profiles/r04a_node_gemm4_microbench.txt): 8 870 vs 6 358 cycles per H = 192 matrix, 10 702 vs 8 388 at 208 -- the on-the-fly split costs 44 vector instructions of 4 cycles per tile pair and loses
+#endif
+template <int HP, bool SPLIT>
+struct NodeEngineT {
+  using PF = NodePF<HP>;
+  // the first weight tiles of the node GEMM that follows an edge phase travel ACROSS that phase (16 registers)
+  static constexpr bool kCrossEdge = true;
+  __device__ __forceinline__ static void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tail_w) {
+    node_prefetch<HP>(pf, wb, W, wave, lane, tail_w);
+  }
+  template <int EPI, bool PRE = false>
+  __device__ __forceinline__ static void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sBias,
+                                              float* sY, const float* sRes, const float* sMask, int N, int wave, int lane, bool tail_w,
+                                              PF* pf = nullptr, int nextW = -1, float* gPre = nullptr) {
+    node_gemm<HP, EPI, PRE>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, tail_w, pf, nextW, gPre);
+  }
+};
+template <int HP>
+struct NodeEngineT<HP, true> {
+  using PF = NodePF4<HP>;
+  // three tiles x two chunks = 24 registers would have to live through the register-tight edge GEMMs: the prefetch for the node
+  // GEMM that follows an edge phase is issued after the phase instead (covered by the partial-sum pass and its barrier)
+  static constexpr bool kCrossEdge = false;
+  __device__ __forceinline__ static void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tail_w) {
+    node_prefetch4<HP>(pf, wb, W, wave, lane, tail_w);
+  }
+  template <int EPI, bool PRE = false>
+  __device__ __forceinline__ static void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sBias,
+                                              float* sY, const float* sRes, const float* sMask, int N, int wave, int lane, bool tail_w,
+                                              PF* pf = nullptr, int nextW = -1, float* gPre = nullptr) {
+    node_gemm4<HP, EPI, PRE>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, tail_w, pf, nextW, gPre);
+  }
+};
+template <int HP, int SP>
+using NodeEngine = NodeEngineT<HP, (GAUDI_NODE_SPLIT != 0) && SP != 0>;
 
 }  // namespace w8
 }  // namespace gaudi

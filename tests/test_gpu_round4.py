@@ -39,8 +39,8 @@ def test_callback_targets_on_large_molecules_vs_oracle(N):
     from oracle import gaudi_oracle as O
     T = 3
     eargs, pargs = synth.edm_args(diffusion_steps=T), synth.pred_args()
-    esd = synth.synth_edm_state_dict(eargs, 1, seed=41, amplify_coord=True)
-    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=42, amplify_coord=True)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=41)  # (default init, as test_nonlinear_target_full_size_vs_oracle: a free-running
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=42)  # chain through amplified heads is not a 1e-4 comparison)
     nm, em = O.build_masks([N, N - 9], N, False)
     B = 2
     em = np.asarray(em, np.float32).reshape(B, N, N)
