@@ -396,11 +396,12 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     variant = "w4" if wv == 4 else ("w8s" if em_mode else "w8")
     # workgroups of the launches that actually ran (molecules, or the groups the call packed them into): the issued-instruction
     # model below must describe THAT launch, so the host-side plan is only used when it agrees with it
-    run_groups = eng.last_workgroups()
+    run_groups, run_slots = eng.last_launch_shape()
     units, ncols = graph_meta(nm, em) if variant == "w4" else graph_meta8(nm, em)
     if variant != "w4" and run_groups != B:
-        units, ncols = graph_meta8_packed(nm, em)
-        assert len(ncols) == run_groups, f"the launch ran {run_groups} workgroups, the host pack plan says {len(ncols)}"
+        # packed: small molecules share a workgroup; node slots > N = WIDE groups (two rounds of edge tiles, up to 2 N node slots)
+        G_, _, units, ncols = eng.pack_plan(nm, em, node_slots=run_slots if run_slots > N else None)
+        assert G_ == run_groups, f"the launch ran {run_groups} workgroups, the host pack plan says {G_}"
     npairs = units
     G = len(ncols)  # workgroups per call: molecules, or groups of molecules when the call packs
     pa = pargs if guided else None
@@ -415,7 +416,11 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     per_launch = (cnt * steps_done + cnt_edm * steps) / max(n_launch, 1)
     f32_flop, bf_flop = per_launch[0] * flops.FLOP_MFMA_F32, per_launch[1] * flops.FLOP_MFMA_BF16
     evals = steps_done + steps * (edm_only / max(mfma_step, 1))
-    wstream = flops.step_weight_stream_bytes(eargs, pa, equiv_variant if variant != "w8s" else "w8s")
+    wvar = equiv_variant if variant != "w8s" else "w8s"
+    if variant == "w4":
+        wstream = flops.step_weight_stream_bytes(eargs, pa, wvar)
+    else:  # mean over the workgroups: an edge-level matrix is streamed once per round of eight tiles
+        wstream = float(np.mean([flops.step_weight_stream_bytes(eargs, pa, wvar, rounds=max(1, -(-int(u) // 8))) for u in units]))
     avg_launch_ms = kern_ms / max(n_launch, 1)
     t_launch = avg_launch_ms * 1e-3
     achieved = (f32_flop + bf_flop) / t_launch / 1e12
@@ -447,7 +452,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
         "dtype": "f32", "edge_gemm_math": "bf16x3 split operands, f32 accumulate" if variant == "w8s" else "f32",
         "data": "synthetic (seeded default-init weights, on-device Philox noise)",
         "config": {"workload": label, "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
-                   "workgroups_per_call": G,
+                   "workgroups_per_call": G, "node_slots_per_workgroup": run_slots,
                    "edm": "nf=192,n_layers=9", "predictor": "nf=196,n_layers=12" if guided else None,
                    "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
                    "steps_per_launch": a.steps_per_launch,

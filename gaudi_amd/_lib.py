@@ -91,7 +91,9 @@ EXPORTS = {
                                          C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_int32, C.POINTER(C.c_int32)]),
     "gaudi_kernel_variant": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gaudi_edge_math": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "gaudi_last_workgroups": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "gaudi_last_workgroups": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gaudi_host_pack_plan_wide": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, FP, FP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gaudi_set_plan_hint": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "gaudi_host_pack_plan": (C.c_int, [C.c_int, C.c_int, FP, FP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32)]),

@@ -88,6 +88,11 @@ struct gaudi_handle {
   int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
   bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
   bool pack = true;           // several small molecules per workgroup in sampling calls (GAUDI_PACK=0: off)
+  int pairs = 1;              // wide groups (more node slots than a molecule has, two rounds of edge tiles: e.g. two 11-ring cata
+                              // molecules per workgroup): 1 = when the batch holds at least two molecules per CU, 0 = never, 2 = always
+                              // (GAUDI_PAIRS)
+  int num_cus = 256;
+  int run_nslots = 0;         // node slots per workgroup of the current call (= N unless the call runs wide groups)
   bool pred_rounds = true;    // GAUDI_PRED_ROUNDS=0: guided calls with more than 128 edge slots go to the 4-wave kernels
   bool pack_now = false;      // set by run_chain around stage_graph: this call may pack
   int run_groups = 0;         // workgroups of the CURRENT call (= molecules unless packed)
@@ -795,13 +800,17 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
 // Packed launches: groups of molecules, each group one graph of N node slots
 struct Pack {
   int G = 0;
-  std::vector<float> umask, uemask;   // [G][N], [G][N][N]: the union graphs
-  std::vector<uint8_t> align;         // [G][N]: first slot of every component (tile alignment in build_meta8)
-  std::vector<int32_t> rowmap;        // [G][N]: slot -> molecule * N + node | component << 28, or -1
+  int NG = 0;                         // node slots per group (= N, or more: wide groups)
+  std::vector<float> umask, uemask;   // [G][NG], [G][NG][NG]: the union graphs
+  std::vector<uint8_t> align;         // [G][NG]: first slot of every component (tile alignment in build_meta8)
+  std::vector<int32_t> rowmap;        // [G][NG]: slot -> molecule * N + node | component << 28, or -1
   std::vector<int32_t> compmol;       // [G][kMaxComp]
   std::vector<int32_t> ncomp;         // [G]
 };
-static void pack_groups(int B, int N, const float* node_mask, const float* edge_mask, const Meta8& M, Pack& pk) {
+// NG node slots and TG edge tiles per group (N and 8: the classic packing; more: wide groups, whose edge phases run in rounds)
+static void pack_groups(int B, int N, const float* node_mask, const float* edge_mask, const Meta8& M, Pack& pk, int NG = 0,
+                        int TG = w8::kWaves) {
+  if (NG < N) NG = N;
   // nodes a molecule needs slots for: live ones and any node that touches a live edge, in their own order
   std::vector<std::vector<int>> used(B);
   for (int b = 0; b < B; ++b) {
@@ -826,7 +835,7 @@ static void pack_groups(int B, int N, const float* node_mask, const float* edge_
     const int nn = (int)used[b].size(), nt = M.ntiles[b];
     Group* fit = nullptr;
     for (Group& g : groups)
-      if ((int)g.mols.size() < kMaxComp && g.nodes + nn <= N && g.tiles + nt <= w8::kWaves) {
+      if ((int)g.mols.size() < kMaxComp && g.nodes + nn <= NG && g.tiles + nt <= TG) {
         fit = &g;
         break;
       }
@@ -840,10 +849,11 @@ static void pack_groups(int B, int N, const float* node_mask, const float* edge_
   }
   const int G = (int)groups.size();
   pk.G = G;
-  pk.umask.assign((size_t)G * N, 0.f);
-  pk.uemask.assign((size_t)G * N * N, 0.f);
-  pk.align.assign((size_t)G * N, 0);
-  pk.rowmap.assign((size_t)G * N, -1);
+  pk.NG = NG;
+  pk.umask.assign((size_t)G * NG, 0.f);
+  pk.uemask.assign((size_t)G * NG * NG, 0.f);
+  pk.align.assign((size_t)G * NG, 0);
+  pk.rowmap.assign((size_t)G * NG, -1);
   pk.compmol.assign((size_t)G * kMaxComp, 0);
   pk.ncomp.assign(G, 0);
   std::vector<int> slot_of(N);
@@ -854,13 +864,13 @@ static void pack_groups(int B, int N, const float* node_mask, const float* edge_
       pk.compmol[(size_t)g * kMaxComp + k] = b;
       std::fill(slot_of.begin(), slot_of.end(), -1);
       for (size_t r = 0; r < used[b].size(); ++r) slot_of[used[b][r]] = base + (int)r;
-      if (!used[b].empty()) pk.align[(size_t)g * N + base] = 1;
+      if (!used[b].empty()) pk.align[(size_t)g * NG + base] = 1;
       for (int i : used[b]) {
         const int si = slot_of[i];
-        pk.umask[(size_t)g * N + si] = node_mask[(size_t)b * N + i];
-        pk.rowmap[(size_t)g * N + si] = (b * N + i) | ((int32_t)k << 28);
+        pk.umask[(size_t)g * NG + si] = node_mask[(size_t)b * N + i];
+        pk.rowmap[(size_t)g * NG + si] = (b * N + i) | ((int32_t)k << 28);
         for (int j : used[b])
-          pk.uemask[((size_t)g * N + si) * N + slot_of[j]] = edge_mask[((size_t)b * N + i) * N + j];
+          pk.uemask[((size_t)g * NG + si) * NG + slot_of[j]] = edge_mask[((size_t)b * N + i) * N + j];
       }
       base += (int)used[b].size();
     }
@@ -891,48 +901,80 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   if (!pick_kernel8_mode(hpe, hpp, 0, mr) && !pick_kernel8_mode(hpe, hpp, 1, mr) && !pick_kernel8_mode(hpe, hpp, 2, mr)) return 1;
   const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
   int pubx = 0, pub_ch = 0;
-  // the arithmetic of the edge GEMMs for S edge slots: split-bf16 when the kernel exists and its larger weight ring fits
-  // (1 = full ring, 2 = half ring); else fp32 MFMAs (0); else -1 = this call runs on 4 waves
-  auto plan_for = [&](int S) -> int {
+  // the arithmetic of the edge GEMMs for S edge slots on NS node slots: split-bf16 when the kernel exists and its larger weight
+  // ring fits (1 = full ring, 2 = half ring); else fp32 MFMAs (0); else -1 = this call runs on 4 waves
+  auto plan_for = [&](int NS, int S, bool mrk) -> int {
     if (h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes))
       for (int mode = 1; mode <= 2; ++mode)
-        if (pick_kernel8_mode(hpe, hpp, mode, mr) && plan_pub8(hpe, hpp, N, Dz, S, mode, pubx, pub_ch)) return mode;
-    return pick_kernel8_mode(hpe, hpp, 0, mr) && plan_pub8(hpe, hpp, N, Dz, S, 0, pubx, pub_ch) ? 0 : -1;
+        if (pick_kernel8_mode(hpe, hpp, mode, mrk) && plan_pub8(hpe, hpp, NS, Dz, S, mode, pubx, pub_ch)) return mode;
+    return pick_kernel8_mode(hpe, hpp, 0, mrk) && plan_pub8(hpe, hpp, NS, Dz, S, 0, pubx, pub_ch) ? 0 : -1;
   };
-  const int mode_u = plan_for(M.S);
+  const int mode_u = plan_for(N, M.S, mr);
   if (mode_u < 0) return 1;
   Pack pk;
   const int B0 = B;
   const float* nm_used = node_mask;
+  int n_slots = N, mode_run = mode_u;
+  bool mr_run = mr;
   // (a row of the map holds molecule * N + node in 28 bits)
   if (h->pack_now && h->pack && B > 1 && (int64_t)B * N < (1 << 28)) {
-    pack_groups(B, N, node_mask, edge_mask, M, pk);
-    if (pk.G < B) {
-      Meta8 M2;
-      rc = build_meta8(pk.G, N, pk.umask.data(), pk.uemask.data(), M2, err, M.S, pk.align.data());
-      // a packed launch has more edge slots per workgroup; it must keep the arithmetic the unpacked plan has (the plan of a
-      // sharded batch is the same on every rank, gaudi_set_plan_hint, and packing must not move a rank off it)
-      if (rc == GAUDI_OK && M2.S <= std::max(M.S, 16 * w8::kWaves) && plan_for(M2.S) == mode_u) {  // (a group holds <= 8 tiles)
-        M = std::move(M2);
-        B = pk.G;
-        nm_used = pk.umask.data();
-      } else {
-        plan_for(M.S);  // keep the unpacked plan
+    // Candidate group shapes, widest first.  WIDE groups (a batch of at least two molecules per CU; GAUDI_PAIRS): up to 2 N node
+    // slots and two rounds of eight edge tiles -- e.g. two 11-ring cata molecules, or three to four small hetero ones, per
+    // workgroup.  Every node-level matrix is then streamed from L2 once for all of them (the L2 -> CU weight stream is paid per
+    // workgroup) and the per-GEMM fixed costs are shared; the edge phases run their rounds one after the
+    // other (the predictor on the MR kernels).  Then the classic shape: N node slots, one round.
+    struct Cand {
+      int NG, TG;
+    };
+    std::vector<Cand> cands;
+    if (h->pairs == 2 || (h->pairs == 1 && B >= 2 * h->num_cus))
+      for (int ng = std::min(2 * N, 32); ng > N; --ng) {
+        const long long cap = 160 * 1024 / 4 - 64;
+        if ((long long)lds_floats8_base(hpe, hpp, ng, Dz, 16 * (w8::kWaves + 1), h->split ? 2 : 0) > cap) continue;  // cannot fit whatever the slots
+        cands.push_back({ng, 2 * w8::kWaves});
       }
+    cands.push_back({N, w8::kWaves});
+    bool taken = false;
+    for (const Cand& cd : cands) {
+      const bool wide = cd.NG > N;
+      pack_groups(B, N, node_mask, edge_mask, M, pk, cd.NG, cd.TG);
+      if (pk.G >= B) continue;
+      Meta8 M2;
+      rc = build_meta8(pk.G, cd.NG, pk.umask.data(), pk.uemask.data(), M2, err, wide ? 0 : M.S, pk.align.data());
+      if (rc != GAUDI_OK) continue;
+      const bool mr2 = hpp && M2.S > 16 * w8::kWaves;
+      if (!wide && M2.S > std::max(M.S, 16 * w8::kWaves)) continue;  // (a classic group holds <= 8 tiles)
+      if (mr2 && !mr && !h->pred_rounds) continue;
+      // a packed launch has more edge slots per workgroup; it must keep the ARITHMETIC the unpacked plan has -- split operands
+      // (full or half ring: the same sums in the same order) or fp32 instructions -- because the plan of a sharded batch is the
+      // same on every rank (gaudi_set_plan_hint) and packing must not move a rank off it
+      const int mode2 = plan_for(cd.NG, M2.S, mr2);
+      if (mode2 < 0 || (mode2 != 0) != (mode_u != 0)) continue;
+      M = std::move(M2);
+      B = pk.G;
+      nm_used = pk.umask.data();
+      n_slots = cd.NG;
+      mode_run = mode2;
+      mr_run = mr2;
+      taken = true;
+      break;
     }
+    if (!taken) plan_for(N, M.S, mr);  // keep the unpacked plan (pubx / pub_ch)
   }
   const bool packed = B != B0;
-  h->run_split = mode_u;
+  h->run_split = mode_run;
   P.pubx = pubx;
   P.pub_ch = pub_ch;
-  if (getenv("GAUDI_DEBUG_PLAN")) fprintf(stderr, "[plan] N=%d S=%d split=%d pub_ch=%d pubx=%d lds=%zu\n", N, M.S, h->run_split, pub_ch, pubx, lds_bytes8(hpe, hpp, N, Dz, M.S, pubx, h->run_split));
+  if (getenv("GAUDI_DEBUG_PLAN"))
+    fprintf(stderr, "[plan] molecules=%d workgroups=%d N=%d node slots=%d S=%d split=%d mr=%d pub_ch=%d pubx=%d lds=%zu\n", B0, B, N, n_slots,
+            M.S, h->run_split, (int)mr_run, pub_ch, pubx, lds_bytes8(hpe, hpp, n_slots, Dz, M.S, pubx, h->run_split));
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = d.reserve(bytes);
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, h->stream);
   };
   HIPCHECK(h, up(h->d_ncols, M.ncols.data(), sizeof(int) * B));
-  HIPCHECK(h, up(h->d_mask, nm_used, sizeof(float) * B * N));
+  HIPCHECK(h, up(h->d_mask, nm_used, sizeof(float) * B * n_slots));
   if (packed) {
     HIPCHECK(h, up(h->d_rowmap, pk.rowmap.data(), sizeof(int32_t) * pk.rowmap.size()));
     HIPCHECK(h, up(h->d_compmol, pk.compmol.data(), sizeof(int32_t) * pk.compmol.size()));
@@ -947,7 +989,8 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   HIPCHECK(h, up(h->d_sidx, M.sidx.data(), sizeof(uint16_t) * M.sidx.size()));
   HIPCHECK(h, hipStreamSynchronize(h->stream));  // M goes out of scope
   P.B = B;
-  P.N = N;
+  P.N = n_slots;
+  P.NR = N;
   P.EW = M.S;
   P.node_mask = h->d_mask.as<float>();
   P.order = h->d_order.as<int>();
@@ -962,7 +1005,8 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   P.compmol = packed ? h->d_compmol.as<int32_t>() : nullptr;
   P.ncomp = packed ? h->d_ncomp.as<int32_t>() : nullptr;
   h->run_groups = B;
-  h->run_mr = mr;
+  h->run_nslots = n_slots;
+  h->run_mr = mr_run;
   return GAUDI_OK;
 }
 
@@ -977,6 +1021,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   h->run_gn = false;
   h->run_mr = false;
   h->run_groups = B;
+  h->run_nslots = N;
   if (h->variant == 8 && !h->force_gn) {
     const int rc8 = stage_graph8(h, B, N, node_mask, edge_mask, P, hpe, hpp);
     if (rc8 <= 0) return rc8;
@@ -1009,6 +1054,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   HIPCHECK(h, hipStreamSynchronize(h->stream));  // M goes out of scope
   P.B = B;
   P.N = N;
+  P.NR = N;
   P.EW = M.EW;
   P.node_mask = h->d_mask.as<float>();
   P.order = h->d_order.as<int>();
@@ -1078,6 +1124,11 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_EDGE_MATH")) h->split = std::string(v) != "fp32";
   if (const char* v = getenv("GAUDI_FORCE_GN")) h->force_gn = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PACK")) h->pack = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_PAIRS")) h->pairs = atoi(v);
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cus = cus;
+  }
   if (const char* v = getenv("GAUDI_PRED_ROUNDS")) h->pred_rounds = atoi(v) != 0;
   h->run_variant = h->variant;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1773,6 +1824,28 @@ int gaudi_host_pack_plan(int B, int N, const float* node_mask, const float* edge
   return GAUDI_OK;
 }
 
+int gaudi_host_pack_plan_wide(int B, int N, int node_slots, int tiles, const float* node_mask, const float* edge_mask,
+                              int32_t* groups_out, int32_t* group_of_out, int32_t* ntiles_out, int32_t* ncols_out) {
+  if (B <= 0 || N <= 0 || node_slots < N || node_slots > 255 || tiles < 1 || !node_mask || !edge_mask || !groups_out) return GAUDI_E_INVALID;
+  Meta8 M;
+  std::string err;
+  int rc = build_meta8(B, N, node_mask, edge_mask, M, err);
+  if (rc) return rc;
+  Pack pk;
+  pack_groups(B, N, node_mask, edge_mask, M, pk, node_slots, tiles);
+  Meta8 M2;
+  rc = build_meta8(pk.G, node_slots, pk.umask.data(), pk.uemask.data(), M2, err, 0, pk.align.data());
+  if (rc) return rc;
+  *groups_out = pk.G;
+  for (int g = 0; g < pk.G; ++g) {
+    if (ntiles_out) ntiles_out[g] = M2.ntiles[g];
+    if (ncols_out) ncols_out[g] = M2.ncols[g];
+    if (group_of_out)
+      for (int k = 0; k < pk.ncomp[g]; ++k) group_of_out[pk.compmol[(size_t)g * kMaxComp + k]] = g;
+  }
+  return GAUDI_OK;
+}
+
 int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* last_call) {
   if (!h) return GAUDI_E_INVALID;
   if (configured) *configured = h->variant;
@@ -1780,9 +1853,10 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
   return GAUDI_OK;
 }
 
-int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups) {
+int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups, int32_t* node_slots) {
   if (!h || !workgroups) return GAUDI_E_INVALID;
   *workgroups = h->run_groups;
+  if (node_slots) *node_slots = h->run_nslots;
   return GAUDI_OK;
 }
 

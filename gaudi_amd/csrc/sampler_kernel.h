@@ -16,7 +16,9 @@ namespace gaudi {
 enum Mode { MODE_PHI = 0, MODE_SAMPLE = 1, MODE_PRED_FWD = 2, MODE_PRED_GRAD = 3, MODE_GUIDE = 4 };
 
 struct KParams {
-  int mode, B, N, F, EW;
+  int mode, B, N, F, EW;   // B workgroups (molecules, or groups of them), N node slots per workgroup
+  int NR;                   // rows per molecule in the global [molecules][NR][.] arrays (= N unless the launch runs wide groups:
+                            // gaudi_hip.hip, stage_graph8 -- a group of several molecules then has MORE node slots than a molecule)
   int do_init, do_decode, guided;
   int s_hi, s_lo, T;
   // graph metadata (device)
@@ -92,7 +94,7 @@ struct V4T {
   static constexpr bool kGlobalNodes = GN;
   using Graph = gaudi::MolGraph;
   template <int HP> using EdmSmem = gaudi::NetSmem<HP, GN>;
-  __device__ __forceinline__ static void set_rows(Graph&, const int*, int) {}  // the 4-wave kernels are never packed
+  __device__ __forceinline__ static void set_rows(Graph&, const int*, int, int) {}  // the 4-wave kernels are never packed
   __host__ __device__ static int graph_floats(int N, int EW) { return 2 * gaudi::kWaves * EW + align16(N); }
   __device__ __forceinline__ static float* load_graph(const KParams& P, int b, float* base, const float* sMask, Graph& mg, int tid, int wave) {
     const int N = P.N, EW = P.EW;
@@ -185,6 +187,7 @@ __device__ __forceinline__ w8::MolGraph graph8(const Lds8& L, const Graph8Args& 
   mg.mask = L.sMask; mg.edge = L.sEdge; mg.em = L.sEm; mg.seg = L.sSeg; mg.soff = L.sOff; mg.sidx = L.sIdx;
   mg.row = L.sRow;
   mg.ncomp = __builtin_amdgcn_readfirstlane(L.sCmol[4]);
+  mg.NR = a.N;  // (the out-of-line phases never map a slot to its global row)
   return mg;
 }
 // Function arguments arrive in VGPRs: without these the callee treats every size, offset and buffer descriptor as
@@ -285,7 +288,7 @@ struct V8T {
     mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg; mg.soff = sOff; mg.sidx = sIdx;
     return base;
   }
-  __device__ __forceinline__ static void set_rows(Graph& mg, const int* row, int ncomp) { mg.row = row; mg.ncomp = ncomp; }
+  __device__ __forceinline__ static void set_rows(Graph& mg, const int* row, int ncomp, int NR) { mg.row = row; mg.ncomp = ncomp; mg.NR = NR; }
   __device__ __forceinline__ static Graph8Args gargs(const Graph& mg) {
     return Graph8Args{mg.N, mg.D, mg.S, mg.NC, mg.ntiles, mg.pubx, mg.pub_ch};
   }
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
   int* sCmol = (int*)base; base += 16;
   for (int i = tid; i < N; i += kThreads) {
     sMask[i] = P.node_mask[b * N + i];
-    sRow[i] = P.rowmap != nullptr ? P.rowmap[(size_t)b * N + i] : b * N + i;  // not packed: slot i = node i of molecule b
+    sRow[i] = P.rowmap != nullptr ? P.rowmap[(size_t)b * N + i] : b * N + i;  // not packed: slot i = node i of molecule b (NR = N)
   }
   if (tid < kMaxComp) sCmol[tid] = P.rowmap != nullptr ? P.compmol[(size_t)b * kMaxComp + tid] : b;
   if (tid == kMaxComp) sCmol[kMaxComp] = P.rowmap != nullptr ? P.ncomp[b] : 1;
@@ -369,19 +372,19 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
   float* net = V::load_graph(P, b, base, sMask, mg, tid, wave);
   __syncthreads();
   const int ncomp = __builtin_amdgcn_readfirstlane(sCmol[kMaxComp]);
-  V::set_rows(mg, sRow, ncomp);
+  V::set_rows(mg, sRow, ncomp, P.NR);
 
   // locals (not references into the kernarg struct) so nothing forces P onto the stack
   const float* const noise_p = P.noise;
   const long long draw_stride = P.draw_stride, sample_offset = P.sample_offset, fix_key = P.fix_key;
-  const int draw_base = P.draw_base, fix_noise = P.fix_noise;
+  const int draw_base = P.draw_base, fix_noise = P.fix_noise, NR = P.NR;
   const unsigned long long seed = P.seed;
   // raw N(0,1) draw `draw`, element (slot n, column d): keyed by the molecule's GLOBAL sample index and the node's index
   // inside its own molecule, so a molecule's noise does not depend on which workgroup (or which slot) holds it
   auto raw_noise = [=](int draw, int n, int d) -> float {
     const int w = sRow[n];
     if (w < 0) return 0.f;
-    const int row = row_of(w), local = (row % N) * D + d;
+    const int row = row_of(w), local = (row % NR) * D + d;
     if (noise_p != nullptr)
       return noise_p[(size_t)(draw - draw_base) * draw_stride + (fix_noise ? (size_t)local : (size_t)row * D + d)];
     const uint64_t gsample = (uint64_t)(fix_noise ? fix_key : sample_offset + sCmol[comp_of(w)]);
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
     for (int e = tid; e < N * D; e += kThreads) {
       const int n = e / D, d = e % D;
       const long long gi = gidx(n, d, D);
-      const int mol = gi < 0 ? 0 : (int)(gi / ((long long)N * D));
+      const int mol = gi < 0 ? 0 : (int)(gi / ((long long)NR * D));
       const float a_t = P.alpha_sigma[2 * mol], s_t = P.alpha_sigma[2 * mol + 1];
       const float raw = gi < 0 ? 0.f : P.z_in[gi];
       const float xh = d < 3 ? raw / nv0 : (raw - 0.0f) / nv1 * sMask[n];  // en_diffusion.py:384-392

@@ -532,6 +532,7 @@ struct MolGraph {
   // gravity, gradient clip, NaN scrub) run per component.  row[n] = global row | component << 28, -1 = empty slot
   const int* row;         // LDS [N]
   int ncomp;
+  int NR;                 // rows per molecule of the global arrays (N, or less when the group is wider than a molecule)
 };
 __device__ __forceinline__ int mg_comp(const MolGraph& mg, int n) { return (mg.row[n] >> 28) & 7; }
 

@@ -618,7 +618,7 @@ __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, fl
     float s = 0.f;
     for (int n = 0; n < N; ++n) {
       if (mg_comp(mg, n) != k) continue;
-      const int local = ((mg.row[n] & 0x0fffffff) % N) * D;
+      const int local = ((mg.row[n] & 0x0fffffff) % mg.NR) * D;
       for (int d = 0; d < D; ++d)
         if (((local + d) & 63) == lane) s += sGrad[n * D + d] * sGrad[n * D + d];
     }

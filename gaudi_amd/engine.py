@@ -323,9 +323,13 @@ class Engine:
 
     def last_workgroups(self) -> int:
         """Workgroups of the most recent launch (molecules, or the groups they were packed into)."""
-        n = C.c_int32()
-        self._check(self.lib.gaudi_last_workgroups(self.h, C.byref(n)), "gaudi_last_workgroups")
-        return n.value
+        return self.last_launch_shape()[0]
+
+    def last_launch_shape(self):
+        """-> (workgroups, node slots per workgroup) of the most recent launch; node slots > N: wide groups."""
+        n, ns = C.c_int32(), C.c_int32()
+        self._check(self.lib.gaudi_last_workgroups(self.h, C.byref(n), C.byref(ns)), "gaudi_last_workgroups")
+        return n.value, ns.value
 
     def set_plan_hint(self, min_slots: int = 0, force_waves: int = 0):
         """Plan the following calls with the graph figures of a larger logical batch (see gaudi_set_plan_hint)."""
@@ -347,18 +351,22 @@ class Engine:
             raise GaudiError(f"gaudi_host_graph_meta8 failed ({rc})")
         return int(slots.value), 0
 
-    def pack_plan(self, node_mask, edge_mask):
+    def pack_plan(self, node_mask, edge_mask, node_slots=None, tiles=16):
         """-> (G, group_of[B], ntiles[G], ncols[G]): the workgroups a sampling call of the 8-wave kernels launches for this
         batch -- small molecules share a workgroup as components of one disjoint graph (device-free: gaudi_host_pack_plan;
-        G = B when nothing packs)."""
+        G = B when nothing packs).  node_slots > N: the plan of WIDE groups (gaudi_host_pack_plan_wide)."""
         nm = f32(node_mask)
         B, N = nm.shape[0], nm.shape[1]
         nm, em = self._masks(nm, edge_mask, B, N)
         G = C.c_int32()
         group_of, ntiles, ncols = (np.zeros(B, np.int32) for _ in range(3))
         i32 = C.POINTER(C.c_int32)
-        rc = self.lib.gaudi_host_pack_plan(B, N, fptr(nm), fptr(em), C.byref(G), group_of.ctypes.data_as(i32),
-                                           ntiles.ctypes.data_as(i32), ncols.ctypes.data_as(i32))
+        if node_slots is not None and node_slots > N:
+            rc = self.lib.gaudi_host_pack_plan_wide(B, N, int(node_slots), int(tiles), fptr(nm), fptr(em), C.byref(G),
+                                                    group_of.ctypes.data_as(i32), ntiles.ctypes.data_as(i32), ncols.ctypes.data_as(i32))
+        else:
+            rc = self.lib.gaudi_host_pack_plan(B, N, fptr(nm), fptr(em), C.byref(G), group_of.ctypes.data_as(i32),
+                                               ntiles.ctypes.data_as(i32), ncols.ctypes.data_as(i32))
         if rc != 0:
             raise GaudiError(f"gaudi_host_pack_plan failed ({rc})")
         return G.value, group_of, ntiles[:G.value], ncols[:G.value]

@@ -127,12 +127,13 @@ def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
     return step_mfma_counts(edge_units, ncols, edm, pred, variant)[0]
 
 
-def step_weight_stream_bytes(edm, pred=None, variant="w8s"):
+def step_weight_stream_bytes(edm, pred=None, variant="w8s", rounds=1):
     """Bytes of packed weights ONE workgroup streams from L2 per reverse step: every node-level matrix as (16 T)^2 fp32
     (lane-linear tiles), every edge-level matrix as fp32 tiles or, for "w8s", as its split image (units of 1 KiB: K chunks x
     output tiles x 3 bf16 pieces; a K tail as T fp32 tiles).  Same matrix counts as step_mfma_counts.  No reuse across
     workgroups inside a CU -- one molecule (or packed group) per workgroup -- so a launch of G workgroups moves G times this
-    through the L2 -> CU fabric per step."""
+    through the L2 -> CU fabric per step.  rounds: rounds of eight edge tiles of the workgroup's graph (wide groups: 2) -- an
+    edge-level matrix is streamed once per round, a node-level one once per workgroup."""
     def node_b(T):
         return (16 * T) ** 2 * 4
 
@@ -145,11 +146,11 @@ def step_weight_stream_bytes(edm, pred=None, variant="w8s"):
 
     Te = _pad_hidden_kernel(edm["nf"]) // 16
     L, S = edm["n_layers"], edm.get("inv_sublayers", 1)
-    total = L * ((S * 5 + 2) * node_b(Te) + (S + 1) * edge_b(Te, edm["nf"]))
+    total = L * ((S * 5 + 2) * node_b(Te) + rounds * (S + 1) * edge_b(Te, edm["nf"]))
     if pred is not None:
         Tp = _pad_hidden_kernel(pred["nf"]) // 16
         Lp = pred["n_layers"]
-        total += 2 * Lp * 5 * node_b(Tp) + 2 * (2 * Lp - 1) * edge_b(Tp, pred["nf"])
+        total += 2 * Lp * 5 * node_b(Tp) + rounds * 2 * (2 * Lp - 1) * edge_b(Tp, pred["nf"])
     return total
 
 

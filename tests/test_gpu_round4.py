@@ -176,3 +176,95 @@ def test_four_wave_callbacks_on_sparse_hetero_graphs_of_18_to_20_nodes(rings):
     c = eng8.sample_callback(nm, em, lambda pred, t: np.broadcast_to(w, pred.shape), seed=3, scale=0.6)
     eng8.close()
     assert rel_err(c[0], a[0]) < 1e-4 and np.array_equal(c[1], a[1])
+
+
+# ------------------------------------------------------------------------------------------------ wide groups ("pairs")
+def _wide_case(dataset, sizes, widths, T=5):
+    from gaudi_amd.sampling_edm import build_masks
+    F = synth.num_node_features(dataset)
+    over_e, over_p = (TINY, TINY_P) if widths == "tiny" else ({}, {})
+    eargs = synth.edm_args(dataset=dataset, diffusion_steps=T, **over_e)
+    pargs = synth.pred_args(dataset=dataset, **over_p)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=11, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=12, amplify_coord=True)
+    nm3, em_flat, N = build_masks(sizes, max(sizes), dataset != "cata")
+    B = len(sizes)
+    return eargs, esd, pargs, psd, nm3.reshape(B, N), em_flat.reshape(B, N, N), N
+
+
+@pytest.mark.parametrize("widths", ["tiny", "default"])
+@pytest.mark.parametrize("dataset,sizes", [("cata", [11] * 6), ("cata", [11, 7, 11, 9, 11, 4, 11, 10, 3]),
+                                           ("hetro", [3, 10, 4, 3, 5, 7, 3, 6, 4, 9, 3, 4, 8, 5, 3, 3, 10, 10])])
+def test_wide_groups_equal_one_molecule_per_workgroup(dataset, sizes, widths):
+    """a batch of at least two molecules per CU gives a workgroup MORE node slots than a molecule has -- two
+    11-ring cata molecules, three or four small hetero ones -- and two rounds of eight edge tiles, so that every node-level
+    weight matrix is streamed once for all of them.  Forced here on small batches (GAUDI_PAIRS=2): guided and unguided chains,
+    Philox and injected noise, must equal the one-molecule-per-workgroup run (GAUDI_PACK=0) BIT FOR BIT -- a molecule keeps its
+    own tiles, noise keys, reductions and accumulation orders -- and a teacher-forced step must match the oracle."""
+    from oracle import gaudi_oracle as O
+    eargs, esd, pargs, psd, nm, em, N = _wide_case(dataset, sizes, widths)
+    B, T, D = len(sizes), eargs["diffusion_steps"], 3 + synth.num_node_features(dataset)
+    w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
+    noise = np.random.default_rng(3).standard_normal((T + 2, B, N, D)).astype(np.float32)
+    wide = _engine(eargs, esd, pargs, psd, GAUDI_PAIRS=2)
+    solo = _engine(eargs, esd, pargs, psd, GAUDI_PACK=0)
+    for kw in (dict(seed=9, sample_offset=4, target_w=w, scale=0.6), dict(seed=9, sample_offset=4), dict(noise=noise, target_w=w, scale=0.6)):
+        a = wide.sample(nm, em, return_z0=True, **kw)
+        G, slots = wide.last_launch_shape()
+        assert wide.kernel_variant()[1] == 8 and G < B and slots > N, (G, slots)
+        b = solo.sample(nm, em, return_z0=True, **kw)
+        assert solo.last_launch_shape() == (B, N)
+        for u, v in zip(a, b):
+            if isinstance(u, np.ndarray):
+                assert np.array_equal(u, v)
+        assert np.isfinite(a[0]).all()
+    # a teacher-forced guided step of the wide launch against the oracle
+    rng = np.random.default_rng(5)
+    z = O._combined_noise(rng.standard_normal((B, N, D)).astype(np.float32), nm[:, :, None])
+    eps = rng.standard_normal((B, N, D)).astype(np.float32)
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    got = wide.step(2, z, nm, em, eps, target_w=w, scale=0.6)
+    assert wide.last_launch_shape()[1] > N
+    want = O.step_guided(esd, eargs, psd, pargs, gamma, 2, z, nm[:, :, None], em, eps, w, 0.6)
+    assert rel_err(got, want) < 1e-4
+    wide.close()
+    solo.close()
+
+
+def test_full_batch_b1024_guided_step_vs_cpp_port():
+    """C5's per-GPU shape (1024 cata molecules of 11 nodes: the batch pairs up by itself, 512 workgroups of two molecules)
+    through ONE teacher-forced guided step at the default architectures against the C++/OpenMP restatement: every molecule
+    at 1e-4, and bit-equal to the unpaired launch."""
+    from oracle import build_cpu
+    from oracle import gaudi_oracle as O
+    if not build_cpu.cpu_ok():
+        pytest.skip("host CPU lacks the ISA the C++ port is built for")
+    T, B, N = 1000, 1024, 11
+    eargs, pargs = synth.edm_args(diffusion_steps=T), synth.pred_args()
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=0, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=1, amplify_coord=True)
+    nm = np.ones((B, N), np.float32)
+    em = np.broadcast_to(1.0 - np.eye(N, dtype=np.float32), (B, N, N)).copy()
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    rng = np.random.default_rng(78)
+    z = O._combined_noise(rng.standard_normal((B, N, 4)).astype(np.float32), nm[:, :, None])
+    eps = rng.standard_normal((B, N, 4)).astype(np.float32)
+    s = 500
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    port = build_cpu.CpuPort()
+    port.load_edm(eargs, esd)
+    port.load_predictor(pargs, psd)
+    want = port.step(O.step_coefficients(gamma, s, s + 1), np.float32(np.float32(s + 1) / np.float32(T)), z, nm, em, eps,
+                     target_w=w, scale=0.6)
+    port.close()
+    eng = _engine(eargs, esd, pargs, psd)
+    got = eng.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+    assert eng.last_launch_shape() == (B // 2, 2 * N), eng.last_launch_shape()
+    eng.close()
+    per_mol = np.abs(got - want).reshape(B, -1).max(1) / np.abs(want).reshape(B, -1).max(1)
+    assert per_mol.max() < 1e-4, (int(per_mol.argmax()), float(per_mol.max()))
+    solo = _engine(eargs, esd, pargs, psd, GAUDI_PAIRS=0)
+    ref = solo.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+    assert solo.last_launch_shape() == (B, N)
+    solo.close()
+    assert np.array_equal(got, ref)

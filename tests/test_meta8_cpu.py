@@ -121,3 +121,34 @@ def test_pack_plan_groups_small_molecules():
     nm, em = np.ascontiguousarray(nm3.reshape(8, N)), np.ascontiguousarray(em_flat.reshape(8, N, N))
     G = C.c_int32()
     assert lib.gaudi_host_pack_plan(8, N, _lib.fptr(nm), _lib.fptr(em), C.byref(G), None, None, None) == 0 and G.value == 8
+
+
+def test_wide_group_plan_pairs_cata_molecules():
+    """gaudi_host_pack_plan_wide (device-free): with 2 N node slots and 16 edge tiles per group, 11-ring cata molecules (11
+    nodes, 110 live edges = 7 tiles) pair up; a ragged batch packs by node slots and tiles, at most 4 molecules per group."""
+    import ctypes as C
+    from gaudi_amd import _lib
+    from gaudi_amd.sampling_edm import build_masks
+    lib = _lib.load_library()
+    i32 = C.POINTER(C.c_int32)
+
+    def plan(sizes, orientation, slots, tiles):
+        nm3, em_flat, N = build_masks(sizes, max(sizes), orientation)
+        B = len(sizes)
+        nm, em = np.ascontiguousarray(nm3.reshape(B, N)), np.ascontiguousarray(em_flat.reshape(B, N, N))
+        G = C.c_int32()
+        group_of, ntiles, ncols = (np.zeros(B, np.int32) for _ in range(3))
+        rc = lib.gaudi_host_pack_plan_wide(B, N, slots if slots else 2 * N, tiles, _lib.fptr(nm), _lib.fptr(em), C.byref(G),
+                                           group_of.ctypes.data_as(i32), ntiles.ctypes.data_as(i32), ncols.ctypes.data_as(i32))
+        assert rc == 0
+        return G.value, group_of, ntiles[:G.value], ncols[:G.value], N
+
+    G, group_of, ntiles, ncols, N = plan([11] * 6, False, 0, 16)
+    assert G == 3 and sorted(np.bincount(group_of)) == [2, 2, 2] and list(ntiles) == [14] * 3 and list(ncols) == [22] * 3
+    G, group_of, ntiles, ncols, N = plan([3, 10, 4, 3, 5, 7, 3, 6, 4, 9, 3, 4, 8, 5, 3, 3], True, 22, 16)
+    assert G < 16 and np.bincount(group_of).max() <= 4 and ntiles.max() <= 16 and ncols.max() <= 22
+    # node_slots < N is refused
+    nm = np.ones((2, 5), np.float32)
+    em = np.ascontiguousarray(np.broadcast_to(1.0 - np.eye(5, dtype=np.float32), (2, 5, 5)))
+    Gc = C.c_int32()
+    assert lib.gaudi_host_pack_plan_wide(2, 5, 4, 16, _lib.fptr(nm), _lib.fptr(em), C.byref(Gc), None, None, None) != 0

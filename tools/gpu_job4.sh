@@ -15,8 +15,12 @@ for step in "$@"; do
     bench) timeout 1200 python3 bench.py --steps 2 --warmup 1 > $out/bench.json 2> $out/bench.err ;;
     bench_quick) timeout 600 $B > $out/bench_quick.json 2> $out/bench_quick.err ;;
     bench_c2) timeout 600 $B --workload c2 > $out/bench_c2.json 2> $out/bench_c2.err ;;
-    bench_c4) timeout 600 $B --workload c4 > $out/bench_c4.json 2> $out/bench_c4.err ;;
-    bench_b1024) timeout 600 $B --batch 1024 > $out/bench_b1024.json 2> $out/bench_b1024.err ;;
+    bench_c4) GAUDI_DEBUG_PLAN=1 timeout 600 $B --workload c4 > $out/bench_c4.json 2> $out/bench_c4.err ;;
+    bench_b1024) GAUDI_DEBUG_PLAN=1 timeout 600 $B --batch 1024 > $out/bench_b1024.json 2> $out/bench_b1024.err ;;
+    bench_b1024_nopairs) GAUDI_PAIRS=0 timeout 600 $B --batch 1024 > $out/bench_b1024_nopairs.json 2> $out/bench_b1024_nopairs.err ;;
+    bench_c4_nopairs) GAUDI_PAIRS=0 timeout 600 $B --workload c4 > $out/bench_c4_nopairs.json 2> $out/bench_c4_nopairs.err ;;
+    bench_c2_b1024) timeout 600 $B --workload c2 --batch 1024 > $out/bench_c2_b1024.json 2> $out/bench_c2_b1024.err ;;
+    bench_c2_b1024_nopairs) GAUDI_PAIRS=0 timeout 600 $B --workload c2 --batch 1024 > $out/bench_c2_b1024_nopairs.json 2> $out/bench_c2_b1024_nopairs.err ;;
     bench_exp) for v in $GAUDI_VARIANTS; do [ -f gaudi_amd/libgaudi_var_$v.so ] && GAUDI_LIB=$PWD/gaudi_amd/libgaudi_var_$v.so timeout 600 $B > $out/bench_$v.json 2> $out/bench_$v.err; done ;;
     bench_dist) timeout 600 $B --dist > $out/bench_dist.json 2> $out/bench_dist.err ;;
     *) echo "unknown step $step" ;;
