@@ -88,9 +88,9 @@ struct gaudi_handle {
   int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
   bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
   bool pack = true;           // several small molecules per workgroup in sampling calls (GAUDI_PACK=0: off)
-  int pairs = 1;              // wide groups (more node slots than a molecule has, two rounds of edge tiles: e.g. two 11-ring cata
-                              // molecules per workgroup): 1 = when the batch holds at least two molecules per CU, 0 = never, 2 = always
-                              // (GAUDI_PAIRS)
+  int pairs = 0;              // wide groups (more node slots than a molecule has, two rounds of edge tiles: e.g. two 11-ring cata
+                              // molecules per workgroup): 0 = never (default: measured -2 % on C3 at 1024 molecules, +1 % unguided,
+                              // DESIGN.md section 8), 1 = when the batch holds at least two molecules per CU, 2 = always (GAUDI_PAIRS)
   int num_cus = 256;
   int run_nslots = 0;         // node slots per workgroup of the current call (= N unless the call runs wide groups)
   bool pred_rounds = true;    // GAUDI_PRED_ROUNDS=0: guided calls with more than 128 edge slots go to the 4-wave kernels
@@ -918,11 +918,13 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   bool mr_run = mr;
   // (a row of the map holds molecule * N + node in 28 bits)
   if (h->pack_now && h->pack && B > 1 && (int64_t)B * N < (1 << 28)) {
-    // Candidate group shapes, widest first.  WIDE groups (a batch of at least two molecules per CU; GAUDI_PAIRS): up to 2 N node
-    // slots and two rounds of eight edge tiles -- e.g. two 11-ring cata molecules, or three to four small hetero ones, per
-    // workgroup.  Every node-level matrix is then streamed from L2 once for all of them (the L2 -> CU weight stream is paid per
-    // workgroup) and the per-GEMM fixed costs are shared; the edge phases run their rounds one after the
-    // other (the predictor on the MR kernels).  Then the classic shape: N node slots, one round.
+    // Candidate group shapes, widest first.  WIDE groups (opt-in: GAUDI_PAIRS=1 for batches of at least two molecules per CU, 2
+    // always): up to 2 N node slots and two rounds of eight edge tiles -- e.g. two 11-ring cata molecules, or three to four small
+    // hetero ones, per workgroup.  Every node-level matrix is then streamed from L2 once for all of them and the per-GEMM fixed
+    // costs are shared; the edge phases run their rounds one after the other on the half ring (the predictor on the MR
+    // kernels).  Bit-identical to the narrow launch, and measured slightly SLOWER on the guided path (what the shared stream
+    // saves, the second round's half-ring trips and parked du cost: DESIGN.md section 8), hence not the default.  Then the
+    // classic shape: N node slots, one round.
     struct Cand {
       int NG, TG;
     };

@@ -5,7 +5,6 @@
 #include "edm_device.h"
 #include "w8_common.h"
 #include "w8_split.h"
-#include "w8_nodes.h"
 
 namespace gaudi {
 namespace w8 {
@@ -118,7 +117,6 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
   constexpr int PK = HP * HP;
-  using NE = NodeEngine<HP, SP>;  // node-level GEMMs: split operands on four waves beside split edge GEMMs, else fp32 instructions
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1;
   EdmLayout lay{HP, F1, W.L, W.S};
@@ -152,8 +150,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   typename EdgeRing<HP, SP>::type ring;
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
   er_start<HP>(ring, wbe, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
-  typename NE::PF pf;  // first weight tiles of the next node GEMM, loaded ahead of it
-  NE::prefetch(pf, wb, lay.gcl(0, 0), wave, lane, tw);
+  NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it
+  node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane, tw);
   constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next sub-layer's vectors (GCL: 7 HP + 16 floats, EquivariantUpdate: 5 HP), loaded a phase ahead
   vec_prefetch<NV, kThreads>(vpf, wb, lay.gcl(0, 0) + 6 * PK, 7 * HP + 16, tid);
@@ -176,9 +174,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
                   *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
       const float ba = sm.vec[7 * HP];
-      NE::template gemm<EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, G + PK);
-      NE::template gemm<EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
-                                    NE::kCrossEdge ? G + 3 * PK : -1);  // node MLP weights travel across the edge phase
+      node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, G + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
+                                    G + 3 * PK);  // node MLP weights travel across the edge phase
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
@@ -207,7 +205,6 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         }
         STAMP(ST_EDGE_EPI);
       }
-      if (!NE::kCrossEdge) NE::prefetch(pf, wb, G + 3 * PK, wave, lane, tw);
       __syncthreads();
       STAMP(ST_BARRIER);
       for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = (partial 0 + partial 1) / normalization_factor
@@ -216,14 +213,14 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       }
       __syncthreads();
       STAMP(ST_MISC);
-      NE::template gemm<EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw,
+      node_gemm<HP, EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw,
                                     &pf, G + 5 * PK);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
       vec_prefetch<NV, kThreads>(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK,
                                  s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
-      NE::template gemm<EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave, lane, tw,
+      node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave, lane, tw,
                                              &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
       __syncthreads();
@@ -237,9 +234,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       __syncthreads();
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
-      NE::template gemm<EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, E + PK);
-      NE::template gemm<EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
-                                    NE::kCrossEdge && l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
+      node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, E + PK);
+      node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
+                                    l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
@@ -265,7 +262,6 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         STAMP(ST_EDGE_EPI);
       }
       if (l + 1 < W.L) vec_prefetch<NV, kThreads>(vpf, wb, lay.gcl(l + 1, 0) + 6 * PK, 7 * HP + 16, tid);
-      if (!NE::kCrossEdge && l + 1 < W.L) NE::prefetch(pf, wb, lay.gcl(l + 1, 0), wave, lane, tw);
       __syncthreads();
       STAMP(ST_BARRIER);
       coord_update(sm, mg, W.normf, tid);

@@ -79,7 +79,6 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
                                              float t_val, float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
-  using NE = NodeEngine<HP, SP>;  // node-level GEMMs (w8_nodes.h)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1, K = W.K, S = mg.S;
   PredLayout lay{HP, F1, K, W.L};
@@ -115,8 +114,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   typename EdgeRing<HP, SP>::type ring;
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
   er_start<HP>(ring, wbe, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
-  typename NE::PF pf;
-  NE::prefetch(pf, wb, lay.layer(0), wave, lane, tw);
+  NodePF<HP> pf;
+  node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane, tw);
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next layer's vectors, loaded one node GEMM ahead
   vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(0), HP), PredLayerW::vec_count(HP), tid);
@@ -134,9 +133,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     compute_geo(sm, mg, 1.0f, tid, false);  // gcl.py:308-316
     __syncthreads();
     STAMP(ST_STAGE);
-    NE::template gemm<EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Bm);
-    NE::template gemm<EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
-                                      NE::kCrossEdge ? Lw.Wn1h : -1);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Bm);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1h);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
@@ -215,7 +213,6 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         if (++rd < mg.rounds) goto pred_fwd_round;
       }
     }
-    if (!NE::kCrossEdge) NE::prefetch(pf, wb, Lw.Wn1h, wave, lane, tw);
     __syncthreads();
     STAMP(ST_BARRIER);
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = partial 0 + partial 1
@@ -224,13 +221,13 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     }
     __syncthreads();
     STAMP(ST_MISC);
-    NE::template gemm<EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn2,
+    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn2,
                                   st + 2 * N * HP /* npre -> stash */);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
     vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), PredLayerW::vec_count(HP), tid);
-    NE::template gemm<EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, tw, &pf,
+    node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, tw, &pf,
                                            l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
     STAMP(ST_NODE);
@@ -268,7 +265,6 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
                                               float* sGrad, float readout_div, int pub_ch, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
-  using NE = NodeEngine<HP, SP>;  // node-level GEMMs (w8_nodes.h)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1, K = W.K, S = mg.S;
   PredLayout lay{HP, F1, K, W.L};
@@ -318,8 +314,8 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     const int L0 = lay.layer(W.L - 1);
     er_start<HP>(ring, wbe, L0 + 9 * HP * HP /* W2^T of the last layer (its coordinate branch is skipped) */, wave, lane);
   }
-  typename NE::PF pf;
-  NE::prefetch(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane, tw);
+  NodePF<HP> pf;
+  node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane, tw);
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;
   vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(W.L - 1), HP), PredLayerW::vec_count(HP), tid);
@@ -346,11 +342,11 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     compute_geo(sm, mg, 1.0f, tid, false);
     STAMP(ST_STASH);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
-    NE::template gemm<EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1ht);
+    node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1ht);
     __syncthreads();
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
-    NE::template gemm<EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1at);
-    NE::template gemm<EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, tw, &pf);
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1at);
+    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, tw, &pf);
     __syncthreads();
     STAMP(ST_BWD_NODE);
     // (e) edge pass: MLP chain backward for the wave's tile, then du of all slots is published CH feature tiles at a time
@@ -504,7 +500,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         __syncthreads();
       }
       if (SP != 0 && l > 0) er_start<HP>(ring, wbe, lay.layer(l - 1) + 10 * HP * HP /* Wc1^T of the layer below */, wave, lane);
-      NE::prefetch(pf, wb, Lw.At, wave, lane, tw);
+      node_prefetch<HP>(pf, wb, Lw.At, wave, lane, tw);
       STAMP(ST_BWD_COL);
     }
     // dx <- dx*mask + sum_{e: i=n} ddiff_e - sum_{e: j=n} ddiff_e, in slot order
@@ -520,7 +516,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     }
     // (f) dh += A^T dP + Bm^T dQ
     vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l > 0 ? l - 1 : 0), HP), PredLayerW::vec_count(HP), tid);
-    NE::template gemm<EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf,
+    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf,
                                    l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
     STAMP(ST_BWD_NODE);

@@ -234,11 +234,12 @@ int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_ca
  * groups they were packed into; node_slots (may be NULL): node slots per workgroup -- the call's N, or more when the launch
  * ran WIDE groups (below).  bench.py prices its roofline with these figures, not with the host-side plan. */
 int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups, int32_t* node_slots);
-/* The same plan for WIDE groups (device-free): groups of up to node_slots (>= N) node slots and `tiles` edge tiles.  A sampling
- * call of a batch that holds at least two molecules per CU (environment GAUDI_PAIRS: 0 never, 1 automatic = default, 2 always)
- * gives a workgroup more node slots than a molecule has -- two 11-ring cata molecules, three or four small hetero ones -- and
- * two rounds of eight edge tiles: every node-level weight matrix is then streamed from L2 once for all of them.  Results do
- * not depend on the grouping (tests/test_gpu_round4.py). */
+/* The same plan for WIDE groups (device-free): groups of up to node_slots (>= N) node slots and `tiles` edge tiles.  Opt-in
+ * (environment GAUDI_PAIRS at gaudi_create: 0 never = default, 1 for batches of at least two molecules per CU, 2 always): a
+ * sampling call then gives a workgroup more node slots than a molecule has -- two 11-ring cata molecules, three or four small
+ * hetero ones -- and two rounds of eight edge tiles, so that every node-level weight matrix is streamed from L2 once for all of
+ * them.  Results do not depend on the grouping, bit for bit (tests/test_gpu_round4.py); the guided path measured 2 % slower
+ * this way at 1024 molecules, which is why it is not the default. */
 int gaudi_host_pack_plan_wide(int B, int N, int node_slots, int tiles, const float* node_mask, const float* edge_mask,
                               int32_t* groups_out, int32_t* group_of_out, int32_t* ntiles_out, int32_t* ncols_out);
 /* How a sampling call of the 8-wave kernels packs a batch (device-free): small molecules share a workgroup as the components

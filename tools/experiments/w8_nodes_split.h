@@ -1,4 +1,10 @@
-// w8_nodes.h -- node-level GEMMs of the 8-wave kernels on the bf16 matrix pipe with fp32-equivalent accuracy ("NG4").
+// w8_nodes_split.h -- EXPERIMENT (round 4, measured and rejected; tools/node_gemm4_microbench.hip is its only user): node-level
+// GEMMs of the 8-wave kernels on the bf16 matrix pipe with fp32-equivalent accuracy ("NG4").
+// Result (profiles/r04a_node_gemm4_microbench.txt, 256 workgroups): 8 870 cycles per H = 192 matrix against 6 358 for the fp32
+// form of w8_common.h, 10 702 against 8 388 at H = 196 -> 208 (N = 11); 12 886 / 11 846 and 15 170 / 14 553 at N = 22.  Splitting
+// a weight tile pair in registers costs 44 vector instructions of 4 issue cycles each for 6 matrix instructions of 16, a
+// buffer_load_dwordx4 about 60 issue cycles, and on one SIMD all of them ADD: the matrix time saved (2.67x) is less than the
+// vector time spent.  Numerics are at the fp32 instruction's level (same file).  DESIGN.md section 8.
 //
 // Y[n][o] = epi( sum_k Wa[o][k] Xa[n][k] (+ sum_k Wb[o][k] Xb[n][k]) + bias[o] ) for the N <= 32 nodes of a workgroup: the
 // P / Q / node-MLP GEMMs of every layer and their transposes in the reverse pass (edm/egnn/egnn_new.py:59-73,
@@ -292,48 +298,6 @@ __device__ __forceinline__ void node_gemm4(const WBuf& wb, int Wa, const float* 
                                                                                        lane, pf, nextW, gPre);
   });
 }
-
-// ---------------------------------------------------------------------------------------------
-// One interface over both node-GEMM engines: the kernels whose edge GEMMs run on split operands (SP != 0) run their node GEMMs
-// on split operands too; the fp32-instruction kernels (GAUDI_EDGE_MATH=fp32) keep v_mfma_f32_16x16x4_f32 throughout.
-// -DGAUDI_NODE_SPLIT=0 builds the round-3 arrangement (split edge GEMMs, fp32-instruction node GEMMs) for A/B runs.
-// ---------------------------------------------------------------------------------------------
-#ifndef GAUDI_NODE_SPLIT
-#define GAUDI_NODE_SPLIT 0  // measured (profiles/r04a_node_gemm4_microbench.txt): 8 870 vs 6 358 cycles per H = 192 matrix, 10 702 vs 8 388 at 208 -- the on-the-fly split costs 44 vector instructions of 4 cycles per tile pair and loses
-#endif
-template <int HP, bool SPLIT>
-struct NodeEngineT {
-  using PF = NodePF<HP>;
-  // the first weight tiles of the node GEMM that follows an edge phase travel ACROSS that phase (16 registers)
-  static constexpr bool kCrossEdge = true;
-  __device__ __forceinline__ static void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tail_w) {
-    node_prefetch<HP>(pf, wb, W, wave, lane, tail_w);
-  }
-  template <int EPI, bool PRE = false>
-  __device__ __forceinline__ static void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sBias,
-                                              float* sY, const float* sRes, const float* sMask, int N, int wave, int lane, bool tail_w,
-                                              PF* pf = nullptr, int nextW = -1, float* gPre = nullptr) {
-    node_gemm<HP, EPI, PRE>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, tail_w, pf, nextW, gPre);
-  }
-};
-template <int HP>
-struct NodeEngineT<HP, true> {
-  using PF = NodePF4<HP>;
-  // three tiles x two chunks = 24 registers would have to live through the register-tight edge GEMMs: the prefetch for the node
-  // GEMM that follows an edge phase is issued after the phase instead (covered by the partial-sum pass and its barrier)
-  static constexpr bool kCrossEdge = false;
-  __device__ __forceinline__ static void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tail_w) {
-    node_prefetch4<HP>(pf, wb, W, wave, lane, tail_w);
-  }
-  template <int EPI, bool PRE = false>
-  __device__ __forceinline__ static void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sBias,
-                                              float* sY, const float* sRes, const float* sMask, int N, int wave, int lane, bool tail_w,
-                                              PF* pf = nullptr, int nextW = -1, float* gPre = nullptr) {
-    node_gemm4<HP, EPI, PRE>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, tail_w, pf, nextW, gPre);
-  }
-};
-template <int HP, int SP>
-using NodeEngine = NodeEngineT<HP, (GAUDI_NODE_SPLIT != 0) && SP != 0>;
 
 }  // namespace w8
 }  // namespace gaudi

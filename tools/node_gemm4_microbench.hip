@@ -1,14 +1,14 @@
 // Microbenchmark + numerics probe of the node-level GEMMs: V = 0 the fp32-instruction form on 8 waves (w8_common.h: node_gemm),
-// V = 1 the split-operand form on 4 waves (w8_nodes.h: node_gemm4).  Weights streamed from L2 /
+// V = 1 the split-operand form on 4 waves (tools/experiments/w8_nodes_split.h: node_gemm4; measured and rejected).  Weights streamed from L2 /
 // Infinity Cache, one matrix after the other with a barrier in between (as the layers do), N = 11 or 20 graph nodes in LDS.
 // `tail` = the 4-valid-row output tile of H % 16 == 4 widths computed with v_mfma_f32_4x4x1_16B_f32 (w8_common.h: tail_lane).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I gaudi_amd/csrc tools/node_gemm4_microbench.hip -o gaudi_amd/ngemm4_mb && ./ngemm_mb
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I gaudi_amd/csrc -I tools/experiments tools/node_gemm4_microbench.hip -o gaudi_amd/ngemm4_mb && ./ngemm_mb
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
 #include <random>
 #include <vector>
-#include "w8_nodes.h"
+#include "w8_nodes_split.h"  // tools/experiments
 using namespace gaudi;
 
 template <int HP, int V>
