@@ -185,6 +185,29 @@ static int fail(gaudi_handle* h, int code, const std::string& msg) {
 // (edm/equivariant_diffusion/en_diffusion.py:32-61, 191-218), float64 like the reference's numpy.
 static std::vector<float> make_gamma(int T, double power, double precision) {
   const int steps = T + 1;
+  if (power <= 0.0) {
+    // the 'cosine' schedule (cosine_beta_schedule, en_diffusion.py:64-81; encoded as noise_power = 0): alphas_cumprod of
+    // T + 2 points of cos^2, betas clipped to [0, 0.999]; no precision blend
+    const int n = T + 2;
+    const double s_ = 0.008, pi = 3.14159265358979323846;
+    std::vector<double> ac(n);
+    for (int i = 0; i < n; ++i) {
+      const double x = (i == n - 1) ? (double)n : i * ((double)n / (double)(n - 1));  // np.linspace(0, n, n)
+      const double c = std::cos(((x / n) + s_) / (1.0 + s_) * pi * 0.5);
+      ac[i] = c * c;
+    }
+    const double a0 = ac[0];
+    for (double& v : ac) v /= a0;
+    std::vector<float> g(steps);
+    double cum = 1.0;
+    for (int i = 0; i < steps; ++i) {
+      double beta = 1.0 - ac[i + 1] / ac[i];
+      beta = std::min(std::max(beta, 0.0), 0.999);
+      cum *= 1.0 - beta;
+      g[i] = (float)(-(std::log(cum) - std::log(1.0 - cum)));
+    }
+    return g;
+  }
   std::vector<double> a2(steps);
   const double step = (double)steps / (double)(steps - 1);  // np.linspace(0, steps, steps)
   for (int i = 0; i < steps; ++i) {
@@ -1099,7 +1122,9 @@ static void fill_edm(gaudi_handle* h, KParams& P) {
   P.edm.use_tanh = c.tanh;
   P.edm.coords_range = c.coords_range;
   P.edm.norm_constant = c.norm_constant;
-  P.edm.normf = c.normalization_factor;
+  // aggregation_method 'mean' (normalization_factor = 0 in the config): unsorted_segment_sum divides by the number of edges of
+  // the dense list that share the row, masked ones included (egnn_new.py:416-420) = the call's padded node count
+  P.edm.normf = c.normalization_factor > 0.f ? c.normalization_factor : (float)P.NR;
   P.edm.ktail = h->run_variant == 8 && has_ktail(c.hidden_nf, h->HPE);
   P.edm.ws = h->edm_ws.as<float>();
   P.edm.ws_bytes = (unsigned)h->edm_ws_bytes;
@@ -1170,7 +1195,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   if (H <= 0 || H > 256) return fail(h, GAUDI_E_INVALID, "hidden_nf must be in 1..256");
   if (F < 1 || F > 15) return fail(h, GAUDI_E_INVALID, "in_node_nf must be in 1..15");
   if (L < 1 || S < 1 || cfg->diffusion_steps < 1) return fail(h, GAUDI_E_INVALID, "bad n_layers/inv_sublayers/diffusion_steps");
-  if (!(cfg->normalization_factor > 0.f)) return fail(h, GAUDI_E_INVALID, "normalization_factor must be > 0");
+  if (!(cfg->normalization_factor >= 0.f)) return fail(h, GAUDI_E_INVALID, "normalization_factor must be > 0 (or 0: 'mean' aggregation)");
   const int HP = round_hidden(H);
   if (!HP) return fail(h, GAUDI_E_INVALID, "no kernel instantiated for this hidden size");
   Tensors T;
@@ -1749,7 +1774,7 @@ int gaudi_philox_normal(gaudi_handle* h, uint64_t seed, int64_t sample_offset, i
 
 // ---- device-free entry points: the host logic of the library, callable (and tested) without a GPU
 int gaudi_host_schedule(int T, float noise_power, float noise_precision, float* gamma_out, float* coef_out) {
-  if (T < 1 || !gamma_out) return GAUDI_E_INVALID;
+  if (T < 1 || !gamma_out || !(noise_power >= 0.f)) return GAUDI_E_INVALID;
   const std::vector<float> g = make_gamma(T, noise_power, noise_precision);
   std::memcpy(gamma_out, g.data(), sizeof(float) * g.size());
   if (coef_out) {

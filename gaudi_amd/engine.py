@@ -20,10 +20,13 @@ def _strip(sd: dict) -> dict:
 
 
 def _noise_power(schedule: str) -> float:
+    """-> gaudi_edm_config.noise_power: p of 'polynomial_<p>', 0 for 'cosine' (PredefinedNoiseSchedule, en_diffusion.py:191-202)."""
+    if schedule == "cosine":
+        return 0.0
     parts = schedule.split("_")
-    if len(parts) != 2 or parts[0] != "polynomial":
-        raise GaudiError(f"unsupported diffusion_noise_schedule {schedule!r}: only 'polynomial_<p>' is implemented "
-                         "(the 'learned'/'cosine' schedules are training-only in the reference)")
+    if len(parts) != 2 or parts[0] != "polynomial" or not float(parts[1]) > 0:
+        raise GaudiError(f"unsupported diffusion_noise_schedule {schedule!r}: 'polynomial_<p>' and 'cosine' are implemented "
+                         "(the 'learned' schedule is training-only in the reference)")
     return float(parts[1])
 
 
@@ -80,8 +83,9 @@ class Engine:
         """args: the checkpoint's args.txt namespace (utils/args_edm.py); state_dict: model.pt."""
         if args.get("sin_embedding", False):
             raise GaudiError("sin_embedding=True checkpoints are not supported")
-        if args.get("aggregation_method", "sum") != "sum":
-            raise GaudiError("only aggregation_method='sum' is supported")
+        agg = args.get("aggregation_method", "sum")
+        if agg not in ("sum", "mean"):
+            raise GaudiError(f"unknown aggregation_method {agg!r}")
         sd = _strip(state_dict)
         emb = sd.get("dynamics.egnn.embedding.weight")
         if emb is None:
@@ -91,7 +95,7 @@ class Engine:
         nv = normalize_factors(args)
         cfg = EdmConfig(F, int(args["nf"]), int(args["n_layers"]), int(args.get("inv_sublayers", 1)),
                         int(bool(args["attention"])), int(bool(args["tanh"])), float(args["coords_range"]),
-                        float(args["norm_constant"]), float(args.get("normalization_factor", 1)),
+                        float(args["norm_constant"]), float(args.get("normalization_factor", 1)) if agg == "sum" else 0.0,
                         int(args["diffusion_steps"]), _noise_power(args["diffusion_noise_schedule"]),
                         float(args["diffusion_noise_precision"]), (C.c_float * 3)(*[float(v) for v in nv]))
         n, c_names, c_ptrs, c_numel, keep = self._tensor_args(sd)

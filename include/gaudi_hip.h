@@ -40,9 +40,11 @@ typedef struct {
   int32_t tanh;                /* args.tanh                                                    */
   float coords_range;          /* args.coords_range (NOT divided by n_layers, egnn_new.py:290) */
   float norm_constant;         /* args.norm_constant                                           */
-  float normalization_factor;  /* args.normalization_factor ("sum" aggregation only)           */
+  float normalization_factor;  /* args.normalization_factor of aggregation_method "sum"; 0 = aggregation_method "mean": divide by the
+                                  number of edges of the dense list per row, masked ones included = the call's padded node
+                                  count N (unsorted_segment_sum, edm/egnn/egnn_new.py:403-421)   */
   int32_t diffusion_steps;     /* args.diffusion_steps (T)                                     */
-  float noise_power;           /* p of "polynomial_<p>" (en_diffusion.py:47-61)                */
+  float noise_power;           /* p of "polynomial_<p>" (en_diffusion.py:47-61); 0 = the "cosine" schedule (:64-81,196-197) */
   float noise_precision;       /* args.diffusion_noise_precision                               */
   float norm_values[3];        /* args.normalize_factors                                       */
 } gaudi_edm_config;
@@ -198,7 +200,7 @@ int gaudi_philox_normal(gaudi_handle* h, uint64_t seed, int64_t sample_offset, i
 
 /* ---- Device-free host logic (no handle, no GPU): exposed so the CPU test suite can check it. ----
  * gamma [T+1] and (optionally) the per-step table [T][4] exactly as gaudi_load_edm builds them. */
-int gaudi_host_schedule(int T, float noise_power, float noise_precision, float* gamma_out, float* coef_out);
+int gaudi_host_schedule(int T, float noise_power /* 0 = cosine */, float noise_precision, float* gamma_out, float* coef_out);
 /* The live-edge metadata gaudi_* calls derive from (node_mask, edge_mask): per-wave capacity EW (multiple of 32),
  * launch order [B] (heaviest first), 32-edge passes per wave [B][4], per-node segment word [B][N]
  * (wave<<30 | start<<15 | len), the padded per-wave edge lists [B][4][EW] (i | j<<8) with their mask values, and

@@ -83,13 +83,26 @@ def polynomial_schedule(timesteps, s=1e-4, power=3.0):
     return precision * alphas2 + s
 
 
+def cosine_beta_schedule(timesteps, s=0.008):
+    """en_diffusion.py:64-81 (raise_to_power = 1) -> alphas_cumprod [T+1]."""
+    steps = timesteps + 2
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    betas = np.clip(1 - (ac[1:] / ac[:-1]), a_min=0, a_max=0.999)
+    return np.cumprod(1.0 - betas, axis=0)
+
+
 def gamma_table(noise_schedule, timesteps, precision):
     """PredefinedNoiseSchedule.__init__, en_diffusion.py:191-218 -> float32 [T+1]."""
-    if "polynomial" not in noise_schedule:
+    if noise_schedule == "cosine":
+        alphas2 = cosine_beta_schedule(timesteps)
+    elif "polynomial" in noise_schedule:
+        splits = noise_schedule.split("_")
+        assert len(splits) == 2
+        alphas2 = polynomial_schedule(timesteps, s=precision, power=float(splits[1]))
+    else:
         raise ValueError(f"unsupported noise schedule {noise_schedule!r}")
-    splits = noise_schedule.split("_")
-    assert len(splits) == 2
-    alphas2 = polynomial_schedule(timesteps, s=precision, power=float(splits[1]))
     sigmas2 = 1 - alphas2
     return (-(np.log(alphas2) - np.log(sigmas2))).astype(F32)
 
@@ -202,8 +215,12 @@ def edm_phi(sd, cfg, z, t, node_mask, edge_mask, dtype=F32):
     d0, _ = _coord2diff(x, 1.0)  # egnn_new.py:301 (radial only)
     h = _linear(h, sd[p + "embedding.weight"], sd[p + "embedding.bias"])
     x_in = x
-    normf = dtype(cfg["normalization_factor"])
-    assert cfg.get("aggregation_method", "sum") == "sum"
+    # unsorted_segment_sum (egnn_new.py:403-421): 'sum' divides by normalization_factor; 'mean' by the number of edges of the
+    # DENSE list that share the row -- masked ones included (their contribution is zero, their count is not) -- i.e. by the
+    # padded node count N
+    agg_method = cfg.get("aggregation_method", "sum")
+    assert agg_method in ("sum", "mean")
+    normf = dtype(cfg["normalization_factor"]) if agg_method == "sum" else dtype(N)
     for l in range(cfg["n_layers"]):
         bp = f"{p}e_block_{l}."
         radial, cdiff = _coord2diff(x, cfg["norm_constant"])  # egnn_new.py:216

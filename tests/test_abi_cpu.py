@@ -56,6 +56,17 @@ def test_host_schedule_matches_reference(golden):
             s = int(row[0])
             np.testing.assert_allclose(coef[s], [row[1], row[3], row[4], row[7]], rtol=1e-5)
     assert lib.gaudi_host_schedule(0, 2.0, 1e-5, L.fptr(gamma), None) != 0
+    # the 'cosine' schedule (noise_power = 0; en_diffusion.py:64-81) against the reference's tables (golden g20)
+    g = golden("g20_cosine_and_mean")
+    for T in (50, 1000):
+        gamma = np.empty(T + 1, np.float32)
+        coef = np.empty((T, 4), np.float32)
+        assert lib.gaudi_host_schedule(T, 0.0, 1e-5, L.fptr(gamma), L.fptr(coef)) == 0
+        np.testing.assert_allclose(gamma, g[f"gamma_T{T}"], rtol=3e-7, atol=0)
+        for row in g[f"coef_T{T}"]:
+            s = int(row[0])
+            np.testing.assert_allclose(coef[s], [row[1], row[3], row[4], row[7]], rtol=2e-5)
+    assert lib.gaudi_host_schedule(50, -1.0, 1e-5, L.fptr(gamma), None) != 0
 
 
 def _meta(lib, L, nm, em):

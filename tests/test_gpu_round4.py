@@ -269,3 +269,31 @@ def test_full_batch_b1024_guided_step_vs_cpp_port():
     assert solo.last_launch_shape() == (B, N)
     solo.close()
     assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------ cosine schedule, mean aggregation
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_cosine_schedule_and_mean_aggregation_vs_reference(golden, name):
+    """diffusion_noise_schedule='cosine' (a host table, en_diffusion.py:64-81) and aggregation_method='mean'
+    (one divide by the padded node count, egnn_new.py:416-420) are accepted; phi and guided T = 50 chains against the
+    reference's outputs (golden g20) at 1e-4, on the default kernels and on the 4-wave family."""
+    g = golden("g20_cosine_and_mean")
+    cfg = cfg_of(g, name)
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=cfg["over"], wseed=cfg["eseed"], amp=True), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["pseed"], amp=True))
+    c_eargs, c_esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=cfg["over"], wseed=cfg["chain_eseed"], amp=False),
+                                  diffusion_steps=cfg["T"])
+    c_pargs, c_psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["chain_pseed"], amp=False))
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    for env in ({}, {"GAUDI_WAVES": 4}):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        assert np.allclose(eng.gamma(), g[f"gamma_T{cfg['T']}"], rtol=3e-7, atol=0)
+        eps = eng.phi(g[name + "_z"], g[name + "_t"][:, 0], g[name + "_node_mask"], g[name + "_edge_mask"])
+        assert rel_err(eps, g[name + "_eps"]) < 1e-4
+        eng.close()
+        eng = _engine(c_eargs, c_esd, c_pargs, c_psd, **env)
+        nm = g[name + "_chain_node_mask"]
+        B, N = nm.shape[0], nm.shape[1]
+        x, h, d = eng.sample(nm.reshape(B, N), g[name + "_chain_edge_mask"].reshape(B, N, N), noise=g[name + "_noise"], target_w=w, scale=0.6)
+        assert rel_err(x, g[name + "_x_guided"]) < 1e-4 and np.array_equal(h, g[name + "_h_guided"])
+        eng.close()

@@ -330,3 +330,27 @@ def test_g19_amplified_default_architecture_steps(golden, name):
         for tag in ("fp32", "fp64"):
             assert rel_err(zu, g[f"{name}_s{s}_zs_unguided_{tag}"]) < 5e-5, (s, tag)
             assert rel_err(zg, g[f"{name}_s{s}_zs_guided_{tag}"]) < 5e-5, (s, tag)
+
+
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_g20_cosine_schedule_and_mean_aggregation(golden, name):
+    """The two EDM modes accepted in round 4: diffusion_noise_schedule='cosine' (en_diffusion.py:64-81) and
+    aggregation_method='mean' (egnn_new.py:403-421) -- the restatement against the reference's gamma tables, phi and guided
+    T = 50 chains (golden g20: normalize_factors [1, 2, 2], the reference refuses cosine with the defaults)."""
+    g = golden("g20_cosine_and_mean")
+    for T in (50, 1000):
+        assert np.array_equal(O.gamma_table("cosine", T, 1e-5), g[f"gamma_T{T}"])
+    cfg = cfg_of(g, name)
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=cfg["over"], wseed=cfg["eseed"], amp=True), diffusion_steps=cfg["T"])
+    assert eargs["aggregation_method"] == "mean" and eargs["diffusion_noise_schedule"] == "cosine"
+    eps = O.edm_phi(esd, eargs, g[name + "_z"], g[name + "_t"][:, 0], g[name + "_node_mask"], g[name + "_edge_mask"])
+    assert rel_err(eps, g[name + "_eps"]) < 1e-4
+    # 'mean' really differs from 'sum' on these inputs
+    eps_sum = O.edm_phi(esd, dict(eargs, aggregation_method="sum"), g[name + "_z"], g[name + "_t"][:, 0], g[name + "_node_mask"],
+                        g[name + "_edge_mask"])
+    assert rel_err(eps_sum, g[name + "_eps"]) > 1e-2
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=cfg["over"], wseed=cfg["chain_eseed"], amp=False), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["chain_pseed"], amp=False))
+    x, h, _ = O.sample(esd, eargs, g[name + "_chain_node_mask"], g[name + "_chain_edge_mask"], g[name + "_noise"], std=1.0,
+                       pred_sd=psd, pcfg=pargs, target_w=O.target_max_gap_weights(5), scale=0.6)
+    assert rel_err(x, g[name + "_x_guided"]) < 1e-4 and np.array_equal(h, g[name + "_h_guided"])

@@ -929,6 +929,70 @@ def g16_fix_noise():
     save("g16_fix_noise", **out)
 
 
+def g20_cosine_and_mean():
+    """The two EDM modes SURVEY 2 allowed to refuse and VERDICT r3 asked to accept: diffusion_noise_schedule='cosine'
+    (en_diffusion.py:64-81,196-197) and aggregation_method='mean' (egnn_new.py:403-421: the norm counts EVERY edge of the dense
+    list, masked or not, i.e. the padded node count N).  gamma / coefficient tables, phi with 'mean', and guided T=50 chains
+    with both switched on, tiny configs, injected noise."""
+    out = {}
+    for T in (50, 1000):
+        sd = synth.synth_edm_state_dict(synth.edm_args(nf=8, n_layers=1), 1, seed=0)
+        # (the reference refuses 'cosine' with the default normalize_factors [3, 4, 10]: sigma_0 = 0.041 is too large for a
+        # one-hot scaled by 1/4, en_diffusion.py:336-349 -- a cosine model needs smaller ones)
+        a, model = build_ref_edm("cata", sd, nf=8, n_layers=1, diffusion_steps=T, diffusion_noise_schedule="cosine",
+                                 normalize_factors=[1, 2, 2])
+        out[f"gamma_T{T}"] = model.gamma.gamma.numpy().copy()
+        rows = []
+        for s in ([0, 1, T // 2, T - 2, T - 1]):
+            st = torch.full((1, 1), s) / T
+            tt = (torch.full((1, 1), s) + 1) / T
+            gs, gt = model.gamma(st), model.gamma(tt)
+            zt = torch.zeros(1, 1, 1)
+            s2, s_ts, a_ts = model.sigma_and_alpha_t_given_s(gt, gs, zt)
+            sig_s, sig_t = model.sigma(gs, zt), model.sigma(gt, zt)
+            rows.append([s, a_ts.item(), s2.item(), (s2 / a_ts / sig_t).item(), (s_ts * sig_s / sig_t).item(),
+                         sig_s.item(), sig_t.item(), tt.item()])
+        out[f"coef_T{T}"] = np.array(rows, dtype=np.float64)
+    T = 50
+    for ci, (name, ds, nodes, mx) in enumerate([("cata", "cata", [4, 11, 7, 2, 11], 11), ("hetro", "hetro", [3, 5, 10, 7], 10)]):
+        F = synth.num_node_features(ds)
+        over = dict(diffusion_steps=T, aggregation_method="mean", diffusion_noise_schedule="cosine", normalize_factors=[1, 2, 2], **TINY)
+        esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=2000 + ci, amplify_coord=True)
+        a, model = build_ref_edm(ds, esd, **over)
+        psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **TINY_P), F, 5, seed=2010 + ci, amplify_coord=True)
+        pa, pred = build_ref_pred(ds, psd, **TINY_P)
+        nm, em, z = case_inputs(ds, nodes, mx, seed=2020 + ci)
+        B = z.shape[0]
+        t = np.linspace(0.05, 0.95, B).astype(np.float32).reshape(B, 1)
+        with torch.no_grad():
+            eps = model.phi(torch.from_numpy(z), torch.from_numpy(t), torch.from_numpy(nm), torch.from_numpy(em), None).numpy()
+        out[f"{name}_z"], out[f"{name}_t"], out[f"{name}_node_mask"], out[f"{name}_edge_mask"] = z, t, nm, em
+        out[f"{name}_eps"] = eps
+
+        # the chains run on DEFAULT-init weights (a free-running chain through amplified heads is not a 1e-4 comparison:
+        # BASELINE.md section 2), the phi cases above on amplified ones
+        esd_c = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=2040 + ci)
+        a_c, model_c = build_ref_edm(ds, esd_c, **over)
+        psd_c = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **TINY_P), F, 5, seed=2050 + ci)
+        pa_c, pred_c = build_ref_pred(ds, psd_c, **TINY_P)
+
+        def tf_gap(_in, _nm, _em, _t):
+            return -pred_c(_in, _nm, _em, _t)[:, 1]
+
+        n = torch.tensor(nodes)
+        Nn = max(nodes) * (2 if ds != "cata" else 1)
+        noise = rng_noise(2030 + ci, (T + 2, len(nodes), Nn, 3 + F))
+        with InjectNoise(list(noise)):
+            x, h, nm2, em2 = ref_sampling.sample_guidance(a_c, model_c, tf_gap, n, scale=0.6, std=1.0)
+        out[f"{name}_noise"], out[f"{name}_x_guided"], out[f"{name}_h_guided"] = noise, x.numpy(), h.numpy().astype(np.float32)
+        out[f"{name}_chain_node_mask"], out[f"{name}_chain_edge_mask"] = nm2.numpy(), em2.numpy()
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, T=T, eseed=2000 + ci, pseed=2010 + ci, chain_eseed=2040 + ci,
+                                                      chain_pseed=2050 + ci, nodes=nodes, amp=True,
+                                                      over=dict(TINY, aggregation_method="mean", diffusion_noise_schedule="cosine",
+                                                                normalize_factors=[1, 2, 2]))))
+    save("g20_cosine_and_mean", **out)
+
+
 def g8_checkpoint_roundtrip():
     """The reference's own loader must accept checkpoints written by gaudi_amd.synth.write_checkpoint
     (args.txt + model.pt, with and without the ``module.`` prefix).  Stores nothing but a marker."""
@@ -953,8 +1017,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps, g20=g20_cosine_and_mean)
     for w in which:
         fns[w]()
