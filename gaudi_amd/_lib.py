@@ -49,6 +49,8 @@ FP = C.POINTER(C.c_float)
 IP = C.POINTER(C.c_int32)
 # gaudi_target_cb(user, B, K, pred, t, dT_dpred_out)
 TARGET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, FP, C.c_float, FP)
+# gaudi_target_cbz(user, B, N, D, K, z_s, pred, t, dT_dpred_out, dT_dz_out)
+TARGET_CBZ = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, FP, FP, C.c_float, FP, FP)
 
 EXPORTS = {
     "gaudi_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -69,6 +71,8 @@ EXPORTS = {
                                C.c_float, FP, FP, FP, C.POINTER(Diag)]),
     "gaudi_sample_cb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, TARGET_CB,
                                   C.c_void_p, C.c_float, FP, FP, FP, C.POINTER(Diag)]),
+    "gaudi_sample_cbz": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, TARGET_CBZ,
+                                   C.c_void_p, C.c_float, FP, FP, FP, C.POINTER(Diag)]),
     "gaudi_sample_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, C.c_uint64, C.c_int64, FP, C.c_float, C.c_int, FP]),
     "gaudi_predict_noised": (C.c_int, [C.c_void_p, C.c_int, C.c_int, FP, FP, IP, FP, FP, C.c_uint64, C.c_int64, FP, FP, FP]),
     "gaudi_check_stability": (C.c_int, [C.c_void_p, C.POINTER(RingTables), C.c_int, C.c_int, FP, IP, IP,

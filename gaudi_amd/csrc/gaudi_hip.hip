@@ -80,6 +80,8 @@ struct gaudi_handle {
       d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols, d_soff,
       d_sidx, d_gnode, d_rowmap, d_compmol, d_ncomp;
   PinBuf p_pred, p_dpred;     // gaudi_sample_cb: pred [B,K] device -> host, dT/dpred [B,K] host -> device, once per step
+  PinBuf p_z, p_dz;           // gaudi_sample_cbz: z_s [B,N,D] device -> host, scale * dT/dz host -> device
+  DevBuf d_dz;
   hipEvent_t cb_event = nullptr;
   int steps_per_launch = 25;
   int variant = 8;            // 8 = two waves per SIMD (sampler_kernel8, default), 4 = one wave per SIMD (GAUDI_WAVES=4)
@@ -1180,6 +1182,9 @@ void gaudi_destroy(gaudi_handle* h) {
   for (DevBuf* b : bufs) b->release();
   h->p_pred.release();
   h->p_dpred.release();
+  h->p_z.release();
+  h->p_dz.release();
+  h->d_dz.release();
   if (h->cb_event) (void)hipEventDestroy(h->cb_event);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1615,10 +1620,14 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
   return GAUDI_OK;
 }
 
-int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
-                    int64_t sample_offset, const float* noise, float std, gaudi_target_cb target_grad, void* user,
-                    float scale, float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag) {
-  if (!h || !node_mask || !edge_mask || !x_out || !onehot_out || !target_grad) return GAUDI_E_INVALID;
+}  // extern "C"
+
+// gaudi_sample_cb / gaudi_sample_cbz: exactly one of the two callbacks is set
+static int sample_cb_impl(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                          int64_t sample_offset, const float* noise, float std, gaudi_target_cb target_grad,
+                          gaudi_target_cbz target_grad_z, void* user, float scale, float* x_out, float* onehot_out, float* z0_out,
+                          gaudi_diag* diag) {
+  if (!h || !node_mask || !edge_mask || !x_out || !onehot_out || (!target_grad && !target_grad_z)) return GAUDI_E_INVALID;
   if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
   if (!h->has_pred) return fail(h, GAUDI_E_STATE, "guided sampling needs predictor weights");
   HIPCHECK(h, hipSetDevice(h->device));
@@ -1637,6 +1646,11 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
   HIPCHECK(h, h->d_dpred.reserve(pb));
   HIPCHECK(h, h->p_pred.reserve(pb));
   HIPCHECK(h, h->p_dpred.reserve(pb));
+  if (target_grad_z) {  // the target also depends on z directly: z_s goes to the host, scale * mask * dT/dz comes back
+    HIPCHECK(h, h->d_dz.reserve(zb));
+    HIPCHECK(h, h->p_z.reserve(zb));
+    HIPCHECK(h, h->p_dz.reserve(zb));
+  }
   if (!h->cb_event) HIPCHECK(h, hipEventCreateWithFlags(&h->cb_event, hipEventDisableTiming));
   HIPCHECK(h, hipMemsetAsync(h->d_nan.p, 0, sizeof(int), h->stream));
   const size_t nzb = h->fix_noise ? sizeof(float) * N * D : zb;
@@ -1691,10 +1705,26 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
       if (rc) return rc;
     }
     HIPCHECK(h, hipMemcpyAsync(pred, h->d_pred.p, pb, hipMemcpyDeviceToHost, h->stream));
+    if (target_grad_z) HIPCHECK(h, hipMemcpyAsync(h->p_z.p, zout, zb, hipMemcpyDeviceToHost, h->stream));  // z_s before guidance
     HIPCHECK(h, hipEventRecord(h->cb_event, h->stream));
     HIPCHECK(h, hipEventSynchronize(h->cb_event));
     std::memset(dT, 0, pb);
-    target_grad(user, B, K, pred, (float)(s + 1) / (float)T, dT);
+    if (target_grad_z) {
+      float* dz = h->p_dz.as<float>();
+      std::memset(dz, 0, zb);
+      target_grad_z(user, B, N, D, K, h->p_z.as<float>(), pred, (float)(s + 1) / (float)T, dT, dz);
+      // energy = scale * sum_b T (en_diffusion.py:899-903); the reference asserts that the x part of the gradient is zero on
+      // masked nodes (remove_mean_with_mask, utils.py:33-44): the direct term is masked here
+      for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+          const float m = scale * node_mask[(size_t)b * N + n];
+          for (int d = 0; d < D; ++d) dz[((size_t)b * N + n) * D + d] *= m;
+        }
+      HIPCHECK(h, hipMemcpyAsync(h->d_dz.p, dz, zb, hipMemcpyHostToDevice, h->stream));
+      P.dz_in = h->d_dz.as<float>();
+    } else {
+      target_grad(user, B, K, pred, (float)(s + 1) / (float)T, dT);
+    }
     HIPCHECK(h, hipMemcpyAsync(h->d_dpred.p, dT, pb, hipMemcpyHostToDevice, h->stream));
     // phase B: reverse pass with the caller's dT/dpred, clip / project / apply, CoG removal
     P.mode = gn ? MODE_GUIDE : MODE_SAMPLE;
@@ -1724,6 +1754,24 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   finish_sample(B, N, node_mask, x_out, nanc, diag);
   return GAUDI_OK;
+}
+
+extern "C" {
+
+int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                    int64_t sample_offset, const float* noise, float std, gaudi_target_cb target_grad, void* user,
+                    float scale, float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag) {
+  if (!target_grad) return GAUDI_E_INVALID;
+  return sample_cb_impl(h, B, N, node_mask, edge_mask, seed, sample_offset, noise, std, target_grad, nullptr, user, scale, x_out,
+                        onehot_out, z0_out, diag);
+}
+
+int gaudi_sample_cbz(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                     int64_t sample_offset, const float* noise, float std, gaudi_target_cbz target_grad, void* user,
+                     float scale, float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag) {
+  if (!target_grad) return GAUDI_E_INVALID;
+  return sample_cb_impl(h, B, N, node_mask, edge_mask, seed, sample_offset, noise, std, nullptr, target_grad, user, scale, x_out,
+                        onehot_out, z0_out, diag);
 }
 
 int gaudi_sample_chain(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,

@@ -643,7 +643,7 @@ template <int HP, bool GN = false>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                 float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                 float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase = 0,
-                                const float* dpred_ext = nullptr, float* gnode = nullptr) {
+                                const float* dpred_ext = nullptr, float* gnode = nullptr, const float* dz_ext = nullptr) {
   (void)sTmp;
   const int N = mg.N, D = mg.D;
   PredSmem<HP, GN> sm;
@@ -657,6 +657,10 @@ __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph
   __syncthreads();
   if (phase == 1) return;
   pred_backward<HP>(W, mg, sm, stash, sGrad, readout_div, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
+  if (dz_ext != nullptr) {  // + scale * dT/dz of a target that depends on z outside the predictor (gaudi_sample_cbz), before the clip
+    for (int e = tid; e < N * D; e += kThreads) sGrad[e] += dz_ext[e];
+    __syncthreads();
+  }
   // clip_coef = min(1, 10 / (||g||_2 + 1e-6)) over all N*(3+F) entries   (en_diffusion.py:905-909)
   if (tid < 64) {
     float s = 0.f;

@@ -54,6 +54,8 @@ struct KParams {
   EdmDev edm;
   PredDev pred;
   const float* dpred_in;    // [B][K]  (MODE_PRED_GRAD) or nullptr
+  const float* dz_in;       // [B][N][D] or nullptr: phase B of a callback step (split = 2) adds this to the reverse pass's gradient
+                            // before the clip -- scale * dT/dz of a target that depends on z outside the predictor (gaudi_sample_cbz)
   const float* target_w;    // [K]     (guided sampling)
   float scale;
   float* pred_out;          // [B][K]
@@ -129,9 +131,9 @@ struct V4T {
   __device__ __forceinline__ static void guide(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
-                                               const float* dpred_ext, float* gnode) {
+                                               const float* dpred_ext, float* gnode, const float* dz_ext) {
     gaudi::guidance_update<HP, GN>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
-                                   tid STAMP_ARGS, phase, dpred_ext, gnode);
+                                   tid STAMP_ARGS, phase, dpred_ext, gnode, dz_ext);
   }
   template <int HP>
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
@@ -309,8 +311,9 @@ struct V8T {
   __device__ __forceinline__ static void guide(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
-                                               const float* dpred_ext, float*) {
+                                               const float* dpred_ext, float*, const float* dz_ext) {
 #ifdef GAUDI_STAMPS
+    (void)dz_ext;  // (the stamped diagnostic build times the fused step only)
     w8::guidance_update<HP, SP, MR>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
                             mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext);
 #else
@@ -321,6 +324,10 @@ struct V8T {
     w8::guidance_seed<HP, SP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
     if (phase == 1) return;
     pred_bwd8_call<HP, SP, MR>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0);
+    if (dz_ext != nullptr) {  // + the target's direct dependence on z (callback launches are never packed: slot n = node n)
+      for (int e = tid; e < mg.N * mg.D; e += kThreads) sGrad[e] += dz_ext[e];
+      __syncthreads();
+    }
     w8::guidance_apply(mg, sZ, sGrad, sMean, sigma, tid);
 #endif
   }
@@ -509,7 +516,8 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
                                    P.target_w, P.scale, split == 1 ? P.pred_out + (size_t)b * P.pred.K : nullptr,
                                    P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS, split,
                                    split == 2 ? P.dpred_in + (size_t)b * P.pred.K : nullptr,
-                                   V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr);
+                                   V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr,
+                                   split == 2 && P.dz_in != nullptr ? P.dz_in + (size_t)b * N * D : nullptr);
             }
           }
           if (split == 1) break;  // phase A ends before the projection: phase B resumes from this z_s
@@ -605,7 +613,8 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
                              gsplit == 1 ? P.pred_out + (size_t)b * P.pred.K : nullptr,
                              P.readout_div, P.stash + (size_t)b * P.stash_stride, tid STAMP_ARGS, gsplit,
                              gsplit == 2 ? P.dpred_in + (size_t)b * P.pred.K : nullptr,
-                             V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr);
+                             V::kGlobalNodes ? P.gnode + (size_t)blockIdx.x * P.gnode_stride : nullptr,
+                             gsplit == 2 && P.dz_in != nullptr ? P.dz_in + (size_t)b * N * D : nullptr);
       if (gsplit == 1) return;
       col_means(sZ);
       __syncthreads();

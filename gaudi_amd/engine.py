@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import TARGET_CB, Diag, EdmConfig, GaudiError, PredConfig, f32, fptr
+from ._lib import TARGET_CB, TARGET_CBZ, Diag, EdmConfig, GaudiError, PredConfig, f32, fptr
 
 
 def _strip(sd: dict) -> dict:
@@ -230,9 +230,11 @@ class Engine:
         return zt, pred
 
     def sample_callback(self, node_mask, edge_mask, target_grad, *, seed=0, sample_offset=0, noise=None, std=1.0,
-                        scale=1.0, return_z0=False):
+                        scale=1.0, return_z0=False, with_z=False):
         """Guided chain for an arbitrary target: ``target_grad(pred [B,K], t) -> dT/dpred [B,K]`` is called once per
-        reverse step between the two device phases (include/gaudi_hip.h: gaudi_sample_cb)."""
+        reverse step between the two device phases (include/gaudi_hip.h: gaudi_sample_cb).  with_z=True: the target also
+        depends on z outside the predictor -- ``target_grad(z_s [B,N,D], pred [B,K], t) -> (dT/dpred [B,K], dT/dz [B,N,D])``
+        with dT/dz the DIRECT part, pred held fixed (gaudi_sample_cbz)."""
         nm = f32(node_mask)
         B, N = nm.shape[0], nm.shape[1]
         nm, em = self._masks(nm, edge_mask, B, N)
@@ -260,12 +262,32 @@ class Engine:
                 if not failure:
                     failure.append(exc)
 
-        cb = TARGET_CB(_cb)
-        rc = self.lib.gaudi_sample_cb(self.h, B, N, fptr(nm), fptr(em), int(seed), int(sample_offset), fptr(nz),
-                                      float(std), cb, None, float(scale), fptr(x), fptr(h), fptr(z0), C.byref(diag))
+        def _cbz(_user, b, n, dd, k, z_p, pred_p, t, out_p, outz_p):
+            try:
+                zs = np.ctypeslib.as_array(z_p, shape=(b, n, dd)).copy()
+                pred = np.ctypeslib.as_array(pred_p, shape=(b, k)).copy()
+                g, gz = target_grad(zs, pred, float(t))
+                g = np.ascontiguousarray(g, dtype=np.float32)
+                gz = np.ascontiguousarray(gz, dtype=np.float32)
+                if g.shape != (b, k) or gz.shape != (b, n, dd):
+                    raise GaudiError(f"target_grad must return ([B,K], [B,N,D]) = ({(b, k)}, {(b, n, dd)}), got ({g.shape}, {gz.shape})")
+                np.ctypeslib.as_array(out_p, shape=(b, k))[...] = g
+                np.ctypeslib.as_array(outz_p, shape=(b, n, dd))[...] = gz
+            except BaseException as exc:  # never unwind through the C frames; report after the call returns
+                if not failure:
+                    failure.append(exc)
+
+        if with_z:
+            cb = TARGET_CBZ(_cbz)
+            rc = self.lib.gaudi_sample_cbz(self.h, B, N, fptr(nm), fptr(em), int(seed), int(sample_offset), fptr(nz),
+                                           float(std), cb, None, float(scale), fptr(x), fptr(h), fptr(z0), C.byref(diag))
+        else:
+            cb = TARGET_CB(_cb)
+            rc = self.lib.gaudi_sample_cb(self.h, B, N, fptr(nm), fptr(em), int(seed), int(sample_offset), fptr(nz),
+                                          float(std), cb, None, float(scale), fptr(x), fptr(h), fptr(z0), C.byref(diag))
         if failure:
             raise failure[0]
-        self._check(rc, "gaudi_sample_cb")
+        self._check(rc, "gaudi_sample_cbz" if with_z else "gaudi_sample_cb")
         d = dict(max_masked_leak=diag.max_masked_leak, max_cog_rel=diag.max_cog_rel, max_cog_abs=diag.max_cog_abs,
                  nan_count=diag.nan_count, reprojected=diag.reprojected)
         return (x, h, d, z0) if return_z0 else (x, h, d)

@@ -83,6 +83,38 @@ class LinearTarget:
         return _like_ref((pred @ self.weights + self.const).astype(np.float32))
 
 
+class ZTarget:
+    """A target closure over (z, node_mask, edge_mask, t) that depends on z BOTH through the predictor and directly -- the
+    reference differentiates any function of z_s (en_diffusion.py:899-903).  Per reverse step the host evaluates the closure on
+    the device's z_s with the predictor output replaced by a leaf holding the device's prediction: torch.autograd then yields
+    dT/dpred (fed to the GPU reverse pass) and the direct dT/dz (added to its result before the clip): gaudi_sample_cbz."""
+
+    def __init__(self, cond_predictor, target, name="closure(z)"):
+        self.cond_predictor = cond_predictor
+        self.target = target
+        self.name = name
+
+    def grad(self, z, pred, t, node_mask, edge_mask):
+        import torch
+        cp = self.cond_predictor
+        zt = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32)).requires_grad_(True)
+        p = torch.from_numpy(np.ascontiguousarray(pred, dtype=np.float32)).requires_grad_(True)
+        B = p.shape[0]
+        cp._override, cp._override_used = p, False
+        try:
+            with torch.enable_grad():
+                val = self.target(zt, torch.from_numpy(node_mask), torch.from_numpy(edge_mask), torch.full((B, 1), float(t)))
+                gp, gz = torch.autograd.grad(val.sum(), (p, zt), allow_unused=True)
+        finally:
+            cp._override = None
+        gp = np.zeros_like(pred) if gp is None else gp.detach().numpy().astype(np.float32)
+        gz = np.zeros_like(z) if gz is None else gz.detach().numpy().astype(np.float32)
+        return gp, gz
+
+    def __call__(self, _input, _node_mask, _edge_mask, _t):
+        return self.target(_input, _node_mask, _edge_mask, _t)
+
+
 class PredTarget:
     """Arbitrary differentiable target T = fn(pred, t) of the predictor outputs (any closure the reference's
     sample_guidance accepts has this form, generation_guidance.py:187-211).  ``fn`` takes a torch tensor pred [B,K]
@@ -110,6 +142,10 @@ class PredTarget:
         pred = torch.from_numpy(_to_numpy(self.cond_predictor(_input, _node_mask, _edge_mask, _t)))
         t = float(np.asarray(_to_numpy(_t)).reshape(-1)[0]) if np.ndim(_to_numpy(_t)) else float(_t)
         return self.fn(pred, t)
+
+
+class _DirectZ(Exception):
+    pass
 
 
 def affine_target_weights(fn, K: int, T: int, B: int = 3):
@@ -214,8 +250,9 @@ class GaudiModel:
         """An opaque target closure over (z, node_mask, edge_mask, t), as generation_guidance.py:198-211 writes them
         (``lambda z, nm, em, t: -cond_predictor(z, nm, em, t)[:, 1]``), turned into a PredTarget: while the closure runs, the
         predictor attached to this model returns a stand-in tensor, so torch.autograd yields dT/dpred for the GPU reverse
-        pass.  The closure may be ANY differentiable torch function of the predictor outputs and t; a direct dependence on
-        z (outside the predictor) cannot be followed on the GPU and is refused."""
+        pass.  The closure may be ANY differentiable torch function of the predictor outputs and t: affine ones run fused
+        (LinearTarget), the others through the per-step callback (PredTarget); one that ALSO depends on z outside the
+        predictor becomes a ZTarget (the host adds its direct dT/dz, gaudi_sample_cbz)."""
         cp = getattr(self, "cond_predictor", None)
         if cp is None:
             raise GaudiError("guidance with a target closure needs get_cond_predictor_model(...) on this model first")
@@ -240,20 +277,24 @@ class GaudiModel:
             if not torch.is_tensor(val) or val.dim() == 0 or val.shape[0] != B:
                 raise GaudiError("the target function must return one value per molecule (a torch tensor [B]); use a "
                                  "LinearTarget / PredTarget or a closure over cond_predictor (generation_guidance.py:198-211)")
+            if val.requires_grad:
+                (gz,) = torch.autograd.grad(val.sum(), probe, allow_unused=True, retain_graph=True)
+                if gz is not None and bool((gz != 0).any()):
+                    raise _DirectZ()  # depends on z outside cond_predictor too: the general form (ZTarget)
             # The closure must route through the predictor attached to THIS model: one that closes over another predictor (or a
             # torch module, or uses t only) would give dT/dpred = 0 here and the chain would run unguided without a word.
             if not cp._override_used or (pred.requires_grad and not val.requires_grad):
                 raise GaudiError("the target function does not use the predictor attached to this model (it must call the "
                                  "cond_predictor returned by get_cond_predictor_model(..., model=<this model>)): its value does "
                                  "not depend on the prediction, guidance would be a no-op")
-            if val.requires_grad:
-                (gz,) = torch.autograd.grad(val.sum(), probe, allow_unused=True, retain_graph=True)
-                if gz is not None and bool((gz != 0).any()):
-                    raise GaudiError("the target function depends on z directly (outside cond_predictor): only functions of the "
-                                     "predictor outputs and t can be differentiated on the GPU")
             return val
 
         pt = PredTarget(cp, fn, name=getattr(target, "__name__", "closure"))
+        try:  # one probe evaluation: does the closure route through the predictor, does it depend on z directly?
+            import torch
+            fn(torch.zeros(min(2, int(self._trace_nm.shape[0])), cp.K).requires_grad_(True), 0.5)
+        except _DirectZ:
+            return ZTarget(cp, target, name=pt.name + " (direct z dependence)")
         lin = affine_target_weights(pt.fn, cp.K, self.T)
         if lin is not None:
             # affine in pred and independent of t (both closures the reference ships are, generation_guidance.py:200-211): the
@@ -297,7 +338,7 @@ class GaudiModel:
         em = _to_numpy(edge_mask).astype(np.float32).reshape(B, N, N)
         tw = None
         if target is not None:
-            if not isinstance(target, (LinearTarget, PredTarget)):
+            if not isinstance(target, (LinearTarget, PredTarget, ZTarget)):
                 if not callable(target):
                     raise GaudiError("target_function must be callable")
                 # the reference's own form: a closure over (z, node_mask, edge_mask, t) that calls cond_predictor
@@ -309,7 +350,12 @@ class GaudiModel:
         # fix_noise (en_diffusion.py:562-566,972-978): one raw draw per call, broadcast over the batch
         self.engine.set_fix_noise(bool(fix_noise), off)
         try:
-            if isinstance(target, PredTarget):
+            if isinstance(target, ZTarget):
+                nm3, em_flat = nm.reshape(B, N, 1), em.reshape(B * N * N, 1)
+                x, h, diag = self.engine.sample_callback(nm.reshape(B, N), em, lambda z, p, t: target.grad(z, p, t, nm3, em_flat),
+                                                         seed=seed, sample_offset=off, noise=self.injected_noise, std=std,
+                                                         scale=scale, with_z=True)
+            elif isinstance(target, PredTarget):
                 x, h, diag = self.engine.sample_callback(nm.reshape(B, N), em, target.grad, seed=seed, sample_offset=off,
                                                          noise=self.injected_noise, std=std, scale=scale)
             else:

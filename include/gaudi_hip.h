@@ -150,6 +150,17 @@ int gaudi_sample_cb(gaudi_handle* h, int B, int N, const float* node_mask, const
                     int64_t sample_offset, const float* noise, float std, gaudi_target_cb target_grad, void* user,
                     float scale, float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag);
 
+/* The same for a target that ALSO depends on z outside the predictor -- the reference differentiates any function of z_s
+ * (autograd at en_diffusion.py:899-903).  Between the two phases the callback receives z_s [B,N,D] (D = 3 + F, before the
+ * guidance update) beside pred and t and writes dT/dpred [B,K] and the DIRECT part dT/dz [B,N,D] (pred held fixed); the
+ * library scales it, masks it with node_mask (the reference asserts that the coordinate gradient of masked nodes is zero,
+ * utils.py:33-44) and adds it to the reverse pass's gradient before the clip (en_diffusion.py:905-909). */
+typedef void (*gaudi_target_cbz)(void* user, int B, int N, int D, int K, const float* z_s, const float* pred, float t,
+                                 float* dT_dpred_out, float* dT_dz_out);
+int gaudi_sample_cbz(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
+                     int64_t sample_offset, const float* noise, float std, gaudi_target_cbz target_grad, void* user,
+                     float scale, float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag);
+
 /* EnVariationalDiffusion.sample_chain (en_diffusion.py:1118-1174): the unguided chain with `keep_frames`
  * intermediate states: chain_out [keep_frames,B,N,3+F], frame (s*keep_frames)//T = unnormalize_z(z_s) of the last
  * step s mapping to it, frame 0 = the final [x | one_hot].  (The reference returns the same data viewed as

