@@ -77,19 +77,25 @@ def cpu_baseline(eargs, pargs, esd, psd, guided, T, B):
                          target_w=w if guided else None, scale=0.6)
 
     one(T - 1)  # warm-up
-    # One molecule per thread streams the whole weight set through the core's caches: on a many-core host the memory system,
-    # not the core count, sets the rate, and fewer threads than hardware threads can be faster.  Probe a few thread counts
-    # (one step each) and time the sample with the best; `cores` reports the threads actually used.
+    # A thread owns a GROUP of molecules and runs them layer by layer (one GEMM per Linear over the group's rows): a weight
+    # matrix is read once per group, so the rate follows the cores rather than the memory system (one molecule at a time
+    # re-streams the 25-54 MB weight set per molecule: 0.99 mol/s on 16 threads, 0.64 on 128, round 3).  Probe thread counts x
+    # group sizes (one step each) and time the sample with the best; `cores` reports the threads actually used.
     hw = port.threads
-    best_n, best_t = hw, None
+    best_n, best_g, best_t, probes = hw, 1, None, {}
     for n_thr in sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8)}, reverse=True):
-        port.set_threads(n_thr)
-        t1 = time.time()
-        one(T - 1)
-        dt1 = time.time() - t1
-        if best_t is None or dt1 < best_t:
-            best_n, best_t = n_thr, dt1
+        for grp in (4, 2, 1):
+            port.set_threads(n_thr)
+            port.set_group(grp)
+            t1 = time.time()
+            one(T - 1)
+            dt1 = time.time() - t1
+            probes[f"{n_thr}x{port.group_for(B)}"] = round(B / dt1 / T, 3)
+            if best_t is None or dt1 < best_t:
+                best_n, best_g, best_t = n_thr, grp, dt1
     port.set_threads(best_n)
+    port.set_group(best_g)
+    group_used = port.group_for(B)
     n_steps, t0 = 0, time.time()
     while n_steps < 5 or (time.time() - t0 < 20.0 and n_steps < 100):
         one(T - 2 - n_steps)
@@ -100,13 +106,16 @@ def cpu_baseline(eargs, pargs, esd, psd, guided, T, B):
     threads, isa = best_n, port.isa
     port.close()
     return dict(value=B / total, unit="molecules/s", cores=threads, kind="port",
-                sample=f"C++/OpenMP restatement oracle/gaudi_cpu.cpp ({isa} GEMM micro-kernel, {threads} threads = the fastest of "
-                       f"{hw} / {hw // 2} / {hw // 4} / {hw // 8} on this host, one molecule per thread), B={B} x {n_steps} {'guided' if guided else 'unguided'} reverse steps at N=11 after 1 warm-up, "
+                sample=f"C++/OpenMP restatement oracle/gaudi_cpu.cpp ({isa} GEMM micro-kernel, {threads} threads x groups of {group_used} "
+                       f"molecules per thread = the fastest of {hw} / {hw // 2} / {hw // 4} / {hw // 8} threads x groups of <= 4 / 2 / 1 on this "
+                       f"host), B={B} x {n_steps} {'guided' if guided else 'unguided'} reverse steps at N=11 after 1 warm-up, "
                        f"extrapolated x{T} + decode; {per_step * 1e3:.0f} ms/step.  Cross-check (BASELINE.md section 2): the "
                        f"reference's own PyTorch-CPU path measured {ref} molecules/s on the 8-core build container for this "
                        f"workload, where this port measures 0.141 guided / 0.333 unguided; speedup_vs_cpu_baseline divides by the "
                        f"larger of the port's figure on this host and the reference's 8-core figure",
-                per_core=B / total / max(threads, 1), reference_torch_cpu_8core=ref, reference_torch_cpu_per_core=ref / 8)
+                per_core=B / total / max(threads, 1), reference_torch_cpu_8core=ref, reference_torch_cpu_per_core=ref / 8,
+                hardware_threads=hw, molecules_per_group=group_used,
+                probe_mol_per_s={"note": "threads x molecules per group -> molecules/s of one probe step", **probes})
 
 
 def parity_gate(eng, eargs, pargs, esd, psd, nm, em, tw, T, tol=1e-4):

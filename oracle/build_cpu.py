@@ -81,8 +81,16 @@ class CpuPort:
         return int(self.lib.gcpu_threads())
 
     def set_threads(self, n: int):
-        """OpenMP threads of the following calls (one molecule per thread)."""
+        """OpenMP threads of the following calls (every thread owns groups of molecules)."""
         self.lib.gcpu_set_threads(int(n))
+
+    def set_group(self, g: int):
+        """Upper bound of the molecules one thread runs together, layer by layer (a weight matrix is read once per group);
+        1 = one molecule at a time, the round-3 arrangement.  Results do not depend on it."""
+        self.lib.gcpu_set_group(int(g))
+
+    def group_for(self, B: int) -> int:
+        return int(self.lib.gcpu_group(int(B)))
 
     def _load(self, fn, cfg, sd, prefix):
         sd = {k: _f32(v) for k, v in sd.items() if k.startswith(prefix)}

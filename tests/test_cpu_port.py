@@ -82,3 +82,45 @@ def test_port_agrees_with_numpy_oracle_on_a_default_size_guided_step(port):
     want = O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6)
     got = port.step(O.step_coefficients(gamma, s, s + 1), np.float32(np.float32(s + 1) / np.float32(T)), z, nm, em, eps, target_w=w, scale=0.6)
     assert rel_err(got, want) < 2e-5
+
+
+def test_molecule_groups_do_not_change_a_molecule():
+    """The port runs groups of molecules layer by layer (one GEMM per Linear over the group's rows, so that a weight matrix is
+    read once per group: the CPU baseline scales with the cores instead of with the memory system).  A molecule's result must
+    not depend on the group it is in: groups of 1 (the round-3 arrangement), 3 and 8 agree bit for bit on a ragged hetero batch,
+    guided step and predictor gradient."""
+    from oracle import build_cpu
+    if not build_cpu.cpu_ok():
+        pytest.skip("host CPU lacks AVX2/FMA")
+    from gaudi_amd import synth
+    from gaudi_amd.sampling_edm import build_masks
+    T = 100
+    F = synth.num_node_features("hetro")
+    eargs, pargs = synth.edm_args(dataset="hetro", diffusion_steps=T, nf=32, n_layers=2), synth.pred_args(dataset="hetro", nf=36, n_layers=3)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=3, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=4, amplify_coord=True)
+    rings = [3, 10, 4, 7, 5, 9, 3, 6, 8, 10, 4]
+    nm3, em_flat, N = build_masks(rings, 10, True)
+    B = len(rings)
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    rng = np.random.default_rng(1)
+    z = O._combined_noise(rng.standard_normal((B, N, 3 + F)).astype(np.float32), nm3)
+    eps = rng.standard_normal((B, N, 3 + F)).astype(np.float32)
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    w = np.array([3, 0, 1, 1, 0], np.float32)
+    port = build_cpu.CpuPort()
+    port.load_edm(eargs, esd)
+    port.load_predictor(pargs, psd)
+    outs = []
+    for g in (1, 3, 8):
+        port.set_group(g)
+        port.set_threads(2)  # few threads -> the groups really hold several molecules
+        zs = port.step(O.step_coefficients(gamma, 40, 41), np.float32(0.41), z, nm, em, eps, target_w=w, scale=0.6)
+        pred, grad = port.predictor(z, 0.41, nm, em, dpred=w)
+        outs.append((zs, pred, grad, port.phi(z, 0.41, nm, em)))
+    port.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+    want = O.step_guided(esd, eargs, psd, pargs, gamma, 40, z, nm3, em, eps, w, 0.6)
+    assert rel_err(outs[0][0], want) < 1e-4

@@ -1,4 +1,10 @@
-import os, sys, time, subprocess, json
+"""Scaling curve of the C++/OpenMP CPU baseline (oracle/gaudi_cpu.cpp) on this host: guided C3 steps (B = 256, N = 11, default
+architectures) for several thread counts x molecules per thread-owned group.  Run on the GPU box through gpurun; the output
+is kept under profiles/ (the stated baseline should be the host's best)."""
+import os
+import subprocess
+import sys
+
 code = r'''
 import os, time, numpy as np, sys
 sys.path.insert(0, os.getcwd())
@@ -17,14 +23,19 @@ gamma=O.gamma_table("polynomial_2", T, 1e-5); w=O.target_max_gap_weights(5)
 def one(s):
     eps=rng.standard_normal((B,11,4)).astype(np.float32)
     return port.step(O.step_coefficients(gamma,s,s+1), np.float32(np.float32(s+1)/np.float32(T)), z, nm, em, eps, target_w=w, scale=0.6)
-one(T-1)
-t0=time.time(); n=0
-while n<4: one(T-2-n); n+=1
-per=(time.time()-t0)/n
-print(port.threads, round(per*1e3,1), "ms/step ->", round(B/(per*T),4), "mol/s")
+for grp in (1, 2, 4, 8):
+    port.set_group(grp)
+    one(T-1)
+    t0=time.time(); n=0
+    while n<3: one(T-2-n); n+=1
+    per=(time.time()-t0)/n
+    print("threads", port.threads, "molecules per group", port.group_for(B), ":", round(per*1e3,1), "ms/step ->", round(B/(per*T),3), "guided mol/s (1000-step)", flush=True)
 '''
-print(subprocess.run("lscpu | grep -E 'Model name|^CPU\\(s\\)|Thread|Core|Socket'", shell=True, capture_output=True, text=True).stdout)
-for th in (128, 64, 32):
+print(subprocess.run("lscpu | grep -E 'Model name|^CPU\\(s\\)|Thread|Core|Socket|NUMA node\\(s\\)'", shell=True, capture_output=True, text=True).stdout)
+hw = os.cpu_count() or 8
+for th in sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), 16}, reverse=True):
+    if th > hw:
+        continue
     env = dict(os.environ, OMP_NUM_THREADS=str(th), OMP_PROC_BIND="spread", OMP_PLACES="cores")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
-    print(th, r.stdout.strip(), r.stderr.strip()[-200:])
+    print(r.stdout.strip(), r.stderr.strip()[-300:])

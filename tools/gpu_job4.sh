@@ -11,6 +11,7 @@ for step in "$@"; do
     tests_new) timeout 1500 python3 -m pytest tests/test_gpu_round4.py -q -m gpu > $out/tests_new.txt 2>&1 ;;
     tests_all) timeout 3000 python3 -m pytest tests -x -q -m gpu > $out/tests_all.txt 2>&1 ;;
     tests_core) timeout 1500 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_split.py tests/test_gpu_fullsize.py -x -q -m gpu > $out/tests_core.txt 2>&1 ;;
+    cpu_scaling) timeout 900 python3 tools/cpu_threads_probe.py > $out/cpu_scaling.txt 2>&1 ;;
     smoke) timeout 300 python3 __graft_entry__.py smoke > $out/smoke.txt 2>&1 ;;
     bench) timeout 1200 python3 bench.py --steps 2 --warmup 1 > $out/bench.json 2> $out/bench.err ;;
     bench_quick) timeout 600 $B > $out/bench_quick.json 2> $out/bench_quick.err ;;
