@@ -62,26 +62,41 @@ def check_same_plan(engine, device=None):
 
 
 def gather_to_all(x_local, h_local, total: int, N: int, F: int, device=None):
-    """One all_gather of the per-rank results (padded to the largest shard) -> full [total,N,3], [total,N,F]."""
+    """ONE collective over the per-rank results (padded to the largest shard) -> full [total,N,3], [total,N,F].
+
+    With ``device`` (the RCCL path): the shard is written once into a pinned host tensor, goes to the device in one copy, ONE
+    all_gather_into_tensor fills a single [world, per, N, 3+F] device tensor, and one copy brings it back (the C ABI hands results
+    over in host memory, include/gaudi_hip.h: gaudi_sample).  Without it (gloo, CPU tests): a list all_gather of host tensors."""
     import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(), dist.get_rank()
     per = max(shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world))
-    buf = np.zeros((per, N, 3 + F), np.float32)
-    if x_local is not None:
-        n = x_local.shape[0]
-        buf[:n, :, :3] = x_local
-        buf[:n, :, 3:] = h_local
-    t = torch.from_numpy(buf)
+    D = 3 + F
     if device is not None:
-        t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
+        send = torch.zeros((per, N, D), dtype=torch.float32, pin_memory=True)
+        if x_local is not None:
+            n = x_local.shape[0]
+            send[:n, :, :3] = torch.from_numpy(np.ascontiguousarray(x_local, np.float32))
+            send[:n, :, 3:] = torch.from_numpy(np.ascontiguousarray(h_local, np.float32))
+        dev_send = send.to(device, non_blocking=True)
+        dev_recv = torch.empty((world, per, N, D), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(dev_recv, dev_send)
+        full = dev_recv.cpu().numpy()
+    else:
+        buf = np.zeros((per, N, D), np.float32)
+        if x_local is not None:
+            n = x_local.shape[0]
+            buf[:n, :, :3] = x_local
+            buf[:n, :, 3:] = h_local
+        t = torch.from_numpy(buf)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        full = np.stack([o.numpy() for o in out], 0)
     xs, hs = [], []
     for r in range(world):
         lo, hi = shard_bounds(total, r, world)
-        a = out[r].cpu().numpy()[: hi - lo]
+        a = full[r, : hi - lo]
         xs.append(a[:, :, :3])
         hs.append(a[:, :, 3:])
     return np.concatenate(xs, 0), np.concatenate(hs, 0)

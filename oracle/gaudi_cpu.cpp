@@ -211,6 +211,47 @@ struct Model {
   std::vector<PLayer> pl;             // [L]
 };
 
+// Per-thread scratch arena.  The group functions need tens of MB of temporaries per call; as std::vectors they were mapped,
+// zero-filled and unmapped on every step by every thread (page faults and the kernel's address-space lock under 128 threads:
+// the port ran SLOWER on 128 threads than on 16).  Blocks are kept for the life of the thread and never move; a Mark
+// restores the fill level at scope exit.
+struct Arena {
+  std::vector<std::pair<float*, size_t>> blocks;  // (base, floats)
+  size_t blk = 0, off = 0;
+  ~Arena() {
+    for (auto& b : blocks) std::free(b.first);
+  }
+  float* get(size_t n, bool zero = false) {
+    n = (n + 15) & ~(size_t)15;
+    while (true) {
+      if (blk < blocks.size() && off + n <= blocks[blk].second) {
+        float* p = blocks[blk].first + off;
+        off += n;
+        if (zero) std::memset(p, 0, sizeof(float) * n);
+        return p;
+      }
+      if (blk < blocks.size()) {  // does not fit the current block: move on (the rest of it stays unused until the reset)
+        ++blk;
+        off = 0;
+        continue;
+      }
+      const size_t sz = std::max(n, (size_t)8 << 20);  // 32 MB blocks
+      float* base = (float*)std::aligned_alloc(64, sizeof(float) * sz);
+      blocks.push_back({base, sz});
+    }
+  }
+  struct Mark {
+    Arena& a;
+    size_t blk, off;
+    explicit Mark(Arena& ar) : a(ar), blk(ar.blk), off(ar.off) {}
+    ~Mark() { a.blk = blk; a.off = off; }
+  };
+};
+Arena& tls_arena() {
+  static thread_local Arena a;
+  return a;
+}
+
 // radial = |x_i - x_j|^2, cdiff = (x_i - x_j) / (sqrt(radial + 1e-8) + norm_constant)   (egnn_new.py:394-400, gcl.py:308-316)
 void coord2diff(int N, const float* x, float norm_constant, float* radial, float* cdiff) {
   for (int i = 0; i < N; ++i)
@@ -253,28 +294,31 @@ void edm_phi_grp(const Model& M, int G, int N, const float* z, const float* t, c
   const EdmCfg& c = M.ec;
   const int H = c.H, HP = up16(H), F = c.F, D = 3 + F, E = N * N, LI = up16(2 * H + 2), LN = up16(2 * H);
   const int GN = G * N, GE = G * E;
-  std::vector<float> x(3 * GN), x_in, hin((size_t)GN * (F + 1)), h((size_t)GN * HP), d0(GE), radial(GE), cdiff((size_t)GE * 3);
-  std::vector<float> inp((size_t)GE * LI), u((size_t)GE * HP), m((size_t)GE * HP), nin((size_t)GN * LN), n1((size_t)GN * HP),
-      n2((size_t)GN * HP);
+  Arena& A = tls_arena();
+  Arena::Mark mark(A);
+  float *x = A.get(3 * GN), *x_in = A.get(3 * GN), *hin = A.get((size_t)GN * (F + 1)), *h = A.get((size_t)GN * HP), *d0 = A.get(GE),
+        *radial = A.get(GE), *cdiff = A.get((size_t)GE * 3);
+  float *inp = A.get((size_t)GE * LI), *u = A.get((size_t)GE * HP), *m = A.get((size_t)GE * HP), *nin = A.get((size_t)GN * LN),
+        *n1 = A.get((size_t)GN * HP), *n2 = A.get((size_t)GN * HP);
   for (int r = 0; r < GN; ++r) {
     for (int k = 0; k < 3; ++k) x[3 * r + k] = z[r * D + k] * nm[r];
     for (int k = 0; k < F; ++k) hin[r * (F + 1) + k] = z[r * D + 3 + k] * nm[r];
     hin[r * (F + 1) + F] = t[r / N];  // the time column is not masked (models.py:97-105)
   }
-  x_in = x;
+  std::memcpy(x_in, x, sizeof(float) * 3 * GN);
   for (int q = 0; q < G; ++q) coord2diff(N, &x[3 * q * N], 1.0f, &d0[q * E], nullptr);  // egnn_new.py:301
-  M.emb.fwd(GN, hin.data(), F + 1, h.data(), HP);
+  M.emb.fwd(GN, hin, F + 1, h, HP);
   for (int l = 0; l < c.L; ++l) {
     for (int q = 0; q < G; ++q) coord2diff(N, &x[3 * q * N], c.norm_constant, &radial[q * E], &cdiff[(size_t)q * E * 3]);  // :216
     for (int s = 0; s < c.S; ++s) {
       const Gcl& g = M.gcl[l][s];
       for (int q = 0; q < G; ++q)
         edge_input(N, H, &h[(size_t)q * N * HP], HP, &radial[q * E], &d0[q * E], &inp[(size_t)q * E * LI], LI);
-      g.e1.fwd(GE, inp.data(), LI, u.data(), HP);
-      silu_rows(u.data(), GE, HP, H);
-      g.e2.fwd(GE, u.data(), HP, m.data(), HP);
-      silu_rows(m.data(), GE, HP, H);
-      std::fill(nin.begin(), nin.end(), 0.f);
+      g.e1.fwd(GE, inp, LI, u, HP);
+      silu_rows(u, GE, HP, H);
+      g.e2.fwd(GE, u, HP, m, HP);
+      silu_rows(m, GE, HP, H);
+      std::memset(nin, 0, sizeof(float) * (size_t)GN * LN);
       for (int q = 0; q < G; ++q)
         for (int i = 0; i < N; ++i) {
           const int ri = q * N + i;
@@ -295,19 +339,19 @@ void edm_phi_grp(const Model& M, int G, int N, const float* z, const float* t, c
           }
           for (int k = 0; k < H; ++k) agg[k] /= c.normf;  // egnn_new.py:403-414
         }
-      g.n1.fwd(GN, nin.data(), LN, n1.data(), HP);
-      silu_rows(n1.data(), GN, HP, H);
-      g.n2.fwd(GN, n1.data(), HP, n2.data(), HP);
+      g.n1.fwd(GN, nin, LN, n1, HP);
+      silu_rows(n1, GN, HP, H);
+      g.n2.fwd(GN, n1, HP, n2, HP);
       for (int r = 0; r < GN; ++r)
         for (int k = 0; k < H; ++k) h[(size_t)r * HP + k] = (h[(size_t)r * HP + k] + n2[(size_t)r * HP + k]) * nm[r];
     }
     const Equ& qe = M.equ[l];
     for (int q = 0; q < G; ++q)
       edge_input(N, H, &h[(size_t)q * N * HP], HP, &radial[q * E], &d0[q * E], &inp[(size_t)q * E * LI], LI);
-    qe.c1.fwd(GE, inp.data(), LI, u.data(), HP);
-    silu_rows(u.data(), GE, HP, H);
-    qe.c2.fwd(GE, u.data(), HP, m.data(), HP);
-    silu_rows(m.data(), GE, HP, H);
+    qe.c1.fwd(GE, inp, LI, u, HP);
+    silu_rows(u, GE, HP, H);
+    qe.c2.fwd(GE, u, HP, m, HP);
+    silu_rows(m, GE, HP, H);
     for (int q = 0; q < G; ++q)
       for (int i = 0; i < N; ++i) {
         const int ri = q * N + i;
@@ -325,8 +369,8 @@ void edm_phi_grp(const Model& M, int G, int N, const float* z, const float* t, c
     for (int r = 0; r < GN; ++r)
       for (int k = 0; k < H; ++k) h[(size_t)r * HP + k] *= nm[r];
   }
-  std::vector<float> ho((size_t)GN * 16);
-  M.emb_out.fwd(GN, h.data(), HP, ho.data(), 16);
+  float* ho = A.get((size_t)GN * 16);
+  M.emb_out.fwd(GN, h, HP, ho, 16);
   for (int q = 0; q < G; ++q) {
     float* ep = eps + (size_t)q * N * D;
     const float* mq = nm + (size_t)q * N;
@@ -361,7 +405,7 @@ void edm_phi_grp(const Model& M, int G, int N, const float* z, const float* t, c
 // by hand)
 // ---------------------------------------------------------------------------------------------------------------
 struct PCache {
-  std::vector<float> h, x, u, v, a, cpre, phi, cdiff, radial, npre;
+  float *h, *x, *u, *v, *a, *cpre, *phi, *cdiff, *radial, *npre;
 };
 void predictor_grp(const Model& M, int G, int N, const float* z, const float* t, const float* nm, const float* em, const float* dpred,
                    float* pred, float* grad) {
@@ -369,9 +413,11 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
   const int H = c.H, HP = up16(H), F = c.F, D = 3 + F, K = c.K, E = N * N, LI = up16(2 * H + 2), LN = up16(2 * H);
   const int GN = G * N, GE = G * E;
   const float R = c.coords_range / (float)c.L;  // egnn_predictor/models.py:515
-  std::vector<float> x(3 * GN), x0, hin((size_t)GN * (F + 1)), h((size_t)GN * HP), d0(GE);
-  std::vector<float> inp((size_t)GE * LI), su((size_t)GE * HP), e((size_t)GE * HP), nin((size_t)GN * LN), n1((size_t)GN * HP),
-      n2((size_t)GN * HP), xn(3 * GN);
+  Arena& A = tls_arena();
+  Arena::Mark mark(A);
+  float *x = A.get(3 * GN), *x0 = A.get(3 * GN), *hin = A.get((size_t)GN * (F + 1)), *h = A.get((size_t)GN * HP), *d0 = A.get(GE);
+  float *inp = A.get((size_t)GE * LI), *su = A.get((size_t)GE * HP), *e = A.get((size_t)GE * HP), *nin = A.get((size_t)GN * LN),
+        *n1 = A.get((size_t)GN * HP), *n2 = A.get((size_t)GN * HP), *xn = A.get(3 * GN);
   std::vector<PCache> cache(c.L);
   const bool want = dpred != nullptr;
   for (int r = 0; r < GN; ++r) {
@@ -379,29 +425,31 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
     for (int k = 0; k < F; ++k) hin[r * (F + 1) + k] = z[r * D + 3 + k] * nm[r];
     hin[r * (F + 1) + F] = t[r / N];
   }
-  x0 = x;
+  std::memcpy(x0, x, sizeof(float) * 3 * GN);
   for (int q = 0; q < G; ++q) coord2diff(N, &x[3 * q * N], 1.0f, &d0[q * E], nullptr);  // models.py:452
-  M.pemb.fwd(GN, hin.data(), F + 1, h.data(), HP);
+  M.pemb.fwd(GN, hin, F + 1, h, HP);
   for (int l = 0; l < c.L; ++l) {
     const PLayer& g = M.pl[l];
     PCache& C = cache[l];
-    C.radial.resize(GE); C.cdiff.resize((size_t)GE * 3);
-    C.u.resize((size_t)GE * HP); C.v.resize((size_t)GE * HP); C.a.resize(GE); C.cpre.resize((size_t)GE * HP); C.phi.resize(GE);
-    C.npre.resize((size_t)GN * HP);
-    C.h = h; C.x = x;
+    C.radial = A.get(GE); C.cdiff = A.get((size_t)GE * 3);
+    C.u = A.get((size_t)GE * HP); C.v = A.get((size_t)GE * HP); C.a = A.get(GE); C.cpre = A.get((size_t)GE * HP); C.phi = A.get(GE);
+    C.npre = A.get((size_t)GN * HP);
+    C.h = A.get((size_t)GN * HP); C.x = A.get(3 * GN);
+    std::memcpy(C.h, h, sizeof(float) * (size_t)GN * HP);
+    std::memcpy(C.x, x, sizeof(float) * 3 * GN);
     for (int q = 0; q < G; ++q) {
       coord2diff(N, &x[3 * q * N], 1.0f, &C.radial[q * E], &C.cdiff[(size_t)q * E * 3]);
       edge_input(N, H, &h[(size_t)q * N * HP], HP, &C.radial[q * E], &d0[q * E], &inp[(size_t)q * E * LI], LI);
     }
-    g.e1.fwd(GE, inp.data(), LI, C.u.data(), HP);
-    for (size_t i = 0; i < su.size(); ++i) su[i] = 0.f;
+    g.e1.fwd(GE, inp, LI, C.u, HP);
+    std::memset(su, 0, sizeof(float) * (size_t)GE * HP);
     for (int r = 0; r < GE; ++r) {
       const float* ur = &C.u[(size_t)r * HP];
       float* sr = &su[(size_t)r * HP];
 #pragma omp simd
       for (int k = 0; k < H; ++k) sr[k] = silu_f(ur[k]);
     }
-    g.e2.fwd(GE, su.data(), HP, C.v.data(), HP);
+    g.e2.fwd(GE, su, HP, C.v, HP);
     for (int r = 0; r < GE; ++r) {  // e = silu(v) * a * edge_mask   (gcl.py:231-237)
       const float* vr = &C.v[(size_t)r * HP];
       float* er = &e[(size_t)r * HP];
@@ -417,7 +465,7 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
       for (int k = 0; k < H; ++k) er[k] *= sc;
       for (int k = H; k < HP; ++k) er[k] = 0.f;
     }
-    g.c1.fwd(GE, e.data(), HP, C.cpre.data(), HP);  // coord_model (gcl.py:252-278)
+    g.c1.fwd(GE, e, HP, C.cpre, HP);  // coord_model (gcl.py:252-278)
     for (int q = 0; q < G; ++q)
       for (int i = 0; i < N; ++i) {
         const int ri = q * N + i;
@@ -433,7 +481,7 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
         }
         for (int k = 0; k < 3; ++k) xn[3 * ri + k] = (x[3 * ri + k] + acc[k]) * nm[ri];
       }
-    std::fill(nin.begin(), nin.end(), 0.f);
+    std::memset(nin, 0, sizeof(float) * (size_t)GN * LN);
     for (int q = 0; q < G; ++q)
       for (int i = 0; i < N; ++i) {
         const int ri = q * N + i;
@@ -445,16 +493,16 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
           for (int k = 0; k < H; ++k) agg[k] += er[k];
         }
       }
-    g.n1.fwd(GN, nin.data(), LN, C.npre.data(), HP);
+    g.n1.fwd(GN, nin, LN, C.npre, HP);
     for (int r = 0; r < GN; ++r)
       for (int k = 0; k < HP; ++k) n1[(size_t)r * HP + k] = k < H ? silu_f(C.npre[(size_t)r * HP + k]) : 0.f;
-    g.n2.fwd(GN, n1.data(), HP, n2.data(), HP);
+    g.n2.fwd(GN, n1, HP, n2, HP);
     for (int r = 0; r < GN; ++r)
       for (int k = 0; k < H; ++k) h[(size_t)r * HP + k] = (h[(size_t)r * HP + k] + n2[(size_t)r * HP + k]) * nm[r];
-    x = xn;
+    std::memcpy(x, xn, sizeof(float) * 3 * GN);
   }
-  std::vector<float> ho((size_t)GN * 16);
-  M.pemb_out.fwd(GN, h.data(), HP, ho.data(), 16);
+  float* ho = A.get((size_t)GN * 16);
+  M.pemb_out.fwd(GN, h, HP, ho, 16);
   for (int q = 0; q < G; ++q)
     for (int k = 0; k < K; ++k) {
       float s = 0.f;
@@ -464,12 +512,13 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
   if (!want) return;
 
   // ---- reverse pass (the order of oracle/gaudi_oracle.py: predictor_grad)
-  std::vector<float> dh((size_t)GN * HP, 0.f), dx(3 * GN, 0.f), dd0(GE, 0.f), dho((size_t)GN * 16, 0.f);
+  float *dh = A.get((size_t)GN * HP, true), *dx = A.get(3 * GN, true), *dd0 = A.get(GE, true), *dho = A.get((size_t)GN * 16, true);
   for (int r = 0; r < GN; ++r)
     for (int k = 0; k < K; ++k) dho[r * 16 + k] = dpred[(r / N) * K + k] / (float)N * nm[r];
-  M.pemb_out.bwd(GN, dho.data(), 16, dh.data(), HP);
-  std::vector<float> dn1((size_t)GN * HP), dnin((size_t)GN * LN), de((size_t)GE * HP), dc((size_t)GE * HP), dv((size_t)GE * HP),
-      dt1((size_t)GE * HP), dinp((size_t)GE * LI), dhp((size_t)GN * HP), dxp(3 * GN), ddiff((size_t)GE * 3);
+  M.pemb_out.bwd(GN, dho, 16, dh, HP);
+  float *dn1 = A.get((size_t)GN * HP), *dnin = A.get((size_t)GN * LN), *de = A.get((size_t)GE * HP), *dc = A.get((size_t)GE * HP),
+        *dv = A.get((size_t)GE * HP), *dt1 = A.get((size_t)GE * HP), *dinp = A.get((size_t)GE * LI), *dhp = A.get((size_t)GN * HP),
+        *dxp = A.get(3 * GN), *ddiff = A.get((size_t)GE * 3);
   for (int l = c.L - 1; l >= 0; --l) {
     const PLayer& g = M.pl[l];
     const PCache& C = cache[l];
@@ -477,10 +526,10 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
       for (int k = 0; k < HP; ++k) dh[(size_t)r * HP + k] *= nm[r];
       for (int k = 0; k < 3; ++k) dx[3 * r + k] *= nm[r];
     }
-    g.n2.bwd(GN, dh.data(), HP, dn1.data(), HP);
+    g.n2.bwd(GN, dh, HP, dn1, HP);
     for (int r = 0; r < GN; ++r)
       for (int k = 0; k < HP; ++k) dn1[(size_t)r * HP + k] = k < H ? dn1[(size_t)r * HP + k] * dsilu_f(C.npre[(size_t)r * HP + k]) : 0.f;
-    g.n1.bwd(GN, dn1.data(), HP, dnin.data(), LN);
+    g.n1.bwd(GN, dn1, HP, dnin, LN);
     for (int r = 0; r < GN; ++r)
       for (int k = 0; k < HP; ++k) dhp[(size_t)r * HP + k] = k < H ? dh[(size_t)r * HP + k] + dnin[(size_t)r * LN + k] : 0.f;
     // coordinate branch: dtau, dcdiff; dcpre = dphi * wc2 * silu'(cpre); de = dagg_i + dcpre Wc1
@@ -501,7 +550,7 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
           for (int k = H; k < HP; ++k) dcr[k] = 0.f;
           for (int k = 0; k < 3; ++k) ddiff[(size_t)r * 3 + k] = dx[3 * ri + k] * tau * em[r];  // = dcdiff for now
         }
-    g.c1.bwd(GE, dc.data(), HP, de.data(), HP);
+    g.c1.bwd(GE, dc, HP, de, HP);
     for (int q = 0; q < G; ++q)
       for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j) {
@@ -523,7 +572,7 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
           for (int k = 0; k < H; ++k) dvr[k] = (der[k] * a * mk + ds * g.wa[k]) * dsilu_f(vr[k]);
           for (int k = H; k < HP; ++k) dvr[k] = 0.f;
         }
-    g.e2.bwd(GE, dv.data(), HP, dt1.data(), HP);
+    g.e2.bwd(GE, dv, HP, dt1, HP);
     for (int r = 0; r < GE; ++r) {
       float* d = &dt1[(size_t)r * HP];
       const float* ur = &C.u[(size_t)r * HP];
@@ -531,7 +580,7 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
       for (int k = 0; k < H; ++k) d[k] *= dsilu_f(ur[k]);
       for (int k = H; k < HP; ++k) d[k] = 0.f;
     }
-    g.e1.bwd(GE, dt1.data(), HP, dinp.data(), LI);
+    g.e1.bwd(GE, dt1, HP, dinp, LI);
     for (int q = 0; q < G; ++q)
       for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j) {
@@ -562,11 +611,11 @@ void predictor_grp(const Model& M, int G, int N, const float* z, const float* t,
             dxp[3 * (q * N + i) + k] += v;
             dxp[3 * (q * N + j) + k] -= v;
           }
-    dh = dhp;
-    dx = dxp;
+    std::memcpy(dh, dhp, sizeof(float) * (size_t)GN * HP);
+    std::memcpy(dx, dxp, sizeof(float) * 3 * GN);
   }
-  std::vector<float> dh0((size_t)GN * 16);
-  M.pemb.bwd(GN, dh.data(), HP, dh0.data(), 16);
+  float* dh0 = A.get((size_t)GN * 16);
+  M.pemb.bwd(GN, dh, HP, dh0, 16);
   for (int q = 0; q < G; ++q)
     for (int i = 0; i < N; ++i)
       for (int j = 0; j < N; ++j)
