@@ -32,6 +32,19 @@ for grp in (1, 2, 4, 8):
     print("threads", port.threads, "molecules per group", port.group_for(B), ":", round(per*1e3,1), "ms/step ->", round(B/(per*T),3), "guided mol/s (1000-step)", flush=True)
 '''
 print(subprocess.run("lscpu | grep -E 'Model name|^CPU\\(s\\)|Thread|Core|Socket|NUMA node\\(s\\)'", shell=True, capture_output=True, text=True).stdout)
+def cgroup(name):
+    for base in ("/sys/fs/cgroup", "/sys/fs/cgroup/cpu"):
+        try:
+            return open(os.path.join(base, name)).read().strip().replace("\n", " | ")
+        except OSError:
+            pass
+    return "n/a"
+
+
+# is the process CPU-quota limited?  (a container may SEE 256 hardware threads and be allowed the time of far fewer)
+print("cgroup cpu.max:", cgroup("cpu.max"), "| cpu.cfs_quota_us:", cgroup("cpu.cfs_quota_us"), "| cpu.cfs_period_us:", cgroup("cpu.cfs_period_us"))
+print("cgroup cpu.stat before:", cgroup("cpu.stat"))
+print("sched_getaffinity:", len(os.sched_getaffinity(0)), "cpus; nproc:", subprocess.run("nproc", shell=True, capture_output=True, text=True).stdout.strip())
 hw = os.cpu_count() or 8
 for th in sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), 16}, reverse=True):
     if th > hw:
@@ -39,3 +52,4 @@ for th in sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), 16}, re
     env = dict(os.environ, OMP_NUM_THREADS=str(th), OMP_PROC_BIND="spread", OMP_PLACES="cores")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     print(r.stdout.strip(), r.stderr.strip()[-300:])
+print("cgroup cpu.stat after:", cgroup("cpu.stat"))

@@ -24,4 +24,12 @@ for wl in c3 c2 c4; do
   rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES \
     --kernel-trace --output-format csv -d $out/pmc_${wl}_sq2 -- $B --diffusion-steps 100 --workload $wl > $out/pmc_${wl}_sq2.json 2> $out/pmc_${wl}_sq2.log
 done
+# round 4: wide groups (GAUDI_PAIRS=1: two cata molecules per workgroup at 1024 molecules) beside the default launch of the same batch
+for pr in 0 1; do
+  GAUDI_PAIRS=$pr $R -d $out/wide_pairs${pr}_stats -- $B --batch 1024 --diffusion-steps 100 > $out/wide_pairs${pr}_bench.json 2> $out/wide_pairs${pr}.log
+  GAUDI_PAIRS=$pr rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 \
+    --kernel-trace --output-format csv -d $out/wide_pairs${pr}_sq1 -- $B --batch 1024 --diffusion-steps 100 > $out/wide_pairs${pr}_sq1.json 2> $out/wide_pairs${pr}_sq1.log
+  GAUDI_PAIRS=$pr rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES \
+    --kernel-trace --output-format csv -d $out/wide_pairs${pr}_sq2 -- $B --batch 1024 --diffusion-steps 100 > $out/wide_pairs${pr}_sq2.json 2> $out/wide_pairs${pr}_sq2.log
+done
 find $out -name "*.csv" | wc -l

@@ -61,6 +61,40 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as fh:
     w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
     w.writeheader()
     w.writerows(rows)
+# round 4: the wide-group passes (C3 at 1024 molecules, GAUDI_PAIRS = 0 / 1), summarised on their own
+wrows = []
+for d in sorted(glob.glob(os.path.join(src, "wide_pairs*_sq*"))):
+    if not os.path.isdir(d):
+        continue
+    name = os.path.basename(d)
+    f = one(f"{name}/**/*counter_collection.csv")
+    if not f:
+        continue
+    per = {}
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            if "sampler_kernel" not in r["Kernel_Name"]:
+                continue
+            per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], [0.0, 0.0])
+            per[r["Counter_Name"]][r["Dispatch_Id"]][0] += float(r["Counter_Value"])
+            if "End_Timestamp" in r and r["End_Timestamp"]:
+                per[r["Counter_Name"]][r["Dispatch_Id"]][1] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    for key, disp in per.items():
+        vals, durs = [v[0] for v in disp.values()], [v[1] for v in disp.values()]
+        wrows.append(dict(launch="GAUDI_PAIRS=" + name.split("pairs")[1][0], rocprofv3_pass=name, counter=key, launches=len(vals),
+                          mean_value_per_launch=sum(vals) / len(vals), mean_launch_ns=sum(durs) / max(len(durs), 1)))
+if wrows:
+    with open(os.path.join(dst, f"{tag}_wide_groups_pmc.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(wrows[0].keys()))
+        w.writeheader()
+        w.writerows(wrows)
+    for pr in "01":
+        f = one(f"wide_pairs{pr}_stats/**/*kernel_stats.csv")
+        if f:
+            shutil.copy(f, os.path.join(dst, f"{tag}_wide_pairs{pr}_kernel_stats.csv"))
+        b = os.path.join(src, f"wide_pairs{pr}_bench.json")
+        if os.path.exists(b) and os.path.getsize(b):
+            shutil.copy(b, os.path.join(dst, f"{tag}_wide_pairs{pr}_bench_under_rocprof.json"))
 out = {}
 for wl, t in traffic.items():
     if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
