@@ -24,6 +24,8 @@ for step in "$@"; do
     bench_c2_b1024_nopairs) GAUDI_PAIRS=0 timeout 600 $B --workload c2 --batch 1024 > $out/bench_c2_b1024_nopairs.json 2> $out/bench_c2_b1024_nopairs.err ;;
     bench_exp) for v in $GAUDI_VARIANTS; do [ -f gaudi_amd/libgaudi_var_$v.so ] && GAUDI_LIB=$PWD/gaudi_amd/libgaudi_var_$v.so timeout 600 $B > $out/bench_$v.json 2> $out/bench_$v.err; done ;;
     bench_dist) timeout 600 $B --dist > $out/bench_dist.json 2> $out/bench_dist.err ;;
+    bench_gloo2) GAUDI_BENCH_BACKEND=gloo timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
+                   bench.py --gpus 2 --steps 1 --warmup 0 --no-cpu-baseline --batch 256 > $out/bench_gloo2.json 2> $out/bench_gloo2.err ;;
     *) echo "unknown step $step" ;;
   esac
 done
