@@ -31,7 +31,9 @@ def get_target_function_values(x, h, target_function, node_mask, edge_mask, edm_
     bs, n_nodes, _ = _to_numpy(x).shape
     nm = _to_numpy(node_mask).reshape(bs, n_nodes, 1)
     em = _to_numpy(edge_mask).reshape(bs, n_nodes * n_nodes)
-    return target_function(_normalized_xh(x, h, nm, edm_model), nm, em, np.zeros((bs, 1), np.float32))
+    # torch tensors, as the reference passes them: a target closure may combine them with the (torch) prediction
+    return target_function(_like_ref(_normalized_xh(x, h, nm, edm_model)), _like_ref(nm.astype(np.float32)),
+                           _like_ref(em.astype(np.float32)), _like_ref(np.zeros((bs, 1), np.float32)))
 
 
 def eval_stability(x, one_hot, node_mask, edge_mask, dataset="cata", engine=None):

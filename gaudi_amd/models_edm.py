@@ -61,11 +61,22 @@ class PropertyNorm:
         self.mean = np.asarray(_to_numpy(mean), np.float32)
         self.std = np.asarray(_to_numpy(std), np.float32)
 
+    def _ms(self, like):
+        """mean / std in the type of ``like``: the reference's DistributionProperty holds torch tensors, and a target closure
+        calls prop_dist.unnormalize on a torch prediction that requires grad (generation_guidance.py:205-211)."""
+        if hasattr(like, "detach"):
+            import torch
+            return (torch.as_tensor(self.mean, dtype=like.dtype, device=like.device),
+                    torch.as_tensor(self.std, dtype=like.dtype, device=like.device))
+        return self.mean, self.std
+
     def normalize(self, pred):
-        return (pred - self.mean) / self.std
+        mean, std = self._ms(pred)
+        return (pred - mean) / std
 
     def unnormalize(self, pred):
-        return pred * self.std + self.mean
+        mean, std = self._ms(pred)
+        return pred * std + mean
 
 
 class LinearTarget:

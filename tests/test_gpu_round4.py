@@ -87,7 +87,7 @@ def test_affine_closures_run_on_the_fused_kernel(golden):
 
     def opv(_input, _node_mask, _edge_mask, _t):  # generation_guidance.py:205-211
         pred = cond_predictor(_input, _node_mask, _edge_mask, _t)
-        pred = pred * torch.from_numpy(prop_dist.std) + torch.from_numpy(prop_dist.mean)  # prop_dist.unnormalize (models_edm.py:186-188)
+        pred = prop_dist.unnormalize(pred)  # as the reference writes it (models_edm.py:186-188)
         gap, ea, ip = pred[:, 0], pred[:, 2], pred[:, 3]
         return ip + ea + 3 * gap
 
@@ -341,4 +341,44 @@ def test_target_closure_with_direct_z_dependence_vs_reference(golden, name):
 
     x3, _, _, _ = sampling_edm.sample_guidance(args, model, geometry_only, cfg["nodes"], scale=0.6)
     assert np.isfinite(x3.numpy()).all() and rel_err(x3.numpy(), g[name + "_x"]) > 1e-3
+    model.engine.close()
+
+
+def test_design_with_the_reference_opv_closure():
+    """generation_guidance.main as the reference writes it (lines 187-222): get_model, get_cond_predictor_model(args, dataset),
+    the OPV closure that calls prop_dist.unnormalize on the torch prediction, design(...).  The closure is affine: design runs on
+    the fused kernel and returns what the declarative target returns, bit for bit -- sampling, target values, ranking."""
+    import types
+
+    from gaudi_amd import generation_guidance as gg
+    from gaudi_amd.models_edm import PropertyNorm, get_cond_predictor_model, get_model, target_function_opv
+    eargs = synth.edm_args(nf=32, n_layers=2, diffusion_steps=10)
+    pargs = synth.pred_args(nf=36, n_layers=2)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=51)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=52)
+    model, _, _ = get_model(eargs, state_dict=esd)
+    cond_predictor = get_cond_predictor_model(pargs, None, state_dict=psd)
+    prop_dist = PropertyNorm(mean=[0.3, -1.0, 0.5, 2.0, 0.1], std=[1.5, 0.7, 2.0, 0.9, 1.1])
+
+    def target_function_opv_ref(_input, _node_mask, _edge_mask, _t):  # generation_guidance.py:205-211, verbatim
+        pred = cond_predictor(_input, _node_mask, _edge_mask, _t)
+        pred = prop_dist.unnormalize(pred)
+        gap = pred[:, 0]
+        ea = pred[:, 2]
+        ip = pred[:, 3]
+        return ip + ea + 3 * gap
+
+    args = types.SimpleNamespace(device="cuda", dataset="cata", batch_size=6)
+    outs = []
+    for target in (target_function_opv_ref, target_function_opv(cond_predictor, prop_dist)):
+        model.seed, model.sample_offset = 11, 0
+        model.engine.profile_reset(True)
+        outs.append(gg.design(args, model, cond_predictor, target, None, prop_dist, scale=0.6, n_nodes=7))
+        launches = model.engine.profile_get()[0]
+        model.engine.profile_reset(False)
+        assert launches <= 4  # one sampling launch (T = 10 < 25 steps) + the t = 0 predictor evaluations, no per-step callback
+    a, b = outs
+    assert np.array_equal(a["x"].numpy(), b["x"].numpy()) and np.array_equal(a["one_hot"].numpy(), b["one_hot"].numpy())
+    assert rel_err(a["target_function_values"].numpy(), b["target_function_values"].numpy()) < 1e-6
+    assert a["best"].tolist() == b["best"].tolist()
     model.engine.close()

@@ -133,3 +133,23 @@ def test_affine_target_probe():
     assert A(lambda p, t: torch.zeros(3), 5, 1000) is None                         # does not depend on pred
     assert A(lambda p, t: p[:, 0].abs(), 5, 1000) is None                          # piecewise linear
     assert A(lambda p, t: (p[:, 0] / 0.0), 5, 1000) is None                        # non-finite gradient
+
+
+def test_property_norm_accepts_torch_predictions_that_require_grad():
+    """The reference's OPV closure calls prop_dist.unnormalize(pred) on the predictor's torch output inside autograd
+    (generation_guidance.py:205-211, models_edm.py:186-192): the mirror's PropertyNorm must stay differentiable there -- and the
+    closure must come out as the affine target it is."""
+    import torch
+    from gaudi_amd.models_edm import PropertyNorm, affine_target_weights
+    pd = PropertyNorm(np.array([0.1, -0.2, 0.3, 0.4, 0.5]), np.array([1.5, 0.5, 2.0, 0.7, 1.0]))
+    p = torch.randn(3, 5, requires_grad=True)
+    u = pd.unnormalize(p)
+    assert torch.is_tensor(u) and u.requires_grad and torch.allclose(pd.normalize(u), p, atol=1e-6)
+    assert isinstance(pd.unnormalize(np.ones((2, 5), np.float32)), np.ndarray)
+
+    def opv(pred, t):  # generation_guidance.py:205-211
+        pred = pd.unnormalize(pred)
+        gap, ea, ip = pred[:, 0], pred[:, 2], pred[:, 3]
+        return ip + ea + 3 * gap
+
+    np.testing.assert_allclose(affine_target_weights(opv, 5, 1000), [4.5, 0, 2.0, 0.7, 0], rtol=1e-6)
