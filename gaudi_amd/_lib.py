@@ -95,6 +95,7 @@ EXPORTS = {
                                          C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_int32, C.POINTER(C.c_int32)]),
     "gaudi_kernel_variant": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gaudi_edge_math": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gaudi_node_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gaudi_last_workgroups": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gaudi_host_pack_plan_wide": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, FP, FP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -89,6 +89,9 @@ struct gaudi_handle {
   bool split = true;          // 8-wave kernels: edge GEMMs on the bf16 matrix pipe with 3-way split operands (GAUDI_EDGE_MATH=fp32: off)
   int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
   bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
+  bool run_gn8 = false;       // ... on the 8-wave kernels with node buffers in global memory (V8G, round 4)
+  bool gn8 = true;            // GAUDI_GN8=0: molecules beyond the LDS limit go to the 4-wave V4G kernels, as in round 3
+  bool force_gn8 = false;     // GAUDI_FORCE_GN8=1: V8G whenever it can run (test knob)
   bool pack = true;           // several small molecules per workgroup in sampling calls (GAUDI_PACK=0: off)
   int pairs = 0;              // wide groups (more node slots than a molecule has, two rounds of edge tiles: e.g. two 11-ring cata
                               // molecules per workgroup): 0 = never (default: measured -2 % on C3 at 1024 molecules, +1 % unguided,
@@ -702,6 +705,23 @@ static kernel_fn pick_kernel8m(int hpe, int hpp, int mode) {
   return f;
 }
 #endif
+// ... and the 8-wave kernels with the node buffers in global memory (kern8g_*.hip: V8G)
+#ifdef GAUDI_STAMP_STUBS
+static kernel_fn pick_kernel8g(int, int) { return nullptr; }
+#else
+#define GAUDI_KERNEL8G_TUS(X) X(fused_192_208) X(edm_192) X(pred_208) X(fused_tiny) X(edm_small) X(pred_small)
+#define X(name) kernel_fn gaudi_kern8g_##name(int hpe, int hpp);
+GAUDI_KERNEL8G_TUS(X)
+#undef X
+static kernel_fn pick_kernel8g(int hpe, int hpp) {
+  kernel_fn f = nullptr;
+#define X(name) \
+  if (!f) f = gaudi_kern8g_##name(hpe, hpp);
+  GAUDI_KERNEL8G_TUS(X)
+#undef X
+  return f;
+}
+#endif
 // mr: the call holds a graph of more than one round of edge tiles AND runs the predictor
 static kernel_fn pick_kernel8_mode(int hpe, int hpp, int mode, bool mr = false) {
   if (mr) return pick_kernel8m(hpe, hpp, mode);
@@ -731,24 +751,28 @@ static size_t gnode_floats(int hpe, int hpp, int N) {
   return std::max((size_t)(hpe ? 4 * N * (hpe + 4) : 0), (size_t)(hpp ? 5 * N * (hpp + 4) : 0));
 }
 
-static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split) {
+static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split, bool gn = false) {
   size_t net = 0;
-  if (hpe) net = std::max(net, (size_t)(5 * N * (hpe + 4) + w8::edge_ring_floats(hpe, split) + 8 * N + S * 9 + 8 * hpe));
-  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + 5 * N * (hpp + 4) + 12 * N + S * 10 + 32 + 10 * hpp));
+  if (hpe) net = std::max(net, (size_t)((gn ? 0 : 5 * N * (hpe + 4)) + w8::edge_ring_floats(hpe, split) + 8 * N + S * 9 + 8 * hpe));
+  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + (gn ? 0 : 5 * N * (hpp + 4)) + 12 * N + S * 10 + 32 + 10 * hpp));
   return common_floats8(N, D, S) + net;
+}
+static size_t gnode_floats8(int hpe, int hpp, int N) {
+  return std::max((size_t)(hpe ? 5 * N * (hpe + 4) : 0), (size_t)(hpp ? 5 * N * (hpp + 4) : 0));
 }
 // The reverse pass publishes du of every slot pub_ch feature tiles at a time into [b0 | b1 | pubx extra floats]: pick the
 // largest pub_ch that fits 160 KiB, then the extra floats that choice needs.  false: the molecule does not fit.
-static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pubx, int& pub_ch) {
+static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pubx, int& pub_ch, bool gn = false) {
   pubx = 0;
   pub_ch = 0;
   const long long cap = 160 * 1024 / 4 - 64;  // floats (a little headroom for the runtime's own static LDS)
-  const long long base = (long long)lds_floats8_base(hpe, hpp, N, D, S, split);
+  const long long base = (long long)lds_floats8_base(hpe, hpp, N, D, S, split, gn);
   if (base > cap) return false;
   if (!hpp) return true;
   const int T = hpp / 16;
   // b0 + b1 double as the head of the publish buffer; with the split edge GEMMs the (then idle) weight ring follows them
-  const long long own = 2LL * N * (hpp + 4) + (split ? w8::edge_ring_floats(hpp, split) : 0);
+  // (V8G: b0 / b1 are in global memory, the buffer is the ring and what follows it)
+  const long long own = (gn ? 0LL : 2LL * N * (hpp + 4)) + (split ? w8::edge_ring_floats(hpp, split) : 0);
   pub_ch = w8::pub_chunk_tiles(S, own + (cap - base), T);
   if (pub_ch < 1) return false;
   // prefer the smallest chunk that gives the same number of chunks (less LDS, same barriers)
@@ -757,18 +781,19 @@ static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pub
   pubx = (int)std::max(0LL, (long long)S * (16 * pub_ch + 4) - own);
   return true;
 }
-static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, int split) {
-  return sizeof(float) * (lds_floats8_base(hpe, hpp, N, D, S, split) + (hpp ? pubx : 0));
+static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, int split, bool gn = false) {
+  return sizeof(float) * (lds_floats8_base(hpe, hpp, N, D, S, split, gn) + (hpp ? pubx : 0));
 }
 
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
   const bool v8 = h->run_variant == 8;
-  kernel_fn fn = v8 ? pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp) : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
+  kernel_fn fn = v8 ? (h->run_gn8 ? pick_kernel8g(hpe, hpp) : pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp))
+                    : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
                     (v8 ? " in the 8-wave family" : ""));
-  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW, h->run_gn);
+  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split, h->run_gn8) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW, h->run_gn);
   if (lds > 160 * 1024)
     return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
   {
@@ -934,7 +959,18 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
         if (pick_kernel8_mode(hpe, hpp, mode, mrk) && plan_pub8(hpe, hpp, NS, Dz, S, mode, pubx, pub_ch)) return mode;
     return pick_kernel8_mode(hpe, hpp, 0, mrk) && plan_pub8(hpe, hpp, NS, Dz, S, 0, pubx, pub_ch) ? 0 : -1;
   };
-  const int mode_u = plan_for(N, M.S, mr);
+  int mode_u = plan_for(N, M.S, mr);
+  // V8G (round 4): a molecule whose node buffers do not fit LDS beside the ring runs on the 8-wave kernels with those five
+  // buffers in a per-workgroup global scratch (split edge GEMMs, full ring, several rounds of edge tiles) -- before round 4
+  // such calls fell to the 4-wave V4G kernels (fp32 matrix instructions, two launches per guided step)
+  bool gn8 = false;
+  if ((mode_u < 0 || h->force_gn8) && h->gn8 && h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) &&
+      pick_kernel8g(hpe, hpp) && plan_pub8(hpe, hpp, N, Dz, M.S, 1, pubx, pub_ch, true)) {
+    gn8 = true;
+    mode_u = 1;
+  } else if (h->force_gn8 && mode_u >= 0) {
+    plan_for(N, M.S, mr);  // (restore pubx / pub_ch of the resident plan)
+  }
   if (mode_u < 0) return 1;
   Pack pk;
   const int B0 = B;
@@ -942,7 +978,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   int n_slots = N, mode_run = mode_u;
   bool mr_run = mr;
   // (a row of the map holds molecule * N + node in 28 bits)
-  if (h->pack_now && h->pack && B > 1 && (int64_t)B * N < (1 << 28)) {
+  if (!gn8 && h->pack_now && h->pack && B > 1 && (int64_t)B * N < (1 << 28)) {
     // Candidate group shapes, widest first.  WIDE groups (opt-in: GAUDI_PAIRS=1 for batches of at least two molecules per CU, 2
     // always): up to 2 N node slots and two rounds of eight edge tiles -- e.g. two 11-ring cata molecules, or three to four small
     // hetero ones, per workgroup.  Every node-level matrix is then streamed from L2 once for all of them and the per-GEMM fixed
@@ -994,7 +1030,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   P.pub_ch = pub_ch;
   if (getenv("GAUDI_DEBUG_PLAN"))
     fprintf(stderr, "[plan] molecules=%d workgroups=%d N=%d node slots=%d S=%d split=%d mr=%d pub_ch=%d pubx=%d lds=%zu\n", B0, B, N, n_slots,
-            M.S, h->run_split, (int)mr_run, pub_ch, pubx, lds_bytes8(hpe, hpp, n_slots, Dz, M.S, pubx, h->run_split));
+            M.S, h->run_split, gn8 ? 2 : (int)mr_run, pub_ch, pubx, lds_bytes8(hpe, hpp, n_slots, Dz, M.S, pubx, h->run_split, gn8));
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = d.reserve(bytes);
     if (e != hipSuccess) return e;
@@ -1034,6 +1070,13 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   h->run_groups = B;
   h->run_nslots = n_slots;
   h->run_mr = mr_run;
+  h->run_gn8 = gn8;
+  if (gn8) {
+    const size_t stride = (gnode_floats8(hpe, hpp, N) + 63) / 64 * 64;
+    HIPCHECK(h, h->d_gnode.reserve(sizeof(float) * stride * (size_t)B));
+    P.gnode = h->d_gnode.as<float>();
+    P.gnode_stride = (long long)stride;
+  }
   return GAUDI_OK;
 }
 
@@ -1046,6 +1089,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   h->run_variant = h->variant;
   h->run_split = 0;
   h->run_gn = false;
+  h->run_gn8 = false;
   h->run_mr = false;
   h->run_groups = B;
   h->run_nslots = N;
@@ -1152,6 +1196,8 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_WAVES")) h->variant = atoi(v) == 4 ? 4 : 8;
   if (const char* v = getenv("GAUDI_EDGE_MATH")) h->split = std::string(v) != "fp32";
   if (const char* v = getenv("GAUDI_FORCE_GN")) h->force_gn = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_GN8")) h->gn8 = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_FORCE_GN8")) h->force_gn8 = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PACK")) h->pack = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PAIRS")) h->pairs = atoi(v);
   {
@@ -1932,6 +1978,12 @@ int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups, int32_t* n
   if (!h || !workgroups) return GAUDI_E_INVALID;
   *workgroups = h->run_groups;
   if (node_slots) *node_slots = h->run_nslots;
+  return GAUDI_OK;
+}
+
+int gaudi_node_buffers(const gaudi_handle* h, int32_t* last_call) {
+  if (!h || !last_call) return GAUDI_E_INVALID;
+  *last_call = (h->run_gn || h->run_gn8) ? 1 : 0;
   return GAUDI_OK;
 }
 

@@ -218,48 +218,52 @@ __device__ __forceinline__ PredDev uni(const PredDev& w) {
                  uni(w.ws_bytes)};
 }
 #ifndef GAUDI_STAMPS
-template <int HP, int SP>
-__device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, float t_val_) {
+// GN: the node buffers of the phase live in the workgroup's slice of the global scratch (gnode_), everything else in LDS
+template <int HP, int SP, bool GN = false>
+__device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, float t_val_, float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const EdmDev W = uni(W_);
   const Graph8Args ga = uni(ga_);
   const float t_val = uni(t_val_);
   const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
   const w8::MolGraph mg = graph8(L, ga);
-  w8::NetSmem<HP, SP> sm;
-  sm.carve(L.net, ga.N, ga.S);
-  w8::edm_forward<HP, SP>(W, mg, sm, L.sZ, L.sEps, L.sMean, t_val, (int)threadIdx.x);
+  w8::NetSmem<HP, SP, GN> sm;
+  sm.carve(L.net, ga.N, ga.S, GN ? uni(gnode_) : nullptr);
+  w8::edm_forward<HP, SP, GN>(W, mg, sm, L.sZ, L.sEps, L.sMean, t_val, (int)threadIdx.x);
 }
 // the predictor's forward and reverse passes are separate functions too (the reverse pass holds three 52-register
 // operand sets at its peak; allocated together with the forward it spilled twice as much)
-template <int HP, int SP, bool MR>
-__device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args ga_, float t_val_, float* stash_, float readout_div_) {
+template <int HP, int SP, bool MR, bool GN = false>
+__device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args ga_, float t_val_, float* stash_, float readout_div_,
+                                                         float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PredDev W = uni(W_);
   const Graph8Args ga = uni(ga_);
   const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
   const w8::MolGraph mg = graph8(L, ga);
-  w8::PredSmem<HP, SP> sm;
-  sm.carve(L.net, ga.N, ga.S, ga.pubx);
-  w8::pred_forward<HP, SP, MR>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
+  w8::PredSmem<HP, SP, GN> sm;
+  sm.carve(L.net, ga.N, ga.S, ga.pubx, GN ? uni(gnode_) : nullptr);
+  w8::pred_forward<HP, SP, MR, GN>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
 }
-template <int HP, int SP, bool MR>
-__device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args ga_, float* stash_, float readout_div_, int resume_) {
+template <int HP, int SP, bool MR, bool GN = false>
+__device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args ga_, float* stash_, float readout_div_, int resume_,
+                                                         float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PredDev W = uni(W_);
   const Graph8Args ga = uni(ga_);
   const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
   const w8::MolGraph mg = graph8(L, ga);
-  w8::PredSmem<HP, SP> sm;
-  sm.carve(L.net, ga.N, ga.S, ga.pubx);
-  w8::pred_backward<HP, SP, MR>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
+  w8::PredSmem<HP, SP, GN> sm;
+  sm.carve(L.net, ga.N, ga.S, ga.pubx, GN ? uni(gnode_) : nullptr);
+  w8::pred_backward<HP, SP, MR, GN>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
                         uni(resume_) ? L.sZ : nullptr);
 }
 #endif
 
 // SP: edge GEMMs on the bf16 matrix pipe with three-way split operands (w8_split.h); otherwise fp32 MFMAs
 // MR: the predictor takes graphs of more than one round of eight edge tiles (w8_pred.h); the denoiser always does
-template <int SP, bool MR = false>
+// GN: node buffers in the workgroup's global scratch (V8G, round 4: molecules beyond the LDS limit on the 8-wave kernels)
+template <int SP, bool MR = false, bool GN = false>
 struct V8T {
   static constexpr int kThreads = w8::kThreads;
   static constexpr int kSplit = SP;
@@ -294,36 +298,37 @@ struct V8T {
   __device__ __forceinline__ static Graph8Args gargs(const Graph& mg) {
     return Graph8Args{mg.N, mg.D, mg.S, mg.NC, mg.ntiles, mg.pubx, mg.pub_ch};
   }
-  static constexpr bool kGlobalNodes = false;
+  static constexpr bool kGlobalNodes = GN;
   template <int HP>
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
-                                             float* sMean, float t_val, int tid STAMP_DECL, float*) {
+                                             float* sMean, float t_val, int tid STAMP_DECL, float* gnode) {
 #ifdef GAUDI_STAMPS
+    static_assert(!GN, "the stamped diagnostic build has no V8G kernels");
     w8::NetSmem<HP, SP> sm;
     sm.carve(net, mg.N, mg.S);
     w8::edm_forward<HP, SP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
 #else
     (void)net; (void)sZ; (void)sEps; (void)sMean; (void)tid;
-    edm8_call<HP, SP>(W, gargs(mg), t_val);
+    edm8_call<HP, SP, GN>(W, gargs(mg), t_val, gnode);
 #endif
   }
   template <int HP>
   __device__ __forceinline__ static void guide(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad, float* sTmp,
                                                float* sMean, float t_val, float sigma, const float* target_w, float scale,
                                                float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, int phase,
-                                               const float* dpred_ext, float*, const float* dz_ext) {
+                                               const float* dpred_ext, float* gnode, const float* dz_ext) {
 #ifdef GAUDI_STAMPS
     (void)dz_ext;  // (the stamped diagnostic build times the fused step only)
     w8::guidance_update<HP, SP, MR>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
                             mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext);
 #else
     (void)sTmp;
-    w8::PredSmem<HP, SP> sm;
-    sm.carve(net, mg.N, mg.S, mg.pubx);
-    if (phase != 2) pred_fwd8_call<HP, SP, MR>(W, gargs(mg), t_val, stash, readout_div);
-    w8::guidance_seed<HP, SP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
+    w8::PredSmem<HP, SP, GN> sm;
+    sm.carve(net, mg.N, mg.S, mg.pubx, gnode);
+    if (phase != 2) pred_fwd8_call<HP, SP, MR, GN>(W, gargs(mg), t_val, stash, readout_div, gnode);
+    w8::guidance_seed(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
     if (phase == 1) return;
-    pred_bwd8_call<HP, SP, MR>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0);
+    pred_bwd8_call<HP, SP, MR, GN>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0, gnode);
     if (dz_ext != nullptr) {  // + the target's direct dependence on z (callback launches are never packed: slot n = node n)
       for (int e = tid; e < mg.N * mg.D; e += kThreads) sGrad[e] += dz_ext[e];
       __syncthreads();
@@ -334,9 +339,9 @@ struct V8T {
   template <int HP>
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
                                                     float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
-                                                    float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, float*) {
-    w8::predictor_entry<HP, SP, MR>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
-                            mg.pub_ch, tid STAMP_ARGS);
+                                                    float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, float* gnode) {
+    w8::predictor_entry<HP, SP, MR, GN>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
+                            mg.pub_ch, tid STAMP_ARGS, gnode);
   }
 };
 using V8 = V8T<0>;
@@ -660,5 +665,9 @@ inline constexpr sampler_fn sampler_kernel8h = &sampler_kernel_v<V8H, HPE, HPP>;
 // ... whose predictor runs several rounds of edge tiles (kern8m_*.hip): SP = 0 / 1 / 2 as above
 template <int SP, int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8m = &sampler_kernel_v<V8T<SP, true>, HPE, HPP>;
+// ... and with the node buffers in global memory (kern8g_*.hip: molecules beyond the LDS limit; split edge GEMMs, full ring,
+// several rounds of edge tiles in the predictor)
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel8g = &sampler_kernel_v<V8T<1, true, true>, HPE, HPP>;
 
 }  // namespace gaudi

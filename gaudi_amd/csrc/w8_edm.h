@@ -9,9 +9,14 @@
 namespace gaudi {
 namespace w8 {
 
-// LDS working set of one network evaluation
-template <int HP, int SP = 0>
+// LDS working set of one network evaluation.  GN ("global node buffers", the V8G kernels of round 4): the five [N][HP+4] node
+// buffers -- what outgrows 160 KiB beyond ~22 graph nodes at the default widths -- live in a per-workgroup global scratch
+// instead (the 4-wave family's V4G form of round 3, edm_device.h, on the 8-wave kernels).  The code is the same: the pointers
+// are carved from the scratch, hipcc emits flat / global accesses for them; every cross-wave hand-off of these buffers
+// already sits behind a workgroup barrier, which orders global memory inside a workgroup too.
+template <int HP, int SP = 0, bool GN = false>
 struct NetSmem {
+  static constexpr bool kGlobalNodes = GN;
   float *h, *p, *q;     // [N][HP+4]
   float *agg, *agg1;    // [N][HP+4] the two partial edge->node sums of a node (its run may straddle two tiles)
   float* ring;          // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats)
@@ -21,16 +26,17 @@ struct NetSmem {
   float* trans;         // [S][4]
   float* vec;           // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
   __host__ __device__ static int floats(int N, int S) {
-    return 5 * N * (HP + 4) + EdgeRing<HP, SP>::kFloats + 8 * N + S * 9 + 8 * HP;
+    return (GN ? 0 : 5 * N * (HP + 4)) + EdgeRing<HP, SP>::kFloats + 8 * N + S * 9 + 8 * HP;
   }
-  __device__ void carve(float* base, int N, int S) {
+  __device__ void carve(float* base, int N, int S, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
     ring = base; base += EdgeRing<HP, SP>::kFloats;   // first: 1 KiB tiles stay 16-byte aligned whatever N is
-    h = base; base += N * LD;
-    p = base; base += N * LD;
-    q = base; base += N * LD;
-    agg = base; base += N * LD;
-    agg1 = base; base += N * LD;
+    float*& nb = GN ? gnode : base;
+    h = nb; nb += N * LD;
+    p = nb; nb += N * LD;
+    q = nb; nb += N * LD;
+    agg = nb; nb += N * LD;
+    agg1 = nb; nb += N * LD;
     x = base; base += 4 * N;
     x0 = base; base += 4 * N;
     geo = (f4*)base; base += S * 4;
@@ -111,8 +117,8 @@ __device__ __forceinline__ void scatter_runs(f4 (&e)[HP / 16], const TileCols& t
 }
 
 // eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
-template <int HP, int SP = 0>
-__device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP, SP>& sm, const float* sZ,
+template <int HP, int SP = 0, bool GN = false>
+__device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP, SP, GN>& sm, const float* sZ,
                                             float* sEps, float* sMean /* [4] */, float t_val, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;

@@ -10,8 +10,12 @@
 namespace gaudi {
 namespace w8 {
 
-template <int HP, int SP = 0>
+// GN: the five node buffers live in a per-workgroup global scratch (w8_edm.h: NetSmem); the publish buffer of the reverse
+// pass is then [ring | pub] -- split forms only
+template <int HP, int SP = 0, bool GN = false>
 struct PredSmem {
+  static_assert(!GN || SP != 0, "global node buffers: split edge GEMMs only (the fp32 form's publish buffer starts in b0 / b1)");
+  static constexpr bool kGlobalNodes = GN;
   float *b2, *b3, *b4;            // [N][HP+4] node buffers (roles change per phase, see below)
   float *b0, *b1;                 // [N][HP+4] ... these two open the publish buffer of the reverse pass: [b0 | b1 | (ring) | pub]
   float* ring;                    // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats); split form: idle while du is
@@ -23,16 +27,19 @@ struct PredSmem {
   float* pred;                    // [16] pred | [16] dpred
   float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
   __host__ __device__ static int floats(int N, int S, int pubx) {
-    return EdgeRing<HP, SP>::kFloats + 5 * N * (HP + 4) + pubx + 12 * N + S * 10 + 32 + 10 * HP;
+    return EdgeRing<HP, SP>::kFloats + (GN ? 0 : 5 * N * (HP + 4)) + pubx + 12 * N + S * 10 + 32 + 10 * HP;
   }
-  __device__ void carve(float* base, int N, int S, int pubx) {
+  // the publish buffer of the reverse pass (du of every slot, pub_ch feature tiles at a time)
+  __device__ __forceinline__ float* publish() const { return GN ? ring : b0; }
+  __device__ void carve(float* base, int N, int S, int pubx, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
     if (SP == 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // fp32 form: the ring stays busy across the publish phase
-    b2 = base; base += N * LD;
-    b3 = base; base += N * LD;
-    b4 = base; base += N * LD;
-    b0 = base; base += N * LD;
-    b1 = base; base += N * LD;
+    float*& nb = GN ? gnode : base;
+    b2 = nb; nb += N * LD;
+    b3 = nb; nb += N * LD;
+    b4 = nb; nb += N * LD;
+    b0 = nb; nb += N * LD;
+    b1 = nb; nb += N * LD;
     if (SP != 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // N * LD * 4 bytes is a multiple of 16: units stay aligned
     pub = base; base += pubx;
     x = base; base += 4 * N;
@@ -74,8 +81,8 @@ __host__ __device__ inline int pub_chunk_tiles(int S, long long avail_floats, in
 // MR: the kernel takes graphs of more than one round of eight edge tiles (more than 128 slots).  A separate instantiation: the
 // round loops (and the second copy of the reverse chain that parks du in the stash) cost the single-round kernels 2-4 % when
 // they live in the same function (hipcc's register allocation of the out-of-line phases changes), measured on C3.
-template <int HP, int SP = 0, bool MR = false>
-__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP>& sm, const float* sZ,
+template <int HP, int SP = 0, bool MR = false, bool GN = false>
+__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP, GN>& sm, const float* sZ,
                                              float t_val, float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -260,8 +267,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 //                          B4 = b4: npre (stash) -> dnpre -> dQ
 // pub_ch = 16-feature tiles of du published per chunk into [b0 | b1 | pub] (row = 16 pub_ch + 4 floats per slot)
 // ---------------------------------------------------------------------------------------------
-template <int HP, int SP = 0, bool MR = false>
-__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP>& sm, const float* stash,
+template <int HP, int SP = 0, bool MR = false, bool GN = false>
+__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP, GN>& sm, const float* stash,
                                               float* sGrad, float readout_div, int pub_ch, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -273,7 +280,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   const WBuf wbe = SP ? make_wbuf(W.ws, W.ws_bytes) : wb;  // edge-GEMM matrices (w8_split.h)
   const bool tw = W.ktail != 0;                            // H % 16 == 4: the node GEMMs' tail tile (w8_common.h: tail_lane)
   float *B0 = sm.b0, *B1 = sm.b1, *B2 = sm.b2, *dh = sm.b3, *B4 = sm.b4;
-  float* pub = sm.b0;  // [slots][16 pub_ch + 4]
+  float* pub = sm.publish();  // [slots][16 pub_ch + 4]
   const int PLD = 16 * pub_ch + 4;
   const float* estash = stash + pred_stash_node_floats(N, HP, W.L);
   const float* astash = estash + (size_t)W.L * S * HP * 2;
@@ -552,24 +559,25 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 }
 
 // unit-test entry: pred (and optionally grad into sGrad) for z in sZ
-template <int HP, int SP = 0, bool MR = false>
+template <int HP, int SP = 0, bool MR = false, bool GN = false>
 __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
-                                                float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid STAMP_DECL) {
+                                                float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid STAMP_DECL,
+                                                float* gnode = nullptr) {
   (void)sTmp; (void)sMean;
-  PredSmem<HP, SP> sm;
-  sm.carve(net, mg.N, mg.S, pubx);
-  pred_forward<HP, SP, MR>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
+  PredSmem<HP, SP, GN> sm;
+  sm.carve(net, mg.N, mg.S, pubx, gnode);
+  pred_forward<HP, SP, MR, GN>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
     if (pred_out) pred_out[tid] = sm.pred[tid];
     sm.pred[16 + tid] = dpred ? dpred[tid] : 0.f;
   }
   __syncthreads();
-  if (want_grad) pred_backward<HP, SP, MR>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS);
+  if (want_grad) pred_backward<HP, SP, MR, GN>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS);
 }
 
-template <int HP, int SP = 0>
-__device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP, SP>& sm, const float* target_w, float scale,
+template <class SM>
+__device__ __forceinline__ void guidance_seed(const PredDev& W, const SM& sm, const float* target_w, float scale,
                                               float* pred_out, int tid, int phase, const float* dpred_ext);
 __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, float* sGrad, float* sMean, float sigma, int tid);
 
@@ -586,15 +594,15 @@ __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph
   PredSmem<HP, SP> sm;
   sm.carve(net, N, mg.S, pubx);
   if (phase != 2) pred_forward<HP, SP, MR>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
-  guidance_seed<HP, SP>(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
+  guidance_seed(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
   if (phase == 1) return;
   pred_backward<HP, SP, MR>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
   guidance_apply(mg, sZ, sGrad, sMean, sigma, tid);
 }
 
 // pred -> pred_out (split mode) and the seed of the reverse pass: d(energy)/dpred = scale * dT/dpred
-template <int HP, int SP>
-__device__ __forceinline__ void guidance_seed(const PredDev& W, const PredSmem<HP, SP>& sm, const float* target_w, float scale,
+template <class SM>
+__device__ __forceinline__ void guidance_seed(const PredDev& W, const SM& sm, const float* target_w, float scale,
                                               float* pred_out, int tid, int phase, const float* dpred_ext) {
   if (tid < W.K) {
     if (pred_out && phase != 2) pred_out[tid] = sm.pred[tid];

@@ -347,6 +347,13 @@ class Engine:
         self._check(self.lib.gaudi_edge_math(self.h, C.byref(a), C.byref(b)), "gaudi_edge_math")
         return a.value, b.value
 
+    def node_buffers_global(self) -> bool:
+        """True if the most recent call kept its node buffers in a global scratch (molecules beyond the LDS limit: the V8G kernels
+        on 8 waves, the V4G kernels on 4 -- kernel_variant() tells which)."""
+        v = C.c_int32()
+        self._check(self.lib.gaudi_node_buffers(self.h, C.byref(v)), "gaudi_node_buffers")
+        return bool(v.value)
+
     def last_workgroups(self) -> int:
         """Workgroups of the most recent launch (molecules, or the groups they were packed into)."""
         return self.last_launch_shape()[0]

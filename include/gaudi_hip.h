@@ -243,6 +243,11 @@ int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* la
  * split with the full ring (a 32-input chunk of all output tiles per trip), 2 = split with the half ring (two trips per
  * chunk: molecules whose node buffers leave less LDS), 0 = fp32 instructions. */
 int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
+/* Where the most recent call kept its [N][hidden] node buffers: 0 = LDS (the resident kernels), 1 = a per-workgroup global
+ * scratch -- molecules beyond the LDS limit (about 22 graph nodes at the default widths; the reference has no cap,
+ * sampling_edm.py:172-209): the V8G kernels (8 waves, round 4) or, for graphs outside the 8-wave kernels' limits and with
+ * GAUDI_GN8=0, the V4G kernels (4 waves; gaudi_kernel_variant tells which). */
+int gaudi_node_buffers(const gaudi_handle* h, int32_t* last_call);
 /* Workgroups the most recent kernel launch of the handle ran: the molecules of the call (or of its last sub-batch), or the
  * groups they were packed into; node_slots (may be NULL): node slots per workgroup -- the call's N, or more when the launch
  * ran WIDE groups (below).  bench.py prices its roofline with these figures, not with the host-side plan. */

@@ -34,7 +34,8 @@ def _engine(eargs, esd, pargs=None, psd=None, **env):
 def test_callback_targets_on_large_molecules_vs_oracle(N):
     """sample_guidance with an arbitrary closure has no size cap in the reference (sampling_edm.py:172-209,
     en_diffusion.py:899-903).  Complete graphs of 24 / 40 nodes at the DEFAULT widths do not fit LDS: gaudi_sample_cb runs them
-    on the V4G kernels (three launches per step).  A nonlinear target against the numpy oracle at 1e-4; a constant-gradient
+    with the node buffers in global memory -- N = 24 on the 8-wave V8G kernels (two launches per step), N = 40 (a node with
+    more than 32 live edges) on the 4-wave V4G kernels (three launches per step).  A nonlinear target against the numpy oracle at 1e-4; a constant-gradient
     callback equals the fused linear chain of the same kernels bit for bit."""
     from oracle import gaudi_oracle as O
     T = 3
@@ -47,7 +48,7 @@ def test_callback_targets_on_large_molecules_vs_oracle(N):
     noise = np.random.default_rng(N).standard_normal((T + 2, B, N, 4)).astype(np.float32)
     eng = _engine(eargs, esd, pargs, psd)
     x, h, d, z0 = eng.sample_callback(nm.reshape(B, N), em, nonlinear_target_grad, noise=noise, scale=0.6, return_z0=True)
-    assert eng.kernel_variant()[1] == 4
+    assert eng.node_buffers_global() and eng.kernel_variant()[1] == (8 if N <= 33 else 4)  # V8G (two launches per step) / V4G (three)
     xo, ho, zo = O.sample(esd, eargs, nm, em, noise, std=1.0, pred_sd=psd, pcfg=pargs, target_w=nonlinear_target_grad, scale=0.6)
     assert rel_err(z0, zo) < 1e-4 and rel_err(x, xo) < 1e-4 and np.array_equal(h, ho)
     w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
@@ -382,3 +383,83 @@ def test_design_with_the_reference_opv_closure():
     assert rel_err(a["target_function_values"].numpy(), b["target_function_values"].numpy()) < 1e-6
     assert a["best"].tolist() == b["best"].tolist()
     model.engine.close()
+
+
+# ------------------------------------------------------------------------------------------------ V8G: large molecules on 8 waves
+@pytest.mark.parametrize("widths", ["tiny", "default"])
+def test_v8g_kernels_agree_with_the_resident_kernels(widths):
+    """The V8G kernels (round 4) are the 8-wave kernels with the five node buffers in a per-workgroup global scratch: the path
+    molecules beyond the LDS limit take instead of the 4-wave V4G kernels.  Forced on a small ragged hetero batch
+    (GAUDI_FORCE_GN8=1) they must agree with the resident kernels to 2e-6 (same source, another address space and the MR
+    round structure: hipcc contracts a few multiply-adds differently) for phi, the predictor + gradient, a guided step and a
+    short guided chain; and with the oracle at 1e-4."""
+    from oracle import gaudi_oracle as O
+    from gaudi_amd.sampling_edm import build_masks
+    T = 6
+    F = synth.num_node_features("hetro")
+    over_e, over_p = (TINY, TINY_P) if widths == "tiny" else ({}, {})
+    eargs, pargs = synth.edm_args(dataset="hetro", diffusion_steps=T, **over_e), synth.pred_args(dataset="hetro", **over_p)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=21, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=22, amplify_coord=True)
+    rings = [3, 10, 6, 8]
+    nm3, em_flat, N = build_masks(rings, 10, True)
+    B = len(rings)
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    rng = np.random.default_rng(4)
+    z = O._combined_noise(rng.standard_normal((B, N, 3 + F)).astype(np.float32), nm3)
+    eps = rng.standard_normal((B, N, 3 + F)).astype(np.float32)
+    t = np.full(B, 0.5, np.float32)
+    w = np.array([3, 0, 1, 1, 0], np.float32)
+    dp = np.broadcast_to(w * np.float32(0.6), (B, 5)).copy()
+    outs = []
+    for env in ({}, {"GAUDI_FORCE_GN8": 1}):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        phi = eng.phi(z, t, nm, em)
+        assert eng.node_buffers_global() == bool(env) and eng.kernel_variant()[1] == 8
+        pred, grad = eng.predictor_grad(z, t, nm, em, dp)
+        assert eng.node_buffers_global() == bool(env)
+        zs = eng.step(2, z, nm, em, eps, target_w=w, scale=0.6)
+        assert eng.node_buffers_global() == bool(env)
+        x, h, d = eng.sample(nm, em, seed=5, target_w=w, scale=0.6)
+        xb, hb, _ = eng.sample(nm, em, seed=5, target_w=w, scale=0.6)
+        assert np.array_equal(x, xb)  # bitwise reproducible
+        outs.append((phi, pred, grad, zs))
+        eng.close()
+    for a, b in zip(*outs):
+        assert rel_err(b, a) < 2e-6
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    assert rel_err(outs[1][0], O.edm_phi(esd, eargs, z, t, nm3, em)) < 1e-4
+    opred, ograd = O.predictor_grad(psd, pargs, z, nm3, em, t, dp)
+    assert rel_err(outs[1][1], opred) < 1e-4 and rel_err(outs[1][2], ograd) < 1e-4
+    assert rel_err(outs[1][3], O.step_guided(esd, eargs, psd, pargs, gamma, 2, z, nm3, em, eps, w, 0.6)) < 1e-4
+
+
+def test_v8g_takes_over_where_lds_ends_and_v4g_where_eight_waves_end():
+    """Default widths: hetero 12 rings = 24 graph nodes do not fit LDS -> V8G (8 waves, node buffers in global memory), against the
+    oracle; GAUDI_GN8=0 restores round 3's choice (the 4-wave V4G kernels), which must agree at 1e-4."""
+    from oracle import gaudi_oracle as O
+    from gaudi_amd.sampling_edm import build_masks
+    T = 1000
+    F = synth.num_node_features("hetro")
+    eargs, pargs = synth.edm_args(dataset="hetro", diffusion_steps=T), synth.pred_args(dataset="hetro")
+    esd = synth.synth_edm_state_dict(eargs, F, seed=31, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=32, amplify_coord=True)
+    rings = [12, 5, 9]
+    nm3, em_flat, N = build_masks(rings, 12, True)
+    B = len(rings)
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    rng = np.random.default_rng(6)
+    z = O._combined_noise(rng.standard_normal((B, N, 3 + F)).astype(np.float32), nm3)
+    eps = rng.standard_normal((B, N, 3 + F)).astype(np.float32)
+    w = np.array([3, 0, 1, 1, 0], np.float32)
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    want = O.step_guided(esd, eargs, psd, pargs, gamma, 300, z, nm3, em, eps, w, 0.6)
+    eng = _engine(eargs, esd, pargs, psd)
+    got8 = eng.step(300, z, nm, em, eps, target_w=w, scale=0.6)
+    assert eng.node_buffers_global() and eng.kernel_variant()[1] == 8
+    eng.close()
+    eng = _engine(eargs, esd, pargs, psd, GAUDI_GN8=0)
+    got4 = eng.step(300, z, nm, em, eps, target_w=w, scale=0.6)
+    assert eng.node_buffers_global() and eng.kernel_variant()[1] == 4
+    eng.close()
+    assert rel_err(got8, want) < 1e-4 and rel_err(got4, want) < 1e-4

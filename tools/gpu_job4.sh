@@ -15,6 +15,8 @@ for step in "$@"; do
     smoke) timeout 300 python3 __graft_entry__.py smoke > $out/smoke.txt 2>&1 ;;
     bench) timeout 1200 python3 bench.py --steps 2 --warmup 1 > $out/bench.json 2> $out/bench.err ;;
     bench_quick) timeout 600 $B > $out/bench_quick.json 2> $out/bench_quick.err ;;
+    bench_c4x) GAUDI_DEBUG_PLAN=1 timeout 900 python3 bench.py --workload c4x --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > $out/bench_c4x.json 2> $out/bench_c4x.err ;;
+    bench_c4x_v4g) GAUDI_GN8=0 timeout 900 python3 bench.py --workload c4x --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > $out/bench_c4x_v4g.json 2> $out/bench_c4x_v4g.err ;;
     bench_c2) timeout 600 $B --workload c2 > $out/bench_c2.json 2> $out/bench_c2.err ;;
     bench_c4) GAUDI_DEBUG_PLAN=1 timeout 600 $B --workload c4 > $out/bench_c4.json 2> $out/bench_c4.err ;;
     bench_b1024) GAUDI_DEBUG_PLAN=1 timeout 600 $B --batch 1024 > $out/bench_b1024.json 2> $out/bench_b1024.err ;;
