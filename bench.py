@@ -426,6 +426,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     wv = eng.kernel_variant()[1]
     em_mode = eng.edge_math()[1]  # 0 fp32 instructions, 1 split operands (full LDS weight ring), 2 split (half ring)
     variant = "w4" if wv == 4 else ("w8s" if em_mode else "w8")
+    v8g = wv == 8 and eng.node_buffers_global()  # molecules beyond the LDS limit on the 8-wave kernels (node buffers in global memory)
     # workgroups of the launches that actually ran (molecules, or the groups the call packed them into): the issued-instruction
     # model below must describe THAT launch, so the host-side plan is only used when it agrees with it
     run_groups, run_slots = eng.last_launch_shape()
@@ -489,11 +490,13 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                    "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
                    "steps_per_launch": a.steps_per_launch,
                    "max_graph_nodes": "resident kernels: 22 at these hidden sizes (one molecule's node buffers in 160 KiB of LDS); "
-                                      "beyond that the V4G kernels (node buffers in global memory): checked at N = 40, bounded "
-                                      "by the edge lists in LDS (a complete graph of about 60 nodes)"},
+                                      "beyond that node buffers in global memory: the V8G kernels (8 waves) while no node has more "
+                                      "than 32 live edges, else the V4G kernels (4 waves): checked at N = 40, bounded by the edge "
+                                      "lists in LDS (a complete graph of about 60 nodes)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": frac, "traffic": traffic,
-                     "kernel": ("sampler_kernel_v<%s%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
+                     "kernel": "sampler_kernel_v<V8T<1,true,true>,192,%s> (V8G: 8 waves, node buffers in a per-workgroup global scratch, several rounds of edge tiles)" % ("208" if guided else "0") if v8g else
+                               ("sampler_kernel_v<%s%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
                                                                     " (MR: several rounds of edge tiles)" if guided and variant != "w4" and int(np.max(units)) > 8 else "",
                                                                     "208" if guided else "0")) if not (variant == "w4" and N > 22) else
                                "sampler_kernel_g<V4G,192,0> + sampler_kernel_g<V4G,0,208> (node buffers in global memory; two launches "
