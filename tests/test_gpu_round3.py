@@ -178,14 +178,16 @@ def test_n40_hetero_vs_reference(golden):
     z, nm, em, eps = g["z"], g["node_mask"], g["edge_mask"], g["eps"]
     t = np.full(z.shape[0], np.float32(s + 1) / np.float32(T), np.float32)
     w = np.array([0, -1, 0, 0, 0], np.float32)
-    eng = _engine(eargs, esd, pargs, psd)
-    assert rel_err(eng.phi(z, t, nm, em), g["phi"]) < 1e-4
-    pred, grad = eng.predictor_grad(z, t, nm, em, np.broadcast_to(w * np.float32(0.6), (z.shape[0], 5)).copy())
-    assert rel_err(pred, g["pred"]) < 1e-4 and rel_err(grad, g["grad_gap"]) < 1e-4
-    assert rel_err(eng.step(s, z, nm, em, eps), g["zs_unguided"]) < 1e-4
-    assert rel_err(eng.step(s, z, nm, em, eps, target_w=w, scale=0.6), g["zs_guided"]) < 1e-4
-    assert eng.kernel_variant()[1] == 4
-    eng.close()
+    # the default (round 4): the V8G kernels -- 8 waves, node buffers in global memory; GAUDI_GN8=0: round 3's V4G kernels (4 waves)
+    for env, waves in (({}, 8), ({"GAUDI_GN8": 0}, 4)):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        assert rel_err(eng.phi(z, t, nm, em), g["phi"]) < 1e-4
+        pred, grad = eng.predictor_grad(z, t, nm, em, np.broadcast_to(w * np.float32(0.6), (z.shape[0], 5)).copy())
+        assert rel_err(pred, g["pred"]) < 1e-4 and rel_err(grad, g["grad_gap"]) < 1e-4
+        assert rel_err(eng.step(s, z, nm, em, eps), g["zs_unguided"]) < 1e-4
+        assert rel_err(eng.step(s, z, nm, em, eps, target_w=w, scale=0.6), g["zs_guided"]) < 1e-4
+        assert eng.kernel_variant()[1] == waves and eng.node_buffers_global()
+        eng.close()
 
 
 # ------------------------------------------------------------------------------------------------ reference-held anchor (g19)
