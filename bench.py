@@ -605,7 +605,8 @@ def main():
             # the other single-GPU configurations, timed by the same harness (short: one or two calls each)
             sec = {}
             for wl, b, st, wu, math in (("c2", 256, 2, 1, None), ("c4", 1024, 2, 1, None), ("c3_b1024", 1024, 2, 1, None),
-                                        ("c3_fp32_mfma", 256, 2, 1, "fp32"), ("c2_fp32_mfma", 256, 2, 1, "fp32")):
+                                        ("c3_fp32_mfma", 256, 2, 1, "fp32"), ("c2_fp32_mfma", 256, 2, 1, "fp32"),
+                                        ("c4x", 1024, 1, 0, None)):  # BASELINE config 4 read literally: 12-40 graph nodes (V8G kernels)
                 r = run_workload(a, engines, wl.split("_")[0], b, st, wu, rank, world, dev, backend, T, edge_math=math)
                 sec[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": st,
                            "warmup": wu, "ms_per_step": r["ms_per_step"], "roofline_frac": r["roofline"]["frac"],
