@@ -8,6 +8,7 @@ B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary"
 for step in "$@"; do
   case $step in
     mb_node4) timeout 300 gaudi_amd/ngemm4_mb > $out/ngemm4_mb.txt 2>&1 ;;
+    mb_node_gx) timeout 300 gaudi_amd/ngemm4_mb g > $out/ngemm_gx.txt 2>&1 ;;
     tests_new) timeout 1500 python3 -m pytest tests/test_gpu_round4.py -q -m gpu > $out/tests_new.txt 2>&1 ;;
     tests_all) timeout 3000 python3 -m pytest tests -x -q -m gpu > $out/tests_all.txt 2>&1 ;;
     tests_core) timeout 1500 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_split.py tests/test_gpu_fullsize.py -x -q -m gpu > $out/tests_core.txt 2>&1 ;;

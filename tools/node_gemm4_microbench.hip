@@ -34,15 +34,16 @@ struct Sel<HP, 1> {
   }
 };
 
-template <int HP, int V>
+// GX: the activations (node buffers) live in a per-workgroup GLOBAL scratch instead of LDS (the V8G kernels of round 4)
+template <int HP, int V, bool GX = false>
 __global__ __launch_bounds__(512) void k(const float* w, unsigned wbytes, int nmat, float* out, unsigned long long* cyc, int gemms,
-                                         int N, int tail) {
+                                         int N, int tail, float* gscratch = nullptr) {
   constexpr int T = HP / 16, LD = HP + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sX = smem;
-  float* sY = sX + 32 * LD;
+  float* sX = GX ? gscratch + (size_t)blockIdx.x * 2 * 48 * LD : smem;
+  float* sY = sX + 48 * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 2 * 32 * LD; i += 512) smem[i] = 0.01f * ((i * 7) % 13) - 0.05f;
+  for (int i = tid; i < 2 * 48 * LD; i += 512) sX[i] = 0.01f * ((i * 7) % 13) - 0.05f;
   __syncthreads();
   const WBuf wb = make_wbuf(w, wbytes);
   typename Sel<HP, V>::PF pf;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(512) void k(const float* w, unsigned wbytes, int nm
     __syncthreads();
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  out[blockIdx.x * 512 + tid] = sX[tid % (32 * LD)];
+  out[blockIdx.x * 512 + tid] = sX[tid % (48 * LD)];
   if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, co
   for (int i = tid; i < N * HP; i += 512) y[i] = sY[(i / HP) * LD + i % HP];
 }
 
-template <int HP, int V>
+template <int HP, int V, bool GX = false>
 void run(int N, int blocks, int nmat, int tail) {
   constexpr int T = HP / 16;
   float *out, *w;
@@ -97,15 +98,17 @@ void run(int N, int blocks, int nmat, int tail) {
   hipMalloc(&out, blocks * 512 * 4);
   hipMalloc(&cyc, blocks * 8 * 8);
   const int gemms = 600;
-  const size_t lds = 2 * 32 * (HP + 4) * 4;
-  hipFuncSetAttribute((const void*)k<HP, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = GX ? 64 : 2 * 48 * (HP + 4) * 4;
+  float* gs = nullptr;
+  if (GX) hipMalloc(&gs, (size_t)blocks * 2 * 48 * (HP + 4) * 4);
+  hipFuncSetAttribute((const void*)k<HP, V, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   float ms = 0;
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k<HP, V>), dim3(blocks), dim3(512), lds, 0, w, (unsigned)(wfloats * 4), nmat, out, cyc, gemms, N, tail);
+    hipLaunchKernelGGL((k<HP, V, GX>), dim3(blocks), dim3(512), lds, 0, w, (unsigned)(wfloats * 4), nmat, out, cyc, gemms, N, tail, gs);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
@@ -116,7 +119,7 @@ void run(int N, int blocks, int nmat, int tail) {
   for (int wv = 0; wv < 8; ++wv) mx = std::max(mx, (double)h[wv]);
   const int crit = ((T + 7) / 8 + (T > 4 ? (T - 4 + 7) / 8 : 0));  // tiles on SIMD 0 (waves 0 and 4)
   printf("%s HP=%d N=%d blocks=%d matrices=%d (%.1f MB) tail44=%d: %.0f cycles, %.3f us per matrix; fp32 MFMA floor of the 8-wave form %d (SIMD 0: %d tiles)\n",
-         V ? "node_gemm4 (4 waves, split operands)" : "node_gemm  (8 waves, fp32 MFMA)     ", HP, N, blocks, nmat, wfloats * 4 / 1e6, tail, mx / gemms, ms * 1e3 / gemms,
+         V ? "node_gemm4 (4 waves, split operands)" : GX ? "node_gemm  (8 waves, fp32 MFMA, activations in GLOBAL memory)" : "node_gemm  (8 waves, fp32 MFMA)     ", HP, N, blocks, nmat, wfloats * 4 / 1e6, tail, mx / gemms, ms * 1e3 / gemms,
          crit * T * 4 * 32 * ((N + 15) / 16), crit);
   hipFree(out);
   hipFree(cyc);
@@ -209,6 +212,15 @@ void all() {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'g') {  // activations in LDS vs in global memory (V8G), fp32 node GEMM, N = 22 / 32 / 40
+    for (int N : {22, 32, 40}) {
+      run<208, 0, false>(N, 256, 120, 1);
+      run<208, 0, true>(N, 256, 120, 1);
+      run<192, 0, false>(N, 256, 63, 0);
+      run<192, 0, true>(N, 256, 63, 0);
+    }
+    return 0;
+  }
   if (argc > 1) {  // one timing configuration (for counter passes): variant N
     if (atoi(argv[1])) run<208, 1>(argc > 2 ? atoi(argv[2]) : 11, 256, 120, 1);
     else run<208, 0>(argc > 2 ? atoi(argv[2]) : 11, 256, 120, 1);
