@@ -760,6 +760,12 @@ static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split,
 static size_t gnode_floats8(int hpe, int hpp, int N) {
   return std::max((size_t)(hpe ? 5 * N * (hpe + 4) : 0), (size_t)(hpp ? 5 * N * (hpp + 4) : 0));
 }
+// V8G stages up to two node buffers in the idle weight ring before each node GEMM (w8_common.h: stage_rows)
+static bool gn8_stage_fits(int hpe, int hpp, int N) {
+  for (int hp : {hpe, hpp})
+    if (hp && 2 * (size_t)w8::stage_stride(N * (hp + 4)) > w8::edge_ring_floats(hp, 1)) return false;
+  return true;
+}
 // The reverse pass publishes du of every slot pub_ch feature tiles at a time into [b0 | b1 | pubx extra floats]: pick the
 // largest pub_ch that fits 160 KiB, then the extra floats that choice needs.  false: the molecule does not fit.
 static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pubx, int& pub_ch, bool gn = false) {
@@ -965,7 +971,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   // such calls fell to the 4-wave V4G kernels (fp32 matrix instructions, two launches per guided step)
   bool gn8 = false;
   if ((mode_u < 0 || h->force_gn8) && h->gn8 && h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) &&
-      pick_kernel8g(hpe, hpp) && plan_pub8(hpe, hpp, N, Dz, M.S, 1, pubx, pub_ch, true)) {
+      pick_kernel8g(hpe, hpp) && gn8_stage_fits(hpe, hpp, N) && plan_pub8(hpe, hpp, N, Dz, M.S, 1, pubx, pub_ch, true)) {
     gn8 = true;
     mode_u = 1;
   } else if (h->force_gn8 && mode_u >= 0) {
@@ -1073,7 +1079,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   h->run_gn8 = gn8;
   if (gn8) {
     const size_t stride = (gnode_floats8(hpe, hpp, N) + 63) / 64 * 64;
-    HIPCHECK(h, h->d_gnode.reserve(sizeof(float) * stride * (size_t)B));
+    HIPCHECK(h, h->d_gnode.reserve(sizeof(float) * (stride * (size_t)B + 256)));  // (+ the staging copies' 1 KiB read granule)
     P.gnode = h->d_gnode.as<float>();
     P.gnode_stride = (long long)stride;
   }

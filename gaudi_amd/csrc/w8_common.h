@@ -514,6 +514,54 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
   }
 }
 
+// node_gemm with up to MAXNT column tiles per pass.  MAXNT = 3 (the kernels with node buffers in global memory, whose molecules
+// have up to 48 nodes): 33..48 nodes run as ONE pass over three column tiles instead of two passes that stream the weights
+// twice.  A node's result does not depend on the column-tile count (one accumulator chain per (column tile, output tile)).
+template <int HP, int EPI, bool PRE, int MAXNT>
+__device__ __forceinline__ void node_gemm_n(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sBias,
+                                            float* sY, const float* sRes, const float* sMask, int N, int wave, int lane, bool tail_w,
+                                            NodePF<HP>* pf = nullptr, int nextW = -1, float* gPre = nullptr) {
+  constexpr int T = HP / 16;
+  if constexpr (MAXNT < 3) {
+    node_gemm<HP, EPI, PRE>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, tail_w, pf, nextW, gPre);
+  } else {
+    if (N <= 32 || N > 48) {
+      node_gemm<HP, EPI, PRE>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, tail_w, pf, nextW, gPre);
+    } else if (owns_tail<HP>(tail_w, wave)) {
+      node_gemm_body<HP, EPI, PRE, 3, (T - 1 >= kWaves ? 2 : 1), true>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf,
+                                                                       nextW, gPre);
+    } else if (wave + kWaves < T) {
+      node_gemm_body<HP, EPI, PRE, 3, 2>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
+    } else if (wave < T) {
+      node_gemm_body<HP, EPI, PRE, 3, 1>(wb, Wa, sXa, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, pf, nextW, gPre);
+    }
+  }
+}
+
+// call-site form: the resident kernels call node_gemm directly (one more inlining level around it moves their instruction
+// schedule: the compiled code of those kernels is kept identical to what was tuned and measured)
+#define NODE_GEMM(EPI, ...)                                                   \
+  do {                                                                        \
+    if constexpr (GN) node_gemm_n<HP, EPI, true, 3>(__VA_ARGS__);             \
+    else node_gemm<HP, EPI, true>(__VA_ARGS__);                               \
+  } while (0)
+
+// Kernels with node buffers in global memory: a node GEMM's input rows are copied once into the idle weight ring of the
+// edge GEMMs (LDS-DMA, 1 KiB per wave-instruction, no register round trip), so that the GEMM reads them from LDS like the
+// resident kernels do -- per-lane global loads of the rows cost +39..55% per matrix (profiles/r04m).  `floats` is rounded
+// up to whole 1 KiB units: the scratch and the ring leave that slack.
+__device__ __forceinline__ void stage_rows(float* lds, const float* g, int floats, int wave, int lane) {
+  const int units = (floats + 255) >> 8;
+  for (int u = wave; u < units; u += kWaves)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + u * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds + u * 256), 16, 0, 0);
+}
+__device__ __forceinline__ void stage_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+__host__ __device__ __forceinline__ constexpr int stage_stride(int floats) { return (floats + 255) & ~255; }
+
 // Per-molecule graph metadata prepared by the host (gaudi_hip.hip: build_meta8) and staged in LDS.
 // Slots = the molecule's live edges sorted by receiving node, padded to whole 16-slot tiles; tile tau is served by wave
 // tau & 7 in round tau >> 3.

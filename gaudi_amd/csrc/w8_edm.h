@@ -155,7 +155,11 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   compute_geo(sm, mg, 0.f, tid, true);  // d0 of the input coordinates (egnn_new.py:301)
   typename EdgeRing<HP, SP>::type ring;
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
-  er_start<HP>(ring, wbe, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
+  // GN: the ring is idle during the node phases -- the node GEMMs' input rows are staged in it (w8_common.h: stage_rows),
+  // and every edge phase requests its first weight group itself instead of having it travel across the node phase
+  float* const xs0 = sm.ring;
+  float* const xs1 = sm.ring + stage_stride(N * LD);
+  if constexpr (!GN) er_start<HP>(ring, wbe, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
   NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it
   node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane, tw);
   constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
@@ -171,26 +175,30 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int G = lay.gcl(l, s);  // float offsets into the weight buffer
       const int Wnext_edge = s + 1 < W.S ? lay.gcl(l, s + 1) + 2 * PK : lay.equ(l) + 2 * PK;
       vec_commit<NV, kThreads>(vpf, sm.vec, 7 * HP + 16, tid);
+      if constexpr (GN) stage_rows(xs0, sm.h, N * LD, wave, lane);
       for (int idx = tid; idx < N * LD; idx += kThreads) {
         sm.agg[idx] = 0.f;
         sm.agg1[idx] = 0.f;
       }
-      __syncthreads();
+      if constexpr (GN) stage_wait();
+      else __syncthreads();
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
                   *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
       const float ba = sm.vec[7 * HP];
-      node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, G + PK);
-      node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
-                                    G + 3 * PK);  // node MLP weights travel across the edge phase
+      NODE_GEMM(EPI_NONE, wb, G, GN ? xs0 : sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
+                                         G + PK);
+      NODE_GEMM(EPI_NONE, wb, G + PK, GN ? xs0 : sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane,
+                                         tw, &pf, G + 3 * PK);  // node MLP weights travel across the edge phase
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
+      if constexpr (GN) er_start<HP>(ring, wbe, G + 2 * PK, wave, lane);
       for (int rd = 0; rd < mg.rounds; ++rd) {
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
-        er_gemm_pq<HP>(acc, ring, wbe, G + 2 * PK, rd + 1 < mg.rounds ? G + 2 * PK : Wnext_edge, b2, cr, cd,
+        er_gemm_pq<HP>(acc, ring, wbe, G + 2 * PK, rd + 1 < mg.rounds ? G + 2 * PK : (GN ? -1 : Wnext_edge), b2, cr, cd,
                          sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
         STAMP(ST_EDGE);
         if (tc.active) {
@@ -213,21 +221,30 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       }
       __syncthreads();
       STAMP(ST_BARRIER);
+      if constexpr (GN) stage_rows(xs0, sm.h, N * LD, wave, lane);
       for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = (partial 0 + partial 1) / normalization_factor
         const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
-        *(f4*)(sm.agg + n * LD + f) = (*(const f4*)(sm.agg + n * LD + f) + *(const f4*)(sm.agg1 + n * LD + f)) / W.normf;
+        if constexpr (GN)  // straight into the staged copy (only this GEMM reads agg)
+          *(f4*)(xs1 + n * LD + f) = (*(const f4*)(sm.agg + n * LD + f) + *(const f4*)(sm.agg1 + n * LD + f)) / W.normf;
+        else
+          *(f4*)(sm.agg + n * LD + f) = (*(const f4*)(sm.agg + n * LD + f) + *(const f4*)(sm.agg1 + n * LD + f)) / W.normf;
       }
-      __syncthreads();
+      if constexpr (GN) stage_wait();
+      else __syncthreads();
       STAMP(ST_MISC);
-      node_gemm<HP, EPI_SILU, true>(wb, G + 3 * PK, sm.h, G + 4 * PK, sm.agg, bn1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw,
-                                    &pf, G + 5 * PK);
+      NODE_GEMM(EPI_SILU, wb, G + 3 * PK, GN ? xs0 : sm.h, G + 4 * PK, GN ? xs1 : sm.agg, bn1, sm.p, nullptr, nullptr,
+                                         mg.NC, wave, lane, tw, &pf, G + 5 * PK);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
       vec_prefetch<NV, kThreads>(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK,
                                  s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
-      node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave, lane, tw,
-                                             &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
+      if constexpr (GN) {
+        stage_rows(xs0, sm.p, N * LD, wave, lane);
+        stage_wait();
+      }
+      NODE_GEMM(EPI_RESIDUAL_MASK, wb, G + 5 * PK, GN ? xs0 : sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave,
+                                                  lane, tw, &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
@@ -237,20 +254,27 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int E = lay.equ(l);
       const int Wnext_edge = l + 1 < W.L ? lay.gcl(l + 1, 0) + 2 * PK : -1;
       vec_commit<NV, kThreads>(vpf, sm.vec, 5 * HP, tid);
-      __syncthreads();
+      if constexpr (GN) {
+        stage_rows(xs0, sm.h, N * LD, wave, lane);
+        stage_wait();
+      } else {
+        __syncthreads();
+      }
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
-      node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, E + PK);
-      node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
-                                    l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
+      NODE_GEMM(EPI_NONE, wb, E, GN ? xs0 : sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
+                                         E + PK);
+      NODE_GEMM(EPI_NONE, wb, E + PK, GN ? xs0 : sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane,
+                                         tw, &pf, l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
+      if constexpr (GN) er_start<HP>(ring, wbe, E + 2 * PK, wave, lane);
       for (int rd = 0; rd < mg.rounds; ++rd) {
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
-        er_gemm_pq<HP>(acc, ring, wbe, E + 2 * PK, rd + 1 < mg.rounds ? E + 2 * PK : Wnext_edge, b2, cr, cd,
+        er_gemm_pq<HP>(acc, ring, wbe, E + 2 * PK, rd + 1 < mg.rounds ? E + 2 * PK : (GN ? -1 : Wnext_edge), b2, cr, cd,
                          sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
         STAMP(ST_EDGE);
         if (tc.active) {

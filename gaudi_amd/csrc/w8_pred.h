@@ -120,7 +120,10 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   compute_geo(sm, mg, 0.f, tid, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
   typename EdgeRing<HP, SP>::type ring;
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
-  er_start<HP>(ring, wbe, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
+  // GN: node-GEMM inputs are staged in the idle ring, every edge phase requests its first weight group itself (w8_edm.h)
+  float* const xs0 = sm.ring;
+  float* const xs1 = sm.ring + stage_stride(N * LD);
+  if constexpr (!GN) er_start<HP>(ring, wbe, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
   NodePF<HP> pf;
   node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane, tw);
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
@@ -131,6 +134,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
     vec_commit<NV, kThreads>(vpf, sm.vec, PredLayerW::vec_count(HP), tid);
+    if constexpr (GN) stage_rows(xs0, h, N * LD, wave, lane);
     for (int idx = tid; idx < N * LD; idx += kThreads) {
       agg[idx] = 0.f;
       agg1[idx] = 0.f;
@@ -138,13 +142,17 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
     for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 3 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
     compute_geo(sm, mg, 1.0f, tid, false);  // gcl.py:308-316
-    __syncthreads();
+    if constexpr (GN) stage_wait();
+    else __syncthreads();
     STAMP(ST_STAGE);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.A, h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Bm);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.Bm, h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1h);
+    NODE_GEMM(EPI_NONE, wb, Lw.A, GN ? xs0 : h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
+                                       Lw.Bm);
+    NODE_GEMM(EPI_NONE, wb, Lw.Bm, GN ? xs0 : h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
+                                       Lw.Wn1h);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
+    if constexpr (GN) er_start<HP>(ring, wbe, Lw.W2, wave, lane);
     // P, Q -> stash as whole rows (storing them from the accumulators in the GEMM epilogue instead -- 64-byte pieces per
     // lane group -- measured 1.5 % slower on C3)
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
@@ -191,8 +199,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       STAMP(ST_EDGE_EPI);
       if (!last) {  // coord_model (gcl.py:252-278): trans = dhat * tanh(wc2 . silu(Wc1 e + bc1)) * R * mask
         f4 cp[T];
-        er_gemm_regs<HP>(cp, acc, ring, wbe, Lw.Wc1, more ? Lw.W2 : lay.layer(l + 1) + 2 * HP * HP, Lw.bc1, nullptr, tc.active, wave,
-                         lane);
+        er_gemm_regs<HP>(cp, acc, ring, wbe, Lw.Wc1, more ? Lw.W2 : (GN ? -1 : lay.layer(l + 1) + 2 * HP * HP), Lw.bc1, nullptr,
+                         tc.active, wave, lane);
         STAMP(ST_EDGE);
         if (tc.active) {
           f4* sc = (f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
@@ -222,20 +230,29 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     }
     __syncthreads();
     STAMP(ST_BARRIER);
+    if constexpr (GN) stage_rows(xs0, h, N * LD, wave, lane);
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = partial 0 + partial 1
       const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
-      *(f4*)(agg + n * LD + f) = *(const f4*)(agg + n * LD + f) + *(const f4*)(agg1 + n * LD + f);
+      if constexpr (GN)  // straight into the staged copy (only this GEMM reads agg)
+        *(f4*)(xs1 + n * LD + f) = *(const f4*)(agg + n * LD + f) + *(const f4*)(agg1 + n * LD + f);
+      else
+        *(f4*)(agg + n * LD + f) = *(const f4*)(agg + n * LD + f) + *(const f4*)(agg1 + n * LD + f);
     }
-    __syncthreads();
+    if constexpr (GN) stage_wait();
+    else __syncthreads();
     STAMP(ST_MISC);
-    node_gemm<HP, EPI_SILU, true>(wb, Lw.Wn1h, h, Lw.Wn1a, agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn2,
-                                  st + 2 * N * HP /* npre -> stash */);
+    NODE_GEMM(EPI_SILU, wb, Lw.Wn1h, GN ? xs0 : h, Lw.Wn1a, GN ? xs1 : agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane,
+                                       tw, &pf, Lw.Wn2, st + 2 * N * HP /* npre -> stash */);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
     vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), PredLayerW::vec_count(HP), tid);
-    node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, Lw.Wn2, p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, tw, &pf,
-                                           l + 1 < W.L ? lay.layer(l + 1) : -1);
+    if constexpr (GN) {
+      stage_rows(xs0, p, N * LD, wave, lane);
+      stage_wait();
+    }
+    NODE_GEMM(EPI_RESIDUAL_MASK, wb, Lw.Wn2, GN ? xs0 : p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, tw, &pf,
+                                                l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
     STAMP(ST_NODE);
     __syncthreads();
@@ -317,7 +334,10 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 
   typename EdgeRing<HP, SP>::type ring;
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
-  {
+  // GN: node-GEMM inputs are staged in the idle ring, every edge pass requests its first weight group itself (w8_edm.h)
+  float* const xs0 = sm.ring;
+  float* const xs1 = sm.ring + stage_stride(N * LD);
+  if constexpr (!GN) {
     const int L0 = lay.layer(W.L - 1);
     er_start<HP>(ring, wbe, L0 + 9 * HP * HP /* W2^T of the last layer (its coordinate branch is skipped) */, wave, lane);
   }
@@ -346,16 +366,25 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       *(f4*)(sm.dx + 4 * idx) = *(const f4*)(sm.dx + 4 * idx) * mg.mask[idx];
     }
     __syncthreads();
+    if constexpr (GN) stage_rows(xs0, dh, N * LD, wave, lane);
     compute_geo(sm, mg, 1.0f, tid, false);
+    if constexpr (GN) stage_wait();
     STAMP(ST_STASH);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
-    node_gemm<HP, EPI_MUL_DSILU, true>(wb, Lw.Wn2t, dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1ht);
+    NODE_GEMM(EPI_MUL_DSILU, wb, Lw.Wn2t, GN ? xs0 : dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, tw, &pf,
+                                            Lw.Wn1ht);
     __syncthreads();
+    if constexpr (GN) {
+      stage_rows(xs0, B4, N * LD, wave, lane);
+      stage_wait();
+    }
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
-    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.Wn1ht, B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf, Lw.Wn1at);
-    node_gemm<HP, EPI_NONE, true>(wb, Lw.Wn1at, B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, tw, &pf);
+    NODE_GEMM(EPI_ACCUM, wb, Lw.Wn1ht, GN ? xs0 : B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf,
+                                        Lw.Wn1at);
+    NODE_GEMM(EPI_NONE, wb, Lw.Wn1at, GN ? xs0 : B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, tw, &pf);
     __syncthreads();
     STAMP(ST_BWD_NODE);
+    if constexpr (GN) er_start<HP>(ring, wbe, last ? Lw.W2t : Lw.Wc1t, wave, lane);
     // (e) edge pass: MLP chain backward for the wave's tile, then du of all slots is published CH feature tiles at a time
     //     and every thread sums one (node, 4 features) of dP_i = sum_j du_ij (receiver runs) and dQ_j = sum_i du_ij
     //     (sender lists) in slot order -- no atomics, fixed order
@@ -506,7 +535,8 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         }
         __syncthreads();
       }
-      if (SP != 0 && l > 0) er_start<HP>(ring, wbe, lay.layer(l - 1) + 10 * HP * HP /* Wc1^T of the layer below */, wave, lane);
+      if (SP != 0 && !GN && l > 0)
+        er_start<HP>(ring, wbe, lay.layer(l - 1) + 10 * HP * HP /* Wc1^T of the layer below */, wave, lane);
       node_prefetch<HP>(pf, wb, Lw.At, wave, lane, tw);
       STAMP(ST_BWD_COL);
     }
@@ -523,8 +553,13 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     }
     // (f) dh += A^T dP + Bm^T dQ
     vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l > 0 ? l - 1 : 0), HP), PredLayerW::vec_count(HP), tid);
-    node_gemm<HP, EPI_ACCUM, true>(wb, Lw.At, B2, Lw.Bmt, B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf,
-                                   l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
+    if constexpr (GN) {  // (the publish loop ended on a barrier: dP / dQ are complete, the ring is free)
+      stage_rows(xs0, B2, N * LD, wave, lane);
+      stage_rows(xs1, B4, N * LD, wave, lane);
+      stage_wait();
+    }
+    NODE_GEMM(EPI_ACCUM, wb, Lw.At, GN ? xs0 : B2, Lw.Bmt, GN ? xs1 : B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw,
+                                        &pf, l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
     STAMP(ST_BWD_NODE);
   }
