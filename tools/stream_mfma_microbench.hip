@@ -19,6 +19,7 @@ __global__ __launch_bounds__(NWV * 64) void k(const float* __restrict__ w, int n
   auto ld = [&](int off_floats) { return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, off_floats * 4, 0)); };
   f4 acc[UT];
   for (int u = 0; u < UT; ++u) acc[u] = (f4){0, 0, 0, 0};
+  extern __shared__ float stage[];
   const float xb = 1.0f + lane * 1e-6f;
   f4 side[UT];
   for (int u = 0; u < UT; ++u) side[u] = (f4){0, 0, 0, 0};
@@ -34,8 +35,19 @@ __global__ __launch_bounds__(NWV * 64) void k(const float* __restrict__ w, int n
     int toff[UT];
     for (int u = 0; u < UT; ++u) { const int t = wave + NW * u; toff[u] = (t < T ? t : wave) * 256; }
     f4 a0[UT], a1[UT], b0[UT], b1[UT], c0[UT], c1[UT];
-    for (int u = 0; u < UT; ++u) { a0[u] = ld(chunk(0) + toff[u]); a1[u] = ld(chunk(1) + toff[u]); }
-    if (SCHED == 1) for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(2) + toff[u]); b1[u] = ld(chunk(3) + toff[u]); }
+    // SCHED 10: per-wave staging, two sets of two K chunks x UT tiles (1 KiB each)
+    float* stA = stage + wave * (4 * UT * 256);
+    float* stB = stA + 2 * UT * 256;
+    auto dma = [&](float* dst, int cc) {
+#pragma unroll
+      for (int u = 0; u < UT; ++u)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + chunk(cc) + toff[u] + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + u * 256), 16, 0, 0);
+    };
+    if (SCHED == 10) { dma(stA, 0); dma(stA + UT * 256, 1); }
+    if (SCHED != 10) for (int u = 0; u < UT; ++u) { a0[u] = ld(chunk(0) + toff[u]); a1[u] = ld(chunk(1) + toff[u]); }
+    if (SCHED == 1 || ((SCHED == 6 || SCHED == 7) && wave >= NW / 2))
+      for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(2) + toff[u]); b1[u] = ld(chunk(3) + toff[u]); }
 #pragma unroll 1
     for (int cc = 0; cc < 12; cc += 4) {
       if (SCHED == 0 || SCHED == 2) {
@@ -74,11 +86,104 @@ __global__ __launch_bounds__(NWV * 64) void k(const float* __restrict__ w, int n
         mmx(a0); mmx(a1);
         __builtin_amdgcn_sched_barrier(0);
         for (int u = 0; u < UT; ++u) side[u] += b0[u] + b1[u] + c0[u] + c1[u];
+      } else if (SCHED == 5) {  // one load after every four matrix instructions (no bursts: the texture path drains between them)
+        auto mm1u = [&](const f4 (&a)[UT], int u) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[u] = mfma1(a[u][q], xb, acc[u]);
+        };
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(cc + 2) + toff[u]); __builtin_amdgcn_sched_barrier(0); mm1u(a0, u); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { b1[u] = ld(chunk(cc + 3) + toff[u]); __builtin_amdgcn_sched_barrier(0); mm1u(a1, u); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { a0[u] = ld(chunk(cc + 4) + toff[u]); __builtin_amdgcn_sched_barrier(0); mm1u(b0, u); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { a1[u] = ld(chunk(cc + 5) + toff[u]); __builtin_amdgcn_sched_barrier(0); mm1u(b1, u); __builtin_amdgcn_sched_barrier(0); }
+      } else if (SCHED == 6 || SCHED == 7) {  // ping-pong, the second wave of every SIMD half an iteration out of phase
+        // (7: + the matrix phase runs at raised priority)
+        if (wave >= NW / 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (SCHED == 7) __builtin_amdgcn_s_setprio(2);
+          mmx(a0); mmx(a1);
+          if (SCHED == 7) __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < UT; ++u) { a0[u] = ld(chunk(cc + 4) + toff[u]); a1[u] = ld(chunk(cc + 5) + toff[u]); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (SCHED == 7) __builtin_amdgcn_s_setprio(2);
+          mmx(b0); mmx(b1);
+          if (SCHED == 7) __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(cc + 6) + toff[u]); b1[u] = ld(chunk(cc + 7) + toff[u]); }
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+          for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(cc + 2) + toff[u]); b1[u] = ld(chunk(cc + 3) + toff[u]); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (SCHED == 7) __builtin_amdgcn_s_setprio(2);
+          mmx(a0); mmx(a1);
+          if (SCHED == 7) __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < UT; ++u) { a0[u] = ld(chunk(cc + 4) + toff[u]); a1[u] = ld(chunk(cc + 5) + toff[u]); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (SCHED == 7) __builtin_amdgcn_s_setprio(2);
+          mmx(b0); mmx(b1);
+          if (SCHED == 7) __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (SCHED == 8) {  // ping-pong with the matrix phase at raised priority
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(cc + 2) + toff[u]); b1[u] = ld(chunk(cc + 3) + toff[u]); }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(2); mmx(a0); mmx(a1); __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { a0[u] = ld(chunk(cc + 4) + toff[u]); a1[u] = ld(chunk(cc + 5) + toff[u]); }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(2); mmx(b0); mmx(b1); __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (SCHED == 9) {  // ping-pong with the LOADS at raised priority (requests leave as early as possible)
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { b0[u] = ld(chunk(cc + 2) + toff[u]); b1[u] = ld(chunk(cc + 3) + toff[u]); }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mmx(a0); mmx(a1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { a0[u] = ld(chunk(cc + 4) + toff[u]); a1[u] = ld(chunk(cc + 5) + toff[u]); }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mmx(b0); mmx(b1);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (SCHED == 10) {  // weights by LDS-DMA into a per-wave staging area, ds_read_b128 from there (no VGPR write-back
+                                 // from the vector-memory path)
+        dma(stB, cc + 2); dma(stB + UT * 256, cc + 3);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UT) : "memory");
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { a0[u] = *(const f4*)(stA + u * 256 + lane * 4); a1[u] = *(const f4*)(stA + (UT + u) * 256 + lane * 4); }
+        __builtin_amdgcn_sched_barrier(0);
+        mmx(a0); mmx(a1);
+        __builtin_amdgcn_sched_barrier(0);
+        dma(stA, cc + 4); dma(stA + UT * 256, cc + 5);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UT) : "memory");
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { b0[u] = *(const f4*)(stB + u * 256 + lane * 4); b1[u] = *(const f4*)(stB + (UT + u) * 256 + lane * 4); }
+        __builtin_amdgcn_sched_barrier(0);
+        mmx(b0); mmx(b1);
+        __builtin_amdgcn_sched_barrier(0);
       } else {  // SCHED 3: MFMA only
         mmx(a0); mmx(a1); mmx(a0); mmx(a1);
       }
     }
-    if (SCHED == 0 || SCHED == 1) mmx(a0); else for (int u = 0; u < UT; ++u) acc[u] += a0[u];
+    if (SCHED == 10) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int u = 0; u < UT; ++u) a0[u] = *(const f4*)(stA + u * 256 + lane * 4);
+    }
+    if (SCHED == 0 || SCHED == 1 || SCHED >= 5) mmx(a0); else for (int u = 0; u < UT; ++u) acc[u] += a0[u];
     __syncthreads();
   }
   f4 s = acc[0] + side[0];
@@ -90,9 +195,9 @@ template <int SCHED, int NW>
 void run(const float* dw, int n_mat, int iters, int blocks, float* dout, const char* name) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  k<SCHED, NW><<<blocks, NW * 64>>>(dw, n_mat, 8, dout);
+  k<SCHED, NW><<<blocks, NW * 64, 65536>>>(dw, n_mat, 8, dout);
   (void)hipEventRecord(e0);
-  k<SCHED, NW><<<blocks, NW * 64>>>(dw, n_mat, iters, dout);
+  k<SCHED, NW><<<blocks, NW * 64, 65536>>>(dw, n_mat, iters, dout);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   { hipError_t e = hipGetLastError(); if (e != hipSuccess) printf("  launch error: %s\n", hipGetErrorString(e)); }
@@ -113,6 +218,12 @@ int main() {
     run<0, NWV>(dw, nm, 2000, 256, dout, "loads + MFMA, ping-pong");
     run<1, NWV>(dw, nm, 2000, 256, dout, "loads + MFMA, refill-after");
     run<4, NWV>(dw, nm, 2000, 256, dout, "MFMA on static regs + loads elsewhere");
+    run<5, NWV>(dw, nm, 2000, 256, dout, "one load per four MFMAs");
+    run<6, NWV>(dw, nm, 2000, 256, dout, "ping-pong, second wave out of phase");
+    run<7, NWV>(dw, nm, 2000, 256, dout, "out of phase + MFMA phase at prio 2");
+    run<8, NWV>(dw, nm, 2000, 256, dout, "ping-pong, MFMA phase at prio 2");
+    run<9, NWV>(dw, nm, 2000, 256, dout, "ping-pong, loads at prio 2");
+    run<10, NWV>(dw, nm, 2000, 256, dout, "weights by LDS-DMA + ds_read");
   }
   return 0;
 }
