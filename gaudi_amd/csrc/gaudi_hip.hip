@@ -101,6 +101,7 @@ struct gaudi_handle {
   bool pred_rounds = true;    // GAUDI_PRED_ROUNDS=0: guided calls with more than 128 edge slots go to the 4-wave kernels
   bool pack_now = false;      // set by run_chain around stage_graph: this call may pack
   int run_groups = 0;         // workgroups of the CURRENT call (= molecules unless packed)
+  bool force_mr = false;      // GAUDI_FORCE_MR
   bool run_mr = false;        // the current call runs the 8-wave kernels whose predictor takes several rounds of edge tiles
   bool force_gn = false;      // GAUDI_FORCE_GN=1 at gaudi_create: use them whenever they exist (test knob)
   bool fix_noise = false;     // en_diffusion.py:562-566: one raw draw per call, broadcast over the batch
@@ -706,10 +707,14 @@ static kernel_fn pick_kernel8m(int hpe, int hpp, int mode) {
 }
 #endif
 // ... and the 8-wave kernels with the node buffers in global memory (kern8g_*.hip: V8G)
-#ifdef GAUDI_STAMP_STUBS
+#if defined(GAUDI_STAMP_STUBS) && !defined(GAUDI_STAMP_G)
 static kernel_fn pick_kernel8g(int, int) { return nullptr; }
 #else
+#ifdef GAUDI_STAMP_STUBS  // tools/build_stamped.sh g: the fused V8G kernel with phase stamps
+#define GAUDI_KERNEL8G_TUS(X) X(fused_192_208)
+#else
 #define GAUDI_KERNEL8G_TUS(X) X(fused_192_208) X(edm_192) X(pred_208) X(fused_tiny) X(edm_small) X(pred_small)
+#endif
 #define X(name) kernel_fn gaudi_kern8g_##name(int hpe, int hpp);
 GAUDI_KERNEL8G_TUS(X)
 #undef X
@@ -947,7 +952,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   // more than one round of eight edge tiles (a graph of more than 128 live-edge slots, e.g. a fully connected molecule of
   // 12+ nodes): the 8-wave kernels run the rounds one after the other (GAUDI_PRED_ROUNDS=0: the round-2 behaviour, such calls
   // go to the 4-wave kernels); the LDS plan below decides whether the larger per-slot arrays and publish buffer still fit
-  const bool mr = hpp && M.S > 16 * w8::kWaves;
+  const bool mr = hpp && (M.S > 16 * w8::kWaves || h->force_mr);
   if (mr && !h->pred_rounds) return 1;
   // ---- packing: small molecules share a workgroup as the components of one graph (sampling calls only).  First-fit in
   // the heaviest-first order; a group holds at most kMaxComp molecules, N node slots and 8 edge tiles (one round on 8
@@ -1204,6 +1209,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_FORCE_GN")) h->force_gn = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_GN8")) h->gn8 = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_FORCE_GN8")) h->force_gn8 = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_FORCE_MR")) h->force_mr = atoi(v) != 0;  // diagnostic: one-round graphs on the MR kernels
   if (const char* v = getenv("GAUDI_PACK")) h->pack = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PAIRS")) h->pairs = atoi(v);
   {

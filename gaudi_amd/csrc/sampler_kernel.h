@@ -303,10 +303,9 @@ struct V8T {
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
                                              float* sMean, float t_val, int tid STAMP_DECL, float* gnode) {
 #ifdef GAUDI_STAMPS
-    static_assert(!GN, "the stamped diagnostic build has no V8G kernels");
-    w8::NetSmem<HP, SP> sm;
-    sm.carve(net, mg.N, mg.S);
-    w8::edm_forward<HP, SP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
+    w8::NetSmem<HP, SP, GN> sm;
+    sm.carve(net, mg.N, mg.S, GN ? uni(gnode) : nullptr);
+    w8::edm_forward<HP, SP, GN>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
 #else
     (void)net; (void)sZ; (void)sEps; (void)sMean; (void)tid;
     edm8_call<HP, SP, GN>(W, gargs(mg), t_val, gnode);
@@ -319,8 +318,8 @@ struct V8T {
                                                const float* dpred_ext, float* gnode, const float* dz_ext) {
 #ifdef GAUDI_STAMPS
     (void)dz_ext;  // (the stamped diagnostic build times the fused step only)
-    w8::guidance_update<HP, SP, MR>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
-                            mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext);
+    w8::guidance_update<HP, SP, MR, GN>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
+                                        mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext, GN ? uni(gnode) : nullptr);
 #else
     (void)sTmp;
     w8::PredSmem<HP, SP, GN> sm;

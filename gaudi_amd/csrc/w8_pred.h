@@ -619,19 +619,20 @@ __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, fl
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 // phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
 // (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
-template <int HP, int SP = 0, bool MR = false>
+template <int HP, int SP = 0, bool MR = false, bool GN = false>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, float sigma, const float* target_w,
                                                 float scale, float* pred_out, float readout_div, float* stash, int pubx,
-                                                int pub_ch, int tid STAMP_DECL, int phase, const float* dpred_ext) {
+                                                int pub_ch, int tid STAMP_DECL, int phase, const float* dpred_ext,
+                                                float* gnode = nullptr) {
   (void)sTmp;
   const int N = mg.N, D = mg.D;
-  PredSmem<HP, SP> sm;
-  sm.carve(net, N, mg.S, pubx);
-  if (phase != 2) pred_forward<HP, SP, MR>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
+  PredSmem<HP, SP, GN> sm;
+  sm.carve(net, N, mg.S, pubx, gnode);
+  if (phase != 2) pred_forward<HP, SP, MR, GN>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   guidance_seed(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
   if (phase == 1) return;
-  pred_backward<HP, SP, MR>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
+  pred_backward<HP, SP, MR, GN>(W, mg, sm, stash, sGrad, readout_div, pub_ch, tid STAMP_ARGS, phase == 2 ? sZ : nullptr);
   guidance_apply(mg, sZ, sGrad, sMean, sigma, tid);
 }
 

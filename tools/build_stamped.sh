@@ -1,8 +1,11 @@
 #!/bin/bash
 # Diagnostic build with in-kernel phase stamps (shares only; never used for reported timings).
-#   tools/build_stamped.sh && GAUDI_LIB=$PWD/gaudi_amd/libgaudi_hip_stamps.so GAUDI_PRINT_STAMPS=1 python bench.py ...
+#   tools/build_stamped.sh [g] && GAUDI_LIB=$PWD/gaudi_amd/libgaudi_hip_stamps.so GAUDI_PRINT_STAMPS=1 python bench.py ...
+#   g: also the fused V8G kernel (node buffers in global memory) -> c4x / GAUDI_FORCE_GN8=1 runs
 set -e
+EXTRA=""
+if [ "$1" = "g" ]; then EXTRA="kern8g_fused_192_208.hip -DGAUDI_STAMP_G"; fi
 cd "$(dirname "$0")/../gaudi_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -shared -DGAUDI_STAMPS \
   -o ../libgaudi_hip_stamps.so gaudi_hip.hip kern_edm_192.hip kern_fused_192_208.hip kern8_edm_192.hip kern8_fused_192_208.hip kern8s_edm_192.hip kern8s_fused_192_208.hip kern8h_fused_192_208.hip \
-  -DGAUDI_STAMP_STUBS
+  -DGAUDI_STAMP_STUBS $EXTRA
