@@ -391,9 +391,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     {
       // One round of eight tiles (every molecule of the reference's datasets; the kernels that are not MR): du stays in
       // registers until it is published.  More rounds (MR kernels): a wave's registers hold one tile, and the publish buffer
-      // overwrites dagg / Q, which the later rounds' chains still read -- so every round parks its du in the stash and the
-      // publish phase reads it back.
-      constexpr bool mr = MR;  // (an MR kernel parks du in the stash for one-round graphs too: they are not its business)
+      // overwrites dagg / Q, which the later rounds' chains still read -- so every round but the last parks its du in the stash
+      // and the publish phase reads it back; the last round's du is published from registers.
+      constexpr bool mr = MR;
       int rd = 0;
     pred_bwd_round:  // (only an MR kernel jumps back here: see pred_forward)
       const bool more = MR && rd + 1 < mg.rounds;
@@ -490,12 +490,15 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         }
       }
       if constexpr (MR) {
-        if (tc.active) {
-          f4* sd = dus + (size_t)tile * (T * 64) + lane;
+        if (more) {  // (the last round's du stays in registers until it is published)
+          if (tc.active) {
+            f4* sd = dus + (size_t)tile * (T * 64) + lane;
 #pragma unroll
-          for (int t = 0; t < T; ++t) stash_store(sd + t * 64, du[t]);
+            for (int t = 0; t < T; ++t) stash_store(sd + t * 64, du[t]);
+          }
+          ++rd;
+          goto pred_bwd_round;
         }
-        if (++rd < mg.rounds) goto pred_bwd_round;
       }
       STAMP(ST_B_DU);
       __syncthreads();  // every wave is done with P (B2), Q (B1) and dagg (B0): the publish buffer may overwrite B0 / B1
@@ -509,7 +512,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
               if (t >= t0 && t < t1) *(f4*)(row + 16 * t) = du[t];
           }
         } else {
-          for (int r2 = 0; r2 < mg.rounds; ++r2) {
+          for (int r2 = 0; r2 + 1 < mg.rounds; ++r2) {  // the earlier rounds' tiles: parked in the stash
             const TileCols tp = load_tile(mg, r2, wave, c);
             if (tp.active) {
               float* row = pub + tp.slot * PLD + 4 * g - 16 * t0;
@@ -518,6 +521,12 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
               for (int t = 0; t < T; ++t)
                 if (t >= t0 && t < t1) *(f4*)(row + 16 * t) = stash_load(sd + t * 64);
             }
+          }
+          if (tc.active) {  // the last round's tile: still in registers
+            float* row = pub + tc.slot * PLD + 4 * g - 16 * t0;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              if (t >= t0 && t < t1) *(f4*)(row + 16 * t) = du[t];
           }
         }
         __syncthreads();
