@@ -371,17 +371,14 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     if constexpr (GN) stage_wait();
     STAMP(ST_STASH);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
-    NODE_GEMM(EPI_MUL_DSILU, wb, Lw.Wn2t, GN ? xs0 : dh, -1, nullptr, nullptr, B4, B4, nullptr, mg.NC, wave, lane, tw, &pf,
+    // (GN: dnpre feeds (d) only -- it is written straight into the second staging area, not to B4 and back)
+    NODE_GEMM(EPI_MUL_DSILU, wb, Lw.Wn2t, GN ? xs0 : dh, -1, nullptr, nullptr, GN ? xs1 : B4, B4, nullptr, mg.NC, wave, lane, tw, &pf,
                                             Lw.Wn1ht);
     __syncthreads();
-    if constexpr (GN) {
-      stage_rows(xs0, B4, N * LD, wave, lane);
-      stage_wait();
-    }
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
-    NODE_GEMM(EPI_ACCUM, wb, Lw.Wn1ht, GN ? xs0 : B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf,
+    NODE_GEMM(EPI_ACCUM, wb, Lw.Wn1ht, GN ? xs1 : B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf,
                                         Lw.Wn1at);
-    NODE_GEMM(EPI_NONE, wb, Lw.Wn1at, GN ? xs0 : B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, tw, &pf);
+    NODE_GEMM(EPI_NONE, wb, Lw.Wn1at, GN ? xs1 : B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, tw, &pf);
     __syncthreads();
     STAMP(ST_BWD_NODE);
     if constexpr (GN) er_start<HP>(ring, wbe, last ? Lw.W2t : Lw.Wc1t, wave, lane);
