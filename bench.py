@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--steps-per-launch", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the untimed full-batch step against the CPU restatement")
+    ap.add_argument("--closure", default=None, choices=["linear", "nonlinear"],
+                    help="c3 only, diagnostic: run the timed calls through sampling_edm.sample_guidance with a reference-form closure")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 / C4 / C3-at-1024 passes after the headline")
     ap.add_argument("--dist", action="store_true",
                     help="N = 1 only: route the run through the SAME distributed code as N > 1 (init_process_group('nccl', "
@@ -484,7 +486,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "edge_gemm_math": "bf16x3 split operands, f32 accumulate" if variant == "w8s" else "f32",
         "data": "synthetic (seeded default-init weights, on-device Philox noise)",
-        "config": {"workload": label, "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
+        "config": {"workload": label + (f"; reference-form closure ({closure}) through gaudi_amd.sampling_edm.sample_guidance"
+                                        if closure else ""), "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
                    "workgroups_per_call": G, "node_slots_per_workgroup": run_slots,
                    "edm": "nf=192,n_layers=9", "predictor": "nf=196,n_layers=12" if guided else None,
                    "parallelism": f"sample-sharded x{world}, one RCCL all_gather per call",
@@ -592,7 +595,7 @@ def main():
     B = a.batch or (1024 if (a.workload in ("c4", "c4x") or world > 1) else 256)
     engines = {}
     out = run_workload(a, engines, a.workload, B, a.steps, a.warmup, rank, world, dev, backend, T, use_dist=use_dist,
-                       gate=not a.no_parity_gate)
+                       gate=not a.no_parity_gate, closure=a.closure if a.workload == "c3" and world == 1 else None)
     if rank == 0 and "parity_gate" in out and not out["parity_gate"]["passed"]:
         sys.stderr.write("bench.py: PARITY GATE FAILED: " + json.dumps(out["parity_gate"]) + "\n")
         emit({"error": "parity gate failed", "parity_gate": out["parity_gate"]})
@@ -620,8 +623,7 @@ def main():
             for wl, cl, st, wu in (("c3_closure_linear", "linear", 2, 1), ("c3_closure_nonlinear", "nonlinear", 1, 0)):
                 try:
                     r = run_workload(a, engines, "c3", 256, st, wu, rank, world, dev, backend, T, closure=cl)
-                    sec[wl] = {"workload": r["config"]["workload"] + f"; reference-form closure ({cl}) through "
-                               "gaudi_amd.sampling_edm.sample_guidance", "value": r["value"], "unit": r["unit"], "steps": st,
+                    sec[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": st,
                                "warmup": wu, "ms_per_step": r["ms_per_step"], "launches": r["roofline"]["launches"],
                                "ratio_to_fused_headline": r["value"] / out["value"]}
                 except Exception as exc:  # a secondary line must not cost the headline

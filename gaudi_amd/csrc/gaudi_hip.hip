@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -1743,7 +1744,12 @@ static int sample_cb_impl(gaudi_handle* h, int B, int N, const float* node_mask,
   // 7.12): phase A is the EDM-only kernel (split = 1: z_t -> z_s before guidance) followed by the predictor-only kernel's
   // forward half (MODE_GUIDE, split = 1), phase B the predictor-only kernel's second half (MODE_GUIDE, split = 2).
   const bool gn = h->run_gn;
+  // GAUDI_DEBUG_CB: where a callback step's host time goes (enqueue / wait for pred / the caller's function)
+  const bool dbg_cb = getenv("GAUDI_DEBUG_CB") != nullptr;
+  double t_enq = 0, t_wait = 0, t_user = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int s = T - 1; s >= 0; --s) {
+    const double t0 = dbg_cb ? now() : 0;
     // phase A: z_t -> z_s (before guidance) and pred = predictor(z_s, t); the activation stash stays on the device
     P.mode = MODE_SAMPLE;
     P.s_hi = P.s_lo = s;
@@ -1765,7 +1771,9 @@ static int sample_cb_impl(gaudi_handle* h, int B, int N, const float* node_mask,
     HIPCHECK(h, hipMemcpyAsync(pred, h->d_pred.p, pb, hipMemcpyDeviceToHost, h->stream));
     if (target_grad_z) HIPCHECK(h, hipMemcpyAsync(h->p_z.p, zout, zb, hipMemcpyDeviceToHost, h->stream));  // z_s before guidance
     HIPCHECK(h, hipEventRecord(h->cb_event, h->stream));
+    const double t1 = dbg_cb ? now() : 0;
     HIPCHECK(h, hipEventSynchronize(h->cb_event));
+    const double t2 = dbg_cb ? now() : 0;
     std::memset(dT, 0, pb);
     if (target_grad_z) {
       float* dz = h->p_dz.as<float>();
@@ -1783,6 +1791,7 @@ static int sample_cb_impl(gaudi_handle* h, int B, int N, const float* node_mask,
     } else {
       target_grad(user, B, K, pred, (float)(s + 1) / (float)T, dT);
     }
+    const double t3 = dbg_cb ? now() : 0;
     HIPCHECK(h, hipMemcpyAsync(h->d_dpred.p, dT, pb, hipMemcpyHostToDevice, h->stream));
     // phase B: reverse pass with the caller's dT/dpred, clip / project / apply, CoG removal
     P.mode = gn ? MODE_GUIDE : MODE_SAMPLE;
@@ -1792,7 +1801,15 @@ static int sample_cb_impl(gaudi_handle* h, int B, int N, const float* node_mask,
     P.z_out = zin;
     rc = launch(h, P, gn ? 0 : h->HPE, h->HPP, 0);
     if (rc) return rc;
+    if (dbg_cb) {
+      t_enq += (t1 - t0) + (now() - t3);
+      t_wait += t2 - t1;
+      t_user += t3 - t2;
+    }
   }
+  if (dbg_cb)
+    fprintf(stderr, "[callback] per step: enqueue %.1f us, wait for pred %.1f us, caller's function %.1f us (%d steps)\n",
+            1e6 * t_enq / T, 1e6 * t_wait / T, 1e6 * t_user / T, T);
   // decode pass
   P.mode = MODE_SAMPLE;
   P.split = 0;

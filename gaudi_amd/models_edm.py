@@ -273,13 +273,17 @@ class GaudiModel:
             import torch
             B = pred.shape[0]
             # stand-in z (deterministic, non-zero: a direct dependence must show up in its gradient; torch's default generator
-            # is not touched -- it keys the noise)
-            shape = (B, model._trace_N, 3 + model.in_node_nf)
-            probe = (0.25 + torch.linspace(0.0, 1.0, int(np.prod(shape))).reshape(shape)).requires_grad_(True)
-            nm_all, em_all = model._trace_nm, model._trace_em.reshape(model._trace_nm.shape[0], -1, 1)
-            rows = np.arange(B) % nm_all.shape[0]  # (the affine probe runs on a few rows only)
-            nm = torch.from_numpy(np.ascontiguousarray(nm_all[rows]))
-            em = torch.from_numpy(np.ascontiguousarray(em_all[rows]).reshape(-1, 1))
+            # is not touched -- it keys the noise).  The stand-ins depend on (B, masks) only: built once per call, not per step.
+            cache, key = model.__dict__.setdefault("_trace_cache", {}), B  # (_run empties it whenever it sets new masks)
+            if cache.get("key") != key:
+                shape = (B, model._trace_N, 3 + model.in_node_nf)
+                nm_all, em_all = model._trace_nm, model._trace_em.reshape(model._trace_nm.shape[0], -1, 1)
+                rows = np.arange(B) % nm_all.shape[0]  # (the affine probe runs on a few rows only)
+                cache.update(key=key,
+                             probe=(0.25 + torch.linspace(0.0, 1.0, int(np.prod(shape))).reshape(shape)).requires_grad_(True),
+                             nm=torch.from_numpy(np.ascontiguousarray(nm_all[rows])),
+                             em=torch.from_numpy(np.ascontiguousarray(em_all[rows]).reshape(-1, 1)))
+            probe, nm, em = cache["probe"], cache["nm"], cache["em"]
             cp._override, cp._override_used = pred, False
             try:
                 val = target(probe, nm, em, torch.full((B, 1), float(t)))
@@ -354,6 +358,7 @@ class GaudiModel:
                     raise GaudiError("target_function must be callable")
                 # the reference's own form: a closure over (z, node_mask, edge_mask, t) that calls cond_predictor
                 self._trace_N, self._trace_nm, self._trace_em = N, nm.reshape(B, N, 1), em.reshape(B * N * N, 1)
+                self._trace_cache = {}
                 target = self._trace_closure(target)
             if target.cond_predictor.engine is not self.engine:
                 raise GaudiError("the target's predictor must be attached to this model (get_cond_predictor_model(..., model=model))")
