@@ -6,6 +6,11 @@
 #include <vector>
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 mfma1(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 mfma_bf(u4 a, u4 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
 constexpr int T = 13;
 
 #ifndef NWV
@@ -191,6 +196,83 @@ __global__ __launch_bounds__(NWV * 64) void k(const float* __restrict__ w, int n
   out[blockIdx.x * 512 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
+// Pre-split node-GEMM weights (three bf16 pieces = 1.5x the bytes, six piece products on v_mfma_f32_16x16x32_bf16): per
+// (tile, 32-input chunk) three 1 KiB loads and six matrix instructions; 7 chunks per H = 208 matrix (the real one: 6.5);
+// activations as static registers.  Ping-pong over chunks like the fp32 form.  LOADS / MFMAS select the parts.
+template <int NW, bool LOADS, bool MFMAS>
+__global__ __launch_bounds__(NWV * 64) void ks(const float* __restrict__ w, int n_mat, int iters, float* out) {
+  constexpr int UT = (T + NW - 1) / NW;
+  constexpr int NC = 7;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7fffffff, 0x00020000);
+  auto ld = [&](int off_floats) { return __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, off_floats * 4, 0)); };
+  f4 acc[UT];
+  for (int u = 0; u < UT; ++u) acc[u] = (f4){0, 0, 0, 0};
+  const u4 bh = (u4){0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, bm = bh + 1u, bl = bh + 2u;
+  u4 side = (u4){0, 0, 0, 0};
+  struct Set { u4 h[UT], m[UT], l[UT]; };
+  auto mm = [&](const Set& a) {
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      acc[u] = mfma_bf(a.l[u], bh, acc[u]);
+      acc[u] = mfma_bf(a.h[u], bl, acc[u]);
+      acc[u] = mfma_bf(a.m[u], bm, acc[u]);
+      acc[u] = mfma_bf(a.m[u], bh, acc[u]);
+      acc[u] = mfma_bf(a.h[u], bm, acc[u]);
+      acc[u] = mfma_bf(a.h[u], bh, acc[u]);
+    }
+  };
+  auto use = [&](const Set& a) {
+    if (MFMAS) mm(a);
+    else
+      for (int u = 0; u < UT; ++u) side += a.h[u] + a.m[u] + a.l[u];
+  };
+  for (int it = 0; it < iters; ++it) {
+    const int base = (it % n_mat) * (T * T * 256);  // (same footprint per matrix as the fp32 form x 1.5: NC * 16 * 3 units)
+    auto load = [&](Set& a, int cc) {
+      const int c = cc < NC ? cc : NC - 1;
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int t = wave + NW * u;
+        const int off = base / 2 * 3 + ((c * 16 + (t < 16 ? t : 0)) * 3) * 256;
+        a.h[u] = ld(off); a.m[u] = ld(off + 256); a.l[u] = ld(off + 512);
+      }
+    };
+    Set A, B;
+    if (LOADS) load(A, 0); else { for (int u = 0; u < UT; ++u) { A.h[u] = bh; A.m[u] = bm; A.l[u] = bl; } B = A; }
+#pragma unroll 1
+    for (int cc = 0; cc < NC - 1; cc += 2) {
+      if (LOADS) load(B, cc + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      use(A);
+      __builtin_amdgcn_sched_barrier(0);
+      if (LOADS) load(A, cc + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      use(B);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    use(A);
+    __syncthreads();
+  }
+  f4 s = acc[0];
+  for (int u = 1; u < UT; ++u) s += acc[u];
+  out[blockIdx.x * 512 + threadIdx.x] = s[0] + s[1] + s[2] + s[3] + (float)(side[0] ^ side[1] ^ side[2] ^ side[3]);
+}
+template <int NW, bool LOADS, bool MFMAS>
+void run_s(const float* dw, int n_mat, int iters, int blocks, float* dout, const char* name) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  ks<NW, LOADS, MFMAS><<<blocks, NW * 64>>>(dw, n_mat, 8, dout);
+  (void)hipEventRecord(e0);
+  ks<NW, LOADS, MFMAS><<<blocks, NW * 64>>>(dw, n_mat, iters, dout);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  { hipError_t e = hipGetLastError(); if (e != hipSuccess) printf("  launch error: %s\n", hipGetErrorString(e)); }
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("%-34s n_mat %3d blocks %3d: %.2f us per matrix (7 chunks x 16 tiles x 3 KiB = 336 KB split image)\n", name, n_mat, blocks,
+         ms * 1e3 / iters);
+}
+
 template <int SCHED, int NW>
 void run(const float* dw, int n_mat, int iters, int blocks, float* dout, const char* name) {
   hipEvent_t e0, e1;
@@ -212,7 +294,7 @@ int main() {
   float* dw; (void)hipMalloc(&dw, (size_t)n_mat * 169 * 1024);
   (void)hipMemset(dw, 0, (size_t)n_mat * 169 * 1024);
   float* dout; (void)hipMalloc(&dout, 256 * 512 * 4);
-  for (int nm : {1, 240}) {
+  for (int nm : {1, 120, 240}) {
     run<2, NWV>(dw, nm, 2000, 256, dout, "loads only");
     run<3, NWV>(dw, nm, 2000, 256, dout, "MFMA only");
     run<0, NWV>(dw, nm, 2000, 256, dout, "loads + MFMA, ping-pong");
@@ -224,6 +306,11 @@ int main() {
     run<8, NWV>(dw, nm, 2000, 256, dout, "ping-pong, MFMA phase at prio 2");
     run<9, NWV>(dw, nm, 2000, 256, dout, "ping-pong, loads at prio 2");
     run<10, NWV>(dw, nm, 2000, 256, dout, "weights by LDS-DMA + ds_read");
+    if (nm <= 160) {  // (the split image is 1.5x: 160 matrices fill the allocation)
+      run_s<NWV, true, false>(dw, nm, 2000, 256, dout, "pre-split weights: loads only");
+      run_s<NWV, false, true>(dw, nm, 2000, 256, dout, "pre-split weights: MFMA only");
+      run_s<NWV, true, true>(dw, nm, 2000, 256, dout, "pre-split weights: loads + MFMA");
+    }
   }
   return 0;
 }
