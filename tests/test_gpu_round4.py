@@ -435,6 +435,41 @@ def test_v8g_kernels_agree_with_the_resident_kernels(widths):
     assert rel_err(outs[1][3], O.step_guided(esd, eargs, psd, pargs, gamma, 2, z, nm3, em, eps, w, 0.6)) < 1e-4
 
 
+def test_one_round_graph_on_the_mr_kernels_matches_the_one_round_kernels():
+    """The MR kernels (several rounds of eight edge tiles) publish the LAST round's du from registers and park only the earlier
+    rounds' in the stash.  Forced onto one-round graphs (GAUDI_FORCE_MR=1: the cata C3 shape and a ragged hetero batch) they
+    run no parking at all and must agree with the one-round kernels to 5e-6 (two instantiations of one template) for the
+    predictor's gradient and a guided step, and reproduce a guided chain bit for bit from call to call."""
+    from gaudi_amd.sampling_edm import build_masks
+    T = 8
+    for ds, rings, pad in (("cata", [11, 11, 7], 11), ("hetro", [3, 10, 6], 10)):
+        F = synth.num_node_features(ds)
+        eargs, pargs = synth.edm_args(dataset=ds, diffusion_steps=T), synth.pred_args(dataset=ds)
+        esd = synth.synth_edm_state_dict(eargs, F, seed=41, amplify_coord=True)
+        psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=42, amplify_coord=True)
+        nm3, em_flat, N = build_masks(rings, pad, ds != "cata")
+        B = len(rings)
+        nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+        rng = np.random.default_rng(7)
+        z = (rng.standard_normal((B, N, 3 + F)).astype(np.float32)) * nm3
+        eps = rng.standard_normal((B, N, 3 + F)).astype(np.float32)
+        t = np.full(B, 0.4, np.float32)
+        w = np.array([3, 0, 1, 1, 0], np.float32)
+        dp = np.broadcast_to(w * np.float32(0.6), (B, 5)).copy()
+        outs = []
+        for env in ({}, {"GAUDI_FORCE_MR": 1}):
+            eng = _engine(eargs, esd, pargs, psd, **env)
+            pred, grad = eng.predictor_grad(z, t, nm, em, dp)
+            zs = eng.step(3, z, nm, em, eps, target_w=w, scale=0.6)
+            x, h, _ = eng.sample(nm, em, seed=9, target_w=w, scale=0.6)
+            xb, _, _ = eng.sample(nm, em, seed=9, target_w=w, scale=0.6)
+            assert np.array_equal(x, xb)
+            outs.append((pred, grad, zs))
+            eng.close()
+        for a, b in zip(*outs):
+            assert rel_err(b, a) < 5e-6
+
+
 def test_v8g_takes_over_where_lds_ends_and_v4g_where_eight_waves_end():
     """Default widths: hetero 15 rings = 30 graph nodes do not fit LDS -> V8G (8 waves, node buffers in global memory), against the
     oracle; GAUDI_GN8=0 restores round 3's choice (the 4-wave V4G kernels), which must agree at 1e-4."""
