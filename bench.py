@@ -440,11 +440,12 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     npairs = units
     G = len(ncols)  # workgroups per call: molecules, or groups of molecules when the call packs
     pa = pargs if guided else None
-    cnt = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, pa, variant) for b in range(G)], dtype=np.float64).sum(0)
-    cnt_edm = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, None, variant) for b in range(G)], dtype=np.float64).sum(0)
+    mct = 3 if v8g else 2  # column tiles per node-GEMM pass (V8G: 33..48 node columns in one pass of three)
+    cnt = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, pa, variant, mct) for b in range(G)], dtype=np.float64).sum(0)
+    cnt_edm = np.array([flops.step_mfma_counts(npairs[b], int(ncols[b]), eargs, None, variant, mct) for b in range(G)], dtype=np.float64).sum(0)
     equiv_variant = "w8" if variant == "w8s" else variant  # the same work issued as fp32 matrix instructions
-    mfma_step = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, pa, equiv_variant) for b in range(G))
-    edm_only = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, None, equiv_variant) for b in range(G))
+    mfma_step = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, pa, equiv_variant, mct) for b in range(G))
+    edm_only = sum(flops.step_mfma_issued(npairs[b], int(ncols[b]), eargs, None, equiv_variant, mct) for b in range(G))
     useful_step = B * flops.step_flops_useful(live_edges, live_nodes, F, eargs, pa, K)
     written_step = B * flops.step_flops_as_written(N, F, eargs, pa, K)
     # per launch: `steps_done` reverse steps + one decode pass (= one EDM evaluation) per call, over n_launch launches

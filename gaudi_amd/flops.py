@@ -71,7 +71,7 @@ def _has_ktail(nf, HP):
     return nf % 16 == 4 and HP - nf == 12
 
 
-def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4"):
+def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4", max_col_tiles=2):
     """(fp32, bf16) matrix instructions ONE molecule issues per reverse step, counted from the kernels' loop structure
     (validated against SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 and SQ_INSTS_VALU_MFMA_MOPS_BF16 / 32: profiles/*pmc_summary.csv).
     fp32 = v_mfma_f32_16x16x4_f32 EQUIVALENTS (1 024 MACs, 32 matrix-pipe cycles on a SIMD): a 4x4x1_16B instruction of the
@@ -81,9 +81,10 @@ def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4"):
     variant "w8"  (8 waves, 16-edge tiles, fp32 MFMAs):        edge_units = number of 16-edge tiles of the molecule
     variant "w8s" (8 waves, edge GEMMs on split-bf16 operands: six v_mfma_f32_16x16x32_bf16 per output tile and 32 inputs,
                    a K tail as one fp32 k-step per tile; node GEMMs as w8)
-    ncols = node columns the node-level GEMMs produce (16-column tiles, pairs of tiles beyond 16)."""
+    ncols = node columns the node-level GEMMs produce (16-column tiles, pairs of tiles beyond 16; max_col_tiles = 3 -- the V8G
+    kernels -- runs 33..48 columns as one pass over three tiles, w8_common.h: node_gemm_n)."""
     ncols = int(ncols)
-    nt = 1 if ncols <= 16 else 2 * (((ncols + 15) // 16 + 1) // 2)
+    nt = 1 if ncols <= 16 else (3 if max_col_tiles >= 3 and 32 < ncols <= 48 else 2 * (((ncols + 15) // 16 + 1) // 2))
     if variant == "w4":
         waves, pairs = 4, int(sum(int(v) for v in edge_units))
         tiles16 = 2 * pairs
@@ -122,9 +123,9 @@ def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4"):
     return f32, bf
 
 
-def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4"):
+def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4", max_col_tiles=2):
     """fp32 matrix instructions per molecule-step of the fp32-MFMA kernel families (see step_mfma_counts)."""
-    return step_mfma_counts(edge_units, ncols, edm, pred, variant)[0]
+    return step_mfma_counts(edge_units, ncols, edm, pred, variant, max_col_tiles)[0]
 
 
 def step_weight_stream_bytes(edm, pred=None, variant="w8s", rounds=1):
