@@ -159,38 +159,103 @@ class _DirectZ(Exception):
     pass
 
 
+# autograd nodes a function that is affine in its leaf can be built from (name without the "BackwardN" suffix).  Anything else
+# -- clamp, where, abs, threshold, relu, pow, exp ... -- is "not affine", whatever the numerical probes say: the backward pass of
+# a mask-style kink (clamp / where / masked_fill) carries no grad_fn either, and random probes only see the side of the kink
+# they land on.  Products / quotients of two pred-dependent factors pass this list and are caught by the
+# differentiable-gradient check below.
+_AFFINE_NODES = frozenset((
+    "Neg", "Mul", "Add", "Sub", "Rsub", "Div", "Select", "Slice", "Index", "IndexSelect", "Gather", "Narrow", "Sum", "Mean",
+    "View", "Reshape", "UnsafeView", "Squeeze", "Unsqueeze", "Expand", "Repeat", "T", "Transpose", "Permute", "Clone",
+    "Contiguous", "Cat", "Stack", "Unbind", "Split", "SplitWithSizes", "Chunk", "ToCopy", "Alias", "Copy", "CopySlices",
+    "AsStrided", "Mm", "Mv", "Dot", "Addmm", "Matmul", "Bmm", "Linear", "AccumulateGrad", "Flatten", "Unflatten", "Movedim",
+    "Diagonal", "Flip", "Roll", "Addcmul"))
+
+
+def _graph_is_affine(val) -> bool:
+    """Every node of val's autograd graph is one a linear map is made of (no kinks, no transcendental functions)."""
+    seen, todo = set(), [val.grad_fn]
+    while todo:
+        node = todo.pop()
+        if node is None or node in seen:
+            continue
+        seen.add(node)
+        name = type(node).__name__
+        cut = name.find("Backward")
+        if (name[:cut] if cut >= 0 else name) not in _AFFINE_NODES:
+            return False
+        todo.extend(fn_ for fn_, _ in node.next_functions)
+    return True
+
+
+def _affine_probe(fn, p, t, ref):
+    """One probe of affine_target_weights: -> dT/dpred of row 0 (== ref in every row when ref is given), or None."""
+    import torch
+    with torch.enable_grad():
+        val = fn(p, t)
+        if not torch.is_tensor(val) or not val.requires_grad or not _graph_is_affine(val):
+            return None
+        (g,) = torch.autograd.grad(val.sum(), p, create_graph=True, allow_unused=True)
+    if g is None or g.requires_grad:
+        return None  # no dependence on pred at all / the gradient depends on pred: not affine
+    g = g.detach()
+    if not bool(torch.isfinite(g).all()):
+        return None
+    if ref is None:
+        ref = g[0].clone()
+    return ref if bool((g == ref[None]).all()) else None
+
+
 def affine_target_weights(fn, K: int, T: int, B: int = 3):
-    """-> w [K] if fn(pred [B,K], t) -> [B] is  w . pred + c  with the same w for every molecule and every t, else None.
-    Checked on the autograd graph (dT/dpred must not depend on pred: asked for a differentiable gradient, it carries no
-    grad_fn -- all Hessian-vector products vanish identically) and numerically: bit-equal gradients at four random
-    predictions of very different magnitude, at the first reverse step's t = 1, the last step's t = 1/T and one in between,
-    and in every row of the batch.  Anything the probe cannot digest is 'not affine' (the general callback path)."""
+    """-> w [K] if fn(pred [B,K], t) -> [B] is  w . pred + c  with the same non-zero w for every molecule and every t, else
+    None.  Three independent checks, all of which must hold: (i) the autograd graph of the value consists of linear nodes only
+    (_AFFINE_NODES: a clamp / where / abs is refused by name, wherever its kink lies); (ii) dT/dpred does not depend on pred --
+    asked for a differentiable gradient, it carries no grad_fn (all Hessian-vector products vanish identically); (iii)
+    numerically: bit-equal gradients at random predictions of five very different magnitudes, at the first reverse step's
+    t = 1, the last step's t = 1/T and one in between, and in every row of the batch.  w = 0 is 'not affine' too: the fused
+    kernel would run an unguided chain where the callback path follows the closure faithfully (e.g. a closure that is
+    switched off outside a window of t).  The probe visits three values of t; affine_gradient_holds() visits ALL of the
+    chain's (GaudiModel._run runs it beside the device call).  Anything the probe cannot digest is 'not affine' (the general
+    callback path, which is always correct)."""
     import torch
     gen = torch.Generator().manual_seed(1234)  # (torch's default generator keys the noise: not touched)
     ref = None
     try:
-        for scale_p in (1.0, 1e-2, 30.0, 1e3):
+        for scale_p in (1.0, 1e-2, 30.0, 1e3, 1e6):
             for t in (1.0, 0.5, 1.0 / max(int(T), 1)):
                 p = (torch.randn(B, K, generator=gen) * scale_p).requires_grad_(True)
-                with torch.enable_grad():
-                    val = fn(p, t)
-                    if not torch.is_tensor(val) or not val.requires_grad:
-                        return None
-                    (g,) = torch.autograd.grad(val.sum(), p, create_graph=True, allow_unused=True)
-                if g is None or g.requires_grad:
-                    return None  # no dependence on pred at all / the gradient depends on pred: not affine
-                g = g.detach()
-                if not bool(torch.isfinite(g).all()):
-                    return None
+                ref = _affine_probe(fn, p, t, ref)
                 if ref is None:
-                    ref = g[0].clone()
-                if not bool((g == ref[None]).all()):
                     return None
     except GaudiError:
         raise
     except Exception:
         return None
+    if not bool((ref != 0).any()):
+        return None
     return ref.numpy().astype(np.float32)
+
+
+def affine_gradient_holds(fn, w, T: int) -> bool:
+    """The closure that affine_target_weights recognised, held to its weight vector at EVERY t the chain passes to it --
+    (s + 1) / T as float32, s = 0 .. T-1 (gaudi_hip.hip: sample_cb_impl) -- with rows of four magnitudes per call.  A closure
+    whose python control flow depends on t (a guidance window) passes the three-point probe when the probe's points fall
+    outside the window; this visits them all (T small torch evaluations; GaudiModel._run overlaps them with the device call)."""
+    import torch
+    K = int(len(w))
+    ref = torch.from_numpy(np.asarray(w, np.float32))
+    gen = torch.Generator().manual_seed(4321)
+    base = torch.randn(4, K, generator=gen) * torch.tensor([[1.0], [1e-2], [30.0], [1e3]])
+    try:
+        for s in range(int(T)):
+            t = float(np.float32(s + 1) / np.float32(T))
+            if _affine_probe(fn, base.clone().requires_grad_(True), t, ref) is None:
+                return False
+    except GaudiError:
+        raise
+    except Exception:
+        return False
+    return True
 
 
 def target_function_max_gap(cond_predictor) -> LinearTarget:
@@ -377,12 +442,33 @@ class GaudiModel:
             else:
                 tw = None if target is None else target.weights
                 fn = getattr(target, "_closure_fn", None)
+                holds, checker = [True], None
+                if fn is not None:
+                    # the closure was recognised as affine at three values of t; while the device runs the fused chain, the host
+                    # holds it to that weight vector at every t of the chain (a closure with a guidance window)
+                    import threading
+
+                    def _check_all_t():
+                        try:
+                            holds[0] = affine_gradient_holds(fn, tw, self.T)
+                        except BaseException:
+                            holds[0] = False
+                    checker = threading.Thread(target=_check_all_t, daemon=True)
+                    checker.start()
                 out = self.engine.sample(nm.reshape(B, N), em, seed=seed, sample_offset=off, noise=self.injected_noise, std=std,
                                          target_w=tw, scale=scale, return_z0=fn is not None)
                 x, h, diag = out[0], out[1], out[2]
-                if fn is not None:
-                    # the closure was recognised as affine on probe predictions; hold it to that at the predictions the chain
-                    # actually ended on (a piecewise-linear closure whose kink the probes missed must not pass silently)
+                if checker is not None:
+                    checker.join()
+                if fn is not None and not holds[0]:
+                    # not the affine function the probe saw: the fused result is discarded and the SAME call (same noise stream)
+                    # runs through the general path, which differentiates the closure at every step
+                    pt = PredTarget(target.cond_predictor, fn, name=target.name + " -> callback")
+                    x, h, diag = self.engine.sample_callback(nm.reshape(B, N), em, pt.grad, seed=seed, sample_offset=off,
+                                                             noise=self.injected_noise, std=std, scale=scale)
+                    diag = dict(diag, affine_recheck_failed=1)
+                elif fn is not None:
+                    # ... and at the predictions the chain actually ended on
                     import torch
                     t_last = 1.0 / self.T
                     p0 = torch.from_numpy(self.engine.predictor_fwd(out[3], t_last, nm.reshape(B, N), em)).requires_grad_(True)

@@ -133,6 +133,18 @@ def test_affine_target_probe():
     assert A(lambda p, t: torch.zeros(3), 5, 1000) is None                         # does not depend on pred
     assert A(lambda p, t: p[:, 0].abs(), 5, 1000) is None                          # piecewise linear
     assert A(lambda p, t: (p[:, 0] / 0.0), 5, 1000) is None                        # non-finite gradient
+    # kinks whose backward pass is a mask (no grad_fn on the gradient) and that random probes do not reach
+    assert A(lambda p, t: -torch.clamp(p[:, 1], -5e3, 5e3), 5, 1000) is None
+    assert A(lambda p, t: torch.where(p[:, 1] > 7e3, 2 * p[:, 1], p[:, 1]), 5, 1000) is None
+    # ... a closure that is switched off at the probed t (w = 0 would run an unguided chain without a word)
+    assert A(lambda p, t: (-p[:, 1] if 0.1 < t < 0.4 else 0 * p[:, 1]), 5, 1000) is None
+    # ... and one whose weight changes inside a window the three-point probe misses: recognised, then caught by the all-t check
+    from gaudi_amd.models_edm import affine_gradient_holds as H
+    windowed = lambda p, t: (-p[:, 1] if not (0.6 < t < 0.9) else -2 * p[:, 1])
+    w = A(windowed, 5, 1000)
+    np.testing.assert_array_equal(w, [0, -1, 0, 0, 0])
+    assert not H(windowed, w, 1000)
+    assert H(lambda p, t: -p[:, 1], w, 1000)
 
 
 def test_property_norm_accepts_torch_predictions_that_require_grad():
