@@ -95,7 +95,7 @@ struct PredLayerW {
     V = L0 + 14 * PK;
     cr = sVec; cd = sVec + HP; b1 = sVec + 2 * HP; b2 = sVec + 3 * HP; wa = sVec + 4 * HP; bc1 = sVec + 5 * HP;
     wc2 = sVec + 6 * HP; bn1 = sVec + 7 * HP; bn2 = sVec + 8 * HP;
-    ba = w[V + 9 * HP];
+    ba = gload(w + V + 9 * HP);
   }
 };
 

@@ -31,6 +31,7 @@ struct NetSmem {
   __device__ void carve(float* base, int N, int S, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
     ring = base; base += EdgeRing<HP, SP>::kFloats;   // first: 1 KiB tiles stay 16-byte aligned whatever N is
+    if (GN) gnode = assume_global(gnode);
     float*& nb = GN ? gnode : base;
     h = nb; nb += N * LD;
     p = nb; nb += N * LD;
@@ -146,9 +147,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int n = idx / HP, f = idx % HP;
       float acc = 0.f;
       const float m = mg.mask[n];
-      for (int k = 0; k < F; ++k) acc += ew[f * F1 + k] * (sZ[n * D + 3 + k] * m);
-      acc += ew[f * F1 + F] * t_val;
-      sm.h[n * LD + f] = acc + eb[f];
+      for (int k = 0; k < F; ++k) acc += gload(ew + f * F1 + k) * (sZ[n * D + 3 + k] * m);
+      acc += gload(ew + f * F1 + F) * t_val;
+      sm.h[n * LD + f] = acc + gload(eb + f);
     }
   }
   __syncthreads();
@@ -315,9 +316,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
     const float* hh = sm.h;
     const float* msk = mg.mask;
     small_dots<kThreads>(
-        N * F, HP, tid, [=](int p, int k) { return ow[(p % F) * HP + k]; },
+        N * F, HP, tid, [=](int p, int k) { return gload(ow + (p % F) * HP + k); },
         [=](int p, int k) { return hh[(p / F) * LD + k]; },
-        [=](int p, float acc) { sEps[(p / F) * D + 3 + p % F] = (acc + ob[p % F]) * msk[p / F]; });
+        [=](int p, float acc) { sEps[(p / F) * D + 3 + p % F] = (acc + gload(ob + p % F)) * msk[p / F]; });
     // `if torch.any(torch.isnan(vel)): vel = torch.nan_to_num(vel, 0.0)` (models.py:138-141), triggered per molecule
     // (= per component of a packed graph)
     int badmask = 0;

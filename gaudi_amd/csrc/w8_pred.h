@@ -34,6 +34,7 @@ struct PredSmem {
   __device__ void carve(float* base, int N, int S, int pubx, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
     if (SP == 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // fp32 form: the ring stays busy across the publish phase
+    if (GN) gnode = assume_global(gnode);
     float*& nb = GN ? gnode : base;
     b2 = nb; nb += N * LD;
     b3 = nb; nb += N * LD;
@@ -111,9 +112,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       const int n = idx / HP, f = idx % HP;
       float acc = 0.f;
       const float m = mg.mask[n];
-      for (int k = 0; k < F; ++k) acc += ew[f * F1 + k] * (sZ[n * D + 3 + k] * m);
-      acc += ew[f * F1 + F] * t_val;
-      h[n * LD + f] = acc + eb[f];
+      for (int k = 0; k < F; ++k) acc += gload(ew + f * F1 + k) * (sZ[n * D + 3 + k] * m);
+      acc += gload(ew + f * F1 + F) * t_val;
+      h[n * LD + f] = acc + gload(eb + f);
     }
   }
   __syncthreads();
@@ -140,7 +141,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       agg1[idx] = 0.f;
     }
     float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
-    for (int idx = tid; idx < N; idx += kThreads) ((f4*)(st + 3 * N * HP))[idx] = *(const f4*)(sm.x + 4 * idx);
+    for (int idx = tid; idx < N; idx += kThreads) gstore4((f4*)(st + 3 * N * HP) + idx, *(const f4*)(sm.x + 4 * idx));
     compute_geo(sm, mg, 1.0f, tid, false);  // gcl.py:308-316
     if constexpr (GN) stage_wait();
     else __syncthreads();
@@ -190,7 +191,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         }
         float a = 1.f;
         if (W.attention) a = sigmoid_f(reduce_groups(sdot) + Lw.ba);
-        if (g == 0) astash[(size_t)l * S + tc.slot] = a;
+        if (g == 0) gstore(astash + (size_t)l * S + tc.slot, a);
         const float sc = a * tc.mk;
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = acc[t] * sc;  // e_ij (gcl.py:231-237)
@@ -218,7 +219,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
             sdot += dot4(sl, *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
           }
           const float phi = reduce_groups(sdot);
-          if (g == 0) pstash[(size_t)l * S + tc.slot] = phi;
+          if (g == 0) gstore(pstash + (size_t)l * S + tc.slot, phi);
           const float tau = (W.use_tanh ? tanhf(phi) * W.coords_range_layer : phi) * tc.mk;
           if (g == 0) *(f4*)(sm.trans + 4 * tc.slot) = (f4){gg[1] * tau, gg[2] * tau, gg[3] * tau, 0.f};
         }
@@ -264,9 +265,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     const float* ob = w + lay.out_b();
     const float* msk = mg.mask;
     small_dots<kThreads>(
-        N * K, HP, tid, [=](int qq, int f) { return ow[(qq % K) * HP + f]; },
+        N * K, HP, tid, [=](int qq, int f) { return gload(ow + (qq % K) * HP + f); },
         [=](int qq, int f) { return h[(qq / K) * LD + f]; },
-        [=](int qq, float acc) { p[qq] = (acc + ob[qq % K]) * msk[qq / K]; });
+        [=](int qq, float acc) { p[qq] = (acc + gload(ob + qq % K)) * msk[qq / K]; });
     __syncthreads();
     if (tid < K) {
       float s = 0.f;
@@ -324,7 +325,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     for (int idx = tid; idx < N * HP; idx += kThreads) {
       const int n = idx / HP, f = idx % HP;
       float acc = 0.f;
-      for (int k = 0; k < K; ++k) acc += (dpred[k] / readout_div) * ow[k * HP + f];
+      for (int k = 0; k < K; ++k) acc += (dpred[k] / readout_div) * gload(ow + k * HP + f);
       dh[n * LD + f] = acc * mg.mask[n];
     }
     for (int idx = tid; idx < N * 4; idx += kThreads) sm.dx[idx] = 0.f;
@@ -362,7 +363,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       *(f4*)(dh + n * LD + f) = *(const f4*)(dh + n * LD + f) * mg.mask[n];
     }
     for (int idx = tid; idx < N; idx += kThreads) {
-      *(f4*)(sm.x + 4 * idx) = ((const f4*)(st + 3 * N * HP))[idx];
+      *(f4*)(sm.x + 4 * idx) = gload4((const f4*)(st + 3 * N * HP) + idx);
       *(f4*)(sm.dx + 4 * idx) = *(const f4*)(sm.dx + 4 * idx) * mg.mask[idx];
     }
     __syncthreads();
@@ -403,7 +404,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       {
         f4 de[T];
         if (tc.active) {
-          a = astash[(size_t)l * S + tc.slot];
+          a = gload(astash + (size_t)l * S + tc.slot);
           dtx = sm.dx[4 * tc.i + 0];  // dtrans = dx'_i
           dty = sm.dx[4 * tc.i + 1];
           dtz = sm.dx[4 * tc.i + 2];
@@ -414,7 +415,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
             const f4* sc = (const f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
 #pragma unroll
             for (int t = 0; t < T; ++t) cp[t] = stash_load(sc + t * 64);  // silu'(cpre)
-            const float phi = pstash[(size_t)l * S + tc.slot];
+            const float phi = gload(pstash + (size_t)l * S + tc.slot);
             const float th = tanhf(phi);
             tau = W.use_tanh ? th * W.coords_range_layer : phi;
             const float dtau = (dtx * gg[1] + dty * gg[2] + dtz * gg[3]) * tc.mk;
@@ -592,7 +593,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     }
     const float* msk = mg.mask;
     small_dots<kThreads>(
-        N * F, HP, tid, [=](int qq, int f) { return ew[f * F1 + qq % F]; },
+        N * F, HP, tid, [=](int qq, int f) { return gload(ew + f * F1 + qq % F); },
         [=](int qq, int f) { return dh[(qq / F) * LD + f]; },
         [=](int qq, float acc) { sGrad[(qq / F) * D + 3 + qq % F] = acc * msk[qq / F]; });
   }
