@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libgaudi_hip.so")
-HEADERS = ["device_common.h", "edm_device.h", "pred_device.h", "sampler_kernel.h", "w8_common.h", "w8_split.h", "w8_edm.h", "w8_pred.h", "pred_host.inc", "stability.inc",
+HEADERS = ["device_common.h", "edm_device.h", "pred_device.h", "sampler_kernel.h", "w8_common.h", "w8_split.h", "w8_nodes_f16.h", "w8_edm.h", "w8_pred.h", "pred_host.inc", "stability.inc",
            os.path.join("..", "..", "include", "gaudi_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
 

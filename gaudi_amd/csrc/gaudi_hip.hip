@@ -75,6 +75,8 @@ struct gaudi_handle {
   DevBuf edm_w, pred_w, coef_d, edm_w4, pred_w4;  // *_w4: row-major tiles for the 4-wave fallback of an 8-wave handle
   DevBuf edm_ws, pred_ws;                         // split-bf16 images of the edge-GEMM matrices (w8_split.h)
   size_t edm_w_bytes = 0, pred_w_bytes = 0, edm_ws_bytes = 0, pred_ws_bytes = 0;
+  float edm_hinv = 0.f, pred_hinv = 0.f;  // 2^-s of the fp16-pair node images inside *_ws (w8_nodes_f16.h); 0: the weight set
+                                          // was refused (node_scale) -- its calls run the fp32-instruction kernels
   std::vector<float> gamma, coef;
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
@@ -276,6 +278,11 @@ struct Tensors {
     }
     return it->second.first;
   }
+  // the tensor if it is there with that size (no complaint: get() of the same tensor reports what is wrong)
+  const float* peek(const std::string& k, int64_t numel) const {
+    auto it = m.find(k);
+    return it == m.end() || it->second.second != numel ? nullptr : it->second.first;
+  }
 };
 
 // Packing context of one checkpoint load (a value passed down -- no file-scope state: two handles may load concurrently).
@@ -290,6 +297,8 @@ struct PackMode {
   bool ktail = false;
   float* wbase = nullptr;
   std::vector<float>* ws = nullptr;
+  float hscale = 0.f;   // 2^s of the network's fp16-pair node images (w8_nodes_f16.h); 0: no such images
+  bool hktail = false;  // ... their K tail (H % 16 == 4)
   PackMode with_ktail(bool kt) const {
     PackMode m = *this;
     m.ktail = kt;
@@ -355,6 +364,78 @@ static void pack_matrix_split(const PackMode& pm, float* dst, const float* W, in
 static void pack_edge_matrix(const PackMode& pm, float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
   pack_matrix(pm, dst, W, H, ldw, col0, HP, transpose);
   if (pm.ws != nullptr) pack_matrix_split(pm, pm.ws->data() + 2 * (size_t)(dst - pm.wbase), W, H, ldw, col0, HP, transpose);
+}
+// fp16-pair image of a node-GEMM matrix (w8_nodes_f16.h): w 2^s = hi + lo 2^-11 with hi = fp16(w 2^s), lo = fp16((w 2^s - hi) 2^11), both
+// round-to-nearest-even (NaN stays NaN; the host refuses infinite weights, node_scale below).  Units of 1 KiB ordered
+// [K chunk m of 32 inputs][output tile t][piece]; lane L = (row L & 15, group g = L >> 4) holds inputs 32 m + 8 g .. +7.
+// ktail (H % 16 == 4, odd tile count >= 3): the 4 tail inputs are a trailing block of T x 64 floats, UNSCALED fp32 -- lane
+// (row, k - 16 (T - 1)) of tile t: one v_mfma_f32_16x16x4_f32 step per output tile.
+static uint16_t f16_bits(float x) {
+  const _Float16 hv = (_Float16)x;
+  uint16_t u;
+  std::memcpy(&u, &hv, 2);
+  return u;
+}
+static float f16_value(uint16_t b) {
+  _Float16 hv;
+  std::memcpy(&hv, &b, 2);
+  return (float)hv;
+}
+static void pack_matrix_f16(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose, bool ktail, float scale) {
+  const int T = HP / 16;
+  const bool tail = w8::nh_has_tail(HP, ktail);
+  const int nc = w8::nh_chunks(HP, ktail);
+  uint16_t* d = (uint16_t*)dst;
+  for (int o = 0; o < H; ++o)
+    for (int k = 0; k < H; ++k) {
+      const float v = transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k];
+      const int t = o / 16, i = o % 16;
+      if (tail && k >= 16 * (T - 1)) {
+        dst[(size_t)nc * w8::nh_chunk_floats(HP) + t * 64 + (k - 16 * (T - 1)) * 16 + i] = v;
+        continue;
+      }
+      const int m = k / 32, L = ((k % 32) / 8) * 16 + i, e = k % 8;
+      const float vs = v * scale;
+      const uint16_t hi = f16_bits(vs);
+      const uint16_t lo = f16_bits((vs - f16_value(hi)) * 2048.f);
+      d[(((size_t)(m * T + t) * 2 + 0) * 64 + L) * 8 + e] = hi;
+      d[(((size_t)(m * T + t) * 2 + 1) * 64 + L) * 8 + e] = lo;
+    }
+}
+// One power of two for all node matrices of a network: the largest finite |w| lands in [2^13, 2^14).  lo carries its own
+// exponent, so an entry keeps 22 significant bits down to 2^-25 of the largest one and an absolute floor of 2^-50 of it below
+// that (w8_nodes_f16.h).  The form is refused -- the call then runs the fp32-instruction kernels -- when a node matrix holds an
+// infinity (fp16 pieces would turn inf x 0 and inf - inf into NaN where the fp32 product keeps inf) or when some matrix lies
+// more than 2^24 below the largest (nothing a trained network shows; kept as a loud boundary rather than a silent loss).
+struct NodeScale {
+  float gmax = 0.f, min_mat = INFINITY;
+  bool inf = false;
+  void see(const float* W, int rows, int ldw, int col0, int cols) {
+    if (!W) return;
+    float m = 0.f;
+    for (int o = 0; o < rows; ++o)
+      for (int k = 0; k < cols; ++k) {
+        const float a = std::fabs(W[(size_t)o * ldw + col0 + k]);
+        if (std::isinf(a)) inf = true;
+        else if (a == a) m = std::max(m, a);
+      }
+    gmax = std::max(gmax, m);
+    if (m > 0.f) min_mat = std::min(min_mat, m);
+  }
+  // -> 2^s (0: refused)
+  float scale() const {
+    if (inf || !(gmax > 0.f) || min_mat < gmax * 5.9604645e-8f) return 0.f;
+    int ex;
+    std::frexp(gmax, &ex);  // gmax = f 2^ex, f in [0.5, 1)
+    return std::ldexp(1.f, 14 - ex);
+  }
+};
+// A node-GEMM matrix: the fp32 tiles and, when the split buffer is being filled and the network's scale is known, its fp16-pair
+// image at twice the float offset (the split buffer's slots of the node matrices)
+static void pack_node_matrix(const PackMode& pm, float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
+  pack_matrix(pm, dst, W, H, ldw, col0, HP, transpose);
+  if (pm.ws != nullptr && pm.hscale > 0.f)
+    pack_matrix_f16(pm.ws->data() + 2 * (size_t)(dst - pm.wbase), W, H, ldw, col0, HP, transpose, pm.hktail, pm.hscale);
 }
 static void pack_vec(float* dst, const float* v, int n) { std::memcpy(dst, v, sizeof(float) * n); }
 static void pack_col(float* dst, const float* W, int H, int ldw, int col) {
@@ -774,9 +855,19 @@ static bool gn8_stage_fits(int hpe, int hpp, int N) {
 }
 // The reverse pass publishes du of every slot pub_ch feature tiles at a time into [b0 | b1 | pubx extra floats]: pick the
 // largest pub_ch that fits 160 KiB, then the extra floats that choice needs.  false: the molecule does not fit.
+// fp16-pair node GEMMs (every split-operand kernel): the split copy of ONE GEMM input must fit the region the kernels use -- the
+// ring's free slot (full ring), the whole ring where it idles across node phases (half ring, gn) -- for N node columns
+static bool node_f16_fits(int hp, int N, int split, bool gn) {
+  if (!hp || !split || !GAUDI_NODE_F16) return true;
+  if (N > 48) return false;  // at most three column tiles per pass
+  const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
+  const int ring = w8::edge_ring_floats(hp, split);
+  return w8::nh_split_floats(hp, nct) <= (gn || split == 2 ? ring : ring / 2);
+}
 static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pubx, int& pub_ch, bool gn = false) {
   pubx = 0;
   pub_ch = 0;
+  if (!node_f16_fits(hpe, N, split, gn) || !node_f16_fits(hpp, N, split, gn)) return false;
   const long long cap = 160 * 1024 / 4 - 64;  // floats (a little headroom for the runtime's own static LDS)
   const long long base = (long long)lds_floats8_base(hpe, hpp, N, D, S, split, gn);
   if (base > cap) return false;
@@ -965,8 +1056,11 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   int pubx = 0, pub_ch = 0;
   // the arithmetic of the edge GEMMs for S edge slots on NS node slots: split-bf16 when the kernel exists and its larger weight
   // ring fits (1 = full ring, 2 = half ring); else fp32 MFMAs (0); else -1 = this call runs on 4 waves
+  // the split-operand kernels run their node GEMMs on fp16 pairs: a weight set whose images were refused (NodeScale) keeps the
+  // fp32-instruction kernels
+  const bool node_f16_ok = !GAUDI_NODE_F16 || ((!hpe || h->edm_hinv > 0.f) && (!hpp || h->pred_hinv > 0.f));
   auto plan_for = [&](int NS, int S, bool mrk) -> int {
-    if (h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes))
+    if (h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) && node_f16_ok)
       for (int mode = 1; mode <= 2; ++mode)
         if (pick_kernel8_mode(hpe, hpp, mode, mrk) && plan_pub8(hpe, hpp, NS, Dz, S, mode, pubx, pub_ch)) return mode;
     return pick_kernel8_mode(hpe, hpp, 0, mrk) && plan_pub8(hpe, hpp, NS, Dz, S, 0, pubx, pub_ch) ? 0 : -1;
@@ -976,8 +1070,8 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   // buffers in a per-workgroup global scratch (split edge GEMMs, full ring, several rounds of edge tiles) -- before round 4
   // such calls fell to the 4-wave V4G kernels (fp32 matrix instructions, two launches per guided step)
   bool gn8 = false;
-  if ((mode_u < 0 || h->force_gn8) && h->gn8 && h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) &&
-      pick_kernel8g(hpe, hpp) && gn8_stage_fits(hpe, hpp, N) && plan_pub8(hpe, hpp, N, Dz, M.S, 1, pubx, pub_ch, true)) {
+  if ((mode_u < 0 || h->force_gn8) && h->gn8 && h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) && node_f16_ok &&
+      pick_kernel8g(hpe, hpp) && (GAUDI_NODE_F16 || gn8_stage_fits(hpe, hpp, N)) && plan_pub8(hpe, hpp, N, Dz, M.S, 1, pubx, pub_ch, true)) {
     gn8 = true;
     mode_u = 1;
   } else if (h->force_gn8 && mode_u >= 0) {
@@ -1186,6 +1280,7 @@ static void fill_edm(gaudi_handle* h, KParams& P) {
   P.edm.ktail = h->run_variant == 8 && has_ktail(c.hidden_nf, h->HPE);
   P.edm.ws = h->edm_ws.as<float>();
   P.edm.ws_bytes = (unsigned)h->edm_ws_bytes;
+  P.edm.hinv = h->edm_hinv;
   P.coef = h->coef_d.as<float>();
   const float g0 = h->gamma[0];
   P.alpha0 = sqrtf(sigmoid_host(-g0));
@@ -1269,6 +1364,22 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   const int PK = HP * HP;
   // tile layout: lane-linear for the 8-wave kernels, row-major for the 4-wave ones (kept as the fallback of the 8-wave
   // variant for graphs that do not fit it)
+  // the exponent of the fp16-pair node images: every node-GEMM matrix of the network (the A | B column blocks of W1, Wn1, Wn2)
+  float hscale = 0.f;
+  {
+    NodeScale ns;
+    for (int l = 0; l < L; ++l) {
+      for (int s = 0; s <= S; ++s) {
+        const std::string q = p + "e_block_" + std::to_string(l) + (s < S ? ".gcl_" + std::to_string(s) + "." : ".gcl_equiv.");
+        ns.see(T.peek(q + (s < S ? "edge_mlp.0.weight" : "coord_mlp.0.weight"), (int64_t)H * (2 * H + 2)), H, 2 * H + 2, 0, 2 * H);
+        if (s < S) {
+          ns.see(T.peek(q + "node_mlp.0.weight", (int64_t)H * 2 * H), H, 2 * H, 0, 2 * H);
+          ns.see(T.peek(q + "node_mlp.2.weight", (int64_t)H * H), H, H, 0, H);
+        }
+      }
+    }
+    hscale = ns.scale();
+  }
   auto pack = [&](bool lane_linear, std::vector<float>& w, std::vector<float>* ws) {
   w.assign((size_t)lay.total(), 0.f);
   if (ws) ws->assign(2 * (size_t)lay.total(), 0.f);
@@ -1278,6 +1389,8 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   pe.ktail = lane_linear && has_ktail(H, HP);
   pe.wbase = w.data();
   pe.ws = ws;
+  pe.hscale = ws ? hscale : 0.f;
+  pe.hktail = has_ktail(H, HP);
   const PackMode pn = pe.with_ktail(false);
   {
     const float* ew = T.get(p + "embedding.weight", (int64_t)H * F1);
@@ -1313,12 +1426,12 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
         ba = T.get(q + "att_mlp.0.bias", 1);
       }
       if (!(W1 && b1 && W2 && b2 && Wn1 && bn1 && Wn2 && bn2) || (cfg->attention && !(wa && ba))) continue;
-      pack_matrix(pn, G, W1, H, ld1, 0, HP);
-      pack_matrix(pn, G + PK, W1, H, ld1, H, HP);
+      pack_node_matrix(pn, G, W1, H, ld1, 0, HP);
+      pack_node_matrix(pn, G + PK, W1, H, ld1, H, HP);
       pack_edge_matrix(pe, G + 2 * PK, W2, H, H, 0, HP);
-      pack_matrix(pn, G + 3 * PK, Wn1, H, 2 * H, 0, HP);
-      pack_matrix(pn, G + 4 * PK, Wn1, H, 2 * H, H, HP);
-      pack_matrix(pn, G + 5 * PK, Wn2, H, H, 0, HP);
+      pack_node_matrix(pn, G + 3 * PK, Wn1, H, 2 * H, 0, HP);
+      pack_node_matrix(pn, G + 4 * PK, Wn1, H, 2 * H, H, HP);
+      pack_node_matrix(pn, G + 5 * PK, Wn2, H, H, 0, HP);
       pack_col(V, W1, H, ld1, 2 * H);
       pack_col(V + HP, W1, H, ld1, 2 * H + 1);
       pack_vec(V + 2 * HP, b1, H);
@@ -1337,8 +1450,8 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
     const float* b2 = T.get(q + "coord_mlp.2.bias", H);
     const float* w3 = T.get(q + "coord_mlp.4.weight", H);
     if (!(W1 && b1 && W2 && b2 && w3)) continue;
-    pack_matrix(pn, E, W1, H, ld1, 0, HP);
-    pack_matrix(pn, E + PK, W1, H, ld1, H, HP);
+    pack_node_matrix(pn, E, W1, H, ld1, 0, HP);
+    pack_node_matrix(pn, E + PK, W1, H, ld1, H, HP);
     pack_edge_matrix(pe, E + 2 * PK, W2, H, H, 0, HP);
     pack_col(V, W1, H, ld1, 2 * H);
     pack_col(V + HP, W1, H, ld1, 2 * H + 1);
@@ -1360,6 +1473,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
     HIPCHECK(h, hipMemcpy(h->edm_ws.p, ws.data(), sizeof(float) * ws.size(), hipMemcpyHostToDevice));
     h->edm_ws_bytes = sizeof(float) * ws.size();
   }
+  h->edm_hinv = want_split && hscale > 0.f ? 1.0f / hscale : 0.f;
   if (h->variant == 8) {
     pack(false, w, nullptr);
     HIPCHECK(h, h->edm_w4.reserve(sizeof(float) * w.size()));

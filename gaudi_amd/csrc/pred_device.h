@@ -37,6 +37,7 @@ struct PredDev {
   int ktail;                 // as EdmDev::ktail
   const float* ws;           // as EdmDev::ws
   unsigned ws_bytes;
+  float hinv;                // as EdmDev::hinv
 };
 
 template <int HP, bool GN = false>  // GN: node buffers in a per-molecule global scratch (edm_device.h: NetSmem)

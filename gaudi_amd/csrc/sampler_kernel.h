@@ -211,11 +211,11 @@ __device__ __forceinline__ Graph8Args uni(const Graph8Args& a) {
 }
 __device__ __forceinline__ EdmDev uni(const EdmDev& w) {
   return EdmDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.L), uni(w.S), uni(w.attention), uni(w.use_tanh), uni(w.coords_range),
-                uni(w.norm_constant), uni(w.normf), uni(w.ktail), uni(w.ws), uni(w.ws_bytes)};
+                uni(w.norm_constant), uni(w.normf), uni(w.ktail), uni(w.ws), uni(w.ws_bytes), uni(w.hinv)};
 }
 __device__ __forceinline__ PredDev uni(const PredDev& w) {
   return PredDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.K), uni(w.L), uni(w.attention), uni(w.use_tanh), uni(w.coords_range_layer), uni(w.ktail), uni(w.ws),
-                 uni(w.ws_bytes)};
+                 uni(w.ws_bytes), uni(w.hinv)};
 }
 #ifndef GAUDI_STAMPS
 // GN: the node buffers of the phase live in the workgroup's slice of the global scratch (gnode_), everything else in LDS

@@ -5,6 +5,7 @@
 #include "edm_device.h"
 #include "w8_common.h"
 #include "w8_split.h"
+#include "w8_nodes_f16.h"
 
 namespace gaudi {
 namespace w8 {
@@ -156,13 +157,27 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   compute_geo(sm, mg, 0.f, tid, true);  // d0 of the input coordinates (egnn_new.py:301)
   typename EdgeRing<HP, SP>::type ring;
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
-  // GN: the ring is idle during the node phases -- the node GEMMs' input rows are staged in it (w8_common.h: stage_rows),
+  // NH: node GEMMs on fp16 pairs (w8_nodes_f16.h); their inputs' split copies live in the weight ring during the node phases
+  constexpr bool NH = NodeMath<SP>::kF16;
+  // RI: the ring is idle during the node phases -- GN: the node GEMMs' input rows are staged in it (w8_common.h: stage_rows; the
+  // fp16 form's split copies instead); half-ring mode with the fp16 form: its free slot alone would not hold a split copy --
   // and every edge phase requests its first weight group itself instead of having it travel across the node phase
+  constexpr bool RI = GN || (NH && SP == 2);
+  constexpr bool STG = GN && !NH;  // fp32 node GEMMs of a GN kernel read staged rows
   float* const xs0 = sm.ring;
   float* const xs1 = sm.ring + stage_stride(N * LD);
-  if constexpr (!GN) er_start<HP>(ring, wbe, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
-  NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it
-  node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane, tw);
+  if constexpr (!RI) er_start<HP>(ring, wbe, lay.gcl(0, 0) + 2 * PK, wave, lane);  // first edge GEMM: W2 of block 0's first GCL
+  typename NodePFSel<HP, NH>::type pf;  // first weight tiles of the next node GEMM, loaded ahead of it
+  node_prefetch_x<HP, NH, kAheadOne>(pf, wb, wbe, lay.gcl(0, 0), mg.NC, wave, lane, tw);
+  // split-copy region of the node GEMMs of this phase (NH)
+  auto hctx = [&]() {
+    if constexpr (NH) {
+      if constexpr (RI) return node_ctx_h<HP>(sm.ring, EdgeRing<HP, SP>::kFloats, mg.NC, W.hinv, tw);
+      else return node_ctx_h<HP>(ring.slot(ring.par ^ 1), EdgeRing<HP, SP>::kFloats / 2, mg.NC, W.hinv, tw);
+    } else {
+      return NodeCtxH{1.f, nullptr, nullptr, tw};
+    }
+  };
   constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next sub-layer's vectors (GCL: 7 HP + 16 floats, EquivariantUpdate: 5 HP), loaded a phase ahead
   vec_prefetch<NV, kThreads>(vpf, wb, lay.gcl(0, 0) + 6 * PK, 7 * HP + 16, tid);
@@ -176,30 +191,34 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int G = lay.gcl(l, s);  // float offsets into the weight buffer
       const int Wnext_edge = s + 1 < W.S ? lay.gcl(l, s + 1) + 2 * PK : lay.equ(l) + 2 * PK;
       vec_commit<NV, kThreads>(vpf, sm.vec, 7 * HP + 16, tid);
-      if constexpr (GN) stage_rows(xs0, sm.h, N * LD, wave, lane);
+      if constexpr (STG) stage_rows(xs0, sm.h, N * LD, wave, lane);
       for (int idx = tid; idx < N * LD; idx += kThreads) {
         sm.agg[idx] = 0.f;
         sm.agg1[idx] = 0.f;
       }
-      if constexpr (GN) stage_wait();
+      if constexpr (STG) stage_wait();
       else __syncthreads();
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
                   *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
       const float ba = sm.vec[7 * HP];
-      NODE_GEMM(EPI_NONE, wb, G, GN ? xs0 : sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
-                                         G + PK);
-      NODE_GEMM(EPI_NONE, wb, G + PK, GN ? xs0 : sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane,
-                                         tw, &pf, G + 3 * PK);  // node MLP weights travel across the edge phase
+      {
+        const NodeCtxH cx = hctx();
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, G, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
+                                                      wave, lane, tw, cx, pf, G + PK);
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne>(wb, wbe, G + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
+                                                      nullptr, mg.NC, wave, lane, tw, cx, pf,
+                                                      G + 3 * PK);  // node MLP weights travel across the edge phase
+      }
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
-      if constexpr (GN) er_start<HP>(ring, wbe, G + 2 * PK, wave, lane);
+      if constexpr (RI) er_start<HP>(ring, wbe, G + 2 * PK, wave, lane);
       for (int rd = 0; rd < mg.rounds; ++rd) {
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
-        er_gemm_pq<HP>(acc, ring, wbe, G + 2 * PK, rd + 1 < mg.rounds ? G + 2 * PK : (GN ? -1 : Wnext_edge), b2, cr, cd,
+        er_gemm_pq<HP>(acc, ring, wbe, G + 2 * PK, rd + 1 < mg.rounds ? G + 2 * PK : (RI ? -1 : Wnext_edge), b2, cr, cd,
                          sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
         STAMP(ST_EDGE);
         if (tc.active) {
@@ -222,30 +241,31 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       }
       __syncthreads();
       STAMP(ST_BARRIER);
-      if constexpr (GN) stage_rows(xs0, sm.h, N * LD, wave, lane);
+      if constexpr (STG) stage_rows(xs0, sm.h, N * LD, wave, lane);
       for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = (partial 0 + partial 1) / normalization_factor
         const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
-        if constexpr (GN)  // straight into the staged copy (only this GEMM reads agg)
+        if constexpr (STG)  // straight into the staged copy (only this GEMM reads agg)
           *(f4*)(xs1 + n * LD + f) = (*(const f4*)(sm.agg + n * LD + f) + *(const f4*)(sm.agg1 + n * LD + f)) / W.normf;
         else
           *(f4*)(sm.agg + n * LD + f) = (*(const f4*)(sm.agg + n * LD + f) + *(const f4*)(sm.agg1 + n * LD + f)) / W.normf;
       }
-      if constexpr (GN) stage_wait();
+      if constexpr (STG) stage_wait();
       else __syncthreads();
       STAMP(ST_MISC);
-      NODE_GEMM(EPI_SILU, wb, G + 3 * PK, GN ? xs0 : sm.h, G + 4 * PK, GN ? xs1 : sm.agg, bn1, sm.p, nullptr, nullptr,
-                                         mg.NC, wave, lane, tw, &pf, G + 5 * PK);
+      node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne>(wb, wbe, G + 3 * PK, sm.h, xs0, true, G + 4 * PK, sm.agg, xs1, bn1, sm.p, nullptr, nullptr,
+                                              mg.NC, wave, lane, tw, hctx(), pf, G + 5 * PK);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
       vec_prefetch<NV, kThreads>(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK,
                                  s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
-      if constexpr (GN) {
+      if constexpr (STG) {
         stage_rows(xs0, sm.p, N * LD, wave, lane);
         stage_wait();
       }
-      NODE_GEMM(EPI_RESIDUAL_MASK, wb, G + 5 * PK, GN ? xs0 : sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave,
-                                                  lane, tw, &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
+      node_gemm_x<HP, EPI_RESIDUAL_MASK, false, GN, NH, kAheadOne, kAheadOne>(wb, wbe, G + 5 * PK, sm.p, xs0, true, -1, nullptr, nullptr, bn2, sm.h, sm.h, mg.mask,
+                                                       mg.NC, wave, lane, tw, hctx(), pf,
+                                                       s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
@@ -255,7 +275,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int E = lay.equ(l);
       const int Wnext_edge = l + 1 < W.L ? lay.gcl(l + 1, 0) + 2 * PK : -1;
       vec_commit<NV, kThreads>(vpf, sm.vec, 5 * HP, tid);
-      if constexpr (GN) {
+      if constexpr (STG) {
         stage_rows(xs0, sm.h, N * LD, wave, lane);
         stage_wait();
       } else {
@@ -263,19 +283,22 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       }
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
-      NODE_GEMM(EPI_NONE, wb, E, GN ? xs0 : sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
-                                         E + PK);
-      NODE_GEMM(EPI_NONE, wb, E + PK, GN ? xs0 : sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane,
-                                         tw, &pf, l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
+      {
+        const NodeCtxH cx = hctx();
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, E, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
+                                                      wave, lane, tw, cx, pf, E + PK);
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne>(wb, wbe, E + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
+                                                      nullptr, mg.NC, wave, lane, tw, cx, pf, l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
+      }
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
-      if constexpr (GN) er_start<HP>(ring, wbe, E + 2 * PK, wave, lane);
+      if constexpr (RI) er_start<HP>(ring, wbe, E + 2 * PK, wave, lane);
       for (int rd = 0; rd < mg.rounds; ++rd) {
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
-        er_gemm_pq<HP>(acc, ring, wbe, E + 2 * PK, rd + 1 < mg.rounds ? E + 2 * PK : (GN ? -1 : Wnext_edge), b2, cr, cd,
+        er_gemm_pq<HP>(acc, ring, wbe, E + 2 * PK, rd + 1 < mg.rounds ? E + 2 * PK : (RI ? -1 : Wnext_edge), b2, cr, cd,
                          sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
         STAMP(ST_EDGE);
         if (tc.active) {

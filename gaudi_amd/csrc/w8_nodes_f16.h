@@ -30,7 +30,7 @@
 //
 // Schedule.  Output tile t -> wave t & 7 (as the fp32 form).  The activations of a GEMM input are split ONCE by all waves into
 // LDS (wave w: rows w, w + 8, ...; one DPP max-scan per row, no cross-wave step) in B-operand order -- two conflict-free
-// ds_read_b128 per chunk and column tile; the weight stream runs kDepthH chunks ahead in registers, across the two sources of
+// ds_read_b128 per chunk and column tile; the weight stream runs up to a whole matrix ahead in registers (nh_depth), across the two sources of
 // a GEMM and across calls (the next matrix's first chunks travel while this one drains).  Accumulation order per output element:
 // K chunks in order, per chunk w_hi x_lo, w_hi x_hi, w_lo x_hi; then the K tail's fp32 step; sources in order -- independent of
 // the column-tile count and of the wave's tile count (packed launches stay bit-identical to unpacked ones).
@@ -44,7 +44,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(2))) uint32_t u2;
 
-constexpr int kDepthH = 3;        // weight chunks in flight per wave
+#ifndef GAUDI_NODE_ABLATE
+#define GAUDI_NODE_ABLATE 0  // microbenchmark only (timing, wrong results): 1 = no split pass, 2 = no matrix instructions, 4 = no weight loads
+#endif
+constexpr int kAblateH = GAUDI_NODE_ABLATE;
 constexpr float kLoScale = 2048.f;  // 2^11
 
 __device__ __forceinline__ f4 mfma_h(const u4 a, const u4 b, const f4 c) {
@@ -76,6 +79,7 @@ struct SplitBufH {
 };
 
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t absbits(float v) { return __builtin_bit_cast(uint32_t, v) & 0x7fffffffu; }
 // max over the wave of an unsigned value that every lane holds (DPP scan inside the 16-lane rows, then the four row ends)
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   auto shr = [](uint32_t x, auto sh_tag) {
@@ -97,39 +101,57 @@ __device__ __forceinline__ uint32_t pk_f16(float a, float b) {  // round to near
 __device__ __forceinline__ f2 unpk_f16(uint32_t p) { return __builtin_convertvector(__builtin_bit_cast(h2, p), f2); }
 
 // all waves: rows [0, N) of X ([N][HP+4], LDS -- or global for the kernels with node buffers in global memory) -> split
-// B operands.  Wave w owns rows w, w + 8, ...: lane j holds inputs 4 j .. 4 j + 3 of the row.  The caller places a barrier
-// between this and the GEMM's reads.  Columns >= N of the last tile are left as they are: a matrix-instruction column depends
-// on its own B column only and those results are never stored.
+// B operands.  Wave w owns rows w, w + 8, ...: lane j holds inputs 4 j .. 4 j + 3 of the row; two rows travel together so that
+// their LDS round trips and DPP wait states cover each other.  The caller places a barrier between this and the GEMM's reads.
+// Columns >= N of the last tile are left as they are: a matrix-instruction column depends on its own B column only and those
+// results are never stored.
+struct SplitRowH {
+  f4 x;
+  uint32_t mx;
+};
+template <int HP>
+__device__ __forceinline__ SplitRowH split_row_load(const float* X, int n, int lane) {
+  constexpr int LD = HP + 4;
+  SplitRowH r;
+  r.x = lane < HP / 4 ? *(const f4*)(X + n * LD + 4 * lane) : splat(0.f);
+  // (absbits takes the element BY VALUE: __builtin_bit_cast applied to an ext-vector element expression reads element 0
+  // whatever the index -- hipcc 7.2; found as rows whose largest entry was not in a lane's first slot getting the wrong scale)
+  r.mx = umax(umax(absbits(r.x[0]), absbits(r.x[1])), umax(absbits(r.x[2]), absbits(r.x[3])));
+  return r;
+}
+template <int HP>
+__device__ __forceinline__ void split_row_store(const SplitBufH& sb, const f4 x, uint32_t mx, int n, bool tail, int nc, int lane) {
+  constexpr int T = HP / 16;
+  const int m = lane >> 3, g = (lane >> 1) & 3, half = lane & 1;
+  // the row's largest exponent -> 14 (values below 2^15 < 65 504); exponents clamped so that both factors are normal numbers
+  int k = 141 - (int)(mx >> 23);
+  k = k > 126 ? 126 : k;
+  const float s = __builtin_bit_cast(float, (uint32_t)(k + 127) << 23), inv = __builtin_bit_cast(float, (uint32_t)(127 - k) << 23);
+  const float y0 = x[0] * s, y1 = x[1] * s, y2 = x[2] * s, y3 = x[3] * s;
+  const uint32_t h01 = pk_f16(y0, y1), h23 = pk_f16(y2, y3);
+  const f2 f01 = unpk_f16(h01), f23 = unpk_f16(h23);
+  const uint32_t l01 = pk_f16((y0 - f01[0]) * kLoScale, (y1 - f01[1]) * kLoScale),
+                 l23 = pk_f16((y2 - f23[0]) * kLoScale, (y3 - f23[1]) * kLoScale);
+  const int ct = n >> 4, c = n & 15;
+  if (m < nc) {
+    float* d = sb.chunk(m) + ct * 512 + (4 * c + g) * 4 + half * 2;
+    *(u2*)d = (u2){h01, h23};
+    *(u2*)(d + 256) = (u2){l01, l23};
+  }
+  if (tail && lane == 4 * (T - 1)) *(f4*)(sb.tail(HP) + ct * 64 + 4 * c) = x;  // inputs 16 (T-1) .. +3, unscaled: the fp32 k-step
+  if (lane == 0) sb.scale(HP)[ct * 16 + c] = inv;
+}
 template <int HP>
 __device__ __forceinline__ void split_rows_h(const SplitBufH& sb, const float* X, int N, bool ktail, int wave, int lane) {
-  constexpr int T = HP / 16, LD = HP + 4;
   const bool tail = nh_has_tail(HP, ktail);
   const int nc = nh_chunks(HP, ktail);
-  const int m = lane >> 3, g = (lane >> 1) & 3, half = lane & 1;
-  float* const tl = sb.tail(HP);
-  float* const sc = sb.scale(HP);
-  for (int n = wave; n < N; n += kWaves) {
-    const f4 x = lane < HP / 4 ? *(const f4*)(X + n * LD + 4 * lane) : splat(0.f);
-    const uint32_t a0 = __builtin_bit_cast(uint32_t, x[0]) & 0x7fffffffu, a1 = __builtin_bit_cast(uint32_t, x[1]) & 0x7fffffffu,
-                   a2 = __builtin_bit_cast(uint32_t, x[2]) & 0x7fffffffu, a3 = __builtin_bit_cast(uint32_t, x[3]) & 0x7fffffffu;
-    const uint32_t mx = wave_max_u32(umax(umax(a0, a1), umax(a2, a3)));
-    // the row's largest exponent -> 14 (values below 2^15 < 65 504); exponents clamped so that both factors are normal numbers
-    int k = 141 - (int)(mx >> 23);
-    k = k > 126 ? 126 : k;
-    const float s = __builtin_bit_cast(float, (uint32_t)(k + 127) << 23), inv = __builtin_bit_cast(float, (uint32_t)(127 - k) << 23);
-    const float y0 = x[0] * s, y1 = x[1] * s, y2 = x[2] * s, y3 = x[3] * s;
-    const uint32_t h01 = pk_f16(y0, y1), h23 = pk_f16(y2, y3);
-    const f2 f01 = unpk_f16(h01), f23 = unpk_f16(h23);
-    const uint32_t l01 = pk_f16((y0 - f01[0]) * kLoScale, (y1 - f01[1]) * kLoScale),
-                   l23 = pk_f16((y2 - f23[0]) * kLoScale, (y3 - f23[1]) * kLoScale);
-    const int ct = n >> 4, c = n & 15;
-    if (m < nc) {
-      float* d = sb.chunk(m) + ct * 512 + (4 * c + g) * 4 + half * 2;
-      *(u2*)d = (u2){h01, h23};
-      *(u2*)(d + 256) = (u2){l01, l23};
-    }
-    if (tail && lane == 4 * (T - 1)) *(f4*)(tl + ct * 64 + 4 * c) = x;  // inputs 16 (T-1) .. +3, unscaled: the fp32 k-step
-    if (lane == 0) sc[ct * 16 + c] = inv;
+  for (int n = wave; n < N; n += 2 * kWaves) {
+    const int n2 = n + kWaves < N ? n + kWaves : n;  // (a second copy of the same row when there is no partner: same stores)
+    SplitRowH a = split_row_load<HP>(X, n, lane), b = split_row_load<HP>(X, n2, lane);
+    a.mx = wave_max_u32(a.mx);
+    b.mx = wave_max_u32(b.mx);
+    split_row_store<HP>(sb, a.x, a.mx, n, tail, nc, lane);
+    if (n2 != n) split_row_store<HP>(sb, b.x, b.mx, n2, tail, nc, lane);
   }
 }
 
@@ -144,9 +166,30 @@ __device__ __forceinline__ void lds_barrier() {
 struct NodeSetH {
   u4 p[2][2];
 };
+// Weight chunks in flight per wave.  The stream is latency-bound when the chunks in flight are few (the weight set does not fit
+// an XCD's L2: every chunk comes from the Infinity Cache at ~1 us), so the depth is what the register file allows: a whole
+// matrix (<= 6 chunks = 96 registers on a two-tile wave) with one column tile of nodes, three chunks with more
+// (tools/node_gemm_h_microbench.hip, profiles/r05b_*).  A matrix's chunks are consumed in turns of D sets: chunk i lives in set
+// i % D of every matrix (a last turn may be partly empty), so no register ever moves and the whole K loop is straight-line code
+// -- hipcc then counts the loads in flight exactly (any branch around a load made it wait for vmcnt(0) at every step).
+#ifndef GAUDI_NODE_MAXDEPTH
+#define GAUDI_NODE_MAXDEPTH 3
+#endif
+#ifndef GAUDI_NODE_DEPTH2
+#define GAUDI_NODE_DEPTH2 3
+#endif
+constexpr int kMaxDepthH = GAUDI_NODE_MAXDEPTH;
+__host__ __device__ constexpr int nh_depth(int HP, bool ktail, int nt) {
+  const int nc = nh_chunks(HP, ktail);
+  const int want = nt == 1 ? kMaxDepthH : (GAUDI_NODE_DEPTH2 < kMaxDepthH ? GAUDI_NODE_DEPTH2 : kMaxDepthH);
+  if (nc <= want) return nc;
+  const int turns = (nc + want - 1) / want;
+  return (nc + turns - 1) / turns;  // the turns as even as they get
+}
 template <int HP>
 struct NodePFH {
-  NodeSetH s[kDepthH];  // chunks 0 .. kDepthH-1 of the next node GEMM, loaded ahead of the call
+  static constexpr int kSets = (HP / 16 + 1) / 2 < kMaxDepthH ? (HP / 16 + 1) / 2 : kMaxDepthH;
+  NodeSetH s[kSets];  // chunks 0 .. of the next node GEMM, loaded ahead of the call
 };
 
 template <int NTW>
@@ -157,15 +200,25 @@ __device__ __forceinline__ void nh_load(NodeSetH& s, const WBuf& wh, int chunk_o
     s.p[u][1] = ldu4h(wh, chunk_off + ((wave + kWaves * u) * 2 + 1) * 256, lane);
   }
 }
-template <int HP>
-__device__ __forceinline__ void node_prefetch_h(NodePFH<HP>& pf, const WBuf& wh, int W /* fp32 float offset */, int wave, int lane) {
+// How many chunks travel ahead of a call: kAheadAll = as many as the call's depth (where the next GEMM follows directly, or
+// from a point in an edge phase where the registers are free again), kAheadOne = ONE chunk (16 registers: across the register-
+// tight parts of an edge phase; the call issues the others itself, and they fly while its input is split).
+constexpr int kAheadOne = 1, kAheadAll = 99;
+template <int HP, int AHEAD = kAheadAll>
+__device__ __forceinline__ void node_prefetch_h(NodePFH<HP>& pf, const WBuf& wh, int W /* fp32 float offset */, int N, bool ktail, int wave,
+                                                int lane) {
   constexpr int T = HP / 16;
+  // (the depth depends on the column-tile count of the GEMMs that follow: nh_depth)
+  const int depth = N <= 16 ? nh_depth(HP, ktail, 1) : nh_depth(HP, ktail, 2);
+  const int nd = AHEAD < depth ? AHEAD : depth;
   if (wave + kWaves < T) {
 #pragma unroll
-    for (int d = 0; d < kDepthH; ++d) nh_load<2>(pf.s[d], wh, 2 * W + d * nh_chunk_floats(HP), wave, lane);
+    for (int d = 0; d < NodePFH<HP>::kSets; ++d)
+      if (d < nd) nh_load<2>(pf.s[d], wh, 2 * W + d * nh_chunk_floats(HP), wave, lane);
   } else if (wave < T) {
 #pragma unroll
-    for (int d = 0; d < kDepthH; ++d) nh_load<1>(pf.s[d], wh, 2 * W + d * nh_chunk_floats(HP), wave, lane);
+    for (int d = 0; d < NodePFH<HP>::kSets; ++d)
+      if (d < nd) nh_load<1>(pf.s[d], wh, 2 * W + d * nh_chunk_floats(HP), wave, lane);
   }
 }
 
@@ -177,31 +230,31 @@ struct NodeCtxH {
   bool ktail;
 };
 
-template <int HP, int EPI, int NT, int NTW>
+// PIN: chunks of Wa that were loaded ahead of the call (pf.s[0 .. min(PIN, D))); POUT: chunks of nextW this call loads ahead
+template <int HP, int EPI, int NT, int NTW, bool KTAIL, bool TWO, int PIN, int POUT>
 __device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const float* sXa, bool do_split_a, int Wb, const float* sXb,
                                                  const float* sBias, float* sY, const float* sRes, const float* sMask, int N, int wave,
                                                  int lane, const NodeCtxH& cx, NodePFH<HP>& pf, int nextW, float* gPre) {
   constexpr int T = HP / 16, LD = HP + 4;
+  constexpr bool tail = nh_has_tail(HP, KTAIL);
+  constexpr int nc = nh_chunks(HP, KTAIL);
+  constexpr int D = nh_depth(HP, KTAIL, NT);
+  constexpr int R = (nc + D - 1) / D;  // turns per matrix
+  constexpr int kIn = PIN < D ? PIN : D, kOut = POUT < D ? POUT : D;
+  static_assert(D <= NodePFH<HP>::kSets, "depth");
   const int c = lane & 15, g = lane >> 4;
-  const bool tail = nh_has_tail(HP, cx.ktail);
-  const int nc = nh_chunks(HP, cx.ktail);
-  const int KT = Wb >= 0 ? 2 * nc : nc;  // two sources run as ONE K loop so the load pipeline never restarts
-  const bool seq = Wb >= 0 && cx.split_b == cx.split_a;
+  const bool seq = TWO && cx.split_b == cx.split_a;
   const SplitBufH sa{cx.split_a, NT}, sb{cx.split_b, NT};
   const int bpos = (4 * c + g) * 4;  // the lane's float offset inside a 1 KiB B unit
-  // float offset (in the image buffer) of chunk cc of the stream Wa | Wb | nextW; past the end: clamped (surplus loads are unused)
-  auto chunk_off = [&](int cc) {
-    if (cc >= KT) {
-      if (nextW >= 0) return 2 * nextW + (cc - KT < nc ? cc - KT : nc - 1) * nh_chunk_floats(HP);
-      cc = KT - 1;
-    }
-    return cc < nc ? 2 * Wa + cc * nh_chunk_floats(HP) : 2 * Wb + (cc - nc) * nh_chunk_floats(HP);
-  };
+  // a matrix that is not there (no next GEMM) is "loaded" with out-of-range lanes: such a load returns 0 and fetches nothing --
+  // no branch around a load anywhere in this function
+  const int lane_next = nextW >= 0 ? lane : kOOBLane;
+  const int Wn = nextW >= 0 ? nextW : Wa;
   struct BH {
     u4 h[NT], l[NT];
   };
-  auto bld = [&](int cc) {
-    const float* q = (cc < nc ? sa.chunk(cc) : sb.chunk(cc - nc)) + bpos;
+  auto bld = [&](const SplitBufH& s_, int i) {
+    const float* q = s_.chunk(i) + bpos;
     BH b;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -210,20 +263,27 @@ __device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const f
     }
     return b;
   };
-  // K-tail weights (one fp32 k-step per output tile and source) travel with the first chunks
+  // chunks that did not travel ahead of the call
+  static_for<D>([&](auto d_tag) {
+    constexpr int d = decltype(d_tag)::value;
+    if constexpr (d >= kIn) nh_load<NTW>(pf.s[d], wh, 2 * Wa + d * nh_chunk_floats(HP), wave, lane);
+  });
+  // K-tail weights (one fp32 k-step per output tile and source)
   float ta[NTW], tb[NTW];
-  if (tail) {
+  if constexpr (tail) {
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
       const int t = wave + kWaves * u;
       ta[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wh.r, lane * 4, (2 * Wa + nc * nh_chunk_floats(HP) + t * 64) * 4, 0));
-      tb[u] = Wb >= 0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wh.r, lane * 4, (2 * Wb + nc * nh_chunk_floats(HP) + t * 64) * 4, 0))
-                      : 0.f;
+      if constexpr (TWO)
+        tb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wh.r, lane * 4, (2 * Wb + nc * nh_chunk_floats(HP) + t * 64) * 4, 0));
     }
   }
-  if (do_split_a) split_rows_h<HP>(sa, sXa, N, cx.ktail, wave, lane);
-  if (Wb >= 0 && !seq) split_rows_h<HP>(sb, sXb, N, cx.ktail, wave, lane);
-  if (do_split_a || (Wb >= 0 && !seq)) lds_barrier();
+  if (!(kAblateH & 1)) {
+    if (do_split_a) split_rows_h<HP>(sa, sXa, N, KTAIL, wave, lane);
+    if (TWO && !seq) split_rows_h<HP>(sb, sXb, N, KTAIL, wave, lane);
+    if (do_split_a || (TWO && !seq)) lds_barrier();
+  }
 
   f4 acc0[NT][NTW], acc1[NT][NTW], y[NT][NTW];
 #pragma unroll
@@ -235,8 +295,8 @@ __device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const f
       y[j][u] = sBias != nullptr ? *(const f4*)(sBias + 16 * (wave + kWaves * u) + 4 * g) : splat(0.f);
     }
   // descale and fold the accumulators of one source into y
-  auto fold = [&](const SplitBufH& s_, const float* X, const float (&tw)[NTW]) {
-    if (tail) {  // the K tail's fp32 step: inputs 16 (T-1) + g on lane group g, unscaled operands
+  auto fold = [&](const SplitBufH& s_, const float (&tw)[NTW]) {
+    if constexpr (tail) {  // the K tail's fp32 step: inputs 16 (T-1) + g on lane group g, unscaled operands
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const float xb = s_.tail(HP)[j * 64 + 4 * c + g];
@@ -244,7 +304,6 @@ __device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const f
         for (int u = 0; u < NTW; ++u) y[j][u] = mfma1(tw[u], xb, y[j][u]);
       }
     }
-    (void)X;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const float sc = s_.scale(HP)[j * 16 + c] * cx.winv;
@@ -257,6 +316,10 @@ __device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const f
     }
   };
   auto mm = [&](const NodeSetH& s, const BH& b) {
+    if (kAblateH & 2) {  // (keep the operands alive)
+      asm volatile("" ::"v"(s.p[0][0]), "v"(s.p[0][1]), "v"(s.p[NTW - 1][0]), "v"(s.p[NTW - 1][1]), "v"(b.h[0]), "v"(b.l[NT - 1]));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -270,46 +333,43 @@ __device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const f
 #pragma unroll
       for (int u = 0; u < NTW; ++u) acc1[j][u] = mfma_h(s.p[u][1], b.h[j], acc1[j][u]);
   };
-  BH bcur = bld(0);
-  auto step = [&](NodeSetH& s, int cc) {  // consume chunk cc from s, refill s with chunk cc + kDepthH of the stream
-    if (Wb >= 0 && cc == nc) {            // the second source begins
-      fold(sa, sXa, ta);
-      if (seq) {
-        __syncthreads();  // (every wave is done with the first source's copy)
-        split_rows_h<HP>(sb, sXb, N, cx.ktail, wave, lane);
-        lds_barrier();
-        bcur = bld(cc);
+  // one source: its nc chunks in order, straight-line.  After chunk i the set is refilled with what it holds next: chunk i + D
+  // of the same matrix, else chunk i % D of the matrix that follows (the second source; after the last source the next GEMM's
+  // matrix, as far as POUT allows).
+  auto source = [&](auto src_tag, const SplitBufH& s_) {
+    constexpr int src = decltype(src_tag)::value;
+    constexpr bool last_src = !TWO || src == 1;
+    const int Wcur = src == 0 ? Wa : Wb;
+    BH bcur = bld(s_, 0);
+    static_for<nc>([&](auto i_tag) {
+      constexpr int i = decltype(i_tag)::value;
+      constexpr int d = i % D;
+      BH bnext = bcur;
+      if constexpr (i + 1 < nc) bnext = bld(s_, i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(pf.s[d], bcur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(kAblateH & 4)) {
+        if constexpr (i + D < nc) nh_load<NTW>(pf.s[d], wh, 2 * Wcur + (i + D) * nh_chunk_floats(HP), wave, lane);
+        else if constexpr (!last_src) nh_load<NTW>(pf.s[d], wh, 2 * Wb + d * nh_chunk_floats(HP), wave, lane);
+        else if constexpr (d < kOut) nh_load<NTW>(pf.s[d], wh, 2 * Wn + d * nh_chunk_floats(HP), wave, lane_next);
       }
-    }
-    const bool more = cc + 1 < KT && !(seq && cc + 1 == nc);
-    BH bnext = bcur;
-    if (more) bnext = bld(cc + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(s, bcur);
-    __builtin_amdgcn_sched_barrier(0);
-    if (cc + kDepthH < KT || nextW >= 0) nh_load<NTW>(s, wh, chunk_off(cc + kDepthH), wave, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) bcur = bnext;
+      __builtin_amdgcn_sched_barrier(0);
+      bcur = bnext;
+    });
   };
-  static_assert(kDepthH == 3, "the K loop below rotates three operand sets");
-#pragma unroll 1
-  for (int cc = 0; cc < KT; cc += 3) {
-    step(pf.s[0], cc);
-    if (cc + 1 < KT) step(pf.s[1], cc + 1);
-    if (cc + 2 < KT) step(pf.s[2], cc + 2);
-  }
-  if (nextW >= 0) {  // the next matrix's chunk i sits in set (KT + i) % 3: bring chunk 0 to set 0
-    const int r = KT % 3;
-    if (r == 1) {
-      const NodeSetH t0 = pf.s[0];
-      pf.s[0] = pf.s[1]; pf.s[1] = pf.s[2]; pf.s[2] = t0;
-    } else if (r == 2) {
-      const NodeSetH t0 = pf.s[0];
-      pf.s[0] = pf.s[2]; pf.s[2] = pf.s[1]; pf.s[1] = t0;
+  source(std::integral_constant<int, 0>{}, sa);
+  fold(sa, ta);
+  if constexpr (TWO) {
+    if (seq) {
+      lds_barrier();  // (every wave is done with the first source's copy; the weight loads in flight stay in flight)
+      split_rows_h<HP>(sb, sXb, N, KTAIL, wave, lane);
+      lds_barrier();
     }
+    source(std::integral_constant<int, 1>{}, sb);
+    fold(sb, tb);
   }
-  if (Wb >= 0) fold(sb, sXb, tb);
-  else fold(sa, sXa, ta);
+  (void)R;
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -342,7 +402,7 @@ __device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const f
 // the first source's split copy in cx.split_a (P and Q share h, the two transposed GEMMs of dnpre share it).  The caller
 // guarantees that nobody still reads the split regions when the call starts (a barrier since their last use) and places a
 // barrier between this call's stores to sY and their readers, as for the fp32 form.
-template <int HP, int EPI, int MAXNT>
+template <int HP, int EPI, bool TWO, int MAXNT, int PIN = kAheadOne, int POUT = kAheadOne>
 __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float* sXa, bool do_split_a, int Wb, const float* sXb,
                                             const float* sBias, float* sY, const float* sRes, const float* sMask, int N, int wave,
                                             int lane, const NodeCtxH& cx, NodePFH<HP>& pf, int nextW = -1, float* gPre = nullptr) {
@@ -350,26 +410,89 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
   const bool two = wave + kWaves < T, one = wave < T;
   if (!one) {
     // a wave without an output tile (hidden sizes below 128): its share of the split and the barriers of the others
-    const bool seq = Wb >= 0 && cx.split_b == cx.split_a;
-    const int nct = N <= 16 ? 1 : (MAXNT < 3 || N <= 32) ? 2 : 3;
+    const bool seq = TWO && cx.split_b == cx.split_a;
+    const int nct = (MAXNT < 2 || N <= 16) ? 1 : (MAXNT < 3 || N <= 32) ? 2 : 3;
     if (do_split_a) split_rows_h<HP>(SplitBufH{cx.split_a, nct}, sXa, N, cx.ktail, wave, lane);
-    if (Wb >= 0 && !seq) split_rows_h<HP>(SplitBufH{cx.split_b, nct}, sXb, N, cx.ktail, wave, lane);
-    if (do_split_a || (Wb >= 0 && !seq)) lds_barrier();
+    if (TWO && !seq) split_rows_h<HP>(SplitBufH{cx.split_b, nct}, sXb, N, cx.ktail, wave, lane);
+    if (do_split_a || (TWO && !seq)) lds_barrier();
     if (seq) {
-      __syncthreads();
+      lds_barrier();
       split_rows_h<HP>(SplitBufH{cx.split_b, nct}, sXb, N, cx.ktail, wave, lane);
       lds_barrier();
     }
     return;
   }
-  auto run = [&](auto nt_tag) {
+  auto run2 = [&](auto nt_tag, auto kt_tag) {
     constexpr int NT = decltype(nt_tag)::value;
-    if (two) node_gemm_h_body<HP, EPI, NT, 2>(wh, Wa, sXa, do_split_a, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre);
-    else node_gemm_h_body<HP, EPI, NT, 1>(wh, Wa, sXa, do_split_a, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre);
+    constexpr bool KTAIL = decltype(kt_tag)::value;
+    if (two)
+      node_gemm_h_body<HP, EPI, NT, 2, KTAIL, TWO, PIN, POUT>(wh, Wa, sXa, do_split_a, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre);
+    else
+      node_gemm_h_body<HP, EPI, NT, 1, KTAIL, TWO, PIN, POUT>(wh, Wa, sXa, do_split_a, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre);
   };
-  if (N <= 16) run(std::integral_constant<int, 1>{});
+  auto run = [&](auto nt_tag) {
+    // (a K tail exists for odd tile counts only: the other widths have one instantiation)
+    if constexpr ((T & 1) && T >= 3) {
+      if (cx.ktail) run2(nt_tag, std::true_type{});
+      else run2(nt_tag, std::false_type{});
+    } else {
+      run2(nt_tag, std::false_type{});
+    }
+  };
+  if (MAXNT < 2 || N <= 16) run(std::integral_constant<int, 1>{});
   else if (MAXNT < 3 || N <= 32) run(std::integral_constant<int, 2>{});
   else if constexpr (MAXNT >= 3) run(std::integral_constant<int, 3>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// One call-site form over both node-GEMM engines.  NH = the fp16-pair form: every kernel whose edge GEMMs run on split operands
+// (SP != 0) unless the build switches it off; the fp32-instruction kernels (SP = 0) keep the fp32 form and are what the host
+// falls back to for weight sets the fp16 images refuse.
+// ---------------------------------------------------------------------------------------------
+#ifndef GAUDI_NODE_F16
+#define GAUDI_NODE_F16 1
+#endif
+template <int SP>
+struct NodeMath {
+  static constexpr bool kF16 = SP != 0 && GAUDI_NODE_F16 != 0;
+};
+template <int HP, bool NH>
+struct NodePFSel {
+  using type = NodePF<HP>;
+};
+template <int HP>
+struct NodePFSel<HP, true> {
+  using type = NodePFH<HP>;
+};
+template <int HP, bool NH, int AHEAD, class PF>
+__device__ __forceinline__ void node_prefetch_x(PF& pf, const WBuf& wb, const WBuf& wbe, int W, int N, int wave, int lane, bool tw) {
+  if constexpr (NH) node_prefetch_h<HP, AHEAD>(pf, wbe, W, N, tw, wave, lane);
+  else node_prefetch<HP>(pf, wb, W, wave, lane, tw);
+}
+// Xa / Xb: the input rows where they live (LDS, or global memory for the GN kernels); XaS / XbS: their staged copies in the idle
+// weight ring, which only the fp32 form of a GN kernel reads (w8_common.h: stage_rows) -- the fp16 form splits the rows straight
+// from where they are.  split_a = false: the previous call's split copy of Xa is still in place.
+template <int HP, int EPI, bool TWO, bool GN, bool NH, int PIN, int POUT, class PF>
+__device__ __forceinline__ void node_gemm_x(const WBuf& wb, const WBuf& wbe, int Wa, const float* Xa, const float* XaS, bool split_a, int Wb,
+                                            const float* Xb, const float* XbS, const float* sBias, float* sY, const float* sRes,
+                                            const float* sMask, int N, int wave, int lane, bool tw, const NodeCtxH& cx, PF& pf,
+                                            int nextW = -1, float* gPre = nullptr) {
+  if constexpr (NH) {
+    node_gemm_h<HP, EPI, TWO, GN ? 3 : 2, PIN, POUT>(wbe, Wa, Xa, split_a, Wb, Xb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre);
+  } else if constexpr (GN) {
+    node_gemm_n<HP, EPI, true, 3>(wb, Wa, XaS, Wb, XbS, sBias, sY, sRes, sMask, N, wave, lane, tw, &pf, nextW, gPre);
+  } else {
+    node_gemm<HP, EPI, true>(wb, Wa, Xa, Wb, Xb, sBias, sY, sRes, sMask, N, wave, lane, tw, &pf, nextW, gPre);
+  }
+}
+// where the split copies of a node phase go: the weight ring's free slot (a resident kernel's other slot holds the first group of
+// the next edge GEMM, requested by the previous one's last trip), or the whole ring where it idles across node phases (RI: the GN
+// kernels and the half-ring mode, whose slot alone is too small).  cap: floats of that region; two inputs side by side if they fit.
+template <int HP>
+__device__ __forceinline__ NodeCtxH node_ctx_h(float* region, int cap, int N, float winv, bool ktail) {
+  const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
+  const int need = nh_split_floats(HP, nct);
+  return NodeCtxH{winv, region, 2 * need <= cap ? region + need : region, ktail};
 }
 
 }  // namespace w8

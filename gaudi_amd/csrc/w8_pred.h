@@ -121,12 +121,24 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   compute_geo(sm, mg, 0.f, tid, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
   typename EdgeRing<HP, SP>::type ring;
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
-  // GN: node-GEMM inputs are staged in the idle ring, every edge phase requests its first weight group itself (w8_edm.h)
+  // NH / RI / STG: see edm_forward (w8_edm.h) -- fp16-pair node GEMMs; the ring idles across node phases (GN: node-GEMM inputs
+  // are staged in it, every edge phase requests its first weight group itself); fp32 node GEMMs of a GN kernel read staged rows
+  constexpr bool NH = NodeMath<SP>::kF16;
+  constexpr bool RI = GN || (NH && SP == 2);
+  constexpr bool STG = GN && !NH;
   float* const xs0 = sm.ring;
   float* const xs1 = sm.ring + stage_stride(N * LD);
-  if constexpr (!GN) er_start<HP>(ring, wbe, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
-  NodePF<HP> pf;
-  node_prefetch<HP>(pf, wb, lay.layer(0), wave, lane, tw);
+  if constexpr (!RI) er_start<HP>(ring, wbe, lay.layer(0) + 2 * HP * HP, wave, lane);  // W2 of layer 0
+  typename NodePFSel<HP, NH>::type pf;
+  node_prefetch_x<HP, NH, kAheadOne>(pf, wb, wbe, lay.layer(0), mg.NC, wave, lane, tw);
+  auto hctx = [&]() {
+    if constexpr (NH) {
+      if constexpr (RI) return node_ctx_h<HP>(sm.ring, EdgeRing<HP, SP>::kFloats, mg.NC, W.hinv, tw);
+      else return node_ctx_h<HP>(ring.slot(ring.par ^ 1), EdgeRing<HP, SP>::kFloats / 2, mg.NC, W.hinv, tw);
+    } else {
+      return NodeCtxH{1.f, nullptr, nullptr, tw};
+    }
+  };
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next layer's vectors, loaded one node GEMM ahead
   vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(0), HP), PredLayerW::vec_count(HP), tid);
@@ -135,7 +147,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     const bool last = l == W.L - 1;  // the last layer's coordinate update never reaches the readout
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
     vec_commit<NV, kThreads>(vpf, sm.vec, PredLayerW::vec_count(HP), tid);
-    if constexpr (GN) stage_rows(xs0, h, N * LD, wave, lane);
+    if constexpr (STG) stage_rows(xs0, h, N * LD, wave, lane);
     for (int idx = tid; idx < N * LD; idx += kThreads) {
       agg[idx] = 0.f;
       agg1[idx] = 0.f;
@@ -143,17 +155,20 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
     for (int idx = tid; idx < N; idx += kThreads) gstore4((f4*)(st + 3 * N * HP) + idx, *(const f4*)(sm.x + 4 * idx));
     compute_geo(sm, mg, 1.0f, tid, false);  // gcl.py:308-316
-    if constexpr (GN) stage_wait();
+    if constexpr (STG) stage_wait();
     else __syncthreads();
     STAMP(ST_STAGE);
-    NODE_GEMM(EPI_NONE, wb, Lw.A, GN ? xs0 : h, -1, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
-                                       Lw.Bm);
-    NODE_GEMM(EPI_NONE, wb, Lw.Bm, GN ? xs0 : h, -1, nullptr, nullptr, q, nullptr, nullptr, mg.NC, wave, lane, tw, &pf,
-                                       Lw.Wn1h);
+    {
+      const NodeCtxH cx = hctx();
+      node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, Lw.A, h, xs0, true, -1, nullptr, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave,
+                                                    lane, tw, cx, pf, Lw.Bm);
+      node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne>(wb, wbe, Lw.Bm, h, xs0, false, -1, nullptr, nullptr, nullptr, q, nullptr, nullptr, mg.NC,
+                                                    wave, lane, tw, cx, pf, Lw.Wn1h);
+    }
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
-    if constexpr (GN) er_start<HP>(ring, wbe, Lw.W2, wave, lane);
+    if constexpr (RI) er_start<HP>(ring, wbe, Lw.W2, wave, lane);
     // P, Q -> stash as whole rows (storing them from the accumulators in the GEMM epilogue instead -- 64-byte pieces per
     // lane group -- measured 1.5 % slower on C3)
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
@@ -200,7 +215,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       STAMP(ST_EDGE_EPI);
       if (!last) {  // coord_model (gcl.py:252-278): trans = dhat * tanh(wc2 . silu(Wc1 e + bc1)) * R * mask
         f4 cp[T];
-        er_gemm_regs<HP>(cp, acc, ring, wbe, Lw.Wc1, more ? Lw.W2 : (GN ? -1 : lay.layer(l + 1) + 2 * HP * HP), Lw.bc1, nullptr,
+        er_gemm_regs<HP>(cp, acc, ring, wbe, Lw.Wc1, more ? Lw.W2 : (RI ? -1 : lay.layer(l + 1) + 2 * HP * HP), Lw.bc1, nullptr,
                          tc.active, wave, lane);
         STAMP(ST_EDGE);
         if (tc.active) {
@@ -231,29 +246,29 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     }
     __syncthreads();
     STAMP(ST_BARRIER);
-    if constexpr (GN) stage_rows(xs0, h, N * LD, wave, lane);
+    if constexpr (STG) stage_rows(xs0, h, N * LD, wave, lane);
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {  // agg = partial 0 + partial 1
       const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
-      if constexpr (GN)  // straight into the staged copy (only this GEMM reads agg)
+      if constexpr (STG)  // straight into the staged copy (only this GEMM reads agg)
         *(f4*)(xs1 + n * LD + f) = *(const f4*)(agg + n * LD + f) + *(const f4*)(agg1 + n * LD + f);
       else
         *(f4*)(agg + n * LD + f) = *(const f4*)(agg + n * LD + f) + *(const f4*)(agg1 + n * LD + f);
     }
-    if constexpr (GN) stage_wait();
+    if constexpr (STG) stage_wait();
     else __syncthreads();
     STAMP(ST_MISC);
-    NODE_GEMM(EPI_SILU, wb, Lw.Wn1h, GN ? xs0 : h, Lw.Wn1a, GN ? xs1 : agg, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane,
-                                       tw, &pf, Lw.Wn2, st + 2 * N * HP /* npre -> stash */);
+    node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne>(wb, wbe, Lw.Wn1h, h, xs0, true, Lw.Wn1a, agg, xs1, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane,
+                                            tw, hctx(), pf, Lw.Wn2, st + 2 * N * HP /* npre -> stash */);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
     vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l + 1 < W.L ? l + 1 : l), HP), PredLayerW::vec_count(HP), tid);
-    if constexpr (GN) {
+    if constexpr (STG) {
       stage_rows(xs0, p, N * LD, wave, lane);
       stage_wait();
     }
-    NODE_GEMM(EPI_RESIDUAL_MASK, wb, Lw.Wn2, GN ? xs0 : p, -1, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave, lane, tw, &pf,
-                                                l + 1 < W.L ? lay.layer(l + 1) : -1);
+    node_gemm_x<HP, EPI_RESIDUAL_MASK, false, GN, NH, kAheadOne, kAheadOne>(wb, wbe, Lw.Wn2, p, xs0, true, -1, nullptr, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave,
+                                                     lane, tw, hctx(), pf, l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
     STAMP(ST_NODE);
     __syncthreads();
@@ -335,15 +350,26 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 
   typename EdgeRing<HP, SP>::type ring;
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
-  // GN: node-GEMM inputs are staged in the idle ring, every edge pass requests its first weight group itself (w8_edm.h)
+  // NH / RI / STG: see edm_forward (w8_edm.h)
+  constexpr bool NH = NodeMath<SP>::kF16;
+  constexpr bool RI = GN || (NH && SP == 2);
+  constexpr bool STG = GN && !NH;
   float* const xs0 = sm.ring;
   float* const xs1 = sm.ring + stage_stride(N * LD);
-  if constexpr (!GN) {
+  if constexpr (!RI) {
     const int L0 = lay.layer(W.L - 1);
     er_start<HP>(ring, wbe, L0 + 9 * HP * HP /* W2^T of the last layer (its coordinate branch is skipped) */, wave, lane);
   }
-  NodePF<HP> pf;
-  node_prefetch<HP>(pf, wb, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, wave, lane, tw);
+  typename NodePFSel<HP, NH>::type pf;
+  node_prefetch_x<HP, NH, kAheadOne>(pf, wb, wbe, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, mg.NC, wave, lane, tw);
+  auto hctx = [&]() {
+    if constexpr (NH) {
+      if constexpr (RI) return node_ctx_h<HP>(sm.ring, EdgeRing<HP, SP>::kFloats, mg.NC, W.hinv, tw);
+      else return node_ctx_h<HP>(ring.slot(ring.par ^ 1), EdgeRing<HP, SP>::kFloats / 2, mg.NC, W.hinv, tw);
+    } else {
+      return NodeCtxH{1.f, nullptr, nullptr, tw};
+    }
+  };
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;
   vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(W.L - 1), HP), PredLayerW::vec_count(HP), tid);
@@ -367,22 +393,26 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       *(f4*)(sm.dx + 4 * idx) = *(const f4*)(sm.dx + 4 * idx) * mg.mask[idx];
     }
     __syncthreads();
-    if constexpr (GN) stage_rows(xs0, dh, N * LD, wave, lane);
+    if constexpr (STG) stage_rows(xs0, dh, N * LD, wave, lane);
     compute_geo(sm, mg, 1.0f, tid, false);
-    if constexpr (GN) stage_wait();
+    if constexpr (STG) stage_wait();
     STAMP(ST_STASH);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
-    // (GN: dnpre feeds (d) only -- it is written straight into the second staging area, not to B4 and back)
-    NODE_GEMM(EPI_MUL_DSILU, wb, Lw.Wn2t, GN ? xs0 : dh, -1, nullptr, nullptr, GN ? xs1 : B4, B4, nullptr, mg.NC, wave, lane, tw, &pf,
-                                            Lw.Wn1ht);
+    // (GN with fp32 node GEMMs: dnpre feeds (d) only -- it is written straight into the second staging area, not to B4 and back)
+    node_gemm_x<HP, EPI_MUL_DSILU, false, GN, NH, kAheadOne, kAheadOne>(wb, wbe, Lw.Wn2t, dh, xs0, true, -1, nullptr, nullptr, nullptr, STG ? xs1 : B4, B4, nullptr,
+                                                 mg.NC, wave, lane, tw, hctx(), pf, Lw.Wn1ht);
     __syncthreads();
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
-    NODE_GEMM(EPI_ACCUM, wb, Lw.Wn1ht, GN ? xs1 : B4, -1, nullptr, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw, &pf,
-                                        Lw.Wn1at);
-    NODE_GEMM(EPI_NONE, wb, Lw.Wn1at, GN ? xs1 : B4, -1, nullptr, nullptr, B0, nullptr, nullptr, mg.NC, wave, lane, tw, &pf);
+    {
+      const NodeCtxH cx = hctx();
+      node_gemm_x<HP, EPI_ACCUM, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, Lw.Wn1ht, B4, xs1, true, -1, nullptr, nullptr, nullptr, dh, dh, nullptr, mg.NC,
+                                                     wave, lane, tw, cx, pf, Lw.Wn1at);
+      node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, 0>(wb, wbe, Lw.Wn1at, B4, xs1, false, -1, nullptr, nullptr, nullptr, B0, nullptr, nullptr,
+                                                    mg.NC, wave, lane, tw, cx, pf);
+    }
     __syncthreads();
     STAMP(ST_BWD_NODE);
-    if constexpr (GN) er_start<HP>(ring, wbe, last ? Lw.W2t : Lw.Wc1t, wave, lane);
+    if constexpr (RI) er_start<HP>(ring, wbe, last ? Lw.W2t : Lw.Wc1t, wave, lane);
     // (e) edge pass: MLP chain backward for the wave's tile, then du of all slots is published CH feature tiles at a time
     //     and every thread sums one (node, 4 features) of dP_i = sum_j du_ij (receiver runs) and dQ_j = sum_i du_ij
     //     (sender lists) in slot order -- no atomics, fixed order
@@ -542,9 +572,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         }
         __syncthreads();
       }
-      if (SP != 0 && !GN && l > 0)
+      if (SP != 0 && !RI && l > 0)
         er_start<HP>(ring, wbe, lay.layer(l - 1) + 10 * HP * HP /* Wc1^T of the layer below */, wave, lane);
-      node_prefetch<HP>(pf, wb, Lw.At, wave, lane, tw);
+      node_prefetch_x<HP, NH, kAheadOne>(pf, wb, wbe, Lw.At, mg.NC, wave, lane, tw);
       STAMP(ST_BWD_COL);
     }
     // dx <- dx*mask + sum_{e: i=n} ddiff_e - sum_{e: j=n} ddiff_e, in slot order
@@ -560,13 +590,13 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     }
     // (f) dh += A^T dP + Bm^T dQ
     vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(l > 0 ? l - 1 : 0), HP), PredLayerW::vec_count(HP), tid);
-    if constexpr (GN) {  // (the publish loop ended on a barrier: dP / dQ are complete, the ring is free)
+    if constexpr (STG) {  // (the publish loop ended on a barrier: dP / dQ are complete, the ring is free)
       stage_rows(xs0, B2, N * LD, wave, lane);
       stage_rows(xs1, B4, N * LD, wave, lane);
       stage_wait();
     }
-    NODE_GEMM(EPI_ACCUM, wb, Lw.At, GN ? xs0 : B2, Lw.Bmt, GN ? xs1 : B4, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw,
-                                        &pf, l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
+    node_gemm_x<HP, EPI_ACCUM, true, GN, NH, kAheadOne, kAheadOne>(wb, wbe, Lw.At, B2, xs0, true, Lw.Bmt, B4, xs1, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw,
+                                             hctx(), pf, l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
     STAMP(ST_BWD_NODE);
   }

@@ -11,13 +11,16 @@
 #include <vector>
 #include "w8_nodes_f16.h"
 using namespace gaudi;
+#ifndef GAUDI_MB_MAXNT
+#define GAUDI_MB_MAXNT 3  // column tiles per pass the fp16 form is instantiated for (2: the resident kernels; N = 40 runs are skipped)
+#endif
 
 template <int HP, int V>
 struct Sel;
 template <int HP>
 struct Sel<HP, 0> {
   using PF = w8::NodePF<HP>;
-  static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tw) { w8::node_prefetch<HP>(pf, wb, W, wave, lane, tw); }
+  static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tw, int) { w8::node_prefetch<HP>(pf, wb, W, wave, lane, tw); }
   template <int EPI>
   static __device__ __forceinline__ void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sB, float* sY, int N,
                                               int wave, int lane, bool tw, PF* pf, int nextW, float*, float, bool) {
@@ -27,13 +30,16 @@ struct Sel<HP, 0> {
 template <int HP>
 struct Sel<HP, 3> {
   using PF = w8::NodePFH<HP>;
-  static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool) { w8::node_prefetch_h<HP>(pf, wb, W, wave, lane); }
+  static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tw, int N) { w8::node_prefetch_h<HP>(pf, wb, W, N, tw, wave, lane); }
   template <int EPI>
   static __device__ __forceinline__ void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sB, float* sY, int N,
                                               int wave, int lane, bool tw, PF* pf, int nextW, float* split, float winv, bool seq) {
     const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
     w8::NodeCtxH cx{winv, split, seq ? split : split + w8::nh_split_floats(HP, nct), tw};
-    w8::node_gemm_h<HP, EPI, 3>(wb, Wa, sXa, true, Wb, sXb, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW);
+    if (Wb >= 0)
+      w8::node_gemm_h<HP, EPI, true, GAUDI_MB_MAXNT, w8::kAheadAll, w8::kAheadAll>(wb, Wa, sXa, true, Wb, sXb, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW);
+    else
+      w8::node_gemm_h<HP, EPI, false, GAUDI_MB_MAXNT, w8::kAheadAll, w8::kAheadAll>(wb, Wa, sXa, true, -1, nullptr, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW);
   }
 };
 
@@ -42,16 +48,17 @@ __global__ __launch_bounds__(512) void k(const float* w, unsigned wbytes, int nm
                                          int N, int tail, int two) {
   constexpr int T = HP / 16, LD = HP + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int R = (N + 15) & ~15;
   float* sX = smem;
-  float* sY = sX + 48 * LD;
-  float* sSplit = smem + 2 * 48 * LD;
+  float* sY = sX + R * LD;
+  float* sSplit = smem + 2 * R * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 2 * 48 * LD; i += 512) sX[i] = 0.01f * ((i * 7) % 13) - 0.05f;
+  for (int i = tid; i < 2 * R * LD; i += 512) sX[i] = 0.01f * ((i * 7) % 13) - 0.05f;
   __syncthreads();
   const WBuf wb = make_wbuf(w, wbytes);
   const int MS = (V == 3 ? 1 : 1) * T * T * 256;  // matrix stride in fp32-offset units (the f16 images sit at 2 W)
   typename Sel<HP, V>::PF pf;
-  Sel<HP, V>::prefetch(pf, wb, 0, wave, lane, tail != 0);
+  Sel<HP, V>::prefetch(pf, wb, 0, wave, lane, tail != 0, N);
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
   for (int m = 0; m < gemms; ++m) {
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(512) void k(const float* w, unsigned wbytes, int nm
     __syncthreads();
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  out[blockIdx.x * 512 + tid] = sX[tid % (48 * LD)];
+  out[blockIdx.x * 512 + tid] = sX[tid % (R * LD)];
   if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
@@ -78,23 +85,24 @@ __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, co
   constexpr int T = HP / 16, LD = HP + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sXa = smem;
-  float* sXb = sXa + 48 * LD;
-  float* sY = sXb + 48 * LD;
-  float* sB = sY + 48 * LD;
+  float* sXb = sXa + N * LD;
+  float* sY = sXb + N * LD;
+  float* sB = sY + N * LD;
   float* sSplit = sB + ((HP + 63) / 64) * 64;
+  const int nct_ = N <= 16 ? 1 : N <= 32 ? 2 : 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 48 * LD; i += 512) {
+  for (int i = tid; i < N * LD; i += 512) {
     const int n = i / LD, f = i % LD;
     sXa[i] = (n < N && f < HP) ? x[n * HP + f] : 0.f;
     sXb[i] = (n < N && f < HP) ? x[(48 + n) * HP + f] : 0.f;
     sY[i] = __builtin_nanf("");  // every feature of every live node must be written
   }
   for (int i = tid; i < HP; i += 512) sB[i] = bias[i];
-  for (int i = tid; i < 2 * w8::nh_split_floats(HP, 3); i += 512) sSplit[i] = __builtin_nanf("");  // stale ring contents
+  for (int i = tid; i < (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct_); i += 512) sSplit[i] = __builtin_nanf("");  // stale ring contents
   __syncthreads();
   const WBuf wb = make_wbuf(w, wbytes);
   typename Sel<HP, V>::PF pf;
-  Sel<HP, V>::prefetch(pf, wb, 0, wave, lane, tail != 0);
+  Sel<HP, V>::prefetch(pf, wb, 0, wave, lane, tail != 0, N);
   Sel<HP, V>::template gemm<EPI_NONE>(wb, 0, sXa, two ? T * T * 256 : -1, sXb, sB, sY, N, wave, lane, tail != 0, &pf, -1, sSplit, winv, two == 2);
   __syncthreads();
   for (int i = tid; i < N * HP; i += 512) y[i] = sY[(i / HP) * LD + i % HP];
@@ -158,7 +166,9 @@ void run(int N, int blocks, int nmat, int tail, int two = 0) {
   hipMalloc(&out, blocks * 512 * 4);
   hipMalloc(&cyc, blocks * 8 * 8);
   const int gemms = 600;
-  const size_t lds = (2 * 48 * (HP + 4) + 2 * w8::nh_split_floats(HP, 3)) * 4;
+  const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
+  const size_t lds = (2 * ((N + 15) & ~15) * (HP + 4) + (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct)) * 4;
+  if (hipFuncSetAttribute((const void*)k<HP, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) printf("LDS %zu refused\n", lds);
   hipFuncSetAttribute((const void*)k<HP, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
@@ -223,10 +233,12 @@ void run_num(int H, int N, int tail, int two, int amp = 0) {
   hipMemcpy(dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(db, bias.data(), HP * 4, hipMemcpyHostToDevice);
-  const size_t lds = (3 * 48 * (HP + 4) + ((HP + 63) / 64) * 64 + 2 * w8::nh_split_floats(HP, 3)) * 4;
-  hipFuncSetAttribute((const void*)k_num<HP, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
+  const size_t lds = (3 * N * (HP + 4) + ((HP + 63) / 64) * 64 + (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct)) * 4;
+  if (hipFuncSetAttribute((const void*)k_num<HP, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) printf("LDS %zu refused\n", lds);
   hipLaunchKernelGGL((k_num<HP, V>), dim3(1), dim3(512), lds, 0, dw, (unsigned)(pk.size() * 4), dx, db, dy, N, tail, two, winv);
   std::vector<float> y((size_t)N * HP);
+  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) printf("launch failed (LDS %zu)\n", lds);
   hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost);
   // error per ROW relative to the row's largest |reference| (rows differ by 16 orders of magnitude in the amp cases)
   double worst = 0, padmax = 0;
@@ -254,7 +266,7 @@ void run_num(int H, int N, int tail, int two, int amp = 0) {
 }
 
 template <int V>
-void all() {
+void numerics() {
   for (int tail = 0; tail < 2; ++tail) {
     run_num<208, V>(196, 11, tail, 0);
     run_num<208, V>(196, 11, tail, 1);
@@ -265,9 +277,11 @@ void all() {
   run_num<208, V>(196, 11, 1, 1, 1);
   run_num<208, V>(196, 11, 1, 0, 2);
   run_num<192, V>(192, 16, 0, 2, 1);
-  run_num<208, V>(196, 22, 1, 1);
-  run_num<208, V>(196, 40, 1, 2);
-  run_num<192, V>(192, 40, 0, 1, 2);
+  if (V == 0 || GAUDI_MB_MAXNT >= 2) run_num<208, V>(196, 22, 1, 1);
+  if (V == 0 || GAUDI_MB_MAXNT >= 3) {
+    run_num<208, V>(196, 40, 1, 2);
+    run_num<192, V>(192, 40, 0, 2, 2);
+  }
   run_num<208, V>(208, 11, 0, 1);
   run_num<192, V>(192, 11, 0, 0);
   run_num<192, V>(192, 16, 0, 1);
@@ -275,6 +289,9 @@ void all() {
   run_num<64, V>(64, 9, 0, 0);
   run_num<128, V>(128, 12, 0, 2);
   run_num<256, V>(256, 11, 0, 1);
+}
+template <int V>
+void timing() {
   run<192, V>(11, 256, 63, 0);
   run<208, V>(11, 256, 120, 1);
   run<208, V>(11, 1, 120, 1);
@@ -282,13 +299,22 @@ void all() {
   run<208, V>(11, 256, 1, 1);  // the weights resident in L2 (one matrix)
   run<208, V>(11, 256, 120, 1, 1);  // two sources per call, both split copies up front
   run<208, V>(11, 256, 120, 1, 2);  // ... split in turn (one region)
-  run<208, V>(20, 256, 120, 1);     // two column tiles (hetero molecules)
-  run<208, V>(20, 256, 120, 1, 2);
-  run<208, V>(40, 256, 120, 1);     // three column tiles
+  if (V == 0 || GAUDI_MB_MAXNT >= 2) {
+    run<208, V>(20, 256, 120, 1);     // two column tiles (hetero molecules)
+    run<208, V>(20, 256, 120, 1, 2);
+  }
+  if (V == 0 || GAUDI_MB_MAXNT >= 3) run<208, V>(40, 256, 120, 1);     // three column tiles
 }
 
-int main() {
-  all<0>();
-  all<3>();
+int main(int argc, char**) {
+  printf("depth <= %d (one column tile) / %d (more), column tiles <= %d, ablation %d\n", GAUDI_NODE_MAXDEPTH, GAUDI_NODE_DEPTH2, GAUDI_MB_MAXNT, GAUDI_NODE_ABLATE);
+  if (argc > 1) {  // any argument: the fp16 form's timings only
+    timing<3>();
+    return 0;
+  }
+  numerics<0>();
+  timing<0>();
+  numerics<3>();
+  timing<3>();
   return 0;
 }
