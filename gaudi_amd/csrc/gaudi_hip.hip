@@ -368,8 +368,8 @@ static void pack_edge_matrix(const PackMode& pm, float* dst, const float* W, int
 // fp16-pair image of a node-GEMM matrix (w8_nodes_f16.h): w 2^s = hi + lo 2^-11 with hi = fp16(w 2^s), lo = fp16((w 2^s - hi) 2^11), both
 // round-to-nearest-even (NaN stays NaN; the host refuses infinite weights, node_scale below).  Units of 1 KiB ordered
 // [K chunk m of 32 inputs][output tile t][piece]; lane L = (row L & 15, group g = L >> 4) holds inputs 32 m + 8 g .. +7.
-// ktail (H % 16 == 4, odd tile count >= 3): the 4 tail inputs are a trailing block of T x 64 floats, UNSCALED fp32 -- lane
-// (row, k - 16 (T - 1)) of tile t: one v_mfma_f32_16x16x4_f32 step per output tile.
+// An odd tile count leaves a last half chunk of 16 inputs: a trailing block of T x 256 floats, UNSCALED fp32, [tile][k-step q]
+// [lane (row, g)] = W[row][16 (T-1) + 4 q + g]: v_mfma_f32_16x16x4_f32 steps (one of them when H % 16 == 4).
 static uint16_t f16_bits(float x) {
   const _Float16 hv = (_Float16)x;
   uint16_t u;
@@ -381,17 +381,16 @@ static float f16_value(uint16_t b) {
   std::memcpy(&hv, &b, 2);
   return (float)hv;
 }
-static void pack_matrix_f16(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose, bool ktail, float scale) {
+static void pack_matrix_f16(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose, float scale) {
   const int T = HP / 16;
-  const bool tail = w8::nh_has_tail(HP, ktail);
-  const int nc = w8::nh_chunks(HP, ktail);
   uint16_t* d = (uint16_t*)dst;
   for (int o = 0; o < H; ++o)
     for (int k = 0; k < H; ++k) {
       const float v = transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k];
       const int t = o / 16, i = o % 16;
-      if (tail && k >= 16 * (T - 1)) {
-        dst[(size_t)nc * w8::nh_chunk_floats(HP) + t * 64 + (k - 16 * (T - 1)) * 16 + i] = v;
+      if (w8::nh_odd(HP) && k >= 16 * (T - 1)) {  // the last half chunk: fp32, unscaled, [tile][k-step q][lane (row, g)]
+        const int kk = k - 16 * (T - 1);
+        dst[(size_t)w8::nh_tail_off(HP) + t * 256 + (kk / 4) * 64 + (kk % 4) * 16 + i] = v;
         continue;
       }
       const int m = k / 32, L = ((k % 32) / 8) * 16 + i, e = k % 8;
@@ -435,7 +434,7 @@ struct NodeScale {
 static void pack_node_matrix(const PackMode& pm, float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose = false) {
   pack_matrix(pm, dst, W, H, ldw, col0, HP, transpose);
   if (pm.ws != nullptr && pm.hscale > 0.f)
-    pack_matrix_f16(pm.ws->data() + 2 * (size_t)(dst - pm.wbase), W, H, ldw, col0, HP, transpose, pm.hktail, pm.hscale);
+    pack_matrix_f16(pm.ws->data() + 2 * (size_t)(dst - pm.wbase), W, H, ldw, col0, HP, transpose, pm.hscale);
 }
 static void pack_vec(float* dst, const float* v, int n) { std::memcpy(dst, v, sizeof(float) * n); }
 static void pack_col(float* dst, const float* W, int H, int ldw, int col) {
@@ -862,7 +861,7 @@ static bool node_f16_fits(int hp, int N, int split, bool gn) {
   if (N > 48) return false;  // at most three column tiles per pass
   const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
   const int ring = w8::edge_ring_floats(hp, split);
-  return w8::nh_split_floats(hp, nct) <= (gn || split == 2 ? ring : ring / 2);
+  return w8::nh_split_floats(hp, nct) <= (w8::node_ring_idle(hp, split, gn) ? ring : ring / 2);
 }
 static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pubx, int& pub_ch, bool gn = false) {
   pubx = 0;

@@ -160,9 +160,10 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   // NH: node GEMMs on fp16 pairs (w8_nodes_f16.h); their inputs' split copies live in the weight ring during the node phases
   constexpr bool NH = NodeMath<SP>::kF16;
   // RI: the ring is idle during the node phases -- GN: the node GEMMs' input rows are staged in it (w8_common.h: stage_rows; the
-  // fp16 form's split copies instead); half-ring mode with the fp16 form: its free slot alone would not hold a split copy --
-  // and every edge phase requests its first weight group itself instead of having it travel across the node phase
-  constexpr bool RI = GN || (NH && SP == 2);
+  // fp16 form's split copies instead); half-ring mode (and the smallest hidden size) with the fp16 form: the free slot alone
+  // would not hold a split copy -- and every edge phase requests its first weight group itself instead of having it travel
+  // across the node phase
+  constexpr bool RI = node_ring_idle(HP, SP, GN);
   constexpr bool STG = GN && !NH;  // fp32 node GEMMs of a GN kernel read staged rows
   float* const xs0 = sm.ring;
   float* const xs1 = sm.ring + stage_stride(N * LD);

@@ -23,17 +23,22 @@
 // scrubs both the same way (models.py:138-141).  The host refuses the form (-> fp32 node GEMMs) for weight sets with
 // infinities or a matrix that lies more than 2^24 below the largest one.
 //
-// Bytes.  hi and lo are 2 + 2 bytes: a matrix image is exactly the fp32 matrix's size (units of 1 KiB ordered
-// [K chunk of 32][output tile][piece], lane L = (row L & 15, inputs 8 (L >> 4) .. +7 of the chunk); a K tail -- H % 16 == 4 --
-// is a trailing block of T x 256 B fp32 k-steps, as in the split edge images).  Images live at float offset 2 W of their own
-// buffer (W = the fp32 buffer's offset; an odd tile count without a K tail needs (T + 1) / T of the fp32 size).
+// Bytes.  hi and lo are 2 + 2 bytes: a matrix image is exactly the fp32 matrix's size -- units of 1 KiB ordered
+// [K chunk of 32][output tile][piece], lane L = (row L & 15, inputs 8 (L >> 4) .. +7 of the chunk).  An odd tile count (208 =
+// 13 tiles, 48 = 3) leaves a last half chunk: those 16 inputs stay fp32, unscaled -- a trailing block [tile][k-step q][lane
+// (row, g)] = W[row][16 (T-1) + 4 q + g], run as v_mfma_f32_16x16x4_f32 steps: ONE step for H % 16 == 4 (196: four valid
+// inputs; only that step's 256 B per tile are ever loaded), four otherwise.  Images live in the split buffer at float offset
+// 2 W (W = the fp32 buffer's offset), in the slots the node matrices leave empty there.
 //
 // Schedule.  Output tile t -> wave t & 7 (as the fp32 form).  The activations of a GEMM input are split ONCE by all waves into
 // LDS (wave w: rows w, w + 8, ...; one DPP max-scan per row, no cross-wave step) in B-operand order -- two conflict-free
-// ds_read_b128 per chunk and column tile; the weight stream runs up to a whole matrix ahead in registers (nh_depth), across the two sources of
-// a GEMM and across calls (the next matrix's first chunks travel while this one drains).  Accumulation order per output element:
-// K chunks in order, per chunk w_hi x_lo, w_hi x_hi, w_lo x_hi; then the K tail's fp32 step; sources in order -- independent of
-// the column-tile count and of the wave's tile count (packed launches stay bit-identical to unpacked ones).
+// ds_read_b128 per chunk and column tile; the weight stream runs kDepthH chunks ahead in registers, across the two sources of
+// a GEMM and across calls (the next matrix's first chunks travel while this one drains).  ONE body serves every wave and every
+// column-tile count: the registers of the weight stream are defined at one program point per chunk (a wave without a second tile
+// loads with out-of-range lanes, which fetch nothing); with one body per case hipcc joined the cases through register copies of
+// loads in flight, i.e. a wait for the whole stream at every call.  Accumulation order per output element: K chunks in order,
+// per chunk w_hi x_lo, w_hi x_hi, w_lo x_hi; then the fp32 tail steps; sources in order -- independent of the column-tile count
+// and of the wave's tile count (packed launches stay bit-identical to unpacked ones).
 #pragma once
 #include "w8_split.h"
 
@@ -44,11 +49,11 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(2))) uint32_t u2;
 
+constexpr float kLoScale = 2048.f;  // 2^11
 #ifndef GAUDI_NODE_ABLATE
 #define GAUDI_NODE_ABLATE 0  // microbenchmark only (timing, wrong results): 1 = no split pass, 2 = no matrix instructions, 4 = no weight loads
 #endif
 constexpr int kAblateH = GAUDI_NODE_ABLATE;
-constexpr float kLoScale = 2048.f;  // 2^11
 
 __device__ __forceinline__ f4 mfma_h(const u4 a, const u4 b, const f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
@@ -58,24 +63,26 @@ __device__ __forceinline__ u4 ldu4h(const WBuf& wh, int off_floats, int lane) {
 }
 
 // ---- geometry shared with the host packer (gaudi_hip.hip: pack_matrix_f16)
-__host__ __device__ constexpr bool nh_has_tail(int HP, bool ktail) { return ktail && ((HP / 16) & 1) && HP / 16 >= 3; }
-__host__ __device__ constexpr int nh_chunks(int HP, bool ktail) { return nh_has_tail(HP, ktail) ? (HP / 16 - 1) / 2 : (HP / 16 + 1) / 2; }
-__host__ __device__ constexpr int nh_chunk_floats(int HP) { return (HP / 16) * 2 * 256; }             // one K chunk of an image
-__host__ __device__ constexpr int nh_image_floats(int HP, bool ktail) {                               // <= 2 HP^2
-  return nh_chunks(HP, ktail) * nh_chunk_floats(HP) + (nh_has_tail(HP, ktail) ? (HP / 16) * 64 : 0);
-}
+__host__ __device__ constexpr bool nh_odd(int HP) { return ((HP / 16) & 1) != 0; }          // a last half chunk: the fp32 tail block
+__host__ __device__ constexpr int nh_chunks(int HP) { return HP / 32; }                      // fp16 chunks of 32 inputs
+__host__ __device__ constexpr int nh_chunk_floats(int HP) { return (HP / 16) * 2 * 256; }    // one K chunk of an image
+__host__ __device__ constexpr int nh_tail_off(int HP) { return nh_chunks(HP) * nh_chunk_floats(HP); }  // [tile][q][64] floats
+// k-steps of the tail block that hold weights: one when only four inputs of the last tile exist (H % 16 == 4), else four
+__host__ __device__ constexpr int nh_tail_steps(bool ktail) { return ktail ? 1 : 4; }
 // split copy of one GEMM input in LDS, NCT column tiles of 16 nodes: [chunk][column tile][piece][64 x 16 B] with 64 B of padding
-// per chunk (the splitting wave's 8-byte stores of one row then fall on distinct banks), then the K tail's fp32 B operands
-// [column tile][64] and the per-node descale factors [column tile][16]
+// per chunk (the splitting wave's 8-byte stores of one row then fall on distinct banks), then the tail's fp32 inputs
+// [column tile][node][16] and the per-node descale factors [column tile][16]
 __host__ __device__ constexpr int nh_chunk_stride(int nct) { return nct * 512 + 16; }
-__host__ __device__ constexpr int nh_split_floats(int HP, int nct) { return ((HP / 16 + 1) / 2) * nh_chunk_stride(nct) + nct * 80; }
+__host__ __device__ constexpr int nh_split_floats(int HP, int nct) {
+  return nh_chunks(HP) * nh_chunk_stride(nct) + (nh_odd(HP) ? nct * 256 : 0) + nct * 16;
+}
 
 struct SplitBufH {
   float* base;
   int nct;  // column tiles
   __device__ __forceinline__ float* chunk(int m) const { return base + m * nh_chunk_stride(nct); }
-  __device__ __forceinline__ float* tail(int HP) const { return base + ((HP / 16 + 1) / 2) * nh_chunk_stride(nct); }
-  __device__ __forceinline__ float* scale(int HP) const { return tail(HP) + nct * 64; }
+  __device__ __forceinline__ float* tail(int HP) const { return base + nh_chunks(HP) * nh_chunk_stride(nct); }
+  __device__ __forceinline__ float* scale(int HP) const { return tail(HP) + (nh_odd(HP) ? nct * 256 : 0); }
 };
 
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -120,8 +127,8 @@ __device__ __forceinline__ SplitRowH split_row_load(const float* X, int n, int l
   return r;
 }
 template <int HP>
-__device__ __forceinline__ void split_row_store(const SplitBufH& sb, const f4 x, uint32_t mx, int n, bool tail, int nc, int lane) {
-  constexpr int T = HP / 16;
+__device__ __forceinline__ void split_row_store(const SplitBufH& sb, const f4 x, uint32_t mx, int n, int lane) {
+  constexpr int T = HP / 16, nc = nh_chunks(HP);
   const int m = lane >> 3, g = (lane >> 1) & 3, half = lane & 1;
   // the row's largest exponent -> 14 (values below 2^15 < 65 504); exponents clamped so that both factors are normal numbers
   int k = 141 - (int)(mx >> 23);
@@ -137,21 +144,20 @@ __device__ __forceinline__ void split_row_store(const SplitBufH& sb, const f4 x,
     float* d = sb.chunk(m) + ct * 512 + (4 * c + g) * 4 + half * 2;
     *(u2*)d = (u2){h01, h23};
     *(u2*)(d + 256) = (u2){l01, l23};
+  } else if (nh_odd(HP) && lane < HP / 4) {  // inputs 16 (T-1) .. +15, unscaled: the fp32 tail steps
+    *(f4*)(sb.tail(HP) + ct * 256 + c * 16 + 4 * (lane - 4 * (T - 1))) = x;
   }
-  if (tail && lane == 4 * (T - 1)) *(f4*)(sb.tail(HP) + ct * 64 + 4 * c) = x;  // inputs 16 (T-1) .. +3, unscaled: the fp32 k-step
   if (lane == 0) sb.scale(HP)[ct * 16 + c] = inv;
 }
 template <int HP>
-__device__ __forceinline__ void split_rows_h(const SplitBufH& sb, const float* X, int N, bool ktail, int wave, int lane) {
-  const bool tail = nh_has_tail(HP, ktail);
-  const int nc = nh_chunks(HP, ktail);
+__device__ __forceinline__ void split_rows_h(const SplitBufH& sb, const float* X, int N, int wave, int lane) {
   for (int n = wave; n < N; n += 2 * kWaves) {
     const int n2 = n + kWaves < N ? n + kWaves : n;  // (a second copy of the same row when there is no partner: same stores)
     SplitRowH a = split_row_load<HP>(X, n, lane), b = split_row_load<HP>(X, n2, lane);
     a.mx = wave_max_u32(a.mx);
     b.mx = wave_max_u32(b.mx);
-    split_row_store<HP>(sb, a.x, a.mx, n, tail, nc, lane);
-    if (n2 != n) split_row_store<HP>(sb, b.x, b.mx, n2, tail, nc, lane);
+    split_row_store<HP>(sb, a.x, a.mx, n, lane);
+    if (n2 != n) split_row_store<HP>(sb, b.x, b.mx, n2, lane);
   }
 }
 
@@ -162,64 +168,63 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// one chunk of the wave's (up to two) output tiles: [tile][piece]
-struct NodeSetH {
-  u4 p[2][2];
+// Weight chunks in flight per wave.  A buffer_load occupies its wave until the CU's vector-memory pipe accepts it (~50 B/clk per
+// CU: the K loop of a matrix cannot be shorter than its bytes take), so a deeper queue buys nothing once the loads of one step
+// are covered (depth 3, 4 and 6 measure the same: profiles/r05d_node_gemm_h_microbench.txt); what pays is issuing them in
+// straight-line code -- hipcc then counts the loads in flight exactly, where any branch around a load made it wait for
+// vmcnt(0) at every step.  A matrix's chunks are consumed in turns of D sets: chunk i lives in set i % D of every matrix.
+#ifndef GAUDI_NODE_DEPTH
+#define GAUDI_NODE_DEPTH 3
+#endif
+template <int HP>
+struct NodeGeoH {
+  static constexpr int T = HP / 16;
+  static constexpr int NTW = T > kWaves ? 2 : 1;  // output tiles per wave (tile t -> wave t & 7)
+  static constexpr int nc = nh_chunks(HP);
+  static constexpr int D = nc < GAUDI_NODE_DEPTH ? (nc > 0 ? nc : 1) : GAUDI_NODE_DEPTH;
+  static constexpr bool odd = nh_odd(HP);
 };
-// Weight chunks in flight per wave.  The stream is latency-bound when the chunks in flight are few (the weight set does not fit
-// an XCD's L2: every chunk comes from the Infinity Cache at ~1 us), so the depth is what the register file allows: a whole
-// matrix (<= 6 chunks = 96 registers on a two-tile wave) with one column tile of nodes, three chunks with more
-// (tools/node_gemm_h_microbench.hip, profiles/r05b_*).  A matrix's chunks are consumed in turns of D sets: chunk i lives in set
-// i % D of every matrix (a last turn may be partly empty), so no register ever moves and the whole K loop is straight-line code
-// -- hipcc then counts the loads in flight exactly (any branch around a load made it wait for vmcnt(0) at every step).
-#ifndef GAUDI_NODE_MAXDEPTH
-#define GAUDI_NODE_MAXDEPTH 3
-#endif
-#ifndef GAUDI_NODE_DEPTH2
-#define GAUDI_NODE_DEPTH2 3
-#endif
-constexpr int kMaxDepthH = GAUDI_NODE_MAXDEPTH;
-__host__ __device__ constexpr int nh_depth(int HP, bool ktail, int nt) {
-  const int nc = nh_chunks(HP, ktail);
-  const int want = nt == 1 ? kMaxDepthH : (GAUDI_NODE_DEPTH2 < kMaxDepthH ? GAUDI_NODE_DEPTH2 : kMaxDepthH);
-  if (nc <= want) return nc;
-  const int turns = (nc + want - 1) / want;
-  return (nc + turns - 1) / turns;  // the turns as even as they get
-}
+// one chunk of the wave's (up to two) output tiles: [tile][piece]
+template <int NTW>
+struct NodeSetH {
+  u4 p[NTW][2];
+};
 template <int HP>
 struct NodePFH {
-  static constexpr int kSets = (HP / 16 + 1) / 2 < kMaxDepthH ? (HP / 16 + 1) / 2 : kMaxDepthH;
-  NodeSetH s[kSets];  // chunks 0 .. of the next node GEMM, loaded ahead of the call
+  NodeSetH<NodeGeoH<HP>::NTW> s[NodeGeoH<HP>::D];  // chunks 0 .. D-1 of the next node GEMM, loaded ahead of the call
 };
 
-template <int NTW>
-__device__ __forceinline__ void nh_load(NodeSetH& s, const WBuf& wh, int chunk_off, int wave, int lane) {
+// the lane offsets of the wave's tiles: a tile the wave does not have is "loaded" with an out-of-range lane (returns 0, fetches
+// nothing) -- every wave runs the same loads, none sits behind a branch
+template <int HP>
+struct TileLanesH {
+  int l[NodeGeoH<HP>::NTW];
+  __device__ __forceinline__ TileLanesH(int wave, int lane, bool on = true) {
 #pragma unroll
-  for (int u = 0; u < NTW; ++u) {
-    s.p[u][0] = ldu4h(wh, chunk_off + ((wave + kWaves * u) * 2 + 0) * 256, lane);
-    s.p[u][1] = ldu4h(wh, chunk_off + ((wave + kWaves * u) * 2 + 1) * 256, lane);
+    for (int u = 0; u < NodeGeoH<HP>::NTW; ++u) l[u] = (on && wave + kWaves * u < NodeGeoH<HP>::T) ? lane : kOOBLane;
+  }
+};
+template <int HP>
+__device__ __forceinline__ void nh_load(NodeSetH<NodeGeoH<HP>::NTW>& s, const WBuf& wh, int chunk_off, int wave, const TileLanesH<HP>& tl) {
+#pragma unroll
+  for (int u = 0; u < NodeGeoH<HP>::NTW; ++u) {
+    const int t = wave + kWaves * u < NodeGeoH<HP>::T ? wave + kWaves * u : 0;
+    s.p[u][0] = ldu4h(wh, chunk_off + (t * 2 + 0) * 256, tl.l[u]);
+    s.p[u][1] = ldu4h(wh, chunk_off + (t * 2 + 1) * 256, tl.l[u]);
   }
 }
-// How many chunks travel ahead of a call: kAheadAll = as many as the call's depth (where the next GEMM follows directly, or
-// from a point in an edge phase where the registers are free again), kAheadOne = ONE chunk (16 registers: across the register-
-// tight parts of an edge phase; the call issues the others itself, and they fly while its input is split).
+// How many chunks travel ahead of a call: kAheadAll = as many as the depth (where the next GEMM follows directly), kAheadOne =
+// ONE chunk (8-16 registers: across the register-tight edge phases; the call issues the others itself, and they fly while its
+// input is split).
 constexpr int kAheadOne = 1, kAheadAll = 99;
 template <int HP, int AHEAD = kAheadAll>
-__device__ __forceinline__ void node_prefetch_h(NodePFH<HP>& pf, const WBuf& wh, int W /* fp32 float offset */, int N, bool ktail, int wave,
-                                                int lane) {
-  constexpr int T = HP / 16;
-  // (the depth depends on the column-tile count of the GEMMs that follow: nh_depth)
-  const int depth = N <= 16 ? nh_depth(HP, ktail, 1) : nh_depth(HP, ktail, 2);
-  const int nd = AHEAD < depth ? AHEAD : depth;
-  if (wave + kWaves < T) {
-#pragma unroll
-    for (int d = 0; d < NodePFH<HP>::kSets; ++d)
-      if (d < nd) nh_load<2>(pf.s[d], wh, 2 * W + d * nh_chunk_floats(HP), wave, lane);
-  } else if (wave < T) {
-#pragma unroll
-    for (int d = 0; d < NodePFH<HP>::kSets; ++d)
-      if (d < nd) nh_load<1>(pf.s[d], wh, 2 * W + d * nh_chunk_floats(HP), wave, lane);
-  }
+__device__ __forceinline__ void node_prefetch_h(NodePFH<HP>& pf, const WBuf& wh, int W /* fp32 float offset */, int wave, int lane) {
+  constexpr int nd = AHEAD < NodeGeoH<HP>::D ? AHEAD : NodeGeoH<HP>::D;
+  const TileLanesH<HP> tl(wave, lane);
+  static_for<nd>([&](auto d_tag) {
+    constexpr int d = decltype(d_tag)::value;
+    nh_load<HP>(pf.s[d], wh, 2 * W + d * nh_chunk_floats(HP), wave, tl);
+  });
 }
 
 // what a call needs beside the fp32 form's arguments
@@ -227,111 +232,113 @@ struct NodeCtxH {
   float winv;       // 2^-s_w: descale of the network's node matrices
   float* split_a;   // LDS: split copy of the first source (nh_split_floats(HP, nct) floats)
   float* split_b;   // ... of the second source; == split_a: the region holds ONE input, the sources are split in turn
-  bool ktail;
+  bool ktail;       // H % 16 == 4: the tail block holds one k-step
 };
 
-// PIN: chunks of Wa that were loaded ahead of the call (pf.s[0 .. min(PIN, D))); POUT: chunks of nextW this call loads ahead
-template <int HP, int EPI, int NT, int NTW, bool KTAIL, bool TWO, int PIN, int POUT>
-__device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const float* sXa, bool do_split_a, int Wb, const float* sXb,
-                                                 const float* sBias, float* sY, const float* sRes, const float* sMask, int N, int wave,
-                                                 int lane, const NodeCtxH& cx, NodePFH<HP>& pf, int nextW, float* gPre) {
-  constexpr int T = HP / 16, LD = HP + 4;
-  constexpr bool tail = nh_has_tail(HP, KTAIL);
-  constexpr int nc = nh_chunks(HP, KTAIL);
-  constexpr int D = nh_depth(HP, KTAIL, NT);
-  constexpr int R = (nc + D - 1) / D;  // turns per matrix
+// One node GEMM of the workgroup (all waves call it; N <= 16 MAXNT node columns).
+//   TWO: a second source (Wb, sXb).  do_split_a = false: an earlier call of this phase left the first source's split copy in
+//   cx.split_a (P and Q share h, the two transposed GEMMs of dnpre share it).  PIN: chunks of Wa that were loaded ahead of the call
+//   (pf.s[0 .. min(PIN, D))); POUT: chunks of nextW this call loads ahead.
+// The caller guarantees that nobody still reads the split regions when the call starts (a barrier since their last use) and
+// places a barrier between this call's stores to sY and their readers, as for the fp32 form.
+template <int HP, int EPI, bool TWO, int MAXNT, int PIN = kAheadOne, int POUT = kAheadOne>
+__device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float* sXa, bool do_split_a, int Wb, const float* sXb,
+                                            const float* sBias, float* sY, const float* sRes, const float* sMask, int N, int wave,
+                                            int lane, const NodeCtxH& cx, NodePFH<HP>& pf, int nextW = -1, float* gPre = nullptr) {
+  using G = NodeGeoH<HP>;
+  constexpr int T = G::T, LD = HP + 4, NTW = G::NTW, nc = G::nc, D = G::D;
   constexpr int kIn = PIN < D ? PIN : D, kOut = POUT < D ? POUT : D;
-  static_assert(D <= NodePFH<HP>::kSets, "depth");
   const int c = lane & 15, g = lane >> 4;
+  // column tiles of this call (wave-uniform; the code below branches on it around matrix instructions and LDS traffic only)
+  const int nt = (MAXNT < 2 || N <= 16) ? 1 : (MAXNT < 3 || N <= 32) ? 2 : 3;
   const bool seq = TWO && cx.split_b == cx.split_a;
-  const SplitBufH sa{cx.split_a, NT}, sb{cx.split_b, NT};
+  const SplitBufH sa{cx.split_a, nt}, sb{cx.split_b, nt};
   const int bpos = (4 * c + g) * 4;  // the lane's float offset inside a 1 KiB B unit
-  // a matrix that is not there (no next GEMM) is "loaded" with out-of-range lanes: such a load returns 0 and fetches nothing --
-  // no branch around a load anywhere in this function
-  const int lane_next = nextW >= 0 ? lane : kOOBLane;
+  const TileLanesH<HP> tl(wave, lane);
+  // a matrix that is not there (no next GEMM) is "loaded" with out-of-range lanes too
+  const TileLanesH<HP> tl_next(wave, lane, nextW >= 0);
   const int Wn = nextW >= 0 ? nextW : Wa;
-  struct BH {
-    u4 h[NT], l[NT];
-  };
-  auto bld = [&](const SplitBufH& s_, int i) {
-    const float* q = s_.chunk(i) + bpos;
-    BH b;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      b.h[j] = *(const u4*)(q + j * 512);
-      b.l[j] = *(const u4*)(q + j * 512 + 256);
-    }
-    return b;
-  };
   // chunks that did not travel ahead of the call
   static_for<D>([&](auto d_tag) {
     constexpr int d = decltype(d_tag)::value;
-    if constexpr (d >= kIn) nh_load<NTW>(pf.s[d], wh, 2 * Wa + d * nh_chunk_floats(HP), wave, lane);
+    if constexpr (d >= kIn) nh_load<HP>(pf.s[d], wh, 2 * Wa + d * nh_chunk_floats(HP), wave, tl);
   });
-  // K-tail weights (one fp32 k-step per output tile and source)
-  float ta[NTW], tb[NTW];
-  if constexpr (tail) {
+  // tail weights (odd tile counts): k-step q of the wave's tiles; steps past the first are loaded only when they hold weights
+  float ta[NTW][4], tb[NTW][4];
+  if constexpr (G::odd) {
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
-      const int t = wave + kWaves * u;
-      ta[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wh.r, lane * 4, (2 * Wa + nc * nh_chunk_floats(HP) + t * 64) * 4, 0));
-      if constexpr (TWO)
-        tb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wh.r, lane * 4, (2 * Wb + nc * nh_chunk_floats(HP) + t * 64) * 4, 0));
+      const int t = wave + kWaves * u < T ? wave + kWaves * u : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ln = (q == 0 || !cx.ktail) ? tl.l[u] : kOOBLane;
+        ta[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wh.r, ln * 4, (2 * Wa + nh_tail_off(HP) + t * 256 + q * 64) * 4, 0));
+        if constexpr (TWO)
+          tb[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wh.r, ln * 4, (2 * Wb + nh_tail_off(HP) + t * 256 + q * 64) * 4, 0));
+      }
     }
   }
   if (!(kAblateH & 1)) {
-    if (do_split_a) split_rows_h<HP>(sa, sXa, N, KTAIL, wave, lane);
-    if (TWO && !seq) split_rows_h<HP>(sb, sXb, N, KTAIL, wave, lane);
+    if (do_split_a) split_rows_h<HP>(sa, sXa, N, wave, lane);
+    if (TWO && !seq) split_rows_h<HP>(sb, sXb, N, wave, lane);
     if (do_split_a || (TWO && !seq)) lds_barrier();
   }
 
-  f4 acc0[NT][NTW], acc1[NT][NTW], y[NT][NTW];
+  f4 acc0[MAXNT][NTW], acc1[MAXNT][NTW], y[MAXNT][NTW];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int j = 0; j < MAXNT; ++j)
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
+      const int t = wave + kWaves * u < T ? wave + kWaves * u : 0;
       acc0[j][u] = splat(0.f);
       acc1[j][u] = splat(0.f);
-      y[j][u] = sBias != nullptr ? *(const f4*)(sBias + 16 * (wave + kWaves * u) + 4 * g) : splat(0.f);
+      y[j][u] = sBias != nullptr ? *(const f4*)(sBias + 16 * t + 4 * g) : splat(0.f);
     }
-  // descale and fold the accumulators of one source into y
-  auto fold = [&](const SplitBufH& s_, const float (&tw)[NTW]) {
-    if constexpr (tail) {  // the K tail's fp32 step: inputs 16 (T-1) + g on lane group g, unscaled operands
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float xb = s_.tail(HP)[j * 64 + 4 * c + g];
-#pragma unroll
-        for (int u = 0; u < NTW; ++u) y[j][u] = mfma1(tw[u], xb, y[j][u]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float sc = s_.scale(HP)[j * 16 + c] * cx.winv;
-#pragma unroll
-      for (int u = 0; u < NTW; ++u) {
-        y[j][u] = y[j][u] + (acc0[j][u] + acc1[j][u] * (1.0f / kLoScale)) * sc;
-        acc0[j][u] = splat(0.f);
-        acc1[j][u] = splat(0.f);
-      }
-    }
+  struct BH {
+    u4 h, l;
   };
-  auto mm = [&](const NodeSetH& s, const BH& b) {
+  auto bld = [&](const SplitBufH& s_, int i, int j) {
+    const float* q = s_.chunk(i) + bpos + j * 512;
+    return BH{*(const u4*)q, *(const u4*)(q + 256)};
+  };
+  // the three piece products of one column tile against one chunk
+  auto mm = [&](const NodeSetH<NTW>& s, const BH& b, int j) {
     if (kAblateH & 2) {  // (keep the operands alive)
-      asm volatile("" ::"v"(s.p[0][0]), "v"(s.p[0][1]), "v"(s.p[NTW - 1][0]), "v"(s.p[NTW - 1][1]), "v"(b.h[0]), "v"(b.l[NT - 1]));
+      asm volatile("" ::"v"(s.p[0][0]), "v"(s.p[0][1]), "v"(s.p[NTW - 1][0]), "v"(s.p[NTW - 1][1]), "v"(b.h), "v"(b.l));
       return;
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int u = 0; u < NTW; ++u) acc1[j][u] = mfma_h(s.p[u][0], b.l, acc1[j][u]);
 #pragma unroll
-      for (int u = 0; u < NTW; ++u) acc1[j][u] = mfma_h(s.p[u][0], b.l[j], acc1[j][u]);
+    for (int u = 0; u < NTW; ++u) acc0[j][u] = mfma_h(s.p[u][0], b.h, acc0[j][u]);
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int u = 0; u < NTW; ++u) acc1[j][u] = mfma_h(s.p[u][1], b.h, acc1[j][u]);
+  };
+  // descale and fold the accumulators of one source into y
+  auto fold = [&](const SplitBufH& s_, const float (&tw)[NTW][4]) {
+    static_for<MAXNT>([&](auto j_tag) {
+      constexpr int j = decltype(j_tag)::value;
+      if (j < nt) {
+        if constexpr (G::odd) {  // the tail's fp32 steps: inputs 16 (T-1) + 4 q + g on lane group g, unscaled operands
+          const float* xt = s_.tail(HP) + j * 256 + c * 16 + g;
 #pragma unroll
-      for (int u = 0; u < NTW; ++u) acc0[j][u] = mfma_h(s.p[u][0], b.h[j], acc0[j][u]);
+          for (int u = 0; u < NTW; ++u) y[j][u] = mfma1(tw[u][0], xt[0], y[j][u]);
+          if (!cx.ktail) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+            for (int q = 1; q < 4; ++q)
 #pragma unroll
-      for (int u = 0; u < NTW; ++u) acc1[j][u] = mfma_h(s.p[u][1], b.h[j], acc1[j][u]);
+              for (int u = 0; u < NTW; ++u) y[j][u] = mfma1(tw[u][q], xt[4 * q], y[j][u]);
+          }
+        }
+        const float sc = s_.scale(HP)[j * 16 + c] * cx.winv;
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) {
+          y[j][u] = y[j][u] + (acc0[j][u] + acc1[j][u] * (1.0f / kLoScale)) * sc;
+          acc0[j][u] = splat(0.f);
+          acc1[j][u] = splat(0.f);
+        }
+      }
+    });
   };
   // one source: its nc chunks in order, straight-line.  After chunk i the set is refilled with what it holds next: chunk i + D
   // of the same matrix, else chunk i % D of the matrix that follows (the second source; after the last source the next GEMM's
@@ -340,19 +347,27 @@ __device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const f
     constexpr int src = decltype(src_tag)::value;
     constexpr bool last_src = !TWO || src == 1;
     const int Wcur = src == 0 ? Wa : Wb;
-    BH bcur = bld(s_, 0);
+    BH bcur = bld(s_, 0, 0);
     static_for<nc>([&](auto i_tag) {
       constexpr int i = decltype(i_tag)::value;
       constexpr int d = i % D;
       BH bnext = bcur;
-      if constexpr (i + 1 < nc) bnext = bld(s_, i + 1);
+      if constexpr (i + 1 < nc) bnext = bld(s_, i + 1, 0);
       __builtin_amdgcn_sched_barrier(0);
-      mm(pf.s[d], bcur);
+      mm(pf.s[d], bcur, 0);
+      if constexpr (MAXNT >= 2) {
+        if (nt >= 2) {  // (matrix instructions and LDS reads only: nothing of the weight stream sits behind this branch)
+          mm(pf.s[d], bld(s_, i, 1), 1);
+          if constexpr (MAXNT >= 3) {
+            if (nt >= 3) mm(pf.s[d], bld(s_, i, 2), 2);
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (!(kAblateH & 4)) {
-        if constexpr (i + D < nc) nh_load<NTW>(pf.s[d], wh, 2 * Wcur + (i + D) * nh_chunk_floats(HP), wave, lane);
-        else if constexpr (!last_src) nh_load<NTW>(pf.s[d], wh, 2 * Wb + d * nh_chunk_floats(HP), wave, lane);
-        else if constexpr (d < kOut) nh_load<NTW>(pf.s[d], wh, 2 * Wn + d * nh_chunk_floats(HP), wave, lane_next);
+        if constexpr (i + D < nc) nh_load<HP>(pf.s[d], wh, 2 * Wcur + (i + D) * nh_chunk_floats(HP), wave, tl);
+        else if constexpr (!last_src) nh_load<HP>(pf.s[d], wh, 2 * Wb + d * nh_chunk_floats(HP), wave, tl);
+        else if constexpr (d < kOut) nh_load<HP>(pf.s[d], wh, 2 * Wn + d * nh_chunk_floats(HP), wave, tl_next);
       }
       __builtin_amdgcn_sched_barrier(0);
       bcur = bnext;
@@ -363,85 +378,42 @@ __device__ __forceinline__ void node_gemm_h_body(const WBuf& wh, int Wa, const f
   if constexpr (TWO) {
     if (seq) {
       lds_barrier();  // (every wave is done with the first source's copy; the weight loads in flight stay in flight)
-      split_rows_h<HP>(sb, sXb, N, KTAIL, wave, lane);
+      split_rows_h<HP>(sb, sXb, N, wave, lane);
       lds_barrier();
     }
     source(std::integral_constant<int, 1>{}, sb);
     fold(sb, tb);
   }
-  (void)R;
+  static_for<MAXNT>([&](auto j_tag) {
+    constexpr int j = decltype(j_tag)::value;
+    if (j < nt) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int u = 0; u < NTW; ++u) {
-      const int t = wave + kWaves * u;
-      const int nd = j * 16 + c;
-      f4 yy = y[j][u];
-      if (nd < N) {
-        float* dst = sY + nd * LD + 16 * t + 4 * g;
-        if (tail && t == T - 1 && g > 0) yy = splat(0.f);  // rows 4 .. 15 of the tail tile are padding
-        if (gPre != nullptr) stash_store((f4*)(gPre + nd * HP + 16 * t + 4 * g), yy);  // stash: write once, read once
-        if (!(tail && t == T - 1 && g > 0)) {
-          if (EPI == EPI_SILU) yy = silu4(yy);
-          if (EPI == EPI_RESIDUAL_MASK) {
-            const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
-            yy = (r + yy) * sMask[nd];
+      for (int u = 0; u < NTW; ++u) {
+        const int t = wave + kWaves * u;
+        const int nd = j * 16 + c;
+        f4 yy = y[j][u];
+        if (t < T && nd < N) {
+          float* dst = sY + nd * LD + 16 * t + 4 * g;
+          const bool pad = G::odd && cx.ktail && t == T - 1 && g > 0;  // rows 4 .. 15 of the last tile of an H % 16 == 4 width
+          if (pad) yy = splat(0.f);
+          if (gPre != nullptr) stash_store((f4*)(gPre + nd * HP + 16 * t + 4 * g), yy);  // stash: write once, read once
+          if (!pad) {
+            if (EPI == EPI_SILU) yy = silu4(yy);
+            if (EPI == EPI_RESIDUAL_MASK) {
+              const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
+              yy = (r + yy) * sMask[nd];
+            }
+            if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
+              const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
+              yy = (f4){yy[0] * dsilu_f(r[0]), yy[1] * dsilu_f(r[1]), yy[2] * dsilu_f(r[2]), yy[3] * dsilu_f(r[3])};
+            }
+            if (EPI == EPI_ACCUM) yy = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g) + yy;
           }
-          if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
-            const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
-            yy = (f4){yy[0] * dsilu_f(r[0]), yy[1] * dsilu_f(r[1]), yy[2] * dsilu_f(r[2]), yy[3] * dsilu_f(r[3])};
-          }
-          if (EPI == EPI_ACCUM) yy = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g) + yy;
+          *(f4*)dst = yy;
         }
-        *(f4*)dst = yy;
       }
     }
-}
-
-// One node GEMM of the workgroup (all waves call it; N <= 16 MAXNT).  do_split_a = false: an earlier call of this phase left
-// the first source's split copy in cx.split_a (P and Q share h, the two transposed GEMMs of dnpre share it).  The caller
-// guarantees that nobody still reads the split regions when the call starts (a barrier since their last use) and places a
-// barrier between this call's stores to sY and their readers, as for the fp32 form.
-template <int HP, int EPI, bool TWO, int MAXNT, int PIN = kAheadOne, int POUT = kAheadOne>
-__device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float* sXa, bool do_split_a, int Wb, const float* sXb,
-                                            const float* sBias, float* sY, const float* sRes, const float* sMask, int N, int wave,
-                                            int lane, const NodeCtxH& cx, NodePFH<HP>& pf, int nextW = -1, float* gPre = nullptr) {
-  constexpr int T = HP / 16;
-  const bool two = wave + kWaves < T, one = wave < T;
-  if (!one) {
-    // a wave without an output tile (hidden sizes below 128): its share of the split and the barriers of the others
-    const bool seq = TWO && cx.split_b == cx.split_a;
-    const int nct = (MAXNT < 2 || N <= 16) ? 1 : (MAXNT < 3 || N <= 32) ? 2 : 3;
-    if (do_split_a) split_rows_h<HP>(SplitBufH{cx.split_a, nct}, sXa, N, cx.ktail, wave, lane);
-    if (TWO && !seq) split_rows_h<HP>(SplitBufH{cx.split_b, nct}, sXb, N, cx.ktail, wave, lane);
-    if (do_split_a || (TWO && !seq)) lds_barrier();
-    if (seq) {
-      lds_barrier();
-      split_rows_h<HP>(SplitBufH{cx.split_b, nct}, sXb, N, cx.ktail, wave, lane);
-      lds_barrier();
-    }
-    return;
-  }
-  auto run2 = [&](auto nt_tag, auto kt_tag) {
-    constexpr int NT = decltype(nt_tag)::value;
-    constexpr bool KTAIL = decltype(kt_tag)::value;
-    if (two)
-      node_gemm_h_body<HP, EPI, NT, 2, KTAIL, TWO, PIN, POUT>(wh, Wa, sXa, do_split_a, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre);
-    else
-      node_gemm_h_body<HP, EPI, NT, 1, KTAIL, TWO, PIN, POUT>(wh, Wa, sXa, do_split_a, Wb, sXb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre);
-  };
-  auto run = [&](auto nt_tag) {
-    // (a K tail exists for odd tile counts only: the other widths have one instantiation)
-    if constexpr ((T & 1) && T >= 3) {
-      if (cx.ktail) run2(nt_tag, std::true_type{});
-      else run2(nt_tag, std::false_type{});
-    } else {
-      run2(nt_tag, std::false_type{});
-    }
-  };
-  if (MAXNT < 2 || N <= 16) run(std::integral_constant<int, 1>{});
-  else if (MAXNT < 3 || N <= 32) run(std::integral_constant<int, 2>{});
-  else if constexpr (MAXNT >= 3) run(std::integral_constant<int, 3>{});
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -466,7 +438,7 @@ struct NodePFSel<HP, true> {
 };
 template <int HP, bool NH, int AHEAD, class PF>
 __device__ __forceinline__ void node_prefetch_x(PF& pf, const WBuf& wb, const WBuf& wbe, int W, int N, int wave, int lane, bool tw) {
-  if constexpr (NH) node_prefetch_h<HP, AHEAD>(pf, wbe, W, N, tw, wave, lane);
+  if constexpr (NH) node_prefetch_h<HP, AHEAD>(pf, wbe, W, wave, lane);
   else node_prefetch<HP>(pf, wb, W, wave, lane, tw);
 }
 // Xa / Xb: the input rows where they live (LDS, or global memory for the GN kernels); XaS / XbS: their staged copies in the idle
@@ -488,6 +460,10 @@ __device__ __forceinline__ void node_gemm_x(const WBuf& wb, const WBuf& wbe, int
 // where the split copies of a node phase go: the weight ring's free slot (a resident kernel's other slot holds the first group of
 // the next edge GEMM, requested by the previous one's last trip), or the whole ring where it idles across node phases (RI: the GN
 // kernels and the half-ring mode, whose slot alone is too small).  cap: floats of that region; two inputs side by side if they fit.
+// (shared with the host's LDS plan, gaudi_hip.hip: node_f16_fits)
+__host__ __device__ constexpr bool node_ring_idle(int HP, int SP, bool GN) {
+  return GN || (SP != 0 && GAUDI_NODE_F16 != 0 && (SP == 2 || HP < 48));
+}
 template <int HP>
 __device__ __forceinline__ NodeCtxH node_ctx_h(float* region, int cap, int N, float winv, bool ktail) {
   const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;

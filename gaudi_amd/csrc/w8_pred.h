@@ -124,7 +124,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   // NH / RI / STG: see edm_forward (w8_edm.h) -- fp16-pair node GEMMs; the ring idles across node phases (GN: node-GEMM inputs
   // are staged in it, every edge phase requests its first weight group itself); fp32 node GEMMs of a GN kernel read staged rows
   constexpr bool NH = NodeMath<SP>::kF16;
-  constexpr bool RI = GN || (NH && SP == 2);
+  constexpr bool RI = node_ring_idle(HP, SP, GN);
   constexpr bool STG = GN && !NH;
   float* const xs0 = sm.ring;
   float* const xs1 = sm.ring + stage_stride(N * LD);
@@ -352,7 +352,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
   // NH / RI / STG: see edm_forward (w8_edm.h)
   constexpr bool NH = NodeMath<SP>::kF16;
-  constexpr bool RI = GN || (NH && SP == 2);
+  constexpr bool RI = node_ring_idle(HP, SP, GN);
   constexpr bool STG = GN && !NH;
   float* const xs0 = sm.ring;
   float* const xs1 = sm.ring + stage_stride(N * LD);

@@ -30,7 +30,7 @@ struct Sel<HP, 0> {
 template <int HP>
 struct Sel<HP, 3> {
   using PF = w8::NodePFH<HP>;
-  static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tw, int N) { w8::node_prefetch_h<HP>(pf, wb, W, N, tw, wave, lane); }
+  static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tw, int N) { w8::node_prefetch_h<HP>(pf, wb, W, wave, lane); }
   template <int EPI>
   static __device__ __forceinline__ void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sB, float* sY, int N,
                                               int wave, int lane, bool tw, PF* pf, int nextW, float* split, float winv, bool seq) {
@@ -133,17 +133,16 @@ static void pack_f32(float* dst, const std::vector<float>& W, int H) {
 }
 // the fp16-pair image (w8_nodes_f16.h; gaudi_hip.hip: pack_matrix_f16): units [chunk][tile][piece][lane L = (row, 8 inputs)]
 template <int HP>
-static void pack_f16(float* dst, const std::vector<float>& W, int H, bool ktail, float scale) {
+static void pack_f16(float* dst, const std::vector<float>& W, int H, bool, float scale) {
   constexpr int T = HP / 16;
-  const bool tail = w8::nh_has_tail(HP, ktail);
-  const int nc = w8::nh_chunks(HP, ktail);
   uint16_t* d = (uint16_t*)dst;
   for (int o = 0; o < H; ++o)
     for (int k = 0; k < H; ++k) {
       const float v = W[(size_t)o * H + k];
       const int t = o / 16, i = o % 16;
-      if (tail && k >= 16 * (T - 1)) {
-        dst[(size_t)nc * w8::nh_chunk_floats(HP) + t * 64 + (k - 16 * (T - 1)) * 16 + i] = v;
+      if (w8::nh_odd(HP) && k >= 16 * (T - 1)) {
+        const int kk = k - 16 * (T - 1);
+        dst[(size_t)w8::nh_tail_off(HP) + t * 256 + (kk / 4) * 64 + (kk % 4) * 16 + i] = v;
         continue;
       }
       const int m = k / 32, g = (k % 32) / 8, e = k % 8, L = g * 16 + i;
@@ -307,7 +306,7 @@ void timing() {
 }
 
 int main(int argc, char**) {
-  printf("depth <= %d (one column tile) / %d (more), column tiles <= %d, ablation %d\n", GAUDI_NODE_MAXDEPTH, GAUDI_NODE_DEPTH2, GAUDI_MB_MAXNT, GAUDI_NODE_ABLATE);
+  printf("depth %d, column tiles <= %d, ablation %d\n", GAUDI_NODE_DEPTH, GAUDI_MB_MAXNT, GAUDI_NODE_ABLATE);
   if (argc > 1) {  // any argument: the fp16 form's timings only
     timing<3>();
     return 0;
