@@ -485,7 +485,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
         "metric": ("guided" if guided else "unguided") + f" molecules/sec ({T}-step)",
         "value": value, "unit": "molecules/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "edge_gemm_math": "bf16x3 split operands, f32 accumulate" if variant == "w8s" else "f32",
+        "dtype": "f32", "edge_gemm_math": "fp16 hi/lo pairs of both operands, 3 piece products, f32 accumulate" if variant == "w8s" else "f32",
+        "node_gemm_math": "fp16 hi/lo pairs of both operands, f32 accumulate" if variant == "w8s" else "f32",
         "data": "synthetic (seeded default-init weights, on-device Philox noise)",
         "config": {"workload": label + (f"; reference-form closure ({closure}) through gaudi_amd.sampling_edm.sample_guidance"
                                         if closure else ""), "global_batch": B * world, "n_nodes": N, "diffusion_steps": T,
@@ -507,15 +508,19 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                                "per guided step, averaged together)",
                      "kernel_variant": {"w4": "4 waves per molecule, fp32 matrix instructions",
                                         "w8": "8 waves per molecule (two per SIMD), fp32 matrix instructions",
-                                        "w8s": "8 waves per molecule (two per SIMD); edge GEMMs: fp32 operands split exactly "
-                                               "into 3 bf16 pieces, 6 piece products accumulated in fp32 on the bf16 matrix "
-                                               "pipe (error vs float64 at the level of the fp32 instruction's own: tests/test_gpu_split.py); "
-                                               "node GEMMs: fp32 matrix instructions (the 4-valid-row tail tile on 4x4x1 blocks); "
+                                        "w8s": "8 waves per molecule (two per SIMD); edge GEMMs (round 5): both operands as fp16 pairs "
+                                               "hi + lo (22 significant bits, power-of-two scales per network / per edge column), 3 piece "
+                                               "products accumulated in fp32 on the fp16 matrix pipe (error vs float64 at the level of the "
+                                               "fp32 instruction's own: tests/test_gpu_split.py); "
+                                               "node GEMMs (round 5): both operands as fp16 pairs hi + 2^-11 lo (22 significant bits, "
+                                               "power-of-two scales per network / per node), 3 piece products accumulated in fp32 "
+                                               "on the fp16 matrix pipe, the same bytes per weight as fp32 (closer to float64 than "
+                                               "the fp32 instruction: profiles/r05b_node_gemm_h_microbench.txt); "
                                                "activation stash written / read non-temporally"}[variant],
                      "flops_basis": "issued matrix instructions counted from the kernel's loop structure (padding included): "
                                     "v_mfma_f32_16x16x4_f32 equivalents (a 4x4x1_16B instruction = 1/4) x 2048 FLOP at 157.3 TFLOP/s + "
-                                    "v_mfma_f32_16x16x32_bf16 x 16384 FLOP at 2516.6 TFLOP/s; frac = matrix-pipe time at peak / launch "
-                                    "time; = SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 and _BF16 / 32 in profiles/",
+                                    "(v_mfma_f32_16x16x32_bf16 + v_mfma_f32_16x16x32_f16) x 16384 FLOP at 2516.6 TFLOP/s; frac = matrix-pipe "
+                                    "time at peak / launch time; = SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 and (_BF16 + _F16) / 32 in profiles/",
                      "l2_weight_stream": {
                          "bytes_per_workgroup_step": wstream,
                          "achieved_TBps": G * wstream * evals / max(n_launch, 1) / t_launch / 1e12,

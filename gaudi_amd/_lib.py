@@ -84,7 +84,9 @@ EXPORTS = {
                                         C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), FP, C.c_int32,
                                         C.POINTER(C.c_int32)]),
     "gaudi_host_pack_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, FP, FP]),
-    "gaudi_host_pack_matrix_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, FP, FP]),
+    "gaudi_host_pack_matrix_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, FP]),
+    "gaudi_host_pack_matrix_f16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, FP]),
+    "gaudi_host_weight_scale": (C.c_int, [C.c_int, C.POINTER(FP), IP, IP, IP, FP]),
     "gaudi_profile_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "gaudi_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "gaudi_set_steps_per_launch": (C.c_int, [C.c_void_p, C.c_int]),
@@ -116,7 +118,12 @@ def load_library() -> C.CDLL:
         raise GaudiError(f"{LIB_PATH} not found: build it with `python -m gaudi_amd.build` "
                          "(there is no CPU fallback for the sampler)")
     lib = C.CDLL(LIB_PATH)
+    # the host-side packers (gaudi_host_*) are test / tooling entry points: a diagnostic library named by GAUDI_LIB (an A/B
+    # build of another revision) may predate some of them; everything else must be there
+    lenient = "GAUDI_LIB" in os.environ
     for name, (res, args) in EXPORTS.items():
+        if lenient and name.startswith("gaudi_host_") and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

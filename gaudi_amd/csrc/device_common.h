@@ -71,6 +71,7 @@ struct Stamps {
 #endif
 
 __host__ __device__ constexpr int align16(int n) { return (n + 15) & ~15; }
+__host__ __device__ constexpr int align4(int n) { return (n + 3) & ~3; }
 __host__ __device__ constexpr int pad_hidden(int h) { return (h + 15) & ~15; }
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): ~2e-7 relative, well inside the 1e-4 parity budget

@@ -8,7 +8,8 @@ namespace gaudi {
 // Packed EDM weight buffer (floats).  HP = hidden padded to 16, PK = HP*HP (tile-packed matrix).
 //   head : emb_w [HP][F1] | emb_b [HP] | out_w [F1][HP] | out_b [16]
 //   block: S x GCL { A, Bm, W2, Wn1h, Wn1a, Wn2 (6 PK) | cr, cd, b1, b2, wa, bn1, bn2 (7 HP) | ba (16) }
-//          EqU     { A, Bm, W2 (3 PK) | cr, cd, b1, b2, w3 (5 HP) }
+//          EqU     { A, Bm, W2 (3 PK) | cr, cd, b1, b2, w3 (5 HP) | max|cr|, max|cd| (16) }
+//          (the GCL's 16-float block holds ba, max|cr|, max|cd|: the column maxima bound the split edge GEMMs' scales, w8_split.h)
 // A/Bm/cr/cd are the column blocks of Linear(2H+2 -> H): W1 = [A | Bm | cr | cd].
 struct EdmLayout {
   int HP, F1, L, S;
@@ -19,7 +20,7 @@ struct EdmLayout {
   __host__ __device__ int out_b() const { return out_w() + align16(F1 * HP); }
   __host__ __device__ int blocks() const { return out_b() + 16; }
   __host__ __device__ int gcl_size() const { return 6 * pk() + 7 * HP + 16; }
-  __host__ __device__ int equ_size() const { return 3 * pk() + 5 * HP; }
+  __host__ __device__ int equ_size() const { return 3 * pk() + 5 * HP + 16; }
   __host__ __device__ int block_size() const { return S * gcl_size() + equ_size(); }
   __host__ __device__ int gcl(int l, int s) const { return blocks() + l * block_size() + s * gcl_size(); }
   __host__ __device__ int equ(int l) const { return blocks() + l * block_size() + S * gcl_size(); }

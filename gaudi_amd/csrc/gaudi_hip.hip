@@ -96,9 +96,10 @@ struct gaudi_handle {
   bool gn8 = true;            // GAUDI_GN8=0: molecules beyond the LDS limit go to the 4-wave V4G kernels, as in round 3
   bool force_gn8 = false;     // GAUDI_FORCE_GN8=1: V8G whenever it can run (test knob)
   bool pack = true;           // several small molecules per workgroup in sampling calls (GAUDI_PACK=0: off)
-  int pairs = 0;              // wide groups (more node slots than a molecule has, two rounds of edge tiles: e.g. two 11-ring cata
-                              // molecules per workgroup): 0 = never (default: measured -2 % on C3 at 1024 molecules, +1 % unguided,
-                              // DESIGN.md section 8), 1 = when the batch holds at least two molecules per CU, 2 = always (GAUDI_PAIRS)
+  int pairs = 1;              // wide groups (more node slots than a molecule has, two rounds of edge tiles: e.g. two 11-ring cata
+                              // molecules per workgroup): 0 = never, 1 = when the batch holds at least two molecules per CU and the
+                              // classic packing shares next to nothing (default since round 5: the fp16-pair node GEMMs made the
+                              // shared weight stream worth the second round), 2 = always (GAUDI_PAIRS)
   int num_cus = 256;
   int run_nslots = 0;         // node slots per workgroup of the current call (= N unless the call runs wide groups)
   bool pred_rounds = true;    // GAUDI_PRED_ROUNDS=0: guided calls with more than 128 edge slots go to the 4-wave kernels
@@ -318,45 +319,41 @@ static void pack_matrix(const PackMode& pm, float* dst, const float* W, int H, i
       dst[tile + in] = v;
     }
 }
-// Split-bf16 image of an edge-GEMM matrix (w8_split.h): units of 1 KiB ordered [K chunk m][output tile t][piece p]; lane L
-// = (row L & 15, group g = L >> 4) holds 8 bf16: slots 0-3 = inputs 16(2m) + 4g .. +3, slots 4-7 = inputs 16(2m+1) + 4g .. +3.
-// Pieces by round-to-nearest-even: w = p0 + p1 + p2 exactly.  NaN-safe: the integer rounding trick turns some NaN payloads
-// into 0 or infinity (MI355X_MICROARCH.md, correctness boundaries), so a NaN keeps a quiet-NaN pattern -- what the
-// device-side v_cvt_pk_bf16_f32 does -- and every piece of a NaN / infinite weight reproduces it (NaN - NaN = NaN; an
-// infinite weight gives inf, then inf - inf = NaN in the lower pieces: the product is non-finite either way, like the
-// fp32 product).
-static uint16_t bf16_rne(float x) {
-  uint32_t u;
-  std::memcpy(&u, &x, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // NaN stays NaN (quieted)
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// fp16 helpers of the weight images (round to nearest even; NaN stays NaN)
+static uint16_t f16_bits(float x) {
+  const _Float16 hv = (_Float16)x;
+  uint16_t u;
+  std::memcpy(&u, &hv, 2);
+  return u;
 }
-static float bf16_to_f(uint16_t b) {
-  const uint32_t u = (uint32_t)b << 16;
-  float f;
-  std::memcpy(&f, &u, 4);
-  return f;
+static float f16_value(uint16_t b) {
+  _Float16 hv;
+  std::memcpy(&hv, &b, 2);
+  return (float)hv;
 }
-// K tail (pm.ktail, odd tile count >= 3 = SplitGeo::kTailOK): the last chunk holds only the tail tile; it is stored as T fp32
-// tiles in pack_matrix's K-tail form and issued as one fp32 k-step per tile.
+// Split image of an edge-GEMM matrix (w8_split.h, round 5: fp16 pairs): units of 1 KiB ordered [K chunk m][output tile t][piece p];
+// lane L = (row L & 15, group g = L >> 4) holds 8 fp16: slots 0-3 = inputs 16(2m) + 4g .. +3, slots 4-7 = inputs 16(2m+1) + 4g .. +3.
+// Pieces of w s (s = the network's power-of-two scale, NodeScale below): hi = fp16(w s), lo = fp16(w s - hi), both round-to-
+// nearest-even; a NaN weight gives NaN pieces (the product is NaN like the fp32 product), infinite weights are refused by
+// NodeScale.  K tail (pm.ktail, odd tile count >= 3 = SplitGeo::kTailOK): the last chunk holds only the tail tile; it is stored
+// as T fp32 tiles in pack_matrix's K-tail form, scaled by s (the accumulators run in scaled units), and issued as one fp32
+// k-step per tile.
 static void pack_matrix_split(const PackMode& pm, float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose) {
   const int T = HP / 16;
   const bool tail = pm.ktail && (T & 1) && T >= 3;
+  const float sc = pm.hscale > 0.f ? pm.hscale : 1.0f;
   uint16_t* d = (uint16_t*)dst;
   for (int o = 0; o < H; ++o)
     for (int k = 0; k < H; ++k) {
-      float v = transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k];
+      const float v = (transpose ? W[(size_t)k * ldw + col0 + o] : W[(size_t)o * ldw + col0 + k]) * sc;
       const int tile = k / 16, m = tile / 2, g = (k % 16) / 4, e = 4 * (tile & 1) + (k & 3), t = o / 16, L = g * 16 + o % 16;
       if (tail && tile == T - 1) {  // k % 16 < 4 here
-        dst[(size_t)(m * T * 3 + t) * 256 + (size_t)((k % 16) * 16 + o % 16) * 4] = v;
+        dst[(size_t)(m * T * w8::kPieces + t) * 256 + (size_t)((k % 16) * 16 + o % 16) * 4] = v;
         continue;
       }
-      for (int pc = 0; pc < 3; ++pc) {
-        const uint16_t b = bf16_rne(v);
-        d[((size_t)((m * T + t) * 3 + pc) * 64 + L) * 8 + e] = b;
-        v -= bf16_to_f(b);
-      }
+      const uint16_t hi = f16_bits(v);
+      d[((size_t)((m * T + t) * w8::kPieces + 0) * 64 + L) * 8 + e] = hi;
+      d[((size_t)((m * T + t) * w8::kPieces + 1) * 64 + L) * 8 + e] = f16_bits(v - f16_value(hi));
     }
 }
 // An edge-GEMM matrix: the fp32 tiles (K tail included where the width has one) and, when a split buffer is being filled,
@@ -370,17 +367,6 @@ static void pack_edge_matrix(const PackMode& pm, float* dst, const float* W, int
 // [K chunk m of 32 inputs][output tile t][piece]; lane L = (row L & 15, group g = L >> 4) holds inputs 32 m + 8 g .. +7.
 // An odd tile count leaves a last half chunk of 16 inputs: a trailing block of T x 256 floats, UNSCALED fp32, [tile][k-step q]
 // [lane (row, g)] = W[row][16 (T-1) + 4 q + g]: v_mfma_f32_16x16x4_f32 steps (one of them when H % 16 == 4).
-static uint16_t f16_bits(float x) {
-  const _Float16 hv = (_Float16)x;
-  uint16_t u;
-  std::memcpy(&u, &hv, 2);
-  return u;
-}
-static float f16_value(uint16_t b) {
-  _Float16 hv;
-  std::memcpy(&hv, &b, 2);
-  return (float)hv;
-}
 static void pack_matrix_f16(float* dst, const float* W, int H, int ldw, int col0, int HP, bool transpose, float scale) {
   const int T = HP / 16;
   uint16_t* d = (uint16_t*)dst;
@@ -401,11 +387,12 @@ static void pack_matrix_f16(float* dst, const float* W, int H, int ldw, int col0
       d[(((size_t)(m * T + t) * 2 + 1) * 64 + L) * 8 + e] = lo;
     }
 }
-// One power of two for all node matrices of a network: the largest finite |w| lands in [2^13, 2^14).  lo carries its own
-// exponent, so an entry keeps 22 significant bits down to 2^-25 of the largest one and an absolute floor of 2^-50 of it below
-// that (w8_nodes_f16.h).  The form is refused -- the call then runs the fp32-instruction kernels -- when a node matrix holds an
+// One power of two for all matrices of a network (node-level AND edge-level: w8_nodes_f16.h, w8_split.h): the largest finite
+// |w| lands in [2^13, 2^14).  An entry keeps 22 significant bits down to 2^-17 of the largest one in the edge images (lo shares
+// hi's exponent range: one accumulator) and down to 2^-25 in the node images (lo carries its own exponent), with fp16's
+// absolute floor below that.  The form is refused -- the call then runs the fp32-instruction kernels -- when a matrix holds an
 // infinity (fp16 pieces would turn inf x 0 and inf - inf into NaN where the fp32 product keeps inf) or when some matrix lies
-// more than 2^24 below the largest (nothing a trained network shows; kept as a loud boundary rather than a silent loss).
+// more than 2^12 below the largest (nothing a trained network shows; kept as a loud boundary rather than a silent loss).
 struct NodeScale {
   float gmax = 0.f, min_mat = INFINITY;
   bool inf = false;
@@ -423,7 +410,7 @@ struct NodeScale {
   }
   // -> 2^s (0: refused)
   float scale() const {
-    if (inf || !(gmax > 0.f) || min_mat < gmax * 5.9604645e-8f) return 0.f;
+    if (inf || !(gmax > 0.f) || min_mat < gmax * 2.44140625e-4f) return 0.f;
     int ex;
     std::frexp(gmax, &ex);  // gmax = f 2^ex, f in [0.5, 1)
     return std::ldexp(1.f, 14 - ex);
@@ -439,6 +426,17 @@ static void pack_node_matrix(const PackMode& pm, float* dst, const float* W, int
 static void pack_vec(float* dst, const float* v, int n) { std::memcpy(dst, v, sizeof(float) * n); }
 static void pack_col(float* dst, const float* W, int H, int ldw, int col) {
   for (int o = 0; o < H; ++o) dst[o] = W[(size_t)o * ldw + col];
+}
+// max |W[o][col]| over the rows (NaN if any entry is: the bound it enters must not hide one)
+static float col_absmax(const float* W, int H, int ldw, int col) {
+  float m = 0.f;
+  bool nan = false;
+  for (int o = 0; o < H; ++o) {
+    const float a = std::fabs(W[(size_t)o * ldw + col]);
+    nan |= a != a;
+    m = std::max(m, a);
+  }
+  return nan ? NAN : m;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -839,8 +837,8 @@ static size_t gnode_floats(int hpe, int hpp, int N) {
 
 static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split, bool gn = false) {
   size_t net = 0;
-  if (hpe) net = std::max(net, (size_t)((gn ? 0 : 5 * N * (hpe + 4)) + w8::edge_ring_floats(hpe, split) + 8 * N + S * 9 + 8 * hpe));
-  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + (gn ? 0 : 5 * N * (hpp + 4)) + 12 * N + S * 10 + 32 + 10 * hpp));
+  if (hpe) net = std::max(net, (size_t)((gn ? 0 : 5 * N * (hpe + 4)) + w8::edge_ring_floats(hpe, split) + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * hpe));
+  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + (gn ? 0 : 5 * N * (hpp + 4)) + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * hpp));
   return common_floats8(N, D, S) + net;
 }
 static size_t gnode_floats8(int hpe, int hpp, int N) {
@@ -858,7 +856,7 @@ static bool gn8_stage_fits(int hpe, int hpp, int N) {
 // ring's free slot (full ring), the whole ring where it idles across node phases (half ring, gn) -- for N node columns
 static bool node_f16_fits(int hp, int N, int split, bool gn) {
   if (!hp || !split || !GAUDI_NODE_F16) return true;
-  if (N > 48) return false;  // at most three column tiles per pass
+  if (N > (gn ? 48 : 32)) return false;  // column tiles of one pass: three in the gn kernels, two in the resident ones
   const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
   const int ring = w8::edge_ring_floats(hp, split);
   return w8::nh_split_floats(hp, nct) <= (w8::node_ring_idle(hp, split, gn) ? ring : ring / 2);
@@ -1088,14 +1086,20 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
     // always): up to 2 N node slots and two rounds of eight edge tiles -- e.g. two 11-ring cata molecules, or three to four small
     // hetero ones, per workgroup.  Every node-level matrix is then streamed from L2 once for all of them and the per-GEMM fixed
     // costs are shared; the edge phases run their rounds one after the other on the half ring (the predictor on the MR
-    // kernels).  Bit-identical to the narrow launch, and measured slightly SLOWER on the guided path (what the shared stream
-    // saves, the second round's half-ring trips and parked du cost: DESIGN.md section 8), hence not the default.  Then the
-    // classic shape: N node slots, one round.
+    // kernels).  Bit-identical to the narrow launch.  Then the classic shape: N node slots, one round.
     struct Cand {
       int NG, TG;
     };
     std::vector<Cand> cands;
-    if (h->pairs == 2 || (h->pairs == 1 && B >= 2 * h->num_cus))
+    // (pairs == 1, the default: when the batch holds at least two molecules per CU AND the classic shape packs next to nothing --
+    // cata molecules fill their N slots; a hetero batch whose small molecules already share workgroups gains nothing from the
+    // second round: C4 -0.9 %, C3 at 1 024 molecules +2.6 %, C2 at 1 024 +6.7 % with the fp16-pair node GEMMs, profiles/r05c_*)
+    bool want_wide = h->pairs == 2;
+    if (h->pairs == 1 && B >= 2 * h->num_cus) {
+      pack_groups(B, N, node_mask, edge_mask, M, pk, N, w8::kWaves);
+      want_wide = (long long)pk.G * 10 >= (long long)B * 9;
+    }
+    if (want_wide)
       for (int ng = std::min(2 * N, 32); ng > N; --ng) {
         const long long cap = 160 * 1024 / 4 - 64;
         if ((long long)lds_floats8_base(hpe, hpp, ng, Dz, 16 * (w8::kWaves + 1), h->split ? 2 : 0) > cap) continue;  // cannot fit whatever the slots
@@ -1371,6 +1375,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
       for (int s = 0; s <= S; ++s) {
         const std::string q = p + "e_block_" + std::to_string(l) + (s < S ? ".gcl_" + std::to_string(s) + "." : ".gcl_equiv.");
         ns.see(T.peek(q + (s < S ? "edge_mlp.0.weight" : "coord_mlp.0.weight"), (int64_t)H * (2 * H + 2)), H, 2 * H + 2, 0, 2 * H);
+        ns.see(T.peek(q + (s < S ? "edge_mlp.2.weight" : "coord_mlp.2.weight"), (int64_t)H * H), H, H, 0, H);
         if (s < S) {
           ns.see(T.peek(q + "node_mlp.0.weight", (int64_t)H * 2 * H), H, 2 * H, 0, 2 * H);
           ns.see(T.peek(q + "node_mlp.2.weight", (int64_t)H * H), H, H, 0, H);
@@ -1439,6 +1444,8 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
       pack_vec(V + 5 * HP, bn1, H);
       pack_vec(V + 6 * HP, bn2, H);
       if (ba) V[7 * HP] = ba[0];
+      V[7 * HP + 1] = col_absmax(W1, H, ld1, 2 * H);      // max |c_r|, max |c_d|: the split edge GEMMs' column scales are
+      V[7 * HP + 2] = col_absmax(W1, H, ld1, 2 * H + 1);  // bounded with them (w8_split.h)
     }
     const std::string q = p + "e_block_" + std::to_string(l) + ".gcl_equiv.";
     float* E = &w[lay.equ(l)];
@@ -1457,6 +1464,8 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
     pack_vec(V + 2 * HP, b1, H);
     pack_vec(V + 3 * HP, b2, H);
     pack_vec(V + 4 * HP, w3, H);
+    V[5 * HP] = col_absmax(W1, H, ld1, 2 * H);
+    V[5 * HP + 1] = col_absmax(W1, H, ld1, 2 * H + 1);
   }
   };
   std::vector<float> w, ws;
@@ -2150,14 +2159,32 @@ int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, cons
   return GAUDI_OK;
 }
 
-int gaudi_host_pack_matrix_split(int H, int ldw, int col0, int HP, int transpose, int ktail, const float* W, float* packed_out) {
-  if (H < 1 || HP < H || HP % 16 || !W || !packed_out) return GAUDI_E_INVALID;
+int gaudi_host_pack_matrix_split(int H, int ldw, int col0, int HP, int transpose, int ktail, float scale, const float* W,
+                                 float* packed_out) {
+  if (H < 1 || HP < H || HP % 16 || !W || !packed_out || !(scale > 0.f)) return GAUDI_E_INVALID;
   const int T = HP / 16;
-  std::memset(packed_out, 0, sizeof(float) * (size_t)((T + 1) / 2) * T * 3 * 256);
+  std::memset(packed_out, 0, sizeof(float) * (size_t)((T + 1) / 2) * T * w8::kPieces * 256);
   PackMode pm;
   pm.lane_linear = true;
   pm.ktail = ktail != 0 && has_ktail(H, HP);
+  pm.hscale = scale;
   pack_matrix_split(pm, packed_out, W, H, ldw, col0, HP, transpose != 0);
+  return GAUDI_OK;
+}
+
+int gaudi_host_pack_matrix_f16(int H, int ldw, int col0, int HP, int transpose, float scale, const float* W, float* packed_out) {
+  if (H < 1 || HP < H || HP % 16 || !W || !packed_out || !(scale > 0.f)) return GAUDI_E_INVALID;
+  std::memset(packed_out, 0, sizeof(float) * (size_t)HP * HP);
+  pack_matrix_f16(packed_out, W, H, ldw, col0, HP, transpose != 0, scale);
+  return GAUDI_OK;
+}
+
+int gaudi_host_weight_scale(int n, const float* const* blocks, const int32_t* rows, const int32_t* cols, const int32_t* ldw,
+                            float* scale_out) {
+  if (n < 1 || !blocks || !rows || !cols || !ldw || !scale_out) return GAUDI_E_INVALID;
+  NodeScale ns;
+  for (int i = 0; i < n; ++i) ns.see(blocks[i], rows[i], ldw[i], 0, cols[i]);
+  *scale_out = ns.scale();
   return GAUDI_OK;
 }
 

@@ -22,12 +22,14 @@ struct NetSmem {
   float *agg, *agg1;    // [N][HP+4] the two partial edge->node sums of a node (its run may straddle two tiles)
   float* ring;          // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats)
   float *x, *x0;        // [N][4]
+  uint32_t *pmax, *qmax;  // [N] bits of max |P_n|, max |Q_n| over the features (the split edge GEMMs' column scales, w8_split.h)
+  float* hsc;             // [2][kScaleFloatsH] per-node descale factors of the fp16 node GEMMs' inputs (w8_nodes_f16.h)
   f4* geo;              // [S] (r, dhat)
   float* d0;            // [S]
   float* trans;         // [S][4]
   float* vec;           // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
   __host__ __device__ static int floats(int N, int S) {
-    return (GN ? 0 : 5 * N * (HP + 4)) + EdgeRing<HP, SP>::kFloats + 8 * N + S * 9 + 8 * HP;
+    return (GN ? 0 : 5 * N * (HP + 4)) + EdgeRing<HP, SP>::kFloats + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * HP;
   }
   __device__ void carve(float* base, int N, int S, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
@@ -41,6 +43,9 @@ struct NetSmem {
     agg1 = nb; nb += N * LD;
     x = base; base += 4 * N;
     x0 = base; base += 4 * N;
+    pmax = (uint32_t*)base; base += align4(N);  // (whole float4s: everything behind stays 16-byte aligned -- geo, trans and the
+    qmax = (uint32_t*)base; base += align4(N);  // layer vectors are read with ds_read_b128)
+    hsc = base; base += 96;
     geo = (f4*)base; base += S * 4;
     d0 = base; base += S;
     trans = base; base += S * 4;
@@ -156,7 +161,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   __syncthreads();
   compute_geo(sm, mg, 0.f, tid, true);  // d0 of the input coordinates (egnn_new.py:301)
   typename EdgeRing<HP, SP>::type ring;
-  er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
+  er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws, W.hinv);
+  static_assert(SP == 0 || NodeMath<SP>::kF16, "the split edge GEMMs take their column scales from the fp16 node GEMMs' row maxima");
   // NH: node GEMMs on fp16 pairs (w8_nodes_f16.h); their inputs' split copies live in the weight ring during the node phases
   constexpr bool NH = NodeMath<SP>::kF16;
   // RI: the ring is idle during the node phases -- GN: the node GEMMs' input rows are staged in it (w8_common.h: stage_rows; the
@@ -173,10 +179,10 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   // split-copy region of the node GEMMs of this phase (NH)
   auto hctx = [&]() {
     if constexpr (NH) {
-      if constexpr (RI) return node_ctx_h<HP>(sm.ring, EdgeRing<HP, SP>::kFloats, mg.NC, W.hinv, tw);
-      else return node_ctx_h<HP>(ring.slot(ring.par ^ 1), EdgeRing<HP, SP>::kFloats / 2, mg.NC, W.hinv, tw);
+      if constexpr (RI) return node_ctx_h<HP>(sm.ring, EdgeRing<HP, SP>::kFloats, mg.NC, W.hinv, tw, sm.hsc);
+      else return node_ctx_h<HP>(ring.slot(ring.par ^ 1), EdgeRing<HP, SP>::kFloats / 2, mg.NC, W.hinv, tw, sm.hsc);
     } else {
-      return NodeCtxH{1.f, nullptr, nullptr, tw};
+      return NodeCtxH{1.f, nullptr, nullptr, tw, nullptr};
     }
   };
   constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
@@ -197,19 +203,24 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         sm.agg[idx] = 0.f;
         sm.agg1[idx] = 0.f;
       }
+      if (tid < N) {
+        sm.pmax[tid] = 0u;
+        sm.qmax[tid] = 0u;
+      }
       if constexpr (STG) stage_wait();
       else __syncthreads();
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
                   *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
       const float ba = sm.vec[7 * HP];
+      const float crmax = sm.vec[7 * HP + 1], cdmax = sm.vec[7 * HP + 2];  // max |c_r|, max |c_d| (host)
       {
         const NodeCtxH cx = hctx();
         node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, G, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
-                                                      wave, lane, tw, cx, pf, G + PK);
+                                                      wave, lane, tw, cx, pf, G + PK, nullptr, sm.pmax);
         node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne>(wb, wbe, G + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
                                                       nullptr, mg.NC, wave, lane, tw, cx, pf,
-                                                      G + 3 * PK);  // node MLP weights travel across the edge phase
+                                                      G + 3 * PK, nullptr, sm.qmax);  // node MLP weights travel across the edge phase
       }
       STAMP(ST_NODE);
       __syncthreads();
@@ -219,8 +230,10 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
+        const float d0v = sm.d0[tc.slot];
+        const float ub = __builtin_bit_cast(float, sm.pmax[tc.i]) + __builtin_bit_cast(float, sm.qmax[tc.j]) + crmax * gg[0] + cdmax * fabsf(d0v);
         er_gemm_pq<HP>(acc, ring, wbe, G + 2 * PK, rd + 1 < mg.rounds ? G + 2 * PK : (RI ? -1 : Wnext_edge), b2, cr, cd,
-                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
+                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], d0v, ub, tc.active, wave, lane STAMP_ARGS);
         STAMP(ST_EDGE);
         if (tc.active) {
           float sdot = 0.f;
@@ -259,7 +272,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       __syncthreads();
       STAMP(ST_BARRIER);
       vec_prefetch<NV, kThreads>(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK,
-                                 s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
+                                 s + 1 < W.S ? 7 * HP + 16 : 5 * HP + 16, tid);
       if constexpr (STG) {
         stage_rows(xs0, sm.p, N * LD, wave, lane);
         stage_wait();
@@ -275,7 +288,11 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
     {
       const int E = lay.equ(l);
       const int Wnext_edge = l + 1 < W.L ? lay.gcl(l + 1, 0) + 2 * PK : -1;
-      vec_commit<NV, kThreads>(vpf, sm.vec, 5 * HP, tid);
+      vec_commit<NV, kThreads>(vpf, sm.vec, 5 * HP + 16, tid);
+      if (tid < N) {
+        sm.pmax[tid] = 0u;
+        sm.qmax[tid] = 0u;
+      }
       if constexpr (STG) {
         stage_rows(xs0, sm.h, N * LD, wave, lane);
         stage_wait();
@@ -284,12 +301,14 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       }
       STAMP(ST_STAGE);
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
+      const float crmax = sm.vec[5 * HP], cdmax = sm.vec[5 * HP + 1];  // max |c_r|, max |c_d| (host)
       {
         const NodeCtxH cx = hctx();
         node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, E, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
-                                                      wave, lane, tw, cx, pf, E + PK);
+                                                      wave, lane, tw, cx, pf, E + PK, nullptr, sm.pmax);
         node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne>(wb, wbe, E + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
-                                                      nullptr, mg.NC, wave, lane, tw, cx, pf, l + 1 < W.L ? lay.gcl(l + 1, 0) : -1);
+                                                      nullptr, mg.NC, wave, lane, tw, cx, pf, l + 1 < W.L ? lay.gcl(l + 1, 0) : -1, nullptr,
+                                                      sm.qmax);
       }
       STAMP(ST_NODE);
       __syncthreads();
@@ -299,8 +318,10 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         const TileCols tc = load_tile(mg, rd, wave, c);
         const f4 gg = sm.geo[tc.slot];
         f4 acc[T];
+        const float d0v = sm.d0[tc.slot];
+        const float ub = __builtin_bit_cast(float, sm.pmax[tc.i]) + __builtin_bit_cast(float, sm.qmax[tc.j]) + crmax * gg[0] + cdmax * fabsf(d0v);
         er_gemm_pq<HP>(acc, ring, wbe, E + 2 * PK, rd + 1 < mg.rounds ? E + 2 * PK : (RI ? -1 : Wnext_edge), b2, cr, cd,
-                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
+                         sm.p + tc.i * LD + 4 * g, sm.q + tc.j * LD + 4 * g, gg[0], d0v, ub, tc.active, wave, lane STAMP_ARGS);
         STAMP(ST_EDGE);
         if (tc.active) {
           float sdot = 0.f;

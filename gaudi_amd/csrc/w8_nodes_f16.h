@@ -45,9 +45,6 @@
 namespace gaudi {
 namespace w8 {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((ext_vector_type(2))) uint32_t u2;
 
 constexpr float kLoScale = 2048.f;  // 2^11
 #ifndef GAUDI_NODE_ABLATE
@@ -69,24 +66,25 @@ __host__ __device__ constexpr int nh_chunk_floats(int HP) { return (HP / 16) * 2
 __host__ __device__ constexpr int nh_tail_off(int HP) { return nh_chunks(HP) * nh_chunk_floats(HP); }  // [tile][q][64] floats
 // k-steps of the tail block that hold weights: one when only four inputs of the last tile exist (H % 16 == 4), else four
 __host__ __device__ constexpr int nh_tail_steps(bool ktail) { return ktail ? 1 : 4; }
-// split copy of one GEMM input in LDS, NCT column tiles of 16 nodes: [chunk][column tile][piece][64 x 16 B] with 64 B of padding
-// per chunk (the splitting wave's 8-byte stores of one row then fall on distinct banks), then the tail's fp32 inputs
-// [column tile][node][16] and the per-node descale factors [column tile][16]
-__host__ __device__ constexpr int nh_chunk_stride(int nct) { return nct * 512 + 16; }
+// split copy of one GEMM input in LDS, NCT column tiles of 16 nodes: [chunk][column tile][piece][64 x 16 B] -- with one column tile
+// 64 B of padding per chunk (the splitting wave's 8-byte stores of one row then fall on distinct banks; with more tiles the copy
+// must fit the half ring exactly: 2 x 6 chunks x 2 KiB at H = 192) -- then the tail's fp32 inputs [column tile][node][16].  The
+// per-node descale factors live in a small array of their own (kScaleFloatsH per input).
+__host__ __device__ constexpr int nh_chunk_stride(int nct) { return nct * 512 + (nct == 1 ? 16 : 0); }
 __host__ __device__ constexpr int nh_split_floats(int HP, int nct) {
-  return nh_chunks(HP) * nh_chunk_stride(nct) + (nh_odd(HP) ? nct * 256 : 0) + nct * 16;
+  return nh_chunks(HP) * nh_chunk_stride(nct) + (nh_odd(HP) ? nct * 256 : 0);
 }
+constexpr int kScaleFloatsH = 48;  // [column tile <= 3][16]
 
 struct SplitBufH {
   float* base;
-  int nct;  // column tiles
+  int nct;    // column tiles
+  float* sc;  // LDS [kScaleFloatsH]: the rows' descale factors
   __device__ __forceinline__ float* chunk(int m) const { return base + m * nh_chunk_stride(nct); }
   __device__ __forceinline__ float* tail(int HP) const { return base + nh_chunks(HP) * nh_chunk_stride(nct); }
-  __device__ __forceinline__ float* scale(int HP) const { return tail(HP) + (nh_odd(HP) ? nct * 256 : 0); }
+  __device__ __forceinline__ float* scale(int) const { return sc; }
 };
 
-__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
-__device__ __forceinline__ uint32_t absbits(float v) { return __builtin_bit_cast(uint32_t, v) & 0x7fffffffu; }
 // max over the wave of an unsigned value that every lane holds (DPP scan inside the 16-lane rows, then the four row ends)
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   auto shr = [](uint32_t x, auto sh_tag) {
@@ -102,10 +100,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return umax(umax(a, b), umax(c, d));
 }
 
-__device__ __forceinline__ uint32_t pk_f16(float a, float b) {  // round to nearest even
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){a, b}, h2));
-}
-__device__ __forceinline__ f2 unpk_f16(uint32_t p) { return __builtin_convertvector(__builtin_bit_cast(h2, p), f2); }
 
 // all waves: rows [0, N) of X ([N][HP+4], LDS -- or global for the kernels with node buffers in global memory) -> split
 // B operands.  Wave w owns rows w, w + 8, ...: lane j holds inputs 4 j .. 4 j + 3 of the row; two rows travel together so that
@@ -176,6 +170,12 @@ __device__ __forceinline__ void lds_barrier() {
 #ifndef GAUDI_NODE_DEPTH
 #define GAUDI_NODE_DEPTH 3
 #endif
+// Of the next matrix's chunks that a call loads ahead, the last GAUDI_NODE_LATE are issued AFTER its K loop -- one behind the
+// loop, one behind the fold -- instead of inside it: the K loop is bound by the CU's vector-memory pipe (its waves sit in
+// buffer_load issue), the split pass and the epilogue leave that pipe idle, so loads moved there cost nothing.
+#ifndef GAUDI_NODE_LATE
+#define GAUDI_NODE_LATE 0
+#endif
 template <int HP>
 struct NodeGeoH {
   static constexpr int T = HP / 16;
@@ -233,6 +233,7 @@ struct NodeCtxH {
   float* split_a;   // LDS: split copy of the first source (nh_split_floats(HP, nct) floats)
   float* split_b;   // ... of the second source; == split_a: the region holds ONE input, the sources are split in turn
   bool ktail;       // H % 16 == 4: the tail block holds one k-step
+  float* scales;    // LDS [2][kScaleFloatsH]: the per-node descale factors of the two sources
 };
 
 // One node GEMM of the workgroup (all waves call it; N <= 16 MAXNT node columns).
@@ -244,15 +245,17 @@ struct NodeCtxH {
 template <int HP, int EPI, bool TWO, int MAXNT, int PIN = kAheadOne, int POUT = kAheadOne>
 __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float* sXa, bool do_split_a, int Wb, const float* sXb,
                                             const float* sBias, float* sY, const float* sRes, const float* sMask, int N, int wave,
-                                            int lane, const NodeCtxH& cx, NodePFH<HP>& pf, int nextW = -1, float* gPre = nullptr) {
+                                            int lane, const NodeCtxH& cx, NodePFH<HP>& pf, int nextW = -1, float* gPre = nullptr,
+                                            uint32_t* sMaxOut = nullptr /* LDS [N], zeroed: max |y| bits of every node's row */) {
   using G = NodeGeoH<HP>;
   constexpr int T = G::T, LD = HP + 4, NTW = G::NTW, nc = G::nc, D = G::D;
   constexpr int kIn = PIN < D ? PIN : D, kOut = POUT < D ? POUT : D;
+  constexpr int kLate = nc < D ? 0 : (GAUDI_NODE_LATE < kOut ? GAUDI_NODE_LATE : kOut);  // (matrices of fewer chunks than sets: all in the loop)
   const int c = lane & 15, g = lane >> 4;
   // column tiles of this call (wave-uniform; the code below branches on it around matrix instructions and LDS traffic only)
   const int nt = (MAXNT < 2 || N <= 16) ? 1 : (MAXNT < 3 || N <= 32) ? 2 : 3;
   const bool seq = TWO && cx.split_b == cx.split_a;
-  const SplitBufH sa{cx.split_a, nt}, sb{cx.split_b, nt};
+  const SplitBufH sa{cx.split_a, nt, cx.scales}, sb{cx.split_b, nt, cx.scales + kScaleFloatsH};
   const int bpos = (4 * c + g) * 4;  // the lane's float offset inside a 1 KiB B unit
   const TileLanesH<HP> tl(wave, lane);
   // a matrix that is not there (no next GEMM) is "loaded" with out-of-range lanes too
@@ -367,13 +370,23 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
       if (!(kAblateH & 4)) {
         if constexpr (i + D < nc) nh_load<HP>(pf.s[d], wh, 2 * Wcur + (i + D) * nh_chunk_floats(HP), wave, tl);
         else if constexpr (!last_src) nh_load<HP>(pf.s[d], wh, 2 * Wb + d * nh_chunk_floats(HP), wave, tl);
-        else if constexpr (d < kOut) nh_load<HP>(pf.s[d], wh, 2 * Wn + d * nh_chunk_floats(HP), wave, tl_next);
+        else if constexpr (d < kOut - kLate) nh_load<HP>(pf.s[d], wh, 2 * Wn + d * nh_chunk_floats(HP), wave, tl_next);
       }
       __builtin_amdgcn_sched_barrier(0);
       bcur = bnext;
     });
   };
+  // the next matrix's chunk d, issued behind the K loop (its set's last use lies behind: chunk nc - D + d .. of the last source)
+  auto late = [&](auto d_tag) {
+    constexpr int d = decltype(d_tag)::value;
+    if constexpr (d >= kOut - kLate && d < kOut) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(kAblateH & 4)) nh_load<HP>(pf.s[d], wh, 2 * Wn + d * nh_chunk_floats(HP), wave, tl_next);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   source(std::integral_constant<int, 0>{}, sa);
+  if constexpr (!TWO) late(std::integral_constant<int, kOut - kLate>{});
   fold(sa, ta);
   if constexpr (TWO) {
     if (seq) {
@@ -382,8 +395,12 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
       lds_barrier();
     }
     source(std::integral_constant<int, 1>{}, sb);
+    late(std::integral_constant<int, kOut - kLate>{});
     fold(sb, tb);
   }
+  static_for<D>([&](auto d_tag) {
+    if constexpr (decltype(d_tag)::value > kOut - kLate) late(d_tag);
+  });
   static_for<MAXNT>([&](auto j_tag) {
     constexpr int j = decltype(j_tag)::value;
     if (j < nt) {
@@ -397,6 +414,8 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
           const bool pad = G::odd && cx.ktail && t == T - 1 && g > 0;  // rows 4 .. 15 of the last tile of an H % 16 == 4 width
           if (pad) yy = splat(0.f);
           if (gPre != nullptr) stash_store((f4*)(gPre + nd * HP + 16 * t + 4 * g), yy);  // stash: write once, read once
+          // the row maxima the edge GEMMs' column scales are bounded with (w8_split.h): one LDS atomic per lane and tile
+          if (sMaxOut != nullptr) atomicMax(sMaxOut + nd, umax(umax(absbits(yy[0]), absbits(yy[1])), umax(absbits(yy[2]), absbits(yy[3]))));
           if (!pad) {
             if (EPI == EPI_SILU) yy = silu4(yy);
             if (EPI == EPI_RESIDUAL_MASK) {
@@ -448,9 +467,10 @@ template <int HP, int EPI, bool TWO, bool GN, bool NH, int PIN, int POUT, class 
 __device__ __forceinline__ void node_gemm_x(const WBuf& wb, const WBuf& wbe, int Wa, const float* Xa, const float* XaS, bool split_a, int Wb,
                                             const float* Xb, const float* XbS, const float* sBias, float* sY, const float* sRes,
                                             const float* sMask, int N, int wave, int lane, bool tw, const NodeCtxH& cx, PF& pf,
-                                            int nextW = -1, float* gPre = nullptr) {
+                                            int nextW = -1, float* gPre = nullptr, uint32_t* sMaxOut = nullptr) {
   if constexpr (NH) {
-    node_gemm_h<HP, EPI, TWO, GN ? 3 : 2, PIN, POUT>(wbe, Wa, Xa, split_a, Wb, Xb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre);
+    node_gemm_h<HP, EPI, TWO, GN ? 3 : 2, PIN, POUT>(wbe, Wa, Xa, split_a, Wb, Xb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre,
+                                                     sMaxOut);
   } else if constexpr (GN) {
     node_gemm_n<HP, EPI, true, 3>(wb, Wa, XaS, Wb, XbS, sBias, sY, sRes, sMask, N, wave, lane, tw, &pf, nextW, gPre);
   } else {
@@ -465,10 +485,10 @@ __host__ __device__ constexpr bool node_ring_idle(int HP, int SP, bool GN) {
   return GN || (SP != 0 && GAUDI_NODE_F16 != 0 && (SP == 2 || HP < 48));
 }
 template <int HP>
-__device__ __forceinline__ NodeCtxH node_ctx_h(float* region, int cap, int N, float winv, bool ktail) {
+__device__ __forceinline__ NodeCtxH node_ctx_h(float* region, int cap, int N, float winv, bool ktail, float* scales) {
   const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
   const int need = nh_split_floats(HP, nct);
-  return NodeCtxH{winv, region, 2 * need <= cap ? region + need : region, ktail};
+  return NodeCtxH{winv, region, 2 * need <= cap ? region + need : region, ktail, scales};
 }
 
 }  // namespace w8

@@ -22,12 +22,14 @@ struct PredSmem {
                                   // published (no group is prefetched across that phase), so it is part of the buffer too
   float* pub;                     // [pubx] extra floats of the publish buffer (reverse pass: du of every slot, CH tiles at a time)
   float *x, *x0, *dx;             // [N][4]
+  uint32_t *pmax, *qmax;          // [N] bits of max |P_n|, max |Q_n| (w8_edm.h: NetSmem)
+  float* hsc;                     // [2][kScaleFloatsH] (w8_edm.h: NetSmem)
   f4* geo;                        // [S]
   float *d0, *trans, *dd0;        // [S], [S][4], [S]
   float* pred;                    // [16] pred | [16] dpred
   float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
   __host__ __device__ static int floats(int N, int S, int pubx) {
-    return EdgeRing<HP, SP>::kFloats + (GN ? 0 : 5 * N * (HP + 4)) + pubx + 12 * N + S * 10 + 32 + 10 * HP;
+    return EdgeRing<HP, SP>::kFloats + (GN ? 0 : 5 * N * (HP + 4)) + pubx + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * HP;
   }
   // the publish buffer of the reverse pass (du of every slot, pub_ch feature tiles at a time)
   __device__ __forceinline__ float* publish() const { return GN ? ring : b0; }
@@ -46,6 +48,9 @@ struct PredSmem {
     x = base; base += 4 * N;
     x0 = base; base += 4 * N;
     dx = base; base += 4 * N;
+    pmax = (uint32_t*)base; base += align4(N);  // (whole float4s: w8_edm.h)
+    qmax = (uint32_t*)base; base += align4(N);
+    hsc = base; base += 96;
     geo = (f4*)base; base += S * 4;
     d0 = base; base += S;
     trans = base; base += S * 4;
@@ -120,7 +125,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   __syncthreads();
   compute_geo(sm, mg, 0.f, tid, true);  // edge_attr = |x_i - x_j|^2 of the input (models.py:452)
   typename EdgeRing<HP, SP>::type ring;
-  er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
+  er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws, W.hinv);
   // NH / RI / STG: see edm_forward (w8_edm.h) -- fp16-pair node GEMMs; the ring idles across node phases (GN: node-GEMM inputs
   // are staged in it, every edge phase requests its first weight group itself); fp32 node GEMMs of a GN kernel read staged rows
   constexpr bool NH = NodeMath<SP>::kF16;
@@ -133,10 +138,10 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
   node_prefetch_x<HP, NH, kAheadOne>(pf, wb, wbe, lay.layer(0), mg.NC, wave, lane, tw);
   auto hctx = [&]() {
     if constexpr (NH) {
-      if constexpr (RI) return node_ctx_h<HP>(sm.ring, EdgeRing<HP, SP>::kFloats, mg.NC, W.hinv, tw);
-      else return node_ctx_h<HP>(ring.slot(ring.par ^ 1), EdgeRing<HP, SP>::kFloats / 2, mg.NC, W.hinv, tw);
+      if constexpr (RI) return node_ctx_h<HP>(sm.ring, EdgeRing<HP, SP>::kFloats, mg.NC, W.hinv, tw, sm.hsc);
+      else return node_ctx_h<HP>(ring.slot(ring.par ^ 1), EdgeRing<HP, SP>::kFloats / 2, mg.NC, W.hinv, tw, sm.hsc);
     } else {
-      return NodeCtxH{1.f, nullptr, nullptr, tw};
+      return NodeCtxH{1.f, nullptr, nullptr, tw, nullptr};
     }
   };
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
@@ -152,6 +157,10 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       agg[idx] = 0.f;
       agg1[idx] = 0.f;
     }
+    if (tid < N) {
+      sm.pmax[tid] = 0u;
+      sm.qmax[tid] = 0u;
+    }
     float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
     for (int idx = tid; idx < N; idx += kThreads) gstore4((f4*)(st + 3 * N * HP) + idx, *(const f4*)(sm.x + 4 * idx));
     compute_geo(sm, mg, 1.0f, tid, false);  // gcl.py:308-316
@@ -161,9 +170,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     {
       const NodeCtxH cx = hctx();
       node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, Lw.A, h, xs0, true, -1, nullptr, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave,
-                                                    lane, tw, cx, pf, Lw.Bm);
+                                                    lane, tw, cx, pf, Lw.Bm, nullptr, sm.pmax);
       node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne>(wb, wbe, Lw.Bm, h, xs0, false, -1, nullptr, nullptr, nullptr, q, nullptr, nullptr, mg.NC,
-                                                    wave, lane, tw, cx, pf, Lw.Wn1h);
+                                                    wave, lane, tw, cx, pf, Lw.Wn1h, nullptr, sm.qmax);
     }
     STAMP(ST_NODE);
     __syncthreads();
@@ -187,8 +196,11 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       const TileCols tc = load_tile(mg, MR ? rd : 0, wave, c);
       const f4 gg = sm.geo[tc.slot];
       f4 acc[T];
+      const float d0f = sm.d0[tc.slot];
+      const float ub = __builtin_bit_cast(float, sm.pmax[tc.i]) + __builtin_bit_cast(float, sm.qmax[tc.j]) + sm.vec[9 * HP + 1] * gg[0] +
+                       sm.vec[9 * HP + 2] * fabsf(d0f);  // (max |c_r|, max |c_d| from the host, behind ba)
       er_gemm_pq<HP>(acc, ring, wbe, Lw.W2, last ? (more ? Lw.W2 : -1) : Lw.Wc1, Lw.b2, Lw.cr, Lw.cd, p + tc.i * LD + 4 * g,
-                       q + tc.j * LD + 4 * g, gg[0], sm.d0[tc.slot], tc.active, wave, lane STAMP_ARGS);
+                       q + tc.j * LD + 4 * g, gg[0], d0f, ub, tc.active, wave, lane STAMP_ARGS);
       STAMP(ST_EDGE);
       const int tile = tc.slot >> 4;
       if (tc.active) {
@@ -349,7 +361,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   __syncthreads();
 
   typename EdgeRing<HP, SP>::type ring;
-  er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws);
+  er_init<HP>(ring, sm.ring, W.ktail != 0, W.ws, W.hinv);
   // NH / RI / STG: see edm_forward (w8_edm.h)
   constexpr bool NH = NodeMath<SP>::kF16;
   constexpr bool RI = node_ring_idle(HP, SP, GN);
@@ -364,10 +376,10 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   node_prefetch_x<HP, NH, kAheadOne>(pf, wb, wbe, lay.layer(W.L - 1) + 13 * HP * HP /* Wn2^T of the last layer */, mg.NC, wave, lane, tw);
   auto hctx = [&]() {
     if constexpr (NH) {
-      if constexpr (RI) return node_ctx_h<HP>(sm.ring, EdgeRing<HP, SP>::kFloats, mg.NC, W.hinv, tw);
-      else return node_ctx_h<HP>(ring.slot(ring.par ^ 1), EdgeRing<HP, SP>::kFloats / 2, mg.NC, W.hinv, tw);
+      if constexpr (RI) return node_ctx_h<HP>(sm.ring, EdgeRing<HP, SP>::kFloats, mg.NC, W.hinv, tw, sm.hsc);
+      else return node_ctx_h<HP>(ring.slot(ring.par ^ 1), EdgeRing<HP, SP>::kFloats / 2, mg.NC, W.hinv, tw, sm.hsc);
     } else {
-      return NodeCtxH{1.f, nullptr, nullptr, tw};
+      return NodeCtxH{1.f, nullptr, nullptr, tw, nullptr};
     }
   };
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;

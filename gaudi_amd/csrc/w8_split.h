@@ -1,20 +1,29 @@
-// w8_split.h -- edge-level GEMMs of the 8-wave kernels on the bf16 matrix pipe with fp32-equivalent accuracy.
+// w8_split.h -- edge-level GEMMs of the 8-wave kernels on the 16-bit matrix pipe with fp32-equivalent accuracy.
 //
-// v_mfma_f32_16x16x4_f32 runs at the vector fp32 rate (64 FLOP/clk/SIMD); v_mfma_f32_16x16x32_bf16 at 16x that.  Every fp32
-// operand is split into three bf16 pieces (round-to-nearest each time: x = h + m + l EXACTLY, |m| <= 2^-9 |x|, |l| <= 2^-17
-// |x|) and a product a.b is accumulated in fp32 from the six piece products of weight >= 2^-18:
-//     ah.bh + ah.bm + am.bh + am.bm + ah.bl + al.bh          (dropped: am.bl + al.bm + al.bl <= 2^-24.4 |a.b|)
-// Piece products are exact in fp32 (8 x 8 significant bits), so the only error beside the fp32 accumulation is the dropped
-// tail -- below the rounding error of ONE fp32 multiply (2^-24 |a.b|).  Measured against float64 the result is about as close as
-// the fp32-MFMA GEMM (tests/test_gpu_split.py, tools/split_gemm_microbench.hip).  Six 16-cycle instructions replace eight
-// 32-cycle ones per 32 inputs: 2.67x less matrix time, and vector-ALU work co-issues with bf16 MFMAs (it does not with
-// fp32 MFMAs).
+// v_mfma_f32_16x16x4_f32 runs at the vector fp32 rate (64 FLOP/clk/SIMD); the 16-bit instructions v_mfma_f32_16x16x32_{bf16,f16}
+// at 16x that.  Round 2 split every fp32 operand into three bf16 pieces (six piece products per product: 2.67x less matrix
+// time than the fp32 instruction).  Round 5: both operands are fp16 PAIRS, x s = hi + lo with hi = fp16(x s), lo = fp16(x s - hi)
+// (round to nearest; s a power of two that brings the largest magnitude to [2^14, 2^15): per network for the weights, on the
+// host; per edge column for the activations, on the device), and a product is accumulated in fp32 from THREE piece products
+//     a_hi b_lo + a_lo b_hi + a_hi b_hi                       (dropped: a_lo b_lo <= 2^-22 |a b|)
+// on v_mfma_f32_16x16x32_f16: half the matrix instructions of the bf16 form, two thirds of its weight bytes (4 B per weight: the
+// ring is 26 KiB per slot instead of 39) and a cheaper operand split (two conversions per value instead of three).  hi carries
+// 11 significant bits, the remainder is exact in fp32 and lo carries its leading 11: 22 bits for every entry within 2^17 of its
+// column's (its network's) largest, degrading to fp16's absolute floor 2^-24 (of a maximum of 2^14: 2^-38 relative to the
+// largest entry) below that; piece products are exact in fp32.  Against float64 the result is as close as the fp32 instruction's
+// (tests/test_gpu_split.py, tools/node_gemm_h_microbench.hip for the same arithmetic in the node GEMMs); unlike the node form
+// (w8_nodes_f16.h: lo scaled by 2^11, two accumulators) the edge form keeps ONE accumulator per output tile -- a wave holds 13
+// of them beside its operands.
+// Range.  The column scale of a CHAINED GEMM is the exact maximum of the lane's own inputs (they are in registers); for the
+// GEMM that generates its inputs chunk by chunk, silu(P_i + Q_j + c_r r + c_d d0), it comes from the bound
+// |silu(u)| <= |u| <= max|P_i| + max|Q_j| + max|c_r| r + max|c_d| |d0| (row maxima from the node GEMMs' epilogues, column maxima
+// from the host) -- a loose bound costs nothing, the pieces have 38 binades of room below the column's largest entry.
 //
 // Layout.  K is consumed in chunks of 32 inputs = two 16-feature tiles (2m, 2m+1); lane (column c, group g) carries inputs
 // 16(2m) + 4g .. +3 in slots 0-3 and 16(2m+1) + 4g .. +3 in slots 4-7, which is exactly the accumulator layout of two output
 // tiles of the previous GEMM of a chain.  The host packs each matrix as units of 1 KiB: unit (m, t, p) = piece p of output
-// tile t against chunk m, lane L = (row L & 15, group L >> 4) holding its 8 bf16 A-operand slots (16 B): one conflict-free
-// ds_read_b128 per unit.  Units are ordered [m][t][p]; a ring group = the CH tiles x 3 pieces one trip consumes.
+// tile t against chunk m, lane L = (row L & 15, group L >> 4) holding its 8 fp16 A-operand slots (16 B): one conflict-free
+// ds_read_b128 per unit.  Units are ordered [m][t][p]; a ring group = the CH tiles x 2 pieces one trip consumes.
 #pragma once
 #include "w8_common.h"
 
@@ -25,10 +34,12 @@
 namespace gaudi {
 namespace w8 {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(2))) float f2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u2;
+constexpr int kPieces = 2;  // fp16 pieces per operand
 
 template <int N, class F>
 __device__ __forceinline__ void static_for(F f) {
@@ -39,33 +50,52 @@ __device__ __forceinline__ void static_for(F f) {
 }
 
 struct B3 {
-  u4 h, m, l;  // the lane's 8 inputs of a K chunk, three bf16 pieces each (slot e in bits 16(e&1) of word e>>1)
+  u4 h, l;  // the lane's 8 inputs of a K chunk, two fp16 pieces each (slot e in bits 16(e&1) of word e>>1)
 };
 
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){a, b}, bf2));
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {  // v_cvt_pk_f16_f32 (round to nearest even)
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){a, b}, h2));
+}
+__device__ __forceinline__ f2 unpk_f16(uint32_t p) { return __builtin_convertvector(__builtin_bit_cast(h2, p), f2); }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// (by value: __builtin_bit_cast applied to an ext-vector element expression reads element 0 whatever the index -- hipcc 7.2)
+__device__ __forceinline__ uint32_t absbits(float v) { return __builtin_bit_cast(uint32_t, v) & 0x7fffffffu; }
+// power-of-two scale that brings a magnitude with these bits to [2^14, 2^15) (below fp16's 65 504), and its inverse; exponents
+// clamped so that both factors are normal numbers
+struct Pow2Scale {
+  float s, inv;
+};
+__device__ __forceinline__ Pow2Scale scale_for(uint32_t maxbits) {
+  int k = 141 - (int)(maxbits >> 23);
+  k = k > 126 ? 126 : k;
+  return Pow2Scale{__builtin_bit_cast(float, (uint32_t)(k + 127) << 23), __builtin_bit_cast(float, (uint32_t)(127 - k) << 23)};
 }
 struct P3 {
-  uint32_t h, m, l;
+  uint32_t h, l;
 };
-__device__ __forceinline__ P3 split2(float a, float b) {
+__device__ __forceinline__ P3 split2(float a, float b) {  // (already scaled)
   P3 r;
-  r.h = pk_bf16(a, b);
-  const float ra = a - __builtin_bit_cast(float, r.h << 16), rb = b - __builtin_bit_cast(float, r.h & 0xffff0000u);
-  r.m = pk_bf16(ra, rb);
-  r.l = pk_bf16(ra - __builtin_bit_cast(float, r.m << 16), rb - __builtin_bit_cast(float, r.m & 0xffff0000u));
+  r.h = pk_f16(a, b);
+  const f2 f = unpk_f16(r.h);
+  r.l = pk_f16(a - f[0], b - f[1]);
   return r;
 }
-__device__ __forceinline__ B3 split8(const f4 lo, const f4 hi) {
-  const P3 p0 = split2(lo[0], lo[1]), p1 = split2(lo[2], lo[3]), p2 = split2(hi[0], hi[1]), p3 = split2(hi[2], hi[3]);
+__device__ __forceinline__ B3 split8(const f4 lo, const f4 hi, float s) {
+  const P3 p0 = split2(lo[0] * s, lo[1] * s), p1 = split2(lo[2] * s, lo[3] * s), p2 = split2(hi[0] * s, hi[1] * s),
+           p3 = split2(hi[2] * s, hi[3] * s);
   B3 r;
   r.h = (u4){p0.h, p1.h, p2.h, p3.h};
-  r.m = (u4){p0.m, p1.m, p2.m, p3.m};
   r.l = (u4){p0.l, p1.l, p2.l, p3.l};
   return r;
 }
-__device__ __forceinline__ f4 mfma_bf(const u4 a, const u4 b, const f4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+__device__ __forceinline__ f4 mfma_bf(const u4 a, const u4 b, const f4 c) {  // (the name is round 2's: the 16-bit matrix instruction)
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+// the largest |.| bits of the lane's column over its 4 lane groups (lanes c, c + 16, c + 32, c + 48)
+__device__ __forceinline__ uint32_t column_max(uint32_t v) {
+  v = umax(v, (uint32_t)__shfl_xor((int)v, 16));
+  v = umax(v, (uint32_t)__shfl_xor((int)v, 32));
+  return v;
 }
 
 // Geometry of a split matrix: T tiles, NC = ceil(T/2) K chunks, trips of CH output tiles (NH per chunk).
@@ -81,15 +111,15 @@ struct SplitGeo {
   static constexpr int NH = (T + CH - 1) / CH;
   static constexpr int kTrips = NC * NH;
   static constexpr int kUnit = 256;                    // floats (1 KiB)
-  static constexpr int kSlotFloats = CH * 3 * kUnit;   // LDS per ring slot
-  static constexpr int kMatFloats = NC * T * 3 * kUnit;  // one packed matrix
-  static constexpr int UT = (CH * 3 + kWaves - 1) / kWaves;
+  static constexpr int kSlotFloats = CH * kPieces * kUnit;   // LDS per ring slot
+  static constexpr int kMatFloats = NC * T * kPieces * kUnit;  // one packed matrix
+  static constexpr int UT = (CH * kPieces + kWaves - 1) / kWaves;
   // K tail (nf % 16 == 4, odd tile count: the last chunk is the tail tile alone): that chunk is stored as T fp32 tiles in
   // the K-tail form of w8_common.h (input 16(T-1)+g on lane group g, element 0) and issued as ONE trip of one fp32 k-step
   // per tile
   static constexpr bool kTailOK = (T & 1) && T >= 3;
   static constexpr int kTripsTail = (NC - 1) * NH + 1;
-  static_assert(!kTailOK || T <= CH * 3, "the fp32 tail tiles must fit one ring slot");
+  static_assert(!kTailOK || T <= CH * kPieces, "the fp32 tail tiles must fit one ring slot");
   __host__ __device__ static constexpr int tiles_of(int h) { return (h + 1) * CH <= T ? CH : T - h * CH; }
 };
 
@@ -100,6 +130,7 @@ struct RingS {
   int par;
   bool ktail;   // the matrices carry a K tail (SplitGeo::kTailOK widths only)
   const float* gbase;  // the split weight buffer (LDS-DMA loads take a plain global address)
+  float winv;          // 2^-s of the network's weight images
   __device__ __forceinline__ float* slot(int p) const { return base + p * G::kSlotFloats; }
 };
 
@@ -116,11 +147,11 @@ __device__ __forceinline__ bool trip_group(const RingS<HP, MODE>& r, int W, int 
   const int base = nxt ? nextW : W;
   if (tail && t2 == n - 1) {
     units = G::T;
-    off = base + (G::NC - 1) * G::T * 3 * G::kUnit;
+    off = base + (G::NC - 1) * G::T * kPieces * G::kUnit;
   } else {
     const int m = t2 / G::NH, h = t2 % G::NH;
-    units = G::tiles_of(h) * 3;
-    off = base + (m * G::T + h * G::CH) * 3 * G::kUnit;
+    units = G::tiles_of(h) * kPieces;
+    off = base + (m * G::T + h * G::CH) * kPieces * G::kUnit;
   }
   off = __builtin_amdgcn_readfirstlane(off);
   units = __builtin_amdgcn_readfirstlane(units);
@@ -186,30 +217,32 @@ __device__ __forceinline__ void rings_mfma_act(f4* acc, const float* slot_lane, 
     mid();
     return;
   }
-  f4 a[2][3];
+  // A units are read TWO tiles ahead (three register sets in rotation): a tile's three matrix instructions last 48 cycles, half of
+  // what the six of the bf16 form did, and no longer cover a ds_read_b128 round trip on their own
+  constexpr int kAhead = NT > 2 ? 2 : 1, kSets = kAhead + 1;
+  f4 a[kSets][kPieces];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) a[0][p] = *(const f4*)(slot_lane + p * U);
+  for (int q = 0; q < kAhead; ++q)
+#pragma unroll
+    for (int p = 0; p < kPieces; ++p) a[q][p] = *(const f4*)(slot_lane + (q * kPieces + p) * U);
   static_for<NT>([&](auto t_tag) {
     constexpr int t = decltype(t_tag)::value;
-    constexpr int cur = t % 2;
+    constexpr int cur = t % kSets;
     if (t == NT / 2) {
       mid();
       __builtin_amdgcn_sched_barrier(0);
     }
     if (t == (NT - 2 > NT / 2 ? NT - 2 : NT - 1)) __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < NT) {
+    if (t + kAhead < NT) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[(t + 1) % 2][p] = *(const f4*)(slot_lane + ((t + 1) * 3 + p) * U);
+      for (int p = 0; p < kPieces; ++p) a[(t + kAhead) % kSets][p] = *(const f4*)(slot_lane + ((t + kAhead) * kPieces + p) * U);
     }
     __builtin_amdgcn_sched_barrier(0);
     {
-      const u4 ah = __builtin_bit_cast(u4, a[cur][0]), am = __builtin_bit_cast(u4, a[cur][1]), al = __builtin_bit_cast(u4, a[cur][2]);
+      const u4 ah = __builtin_bit_cast(u4, a[cur][0]), al = __builtin_bit_cast(u4, a[cur][1]);
       f4 c = acc[t];
       c = mfma_bf(al, b.h, c);  // small terms first
       c = mfma_bf(ah, b.l, c);
-      c = mfma_bf(am, b.m, c);
-      c = mfma_bf(am, b.h, c);
-      c = mfma_bf(ah, b.m, c);
       c = mfma_bf(ah, b.h, c);
       acc[t] = c;
     }
@@ -242,20 +275,25 @@ __device__ __forceinline__ void rings_mfma_tail(f4 (&acc)[HP / 16], const float*
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc = b2 + W2 . silu(u) (see edge_gemm_pq); weights in split format at float offset W of wb
+// acc = b2 + W2 . silu(u) (see edge_gemm_pq); weights in split format at float offset W of wb.  ubound >= |u| for every input of
+// the lane's edge column (the caller's bound: row maxima of P_i and Q_j + column maxima of c_r, c_d times r, |d0|): the column's
+// power-of-two scale.  The accumulators run in scaled units (column scale x network weight scale) and are descaled, bias added,
+// at the end.
 template <int HP, int MODE>
 __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MODE>& ring, const WBuf& wb, int W, int nextW,
                                                const float* sB2, const float* sCr, const float* sCd, const float* pp,
-                                               const float* qq, float r, float d0, bool active, int wave, int lane) {
+                                               const float* qq, float r, float d0, float ubound, bool active, int wave, int lane) {
   using G = SplitGeo<HP, MODE>;
   constexpr int T = G::T;
   const int g = lane >> 4;
 #pragma unroll
-  for (int t = 0; t < T; ++t) acc[t] = *(const f4*)(sB2 + 16 * t + 4 * g);
+  for (int t = 0; t < T; ++t) acc[t] = splat(0.f);
+  const Pow2Scale sc = scale_for(absbits(ubound));
+  const float se = sc.s;
   auto gen = [&](int m) {  // split silu(u) of K chunk m (tiles 2m, 2m+1; an odd T leaves the upper half of the last chunk 0)
     const f4 lo = silu4(edge_u(pp, qq, sCr, sCd, g, 2 * m, r, d0));
     const f4 hi = 2 * m + 1 < T ? silu4(edge_u(pp, qq, sCr, sCd, g, 2 * m + 1 < T ? 2 * m + 1 : 0, r, d0)) : splat(0.f);
-    return split8(lo, hi);
+    return split8(lo, hi, se);
   };
   B3 bin = gen(0), nb = bin;
   static_assert(G::NH <= 3, "at most three trips per K chunk");
@@ -269,7 +307,7 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
       trip_open(ring, lane);
       rings_mfma<HP, MODE, NT>(acc + h * G::CH, ring.slot(ring.par) + lane * 4, bin, active, [&] {
         rings_stage(ring, wb, W, nextW, tr, wave, lane);
-        // every wave generates the NEXT chunk in the middle of its block (vector work co-issues with bf16 MFMAs; the
+        // every wave generates the NEXT chunk in the middle of its block (vector work co-issues with 16-bit MFMAs; the
         // staggered placement of the fp32 form is 2 % slower here, generation right after the barrier 7 %)
         if (h == G::NH - 1) nb = gen(mn);
       });
@@ -289,17 +327,21 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
   }
   if (m < full) chunk(m, bin, nb);
   if constexpr (G::kTailOK) {
-    if (tail) {
+    if (tail) {  // (the tail tiles are fp32, scaled by the network's exponent on the host: the same units as the 16-bit part)
       trip_open(ring, lane);
-      const float bt = silu_f(edge_u_tail(pp, qq, sCr, sCd, g, T, r, d0)[0]);
+      const float bt = silu_f(edge_u_tail(pp, qq, sCr, sCd, g, T, r, d0)[0]) * se;
       rings_mfma_tail<HP, MODE>(acc, ring.slot(ring.par) + lane * 4, bt, active,
                           [&] { rings_stage(ring, wb, W, nextW, G::kTripsTail - 1, wave, lane); });
       trip_close(ring, lane);
     }
   }
+  const float dsc = sc.inv * ring.winv;
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = acc[t] * dsc + *(const f4*)(sB2 + 16 * t + 4 * g);
 }
 
-// Chained edge GEMM, input in registers (accumulator layout of the previous GEMM): out = bias + rowinit + W . in
+// Chained edge GEMM, input in registers (accumulator layout of the previous GEMM): out = bias + rowinit + W . in.  The column scale
+// is the exact maximum of the lane's own inputs (all lane groups of the column).
 template <int HP, int MODE>
 __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], RingS<HP, MODE>& ring, const WBuf& wb,
                                                  int W, int nextW, const float* sBias, const float* rowinit, bool active,
@@ -307,17 +349,19 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
   using G = SplitGeo<HP, MODE>;
   constexpr int T = G::T;
   const int g = lane >> 4;
+  uint32_t mx = 0;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    f4 b = sBias != nullptr ? *(const f4*)(sBias + 16 * t + 4 * g) : splat(0.f);
-    if (rowinit != nullptr) b = b + *(const f4*)(rowinit + 16 * t + 4 * g);
-    out[t] = b;
+    out[t] = splat(0.f);
+    mx = umax(mx, umax(umax(absbits(in[t][0]), absbits(in[t][1])), umax(absbits(in[t][2]), absbits(in[t][3]))));
   }
+  const Pow2Scale sc = scale_for(column_max(mx));
+  const float se = sc.s;
   static_assert(G::NH <= 3, "at most three trips per K chunk");
   const int c = lane & 15;
   auto chunk = [&](auto m_tag) {
     constexpr int m = decltype(m_tag)::value;
-    const B3 bin = split8(in[2 * m], 2 * m + 1 < T ? in[2 * m + 1 < T ? 2 * m + 1 : 0] : splat(0.f));
+    const B3 bin = split8(in[2 * m], 2 * m + 1 < T ? in[2 * m + 1 < T ? 2 * m + 1 : 0] : splat(0.f), se);
     auto trip = [&](auto h_tag) {
       constexpr int h = decltype(h_tag)::value;
       constexpr int tr = m * G::NH + h;
@@ -330,23 +374,34 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
     if constexpr (G::NH > 1) trip(std::integral_constant<int, 1>{});
     if constexpr (G::NH > 2) trip(std::integral_constant<int, 2>{});
   };
+  auto finish = [&] {  // descale, then bias and the per-row initial value
+    const float dsc = sc.inv * ring.winv;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      f4 b = sBias != nullptr ? *(const f4*)(sBias + 16 * t + 4 * g) : splat(0.f);
+      if (rowinit != nullptr) b = b + *(const f4*)(rowinit + 16 * t + 4 * g);
+      out[t] = out[t] * dsc + b;
+    }
+  };
   static_for<G::NC - 1>([&](auto m_tag) { chunk(m_tag); });
   if constexpr (G::kTailOK) {
     if (ring.ktail) {
       trip_open(ring, lane);
-      rings_mfma_tail<HP, MODE>(out, ring.slot(ring.par) + lane * 4, tail_to_b(in[T - 1], c, g)[0], active,
+      rings_mfma_tail<HP, MODE>(out, ring.slot(ring.par) + lane * 4, tail_to_b(in[T - 1], c, g)[0] * se, active,
                           [&] { rings_stage(ring, wb, W, nextW, G::kTripsTail - 1, wave, lane); });
       trip_close(ring, lane);
+      finish();
       return;
     }
   }
   chunk(std::integral_constant<int, G::NC - 1>{});
+  finish();
 }
 
 // ---------------------------------------------------------------------------------------------
 // One interface over both edge-GEMM engines.  Matrix offsets are the fp32 weight buffer's float offsets
-// in both cases: the split image of the matrix at float offset W lives at float offset 2 W of its own buffer (a split
-// matrix is 1.5x, for an odd tile count up to 1.62x, the size of the fp32 one; the holes are never touched).
+// in both cases: the split image of the matrix at float offset W lives at float offset 2 W of its own buffer (an image is
+// the size of the fp32 matrix, for an odd tile count up to 1.08x; the holes are never touched).
 // ---------------------------------------------------------------------------------------------
 template <int HP, int SP>  // SP: 0 = fp32 matrix instructions, 1 / 2 = split operands with the full / half ring (SplitGeo)
 struct EdgeRing {
@@ -361,7 +416,7 @@ struct EdgeRing<HP, 0> {
 __host__ __device__ constexpr int edge_ring_floats(int HP, int mode) {
   const int T = HP / 16;
   const int CH = (mode == 2 || (T + 1) / 2 == 1) && T > 1 ? (T + 1) / 2 : T;  // = SplitGeo<HP, mode>::CH
-  return mode ? 2 * CH * 3 * 256 : 2 * T * 256;
+  return mode ? 2 * CH * kPieces * 256 : 2 * T * 256;
 }
 static_assert(edge_ring_floats(32, 1) == EdgeRing<32, 1>::kFloats && edge_ring_floats(208, 1) == EdgeRing<208, 1>::kFloats &&
                   edge_ring_floats(48, 2) == EdgeRing<48, 2>::kFloats && edge_ring_floats(208, 2) == EdgeRing<208, 2>::kFloats,
@@ -369,17 +424,18 @@ static_assert(edge_ring_floats(32, 1) == EdgeRing<32, 1>::kFloats && edge_ring_f
 __device__ __forceinline__ int split_off(int W) { return W < 0 ? -1 : 2 * W; }
 
 template <int HP>
-__device__ __forceinline__ void er_init(Ring<HP>& r, float* base, bool ktail, const float*) {
+__device__ __forceinline__ void er_init(Ring<HP>& r, float* base, bool ktail, const float*, float) {
   r.base = base;
   r.par = 0;
   r.ktail = ktail;
 }
 template <int HP, int MODE>
-__device__ __forceinline__ void er_init(RingS<HP, MODE>& r, float* base, bool ktail, const float* ws) {
+__device__ __forceinline__ void er_init(RingS<HP, MODE>& r, float* base, bool ktail, const float* ws, float winv) {
   r.base = base;
   r.par = 0;
   r.ktail = ktail;
   r.gbase = ws;
+  r.winv = winv;
 }
 template <int HP>
 __device__ __forceinline__ void er_start(Ring<HP>& r, const WBuf& wb, int W, int wave, int lane) {
@@ -389,17 +445,18 @@ template <int HP, int MODE>
 __device__ __forceinline__ void er_start(RingS<HP, MODE>& r, const WBuf& wb, int W, int wave, int lane) {
   rings_start(r, wb, split_off(W), wave, lane);
 }
+// ubound: an upper bound of |u| over the inputs of the lane's edge (split form: the column's scale; unused by the fp32 form)
 template <int HP>
 __device__ __forceinline__ void er_gemm_pq(f4 (&acc)[HP / 16], Ring<HP>& ring, const WBuf& wb, int W, int nextW, const float* sB2,
                                            const float* sCr, const float* sCd, const float* pp, const float* qq, float r, float d0,
-                                           bool active, int wave, int lane STAMP_DECL) {
+                                           float, bool active, int wave, int lane STAMP_DECL) {
   edge_gemm_pq<HP>(acc, ring, wb, W, nextW, sB2, sCr, sCd, pp, qq, r, d0, active, wave, lane STAMP_ARGS);
 }
 template <int HP, int MODE>
 __device__ __forceinline__ void er_gemm_pq(f4 (&acc)[HP / 16], RingS<HP, MODE>& ring, const WBuf& wb, int W, int nextW, const float* sB2,
                                            const float* sCr, const float* sCd, const float* pp, const float* qq, float r, float d0,
-                                           bool active, int wave, int lane STAMP_DECL) {
-  edge_gemm_pq_s(acc, ring, wb, split_off(W), split_off(nextW), sB2, sCr, sCd, pp, qq, r, d0, active, wave, lane);
+                                           float ubound, bool active, int wave, int lane STAMP_DECL) {
+  edge_gemm_pq_s(acc, ring, wb, split_off(W), split_off(nextW), sB2, sCr, sCd, pp, qq, r, d0, ubound, active, wave, lane);
 }
 template <int HP>
 __device__ __forceinline__ void er_gemm_regs(f4 (&out)[HP / 16], const f4 (&in)[HP / 16], Ring<HP>& ring, const WBuf& wb, int W,

@@ -79,8 +79,9 @@ def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4", max_col_ti
 
     variant "w4"  (4 waves, 32-edge passes):  edge_units = list of 32-edge passes per wave [4]
     variant "w8"  (8 waves, 16-edge tiles, fp32 MFMAs):        edge_units = number of 16-edge tiles of the molecule
-    variant "w8s" (8 waves, edge GEMMs on split-bf16 operands: six v_mfma_f32_16x16x32_bf16 per output tile and 32 inputs,
-                   a K tail as one fp32 k-step per tile; node GEMMs as w8)
+    variant "w8s" (8 waves, edge GEMMs on fp16-pair operands: three v_mfma_f32_16x16x32_f16 per output tile and 32 inputs,
+                   a K tail as one fp32 k-step per tile; node GEMMs on fp16 pairs: three v_mfma_f32_16x16x32_f16 -- the same
+                   rate, counted with the bf16 instructions -- per output-tile slot, column tile and 32 inputs)
     ncols = node columns the node-level GEMMs produce (16-column tiles, pairs of tiles beyond 16; max_col_tiles = 3 -- the V8G
     kernels -- runs 33..48 columns as one pass over three tiles, w8_common.h: node_gemm_n)."""
     ncols = int(ncols)
@@ -91,35 +92,45 @@ def step_mfma_counts(edge_units, ncols, edm, pred=None, variant="w4", max_col_ti
     else:
         waves, tiles16 = 8, int(edge_units)
 
-    def node(T, kt, nf):  # K chunks x 4 k-steps x output tiles (the 4-wave kernels recompute a tile in idle tile slots)
-        if variant == "w4":
-            return kt * 4 * (-(-T // waves)) * waves * nt
-        # 8-wave kernels, widths with a tail tile (196 -> 208, 36 -> 48): that tile issues v_mfma_f32_4x4x1_16B_f32, a quarter of a
-        # 16x16x4 instruction each in MACs and in matrix-pipe cycles (w8_common.h: tail_lane) -> 0.25 instruction-equivalents
+    def node(T, kt, nf):  # -> (fp32, 16-bit) instructions of kt / T node-level matrices
+        if variant == "w4":  # K chunks x 4 k-steps x output tiles (the 4-wave kernels recompute a tile in idle tile slots)
+            return kt * 4 * (-(-T // waves)) * waves * nt, 0
+        if variant == "w8s":
+            # fp16-pair node GEMMs (w8_nodes_f16.h, round 5): three v_mfma_f32_16x16x32_f16 per chunk of 32 inputs, column tile and
+            # output-tile SLOT -- every wave runs the slots of the widest wave (two for more than 8 tiles; a slot without a tile
+            # multiplies zeros) -- and, for an odd tile count, the last 16 inputs as fp32 steps (one when H % 16 == 4, else four)
+            slots = waves * (2 if T > waves else 1)
+            mats = kt // T
+            tail = (1 if _has_ktail(nf, 16 * T) else 4) if T % 2 else 0
+            return mats * slots * tail * nt, mats * (T // 2) * 3 * slots * nt
+        # 8-wave fp32 kernels, widths with a tail tile (196 -> 208, 36 -> 48): that tile issues v_mfma_f32_4x4x1_16B_f32, a quarter
+        # of a 16x16x4 instruction each in MACs and in matrix-pipe cycles (w8_common.h: tail_lane) -> 0.25 instruction-equivalents
         tail44 = _has_ktail(nf, 16 * T) and 16 * T in (208, 48)
-        return kt * 4 * (T - 0.75 if tail44 else T) * nt
+        return kt * 4 * (T - 0.75 if tail44 else T) * nt, 0
 
     def edge(T, nf):  # one 16-edge tile through one T x T matrix -> (fp32, bf16)
         tail = variant != "w4" and _has_ktail(nf, 16 * T)
         if variant == "w8s":
             tail = tail and T % 2 == 1 and T >= 3
             nc = (T + 1) // 2 - (1 if tail else 0)
-            return (T if tail else 0), nc * T * 6
+            return (T if tail else 0), nc * T * 3  # (round 5: fp16 pairs, three piece products; rounds 2-4: bf16 x 3, six)
         return T * (4 * T - 3 if tail else 4 * T), 0
 
     f32 = bf = 0
     Te = _pad_hidden_kernel(edm["nf"]) // 16
     L, S = edm["n_layers"], edm.get("inv_sublayers", 1)
     e32, ebf = edge(Te, edm["nf"])
-    f32 += L * (S * (node(Te, 5 * Te, edm["nf"]) + tiles16 * e32) + node(Te, 2 * Te, edm["nf"]) + tiles16 * e32)
-    bf += L * (S + 1) * tiles16 * ebf
+    n32, n16 = node(Te, (5 * S + 2) * Te, edm["nf"])  # 5 node-level matrices per GCL, 2 per EquivariantUpdate
+    f32 += L * (n32 + (S + 1) * tiles16 * e32)
+    bf += L * (n16 + (S + 1) * tiles16 * ebf)
     if pred is not None:
         Tp = _pad_hidden_kernel(pred["nf"]) // 16
         Lp = pred["n_layers"]
         e32, ebf = edge(Tp, pred["nf"])
         n_edge = 2 * (2 * Lp - 1)  # W2 + Wc1 per layer (no Wc1 in the last), the same again transposed in the reverse pass
-        f32 += 2 * Lp * node(Tp, 5 * Tp, pred["nf"]) + n_edge * tiles16 * e32
-        bf += n_edge * tiles16 * ebf
+        n32, n16 = node(Tp, 5 * Tp, pred["nf"])
+        f32 += 2 * Lp * n32 + n_edge * tiles16 * e32
+        bf += 2 * Lp * n16 + n_edge * tiles16 * ebf
     return f32, bf
 
 
@@ -131,7 +142,7 @@ def step_mfma_issued(edge_units, ncols, edm, pred=None, variant="w4", max_col_ti
 def step_weight_stream_bytes(edm, pred=None, variant="w8s", rounds=1):
     """Bytes of packed weights ONE workgroup streams from L2 per reverse step: every node-level matrix as (16 T)^2 fp32
     (lane-linear tiles), every edge-level matrix as fp32 tiles or, for "w8s", as its split image (units of 1 KiB: K chunks x
-    output tiles x 3 bf16 pieces; a K tail as T fp32 tiles).  Same matrix counts as step_mfma_counts.  No reuse across
+    output tiles x 2 fp16 pieces; a K tail as T fp32 tiles; the node-level images -- fp16 pairs too -- have the fp32 size).  Same matrix counts as step_mfma_counts.  No reuse across
     workgroups inside a CU -- one molecule (or packed group) per workgroup -- so a launch of G workgroups moves G times this
     through the L2 -> CU fabric per step.  rounds: rounds of eight edge tiles of the workgroup's graph (wide groups: 2) -- an
     edge-level matrix is streamed once per round, a node-level one once per workgroup."""
@@ -143,7 +154,7 @@ def step_weight_stream_bytes(edm, pred=None, variant="w8s", rounds=1):
             return (16 * T) ** 2 * 4
         tail = _has_ktail(nf, 16 * T) and T % 2 == 1 and T >= 3
         nc = (T + 1) // 2 - (1 if tail else 0)
-        return nc * T * 3 * 1024 + (T * 1024 if tail else 0)
+        return nc * T * 2 * 1024 + (T * 1024 if tail else 0)
 
     Te = _pad_hidden_kernel(edm["nf"]) // 16
     L, S = edm["n_layers"], edm.get("inv_sublayers", 1)

@@ -279,12 +279,25 @@ int gaudi_set_plan_hint(gaudi_handle* h, int32_t min_slots, int32_t force_waves)
 /* Tile packing of a weight block W[o][col0+k] (o,k < H, row stride ldw) into [HP/16][HP/16][16][16]
  * (k-chunk major), optionally transposed: the layout every GEMM of the kernels streams. */
 int gaudi_host_pack_matrix(int H, int ldw, int col0, int HP, int transpose, const float* W, float* packed_out);
-/* Split-bf16 image of the same block (what the default 8-wave edge GEMMs stream; csrc/w8_split.h): packed_out holds
- * ceil(T/2) * T * 3 units of 1 KiB (T = HP/16), unit (m, t, p) = piece p (bf16, round to nearest; piece 0 + 1 + 2 == w exactly)
- * of output tile t against the 32-input chunk m; lane L = (row L & 15, group g = L >> 4) holds 8 bf16: slots 0-3 = inputs
- * 16(2m) + 4g .. +3, slots 4-7 = inputs 16(2m+1) + 4g .. +3.  ktail != 0 and H % 16 == 4 with an odd T >= 3: the last chunk
- * holds the 4 tail inputs as T fp32 tiles instead (float4 index (k % 16) * 16 + o % 16 of tile t, element 0). */
-int gaudi_host_pack_matrix_split(int H, int ldw, int col0, int HP, int transpose, int ktail, const float* W, float* packed_out);
+/* Split image of the same block (what the default 8-wave EDGE GEMMs stream; csrc/w8_split.h, round 5: fp16 pairs): packed_out
+ * holds ceil(T/2) * T * 2 units of 1 KiB (T = HP/16), unit (m, t, p) = piece p of output tile t against the 32-input chunk m:
+ * piece 0 = fp16(w * scale), piece 1 = fp16(w * scale - piece 0), round to nearest even (|w * scale - p0 - p1| <= 2^-22 |w * scale|
+ * while piece 1 is a normal fp16 number; scale = a power of two, gaudi_host_weight_scale); lane L = (row L & 15, group g = L >> 4)
+ * holds 8 fp16: slots 0-3 = inputs 16(2m) + 4g .. +3, slots 4-7 = inputs 16(2m+1) + 4g .. +3.  ktail != 0 and H % 16 == 4 with
+ * an odd T >= 3: the last chunk holds the 4 tail inputs as T fp32 tiles of w * scale instead (float4 index (k % 16) * 16 + o % 16
+ * of tile t, element 0). */
+int gaudi_host_pack_matrix_split(int H, int ldw, int col0, int HP, int transpose, int ktail, float scale, const float* W,
+                                 float* packed_out);
+/* fp16-pair image of a NODE-GEMM matrix (csrc/w8_nodes_f16.h): packed_out holds HP * HP floats = (T / 2) * T * 2 units of 1 KiB,
+ * unit (m, t, p) as above but lane L = (row L & 15, group g = L >> 4) holds inputs 32 m + 8 g .. +7, piece 0 = fp16(w * scale),
+ * piece 1 = fp16((w * scale - piece 0) * 2^11); an odd T leaves the last 16 inputs as a trailing block of T * 256 fp32 values,
+ * UNSCALED, [tile][k-step q][lane (row, g)] = w[row][16 (T - 1) + 4 q + g]. */
+int gaudi_host_pack_matrix_f16(int H, int ldw, int col0, int HP, int transpose, float scale, const float* W, float* packed_out);
+/* The power-of-two scale gaudi_load_edm / gaudi_load_predictor give a network's weight images: the largest finite |w| of the n
+ * blocks (rows[i] x cols[i], row stride ldw[i]) lands in [2^13, 2^14).  0: refused (an infinite weight, or a block whose largest
+ * entry lies more than 2^12 below the largest of all) -- such a network runs the fp32-instruction kernels. */
+int gaudi_host_weight_scale(int n, const float* const* blocks, const int32_t* rows, const int32_t* cols, const int32_t* ldw,
+                            float* scale_out);
 
 /* Kernel timing with HIP events on the handle's own stream (bench.py roofline).
  * gaudi_profile_reset enables collection; gaudi_profile_get returns the number of step-kernel

@@ -161,51 +161,116 @@ def test_host_pack_matrix_layout():
         assert np.array_equal(got, full)
 
 
-def _bf16_to_f32(u16):
-    return (u16.astype(np.uint32) << 16).view(np.float32)
+def _f16_to_f32(u16):
+    return u16.view(np.float16).astype(np.float32)
 
 
-def test_host_pack_matrix_split_is_exact_and_laid_out_as_documented():
-    """The split-bf16 image the default edge GEMMs stream (csrc/w8_split.h): three bf16 pieces per weight that sum to the
-    weight EXACTLY, in the documented unit / lane / slot positions; a K tail (H % 16 == 4, odd tile count) as fp32 tiles."""
+def test_host_pack_matrix_split_is_laid_out_as_documented():
+    """The fp16-pair image the default edge GEMMs stream (csrc/w8_split.h): two fp16 pieces of w * scale that reproduce it to 22
+    significant bits (to fp16's absolute floor for entries far below the largest), in the documented unit / lane / slot
+    positions; a K tail (H % 16 == 4, odd tile count) as fp32 tiles of w * scale."""
     lib, L = _lib()
     rng = np.random.default_rng(1)
     for H, HP, ktail in ((36, 48, 1), (36, 48, 0), (60, 64, 0), (20, 32, 1), (196, 208, 1)):
         T, NC = HP // 16, (HP // 16 + 1) // 2
         W = (rng.standard_normal((H, H + 3)) * rng.choice([1e-3, 1.0, 30.0], size=(H, H + 3))).astype(np.float32)
+        blocks = (L.FP * 1)(L.fptr(W))
+        scale = np.zeros(1, np.float32)
+        one = lambda v: np.array([v], np.int32).ctypes.data_as(L.IP)
+        assert lib.gaudi_host_weight_scale(1, blocks, one(H), one(H + 3), one(H + 3), L.fptr(scale)) == 0
+        sc = float(scale[0])
+        assert 2.0 ** 13 <= np.abs(W).max() * sc < 2.0 ** 14 and np.log2(sc) == round(np.log2(sc))
         for tr in (0, 1):
-            out = np.empty(NC * T * 3 * 256, np.float32)
-            assert lib.gaudi_host_pack_matrix_split(H, H + 3, 2, HP, tr, ktail, L.fptr(W), L.fptr(out)) == 0
+            out = np.empty(NC * T * 2 * 256, np.float32)
+            assert lib.gaudi_host_pack_matrix_split(H, H + 3, 2, HP, tr, ktail, sc, L.fptr(W), L.fptr(out)) == 0
             blk = W[:, 2:2 + H].T if tr else W[:, 2:2 + H]  # logical [o][k]
             full = np.zeros((HP, HP), np.float32)
-            full[:H, :H] = blk
+            full[:H, :H] = blk * np.float32(sc)
             tail = bool(ktail) and HP - H == 12 and T % 2 == 1 and T >= 3
-            units16 = out.view(np.uint16).reshape(NC, T, 3, 64, 8)
-            units32 = out.reshape(NC, T, 3, 64, 4)
+            units16 = out.view(np.uint16).reshape(NC, T, 2, 64, 8)
+            units32 = out.reshape(NC, T, 2, 64, 4)
             for m in range(NC):
                 for t in range(T):
                     if tail and m == NC - 1:
-                        tile = units32.reshape(NC, T * 3, 64, 4)[m, t]  # fp32 tile t of the tail chunk: [L][4], element 0
+                        tile = units32.reshape(NC, T * 2, 64, 4)[m, t]  # fp32 tile t of the tail chunk: [L][4], element 0
                         for kk in range(4):
                             assert np.array_equal(tile[kk * 16:(kk + 1) * 16, 0], full[16 * t:16 * t + 16, 16 * (T - 1) + kk])
                         continue
-                    pieces = [_bf16_to_f32(units16[m, t, p]) for p in range(3)]  # [64 lanes][8 slots]
-                    total = (pieces[0].astype(np.float64) + pieces[1] + pieces[2]).astype(np.float32)
-                    assert np.array_equal((pieces[0] + pieces[1]) + pieces[2], total)  # the fp32 sum is exact too
+                    hi, lo = _f16_to_f32(units16[m, t, 0]), _f16_to_f32(units16[m, t, 1])  # [64 lanes][8 slots]
                     for Ln in range(64):
                         row, g = Ln & 15, Ln >> 4
                         for e in range(8):
                             k = 16 * (2 * m + (e >> 2)) + 4 * g + (e & 3)
                             want = full[16 * t + row, k] if k < HP else np.float32(0)
-                            assert total[Ln, e] == want, (H, tr, m, t, Ln, e)
-                    assert np.all(np.abs(pieces[1]) <= np.abs(pieces[0]) * 2.0 ** -8 + 1e-45)
-                    assert np.all(np.abs(pieces[2]) <= np.abs(pieces[0]) * 2.0 ** -16 + 1e-45)
+                            assert hi[Ln, e] == np.float32(np.float16(want)), (H, tr, m, t, Ln, e)
+                            assert lo[Ln, e] == np.float32(np.float16(want - hi[Ln, e]))
+                            err = abs(float(hi[Ln, e]) + float(lo[Ln, e]) - float(want))
+                            assert err <= max(abs(float(want)) * 2.0 ** -22, 2.0 ** -25)
+
+
+def test_host_pack_matrix_f16_node_image():
+    """The fp16-pair image of a node-GEMM matrix (csrc/w8_nodes_f16.h): units [K chunk of 32][output tile][piece], lane (row, 8
+    inputs); piece 1 carries the remainder times 2^11; an odd tile count leaves the last 16 inputs as unscaled fp32 k-steps."""
+    lib, L = _lib()
+    rng = np.random.default_rng(4)
+    for H, HP in ((36, 48), (48, 48), (60, 64), (196, 208), (192, 192)):
+        T, nc = HP // 16, HP // 32
+        W = (rng.standard_normal((H, H + 5)) * rng.choice([1e-4, 1.0, 5.0], size=(H, H + 5))).astype(np.float32)
+        sc = 2.0 ** 11
+        for tr in (0, 1):
+            out = np.empty(HP * HP, np.float32)
+            assert lib.gaudi_host_pack_matrix_f16(H, H + 5, 3, HP, tr, sc, L.fptr(W), L.fptr(out)) == 0
+            blk = W[:, 3:3 + H].T if tr else W[:, 3:3 + H]
+            full = np.zeros((HP, HP), np.float32)
+            full[:H, :H] = blk
+            units16 = out[:nc * T * 512].view(np.uint16).reshape(nc, T, 2, 64, 8)
+            for m in range(nc):
+                for t in range(T):
+                    hi, lo = _f16_to_f32(units16[m, t, 0]), _f16_to_f32(units16[m, t, 1])
+                    for Ln in range(64):
+                        row, g = Ln & 15, Ln >> 4
+                        want = full[16 * t + row, 32 * m + 8 * g:32 * m + 8 * g + 8] * np.float32(sc)
+                        assert np.array_equal(hi[Ln], want.astype(np.float16).astype(np.float32))
+                        rec = hi[Ln].astype(np.float64) + lo[Ln].astype(np.float64) / 2048
+                        assert np.all(np.abs(rec - want) <= np.maximum(np.abs(want) * 2.0 ** -22, 2.0 ** -36))
+            if T % 2:  # the last half chunk: [tile][k-step q][lane (row, g)] = w[row][16 (T-1) + 4 q + g], unscaled
+                tail = out[nc * T * 512:nc * T * 512 + T * 256].reshape(T, 4, 4, 16)
+                for t in range(T):
+                    for q in range(4):
+                        for g in range(4):
+                            assert np.array_equal(tail[t, q, g], full[16 * t:16 * t + 16, 16 * (T - 1) + 4 * q + g])
+            else:
+                assert nc * T * 512 == HP * HP
+
+
+def test_host_weight_scale_refusals():
+    """NodeScale (gaudi_hip.hip): an infinite weight, or a matrix whose largest entry lies more than 2^12 below the largest of
+    all, refuses the fp16 images (scale 0: the network runs the fp32-instruction kernels); NaN entries are ignored."""
+    lib, L = _lib()
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((8, 8)).astype(np.float32)
+    b = (rng.standard_normal((8, 8)) * 1e-2).astype(np.float32)
+
+    def scale(*mats):
+        blocks = (L.FP * len(mats))(*[L.fptr(m) for m in mats])
+        arr = lambda v: np.array(v, np.int32).ctypes.data_as(L.IP)
+        out = np.zeros(1, np.float32)
+        assert lib.gaudi_host_weight_scale(len(mats), blocks, arr([m.shape[0] for m in mats]), arr([m.shape[1] for m in mats]),
+                                           arr([m.shape[1] for m in mats]), L.fptr(out)) == 0
+        return float(out[0])
+
+    assert scale(a, b) > 0
+    c = a.copy()
+    c[2, 3] = np.nan
+    assert scale(c, b) == scale(a, b)
+    c[1, 1] = np.inf
+    assert scale(c, b) == 0
+    assert scale(a, (b * 1e-3).astype(np.float32)) == 0  # 1e-5 of the largest matrix
 
 
 def test_host_split_keeps_non_finite_weights_non_finite():
-    """A NaN (any payload, either sign) planted in an edge-GEMM matrix must stay a NaN in every bf16 piece of the split image
-    (the integer rounding trick alone turns 0xFFFFFFFF into +0 and 0x7F800001 into +inf); an infinite weight must give a
-    non-finite product as the fp32 weight would (inf in the high piece, NaN = inf - inf below it)."""
+    """A NaN (any payload, either sign) planted in an edge-GEMM matrix must stay a NaN in every fp16 piece of the split image; an
+    infinite weight gives inf in the high piece and NaN = inf - inf below it (the loaders refuse such a network: NodeScale)."""
     lib, L = _lib()
     H, HP = 36, 48
     T, NC = HP // 16, (HP // 16 + 1) // 2
@@ -216,27 +281,25 @@ def test_host_split_keeps_non_finite_weights_non_finite():
     for (o, k), bits in zip(spots, payloads):
         Wv[o, k] = bits
     W[1, 2], W[9, 30] = np.inf, -np.inf
-    out = np.empty(NC * T * 3 * 256, np.float32)
-    assert lib.gaudi_host_pack_matrix_split(H, H, 0, HP, 0, 0, L.fptr(W), L.fptr(out)) == 0
-    units16 = out.view(np.uint16).reshape(NC, T, 3, 64, 8)
+    out = np.empty(NC * T * 2 * 256, np.float32)
+    assert lib.gaudi_host_pack_matrix_split(H, H, 0, HP, 0, 0, 1024.0, L.fptr(W), L.fptr(out)) == 0
+    units16 = out.view(np.uint16).reshape(NC, T, 2, 64, 8)
 
     def pieces(o, k):
         tile, g, e = k // 16, (k % 16) // 4, 4 * ((k // 16) & 1) + (k & 3)
-        return _bf16_to_f32(units16[tile // 2, o // 16, :, g * 16 + o % 16, e])
+        return _f16_to_f32(units16[tile // 2, o // 16, :, g * 16 + o % 16, e])
 
     for o, k in spots:
         assert np.isnan(pieces(o, k)).all(), (o, k, pieces(o, k))
     for (o, k), sgn in (((1, 2), 1.0), ((9, 30), -1.0)):
         p = pieces(o, k)
         assert np.isinf(p[0]) and np.sign(p[0]) == sgn and not np.isfinite(p).any()
-    # everything else is still split exactly
     fin = np.isfinite(W)
-    tot = np.zeros((HP, HP), np.float32)
     for o in range(H):
         for k in range(H):
             if fin[o, k]:
                 p = pieces(o, k)
-                assert (p[0] + p[1]) + p[2] == W[o, k]
+                assert abs(float(p[0]) + float(p[1]) - float(W[o, k]) * 1024.0) <= abs(float(W[o, k])) * 1024.0 * 2.0 ** -22
 
 
 def test_host_packers_are_reentrant():
@@ -250,8 +313,8 @@ def test_host_packers_are_reentrant():
     W = rng.standard_normal((H, H)).astype(np.float32)
 
     def split(ktail):
-        out = np.zeros(NC * T * 3 * 256, np.float32)
-        assert lib.gaudi_host_pack_matrix_split(H, H, 0, HP, 0, ktail, L.fptr(W), L.fptr(out)) == 0
+        out = np.zeros(NC * T * 2 * 256, np.float32)
+        assert lib.gaudi_host_pack_matrix_split(H, H, 0, HP, 0, ktail, 2048.0, L.fptr(W), L.fptr(out)) == 0
         return out
 
     def plain(tr):

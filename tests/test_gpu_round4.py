@@ -235,8 +235,9 @@ def test_wide_groups_equal_one_molecule_per_workgroup(dataset, sizes, widths):
 
 def test_full_batch_b1024_guided_step_vs_cpp_port():
     """C5's per-GPU shape (1024 cata molecules of 11 nodes) through ONE teacher-forced guided step at the default architectures
-    against the C++/OpenMP restatement, every molecule at 1e-4: the default launch (one molecule per workgroup) and the opt-in
-    wide groups (GAUDI_PAIRS=1: the batch pairs up, 512 workgroups of two molecules), which must be bit-equal to it."""
+    against the C++/OpenMP restatement, every molecule at 1e-4: the wide groups that such a batch gets (GAUDI_PAIRS=1, the default
+    since round 5: the batch pairs up, 512 workgroups of two molecules) and the launch of one molecule per workgroup
+    (GAUDI_PAIRS=0), which must be bit-equal to it."""
     from oracle import build_cpu
     from oracle import gaudi_oracle as O
     if not build_cpu.cpu_ok():
@@ -265,7 +266,7 @@ def test_full_batch_b1024_guided_step_vs_cpp_port():
     eng.close()
     per_mol = np.abs(got - want).reshape(B, -1).max(1) / np.abs(want).reshape(B, -1).max(1)
     assert per_mol.max() < 1e-4, (int(per_mol.argmax()), float(per_mol.max()))
-    solo = _engine(eargs, esd, pargs, psd)
+    solo = _engine(eargs, esd, pargs, psd, GAUDI_PAIRS=0)
     ref = solo.step(s, z, nm, em, eps, target_w=w, scale=0.6)
     assert solo.last_launch_shape() == (B, N)
     solo.close()

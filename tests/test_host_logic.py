@@ -168,16 +168,21 @@ def test_property_norm_accepts_torch_predictions_that_require_grad():
 
 
 def test_mfma_count_model_three_column_tile_pass():
-    """The V8G kernels run 33..48 node columns as ONE pass over three 16-column tiles (w8_common.h: node_gemm_n); the resident
-    kernels' model (pairs of tiles) is unchanged.  Edge-level counts do not depend on it."""
+    """The V8G kernels run 33..48 node columns as ONE pass over three 16-column tiles (w8_common.h: node_gemm_n,
+    w8_nodes_f16.h: node_gemm_h); the resident kernels' model (pairs of tiles) is unchanged.  Edge-level counts do not depend on
+    it."""
     from gaudi_amd import flops, synth
     e, p = synth.edm_args(dataset="hetro"), synth.pred_args(dataset="hetro")
-    base = flops.step_mfma_counts(14, 40, e, p, "w8s")
-    v8g = flops.step_mfma_counts(14, 40, e, p, "w8s", 3)
-    one = flops.step_mfma_counts(14, 16, e, p, "w8s", 3)
-    two = flops.step_mfma_counts(14, 30, e, p, "w8s", 3)
-    assert base[1] == v8g[1] == one[1] == two[1]
-    # node part scales with the column tiles: (fp32 - edge K tails) is 4 : 3 : 2 : 1
-    edge32 = one[0] - (two[0] - one[0])  # fp32 of the edge GEMMs' K-tail steps (column-tile independent)
-    assert abs((base[0] - edge32) / (one[0] - edge32) - 4) < 1e-9 and abs((v8g[0] - edge32) / (one[0] - edge32) - 3) < 1e-9
+    for variant in ("w8", "w8s"):  # fp32 node GEMMs / fp16-pair node GEMMs (16-bit instructions + fp32 tail steps)
+        base = flops.step_mfma_counts(14, 40, e, p, variant)
+        v8g = flops.step_mfma_counts(14, 40, e, p, variant, 3)
+        one = flops.step_mfma_counts(14, 16, e, p, variant, 3)
+        two = flops.step_mfma_counts(14, 30, e, p, variant, 3)
+        # the node part of both instruction classes scales with the column tiles, 4 : 3 : 2 : 1; the edge part does not depend on them
+        for k in (0, 1):
+            edge = one[k] - (two[k] - one[k])
+            if one[k] == edge:
+                assert base[k] == v8g[k] == one[k]
+                continue
+            assert abs((base[k] - edge) / (one[k] - edge) - 4) < 1e-9 and abs((v8g[k] - edge) / (one[k] - edge) - 3) < 1e-9
     assert flops.step_mfma_counts(14, 50, e, p, "w8s", 3) == flops.step_mfma_counts(14, 50, e, p, "w8s")  # 4 tiles either way

@@ -21,6 +21,9 @@ for step in "$@"; do
     ab_c4) ab c4 --workload c4 ;;
     ab_c4x) ab c4x --workload c4x --diffusion-steps 200 ;;
     ab_b1024) ab c3b1024 --batch 1024 --diffusion-steps 250 ;;
+    pairs) for rep in 1 2; do for pr in 0 1; do GAUDI_PAIRS=$pr timeout 900 $B --batch 1024 --diffusion-steps 250 > $out/b1024_pairs${pr}_$rep.json 2> $out/b1024_pairs${pr}_$rep.err
+             GAUDI_PAIRS=$pr timeout 900 $B --workload c4 --diffusion-steps 250 > $out/c4_pairs${pr}_$rep.json 2> $out/c4_pairs${pr}_$rep.err
+             GAUDI_PAIRS=$pr timeout 900 $B --workload c2 --batch 1024 --diffusion-steps 250 > $out/c2b1024_pairs${pr}_$rep.json 2> $out/c2b1024_pairs${pr}_$rep.err; done; done ;;
     mb_h) timeout 600 gaudi_amd/ngemmh_mb > $out/ngemmh_mb.txt 2>&1 ;;
     tests_r5) timeout 1800 python3 -m pytest tests/test_gpu_round5.py -x -q -m gpu > $out/tests_r5.txt 2>&1 ;;
     tests_core) timeout 2400 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_split.py -x -q -m gpu > $out/tests_core.txt 2>&1 ;;

@@ -35,7 +35,7 @@ struct Sel<HP, 3> {
   static __device__ __forceinline__ void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sB, float* sY, int N,
                                               int wave, int lane, bool tw, PF* pf, int nextW, float* split, float winv, bool seq) {
     const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
-    w8::NodeCtxH cx{winv, split, seq ? split : split + w8::nh_split_floats(HP, nct), tw};
+    w8::NodeCtxH cx{winv, split + 96, seq ? split + 96 : split + 96 + w8::nh_split_floats(HP, nct), tw, split};
     if (Wb >= 0)
       w8::node_gemm_h<HP, EPI, true, GAUDI_MB_MAXNT, w8::kAheadAll, w8::kAheadAll>(wb, Wa, sXa, true, Wb, sXb, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW);
     else
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, co
     sY[i] = __builtin_nanf("");  // every feature of every live node must be written
   }
   for (int i = tid; i < HP; i += 512) sB[i] = bias[i];
-  for (int i = tid; i < (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct_); i += 512) sSplit[i] = __builtin_nanf("");  // stale ring contents
+  for (int i = tid; i < (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct_) + 96; i += 512) sSplit[i] = __builtin_nanf("");  // stale ring contents
   __syncthreads();
   const WBuf wb = make_wbuf(w, wbytes);
   typename Sel<HP, V>::PF pf;
@@ -166,7 +166,7 @@ void run(int N, int blocks, int nmat, int tail, int two = 0) {
   hipMalloc(&cyc, blocks * 8 * 8);
   const int gemms = 600;
   const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
-  const size_t lds = (2 * ((N + 15) & ~15) * (HP + 4) + (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct)) * 4;
+  const size_t lds = (2 * ((N + 15) & ~15) * (HP + 4) + (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct) + 96) * 4;
   if (hipFuncSetAttribute((const void*)k<HP, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) printf("LDS %zu refused\n", lds);
   hipFuncSetAttribute((const void*)k<HP, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
@@ -233,7 +233,7 @@ void run_num(int H, int N, int tail, int two, int amp = 0) {
   hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(db, bias.data(), HP * 4, hipMemcpyHostToDevice);
   const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
-  const size_t lds = (3 * N * (HP + 4) + ((HP + 63) / 64) * 64 + (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct)) * 4;
+  const size_t lds = (3 * N * (HP + 4) + ((HP + 63) / 64) * 64 + (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct) + 96) * 4;
   if (hipFuncSetAttribute((const void*)k_num<HP, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) printf("LDS %zu refused\n", lds);
   hipLaunchKernelGGL((k_num<HP, V>), dim3(1), dim3(512), lds, 0, dw, (unsigned)(pk.size() * 4), dx, db, dy, N, tail, two, winv);
   std::vector<float> y((size_t)N * HP);

@@ -1,5 +1,6 @@
-// Microbenchmark + numerics probe of the split-bf16 edge GEMM (w8_split.h) next to the fp32-MFMA one (w8_common.h).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I gaudi_amd/csrc -I tools/experiments tools/split_gemm_microbench.hip -o split_mb && ./split_mb
+// Microbenchmark + numerics probe of the split edge GEMM (w8_split.h: fp16 pairs since round 5; rounds 2-4 measured the bf16 x 3
+// form with this file, profiles/r02d_split_gemm_microbench.txt) next to the fp32-MFMA one (w8_common.h).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I gaudi_amd/csrc tools/split_gemm_microbench.hip -o gaudi_amd/split_mb && gaudi_amd/split_mb
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
@@ -7,25 +8,25 @@
 #include <cstring>
 #include <random>
 #include <vector>
-#include "w8_split_variants.h"  // tools/experiments: the production header without the rejected knobs is gaudi_amd/csrc/w8_split.h
+#include "w8_split.h"
 using namespace gaudi;
 #ifndef SPLIT_MODE
 #define SPLIT_MODE 1  // 2: half ring
 #endif
 
-static uint16_t bf16_rne(float x) {
-  uint32_t u;
-  memcpy(&u, &x, 4);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+static uint16_t f16_rne(float x) {
+  const _Float16 h = (_Float16)x;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
 }
-static float bf16_f(uint16_t h) {
-  uint32_t u = (uint32_t)h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
+static float f16_f(uint16_t b) {
+  _Float16 h;
+  memcpy(&h, &b, 2);
+  return (float)h;
 }
-// W[o][k] (H x H, row-major) -> split units [m][t][p]
+constexpr float kWScale = 16384.f;  // 2^14: the weights below are < 1 in magnitude
+// W[o][k] (H x H, row-major) -> split units [m][t][p] of W * kWScale
 template <int HP>
 static void pack_split(std::vector<float>& dst, const std::vector<float>& W, int H) {
   using G = w8::SplitGeo<HP, SPLIT_MODE>;
@@ -36,12 +37,10 @@ static void pack_split(std::vector<float>& dst, const std::vector<float>& W, int
       for (int L = 0; L < 64; ++L)
         for (int e = 0; e < 8; ++e) {
           const int row = L & 15, g = L >> 4, tile = 2 * m + (e >> 2), k = 16 * tile + 4 * g + (e & 3), o = 16 * t + row;
-          float w = (tile < G::T && k < H && o < H) ? W[(size_t)o * H + k] : 0.f;
-          for (int p = 0; p < 3; ++p) {
-            const uint16_t b = bf16_rne(w);
-            d[((size_t)((m * G::T + t) * 3 + p) * 64 + L) * 8 + e] = b;
-            w -= bf16_f(b);
-          }
+          const float w = ((tile < G::T && k < H && o < H) ? W[(size_t)o * H + k] : 0.f) * kWScale;
+          const uint16_t hi = f16_rne(w);
+          d[((size_t)((m * G::T + t) * 2 + 0) * 64 + L) * 8 + e] = hi;
+          d[((size_t)((m * G::T + t) * 2 + 1) * 64 + L) * 8 + e] = f16_rne(w - f16_f(hi));
         }
 }
 // lane-linear fp32 tiles [k/16][o/16], float4 index L = (row L & 15, k-quad L >> 4)
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, i
   w8::Ring<HP> ring;
   w8::RingS<HP, SPLIT_MODE> rs;
   if (SPLIT) {
-    w8::er_init(rs, smem, false, w);
+    w8::er_init(rs, smem, false, w, 1.0f / kWScale);
     w8::rings_start(rs, wb, 0, wave, lane);
   } else {
     ring.base = smem;
@@ -95,7 +94,7 @@ __global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, i
     f4 acc[T];
     if (SPLIT)
       w8::edge_gemm_pq_s(acc, rs, wb, W, nextW, vec, vec + HP, vec + 2 * HP, sP + i * LD + 4 * g, sQ + j * LD + 4 * g, 0.3f,
-                             0.7f, active, wave, lane);
+                             0.7f, 0.5f, active, wave, lane);
     else
       w8::edge_gemm_pq<HP>(acc, ring, wb, W, nextW, vec, vec + HP, vec + 2 * HP, sP + i * LD + 4 * g, sQ + j * LD + 4 * g, 0.3f,
                            0.7f, active, wave, lane);
@@ -122,7 +121,7 @@ __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, co
   for (int t = 0; t < T; ++t) x[t] = *(const f4*)(in + (size_t)e * HP + 16 * t + 4 * g);
   if (SPLIT) {
     w8::RingS<HP, SPLIT_MODE> rs;
-    w8::er_init(rs, smem, false, w);
+    w8::er_init(rs, smem, false, w, 1.0f / kWScale);
     w8::rings_start(rs, wb, 0, wave, lane);
     w8::edge_gemm_regs_s(y, x, rs, wb, 0, -1, nullptr, nullptr, true, wave, lane);
   } else {
@@ -153,7 +152,7 @@ void run_time(int nactive, int blocks, int nmat) {
   {
     std::vector<uint16_t> h(wfloats * 2);
     std::mt19937 rng(1);
-    for (auto& v : h) v = SPLIT ? bf16_rne(0.1f * ((int)(rng() % 2001) - 1000) / 1000.f) : 0;
+    for (auto& v : h) v = SPLIT ? f16_rne(0.1f * ((int)(rng() % 2001) - 1000) / 1000.f) : 0;
     if (!SPLIT) {
       float* f = (float*)h.data();
       for (size_t i = 0; i < wfloats; ++i) f[i] = 0.1f * ((int)(rng() % 2001) - 1000) / 1000.f;
@@ -196,7 +195,7 @@ void run_time(int nactive, int blocks, int nmat) {
   }
   printf("[memtime %llu ticks, wall %llu ticks of 100 MHz => memtime runs at %.0f MHz] ", hc[0], hc[1], 100.0 * hc[0] / hc[1]);
   printf("%s edge_gemm_pq HP=%d CH=%d active=%d blocks=%d matrices=%d (%.1f MB) LDS %zu B: %.2f us per GEMM (K=%d)\n",
-         SPLIT ? "split-bf16" : "fp32-mfma ", HP, SPLIT ? G::CH : 0, nactive, blocks, nmat, wfloats * 4 / 1e6, lds, ms * 1e3 / gemms, HP);
+         SPLIT ? "fp16 pairs" : "fp32-mfma ", HP, SPLIT ? G::CH : 0, nactive, blocks, nmat, wfloats * 4 / 1e6, lds, ms * 1e3 / gemms, HP);
   hipFree(out);
   hipFree(cyc);
   hipFree(w);
@@ -255,7 +254,7 @@ void run_num(int H) {
         e32 = std::max(e32, std::fabs((double)ref32[(size_t)e * H + o] - ref[(size_t)e * H + o]));
       }
     printf("numerics H=%d HP=%d %s: max|err| vs float64 = %.3e (rms %.3e) of max|ref| %.3e -> %.2e relative; host fmaf chain: %.2e\n", H, HP,
-           split ? "split-bf16 x6" : "fp32 MFMA    ", emax, std::sqrt(erms / (E * H)), refmax, emax / refmax, e32 / refmax);
+           split ? "fp16 pairs x3" : "fp32 MFMA    ", emax, std::sqrt(erms / (E * H)), refmax, emax / refmax, e32 / refmax);
     hipFree(dw);
   }
   hipFree(din);
