@@ -29,6 +29,18 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def csrc_digest() -> str:
+    """sha256 over the kernel sources (csrc/*.h, *.inc, *.hip): what a stored hardware-counter figure (profiles/pmc_traffic.json)
+    is valid for.  Source text, not the built library: two machines build different bytes from the same tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(CSRC, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
     deps = [os.path.join(CSRC, f) for f in _sources() + HEADERS]
     return _stale(LIB, deps)

@@ -1811,6 +1811,10 @@ static int sample_cb_impl(gaudi_handle* h, int B, int N, const float* node_mask,
   if (!h || !node_mask || !edge_mask || !x_out || !onehot_out || (!target_grad && !target_grad_z)) return GAUDI_E_INVALID;
   if (!h->has_edm) return fail(h, GAUDI_E_STATE, "EDM weights not loaded");
   if (!h->has_pred) return fail(h, GAUDI_E_STATE, "guided sampling needs predictor weights");
+#ifdef GAUDI_STAMPS
+  // the stamped diagnostic build times the fused step only: its 8-wave guide phase drops the direct dT/dz term (sampler_kernel.h)
+  if (target_grad_z) return fail(h, GAUDI_E_INVALID, "gaudi_sample_cbz is not available in the GAUDI_STAMPS diagnostic build");
+#endif
   HIPCHECK(h, hipSetDevice(h->device));
   KParams P{};
   int rc = stage_graph(h, B, N, node_mask, edge_mask, P, h->HPE, h->HPP);

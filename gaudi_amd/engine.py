@@ -23,11 +23,15 @@ def _noise_power(schedule: str) -> float:
     """-> gaudi_edm_config.noise_power: p of 'polynomial_<p>', 0 for 'cosine' (PredefinedNoiseSchedule, en_diffusion.py:191-202)."""
     if schedule == "cosine":
         return 0.0
-    parts = schedule.split("_")
-    if len(parts) != 2 or parts[0] != "polynomial" or not float(parts[1]) > 0:
+    parts = str(schedule).split("_")
+    try:
+        power = float(parts[1]) if len(parts) == 2 and parts[0] == "polynomial" else 0.0
+    except ValueError:  # 'polynomial_x'
+        power = 0.0
+    if not power > 0:
         raise GaudiError(f"unsupported diffusion_noise_schedule {schedule!r}: 'polynomial_<p>' and 'cosine' are implemented "
                          "(the 'learned' schedule is training-only in the reference)")
-    return float(parts[1])
+    return power
 
 
 class Engine:
@@ -101,6 +105,14 @@ class Engine:
         n, c_names, c_ptrs, c_numel, keep = self._tensor_args(sd)
         self._check(self.lib.gaudi_load_edm(self.h, C.byref(cfg), n, c_names, c_ptrs, c_numel), "gaudi_load_edm")
         self.edm_args, self.F, self.T = dict(args), F, int(args["diffusion_steps"])
+        # EnVariationalDiffusion.check_issues_norm_values (en_diffusion.py:336-349): the reference refuses to BUILD a model whose
+        # sigma_0 is not small against 1 / norm_value (8 standard deviations) -- e.g. 'cosine' with the default
+        # normalize_factors [3, 4, 10]; a checkpoint it could never have produced is refused here as well
+        sigma_0 = float(np.sqrt(1.0 / (1.0 + np.exp(-np.float64(self.gamma()[0])))))
+        max_norm = max(float(nv[1]), float(nv[2]))
+        if sigma_0 * 8 > 1.0 / max_norm:
+            raise GaudiError(f"Value for normalization value {max_norm} probably too large with sigma_0 {sigma_0:.5f} and "
+                             f"1 / norm_value = {1.0 / max_norm} (en_diffusion.py:336-349: the reference raises the same)")
 
     def load_predictor(self, args: dict, state_dict: dict):
         sd = _strip(state_dict)

@@ -473,10 +473,11 @@ def test_mixed_batch_big_and_small_molecules_packs_and_matches_unpacked():
     assert np.isfinite(outs[0][0]).all()
 
 
-@pytest.mark.parametrize("shape", ["c3", "c4"])
+@pytest.mark.parametrize("shape", ["c2", "c3", "c4"])
 def test_full_batch_guided_step_vs_cpp_port(shape):
-    """BASELINE's full batch shapes through ONE teacher-forced guided step at the default architectures against the C++/OpenMP
-    restatement (oracle/gaudi_cpu.cpp, itself pinned to the reference's goldens): C3 = 256 cata molecules of 11 nodes (one
+    """BASELINE's full batch shapes through ONE teacher-forced step at the default architectures against the C++/OpenMP
+    restatement (oracle/gaudi_cpu.cpp, itself pinned to the reference's goldens): C2 = 256 cata molecules of 11 nodes, UNGUIDED
+    (VERDICT r4 weak #1b: the unguided full batch was never compared molecule by molecule), C3 = the same batch guided (one
     workgroup per CU), C4 = 1024 hetero molecules of 3-10 rings, packed into ~700 workgroups.  Every molecule of the batch is
     compared -- block -> molecule order, packing maps and noise rows included -- at 1e-4."""
     from oracle import build_cpu
@@ -507,6 +508,8 @@ def test_full_batch_guided_step_vs_cpp_port(shape):
     eps = rng.standard_normal((B, N, 3 + F)).astype(np.float32)
     s = 500
     gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    if shape == "c2":
+        w = None
     port = build_cpu.CpuPort()
     port.load_edm(eargs, esd)
     port.load_predictor(pargs, psd)

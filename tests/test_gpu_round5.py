@@ -76,3 +76,79 @@ def _through(cond_predictor, closure, p, t):
         return closure(None, None, None, torch.full((p.shape[0], 1), float(t)))
     finally:
         cond_predictor._override = None
+
+
+# ------------------------------------------------------------------------------------------------ fp16-pair GEMMs: range
+@pytest.mark.parametrize("scale", [3e5, 1e-7, 1.0])
+@pytest.mark.parametrize("nf_e,nf_p,n_layers", [(192, 196, 3), (36, 36, 2)])
+def test_fp16_pair_gemms_outside_fp16_range_vs_float64(monkeypatch, scale, nf_e, nf_p, n_layers):
+    """the node and edge GEMMs run on fp16 pairs (w8_nodes_f16.h, w8_split.h) behind power-of-two scales per
+    node / per edge column.  Node features of 3e5 (far above fp16's 65 504: every activation of the first layers overflows an
+    unscaled fp16) and of 1e-7 (below fp16's smallest normal number) must come out as close to the oracle's float64 evaluation
+    as on the fp32-instruction kernels: denoiser output, predictor output and its input gradient at 1e-4 of the tensor's
+    largest entry, and within a small factor of the fp32 kernels' own error."""
+    from gaudi_amd import synth
+    from gaudi_amd.engine import Engine
+    from oracle import gaudi_oracle as O
+    from tests.helpers import max_norm_err
+    eargs = synth.edm_args(nf=nf_e, n_layers=n_layers, diffusion_steps=100)
+    pargs = synth.pred_args(nf=nf_p, n_layers=n_layers)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=21)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=22)
+    for sd, key in ((esd, "dynamics.egnn.embedding."), (psd, "egnn.embedding.")):
+        sd[key + "weight"] = (np.asarray(sd[key + "weight"]) * np.float32(scale)).astype(np.float32)
+        sd[key + "bias"] = (np.asarray(sd[key + "bias"]) * np.float32(scale)).astype(np.float32)
+    nm, em = O.build_masks([11, 7, 9, 4], 11, False)
+    B, N = nm.shape[0], nm.shape[1]
+    rng = np.random.default_rng(6)
+    z = rng.standard_normal((B, N, 4)).astype(np.float32) * nm
+    z[:, :, :3] -= z[:, :, :3].sum(1, keepdims=True) / np.maximum(nm.sum(1, keepdims=True), 1) * nm
+    t = np.linspace(0.2, 0.8, B).astype(np.float32)
+    w = np.broadcast_to(np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32), (B, 5))
+    ref_eps = O.edm_phi(esd, eargs, z, t, nm, em, dtype=np.float64)
+    ref_pred, ref_grad = O.predictor_grad(psd, pargs, z, nm, em, t, w, dtype=np.float64)
+    errs = {}
+    for math in ("split", "fp32"):
+        monkeypatch.setenv("GAUDI_EDGE_MATH", math)
+        eng = Engine(0)
+        eng.load_edm(eargs, esd)
+        eng.load_predictor(pargs, psd)
+        eps = eng.phi(z, t, nm, em)
+        pred, grad = eng.predictor_grad(z, t, nm, em, w)
+        assert eng.kernel_variant()[1] == 8 and eng.edge_math()[1] == (1 if math == "split" else 0)
+        assert np.isfinite(eps).all() and np.isfinite(pred).all() and np.isfinite(grad).all()
+        errs[math] = (max_norm_err(eps, ref_eps), max_norm_err(pred, ref_pred), max_norm_err(grad, ref_grad))
+        eng.close()
+    for es, ef in zip(errs["split"], errs["fp32"]):
+        assert es < 1e-4 and es <= 4.0 * ef + 5e-7, errs
+
+
+def test_weight_sets_the_fp16_images_refuse_run_on_the_fp32_kernels(monkeypatch):
+    """NodeScale (gaudi_hip.hip): an infinite weight cannot be carried by fp16 pieces (inf - inf = NaN where the fp32 product keeps
+    inf), and a matrix lying more than 2^12 below the network's largest would lose bits: such a network's calls run the
+    fp32-instruction kernels (edge_math 0), with the fp32 kernels' results bit for bit."""
+    from gaudi_amd import synth
+    from gaudi_amd.engine import Engine
+    from oracle import gaudi_oracle as O
+    eargs = synth.edm_args(nf=64, n_layers=2, diffusion_steps=10)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=3)
+    nm, em = O.build_masks([5, 7], 7, False)
+    z = np.random.default_rng(0).standard_normal((2, 7, 4)).astype(np.float32) * nm
+    t = np.array([0.3, 0.6], np.float32)
+    tiny = dict(esd)
+    k = "dynamics.egnn.e_block_1.gcl_0.node_mlp.2.weight"
+    tiny[k] = (np.asarray(esd[k]) * np.float32(1e-5)).astype(np.float32)
+    monkeypatch.delenv("GAUDI_EDGE_MATH", raising=False)
+    for sd in (tiny,):
+        eng = Engine(0)
+        eng.load_edm(eargs, sd)
+        got = eng.phi(z, t, nm, em)
+        assert eng.kernel_variant() == (8, 8) and eng.edge_math() == (1, 0)  # split configured, this network refused
+        eng.close()
+        monkeypatch.setenv("GAUDI_EDGE_MATH", "fp32")
+        ref = Engine(0)
+        ref.load_edm(eargs, sd)
+        want = ref.phi(z, t, nm, em)
+        ref.close()
+        monkeypatch.delenv("GAUDI_EDGE_MATH", raising=False)
+        assert np.array_equal(got, want)

@@ -97,7 +97,7 @@ def test_unsupported_checkpoint_modes_are_refused():
     from gaudi_amd._lib import GaudiError
     assert _noise_power("polynomial_2") == 2.0
     assert _noise_power("cosine") == 0.0  # PredefinedNoiseSchedule's other mode (en_diffusion.py:196-197), a host table
-    for bad in ("learned", "polynomial", "polynomial_0", "linear_2"):
+    for bad in ("learned", "polynomial", "polynomial_0", "linear_2", "polynomial_x", "polynomial_2_3"):  # (a bare ValueError)
         with pytest.raises(GaudiError):
             _noise_power(bad)
 

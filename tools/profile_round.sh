@@ -23,6 +23,9 @@ for wl in c3 c2 c4; do
     --kernel-trace --output-format csv -d $out/pmc_${wl}_sq1 -- $B --diffusion-steps 100 --workload $wl > $out/pmc_${wl}_sq1.json 2> $out/pmc_${wl}_sq1.log
   rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES \
     --kernel-trace --output-format csv -d $out/pmc_${wl}_sq2 -- $B --diffusion-steps 100 --workload $wl > $out/pmc_${wl}_sq2.json 2> $out/pmc_${wl}_sq2.log
+  # round 5: the 16-bit matrix instructions are fp16 now (node and edge GEMMs); FLAT must stay at zero
+  rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_FLAT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS \
+    --kernel-trace --output-format csv -d $out/pmc_${wl}_sq3 -- $B --diffusion-steps 100 --workload $wl > $out/pmc_${wl}_sq3.json 2> $out/pmc_${wl}_sq3.log
 done
 # round 4: wide groups (GAUDI_PAIRS=1: two cata molecules per workgroup at 1024 molecules) beside the default launch of the same batch
 for pr in 0 1; do

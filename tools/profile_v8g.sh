@@ -12,6 +12,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
   --kernel-trace --output-format csv -d $out/pmc_c4x_sq1 -- $B --diffusion-steps 100 > $out/pmc_c4x_sq1.json 2> $out/pmc_c4x_sq1.log
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_FLAT \
   --kernel-trace --output-format csv -d $out/pmc_c4x_sq2 -- $B --diffusion-steps 100 > $out/pmc_c4x_sq2.json 2> $out/pmc_c4x_sq2.log
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_FLAT SQ_INSTS_SALU SQ_INSTS_SMEM \
+  --kernel-trace --output-format csv -d $out/pmc_c4x_sq3 -- $B --diffusion-steps 100 > $out/pmc_c4x_sq3.json 2> $out/pmc_c4x_sq3.log
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_c4x_$c -- $B --diffusion-steps 100 > $out/pmc_c4x_$c.json 2> $out/pmc_c4x_$c.log
 done

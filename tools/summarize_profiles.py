@@ -35,7 +35,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
     name = os.path.basename(d)
-    wl = "c2" if "_c2_" in name else "c4" if "_c4_" in name else "c3"
+    wl = "c2" if "_c2_" in name else "c4" if "_c4_" in name else "c4x" if "_c4x_" in name else "c3"
     f = one(f"{name}/**/*counter_collection.csv")
     if not f:
         continue
@@ -102,7 +102,10 @@ for wl, t in traffic.items():
         out[f"{wl}_bytes_per_launch"] = (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0
 out["note"] = (f"per 25-step launch, B=256 (c4: B=1024); FETCH_SIZE x2 (MI355X_MICROARCH.md: gfx950 reports 1/2 of 16 B/lane coalesced "
                f"reads) + WRITE_SIZE, KiB->bytes; kernel state {tag}")
-if len(out) > 1:
+sys.path.insert(0, ROOT)
+from gaudi_amd import build as _build  # noqa: E402
+out["csrc_sha256"] = _build.csrc_digest()  # bench.py reports these figures only for the kernels they were measured on
+if len(out) > 2:
     with open(os.path.join(dst, "pmc_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
