@@ -50,7 +50,8 @@ constexpr int kPF = GAUDI_KPF;  // prefetch depth of the fully unrolled (chained
 enum { ST_NODE = 0, ST_EDGE = 1, ST_EDGE_EPI = 2, ST_BARRIER = 3, ST_MISC = 4, ST_BWD_NODE = 5, ST_BWD_EDGE = 6,
        ST_BWD_COL = 7, ST_BWD_BARRIER = 8, ST_STASH = 9, ST_B_V = 10, ST_B_EV = 11, ST_B_CP = 12, ST_B_DCP = 13,
        ST_B_DE = 14, ST_B_DV = 15, ST_B_DT1 = 16, ST_B_DU = 17, ST_STAGE = 18, ST_GEO = 19,
-       ST_EDM_IO = 20, ST_UPDATE = 21, ST_PRED_IO = 22, ST_GUIDE = 23, ST_N = 24 };
+       ST_EDM_IO = 20, ST_UPDATE = 21, ST_PRED_IO = 22, ST_GUIDE = 23, ST_X0 = 24, ST_X1 = 25, ST_X2 = 26, ST_X3 = 27,
+       ST_N = 28 };
 struct Stamps {
   unsigned long long acc[ST_N];
   unsigned long long last;
@@ -195,6 +196,15 @@ __device__ __forceinline__ T* assume_global(T* p) {
   // through an integer: a generic -> global -> generic pair of casts is folded away before the inference pass runs
   GAUDI_GLOBAL T* g = (GAUDI_GLOBAL T*)(unsigned long long)p;
   return (T*)g;
+}
+// The same value, but new to the optimizer at this point.  Index arithmetic that only depends on the thread id is loop invariant:
+// LLVM hoists it out of the layer loops and keeps the results -- dozens of LDS addresses -- alive across every GEMM of the pass, i.e.
+// in scratch, and each phase then starts with scratch reads behind `s_waitcnt vmcnt(0)` (a trip to L2 each, one after the other:
+// 17 per reverse layer before this existed).  A phase that derives its addresses from fresh(tid) recomputes them (a handful of
+// integer instructions) and keeps nothing alive past its end.
+__device__ __forceinline__ int fresh(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 __device__ __forceinline__ void gstore(float* p, float v) { *(GAUDI_GLOBAL float*)p = v; }
 __device__ __forceinline__ float gload(const float* p) { return *(const GAUDI_GLOBAL float*)p; }

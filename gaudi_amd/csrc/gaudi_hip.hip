@@ -750,6 +750,25 @@ static kernel_fn pick_kernel8s(int hpe, int hpp) {
   return f;
 }
 
+// ... the same kernel with FR set (kern8s2_*.hip: sampler_kernel.h, V8T): taken for more than 16 node slots where it exists
+#ifdef GAUDI_STAMP_STUBS
+#define GAUDI_KERNEL8S2_TUS(X)
+#else
+#define GAUDI_KERNEL8S2_TUS(X) X(edm_192) X(fused_tiny) X(fused_192_208)
+#endif
+#define X(name) kernel_fn gaudi_kern8s2_##name(int hpe, int hpp);
+GAUDI_KERNEL8S2_TUS(X)
+#undef X
+static kernel_fn pick_kernel8s2(int hpe, int hpp) {
+  kernel_fn f = nullptr;
+#define X(name) \
+  if (!f) f = gaudi_kern8s2_##name(hpe, hpp);
+  GAUDI_KERNEL8S2_TUS(X)
+#undef X
+  (void)hpe; (void)hpp;
+  return f;
+}
+
 // ... and with the half-size ring (kern8h_*.hip): larger molecules
 #ifdef GAUDI_STAMP_STUBS
 #define GAUDI_KERNEL8H_TUS(X) X(fused_192_208)
@@ -889,6 +908,9 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
   const bool v8 = h->run_variant == 8;
   kernel_fn fn = v8 ? (h->run_gn8 ? pick_kernel8g(hpe, hpp) : pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp))
                     : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
+  // two column tiles per node GEMM on the resident full-ring kernel: its FR instantiation (same arithmetic, same results)
+  if (v8 && !h->run_gn8 && h->run_split == 1 && !(h->run_mr && hpp) && P.N > 16 && !getenv("GAUDI_NO_FR"))
+    if (kernel_fn f2 = pick_kernel8s2(hpe, hpp)) fn = f2;
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
@@ -922,10 +944,10 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 32; ++i) h->stamp_acc[i] += tmp[i];
     if (getenv("GAUDI_PRINT_STAMPS")) {
-      static const char* nm[] = {"node_gemm", "edge_gemm", "edge_epilogue", "barrier", "misc", "bwd_node", "bwd_edge",
-                                 "bwd_colsum", "bwd_barrier", "stash", "b_gemm_v", "b_ev", "b_gemm_cp", "b_dcp",
+      static const char* nm[] = {"node_gemm", "edge_gemm", "edge_epilogue", "barrier", "misc", "bwd_node", "bwd_stash_reload",
+                                 "bwd_colsum_tail", "pub_wait", "stash", "pub_write", "colsum_loop", "colsum_barrier", "b_dcp",
                                  "b_gemm_de", "b_dv", "b_gemm_dt1", "b_du", "stage_vectors", "geo", "edm_embed_head", "noise_update",
-                                 "pred_embed_readout", "guide_clip"};
+                                 "bwd_reload_loads", "bwd_vec_commit", "pred_readout", "bwd_prologue", "x2", "x3"};
       unsigned long long tot = 0;
       for (int i = 0; i < ST_N; ++i) tot += h->stamp_acc[i];
       fprintf(stderr, "[stamps] cumulative shares (block 0, wave 0):");

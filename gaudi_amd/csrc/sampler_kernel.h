@@ -219,7 +219,7 @@ __device__ __forceinline__ PredDev uni(const PredDev& w) {
 }
 #ifndef GAUDI_STAMPS
 // GN: the node buffers of the phase live in the workgroup's slice of the global scratch (gnode_), everything else in LDS
-template <int HP, int SP, bool GN = false>
+template <int HP, int SP, bool GN = false, bool FL = false>
 __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, float t_val_, float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const EdmDev W = uni(W_);
@@ -229,11 +229,11 @@ __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, f
   const w8::MolGraph mg = graph8(L, ga);
   w8::NetSmem<HP, SP, GN> sm;
   sm.carve(L.net, ga.N, ga.S, GN ? uni(gnode_) : nullptr);
-  w8::edm_forward<HP, SP, GN>(W, mg, sm, L.sZ, L.sEps, L.sMean, t_val, (int)threadIdx.x);
+  w8::edm_forward<HP, SP, GN, FL>(W, mg, sm, L.sZ, L.sEps, L.sMean, t_val, (int)threadIdx.x);
 }
 // the predictor's forward and reverse passes are separate functions too (the reverse pass holds three 52-register
 // operand sets at its peak; allocated together with the forward it spilled twice as much)
-template <int HP, int SP, bool MR, bool GN = false>
+template <int HP, int SP, bool MR, bool GN = false, bool FL = false>
 __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args ga_, float t_val_, float* stash_, float readout_div_,
                                                          float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -243,9 +243,9 @@ __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args 
   const w8::MolGraph mg = graph8(L, ga);
   w8::PredSmem<HP, SP, GN> sm;
   sm.carve(L.net, ga.N, ga.S, ga.pubx, GN ? uni(gnode_) : nullptr);
-  w8::pred_forward<HP, SP, MR, GN>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
+  w8::pred_forward<HP, SP, MR, GN, FL>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
 }
-template <int HP, int SP, bool MR, bool GN = false>
+template <int HP, int SP, bool MR, bool GN = false, bool FL = false>
 __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args ga_, float* stash_, float readout_div_, int resume_,
                                                          float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -255,7 +255,7 @@ __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args 
   const w8::MolGraph mg = graph8(L, ga);
   w8::PredSmem<HP, SP, GN> sm;
   sm.carve(L.net, ga.N, ga.S, ga.pubx, GN ? uni(gnode_) : nullptr);
-  w8::pred_backward<HP, SP, MR, GN>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
+  w8::pred_backward<HP, SP, MR, GN, FL>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
                         uni(resume_) ? L.sZ : nullptr);
 }
 #endif
@@ -263,8 +263,11 @@ __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args 
 // SP: edge GEMMs on the bf16 matrix pipe with three-way split operands (w8_split.h); otherwise fp32 MFMAs
 // MR: the predictor takes graphs of more than one round of eight edge tiles (w8_pred.h); the denoiser always does
 // GN: node buffers in the workgroup's global scratch (V8G, round 4: molecules beyond the LDS limit on the 8-wave kernels)
-template <int SP, bool MR = false, bool GN = false>
+// FR: the node GEMMs' split passes and epilogues recompute their lane addresses per call (w8_nodes_f16.h: FL) -- always in the MR
+//     and GN kernels; the resident single-round kernel exists in both forms and the host picks by node slots (gaudi_hip.hip)
+template <int SP, bool MR = false, bool GN = false, bool FR = false>
 struct V8T {
+  static constexpr bool kFL = MR || GN || FR;
   static constexpr int kThreads = w8::kThreads;
   static constexpr int kSplit = SP;
   using Graph = w8::MolGraph;
@@ -308,7 +311,7 @@ struct V8T {
     w8::edm_forward<HP, SP, GN>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
 #else
     (void)net; (void)sZ; (void)sEps; (void)sMean; (void)tid;
-    edm8_call<HP, SP, GN>(W, gargs(mg), t_val, gnode);
+    edm8_call<HP, SP, GN, kFL>(W, gargs(mg), t_val, gnode);
 #endif
   }
   template <int HP>
@@ -324,10 +327,10 @@ struct V8T {
     (void)sTmp;
     w8::PredSmem<HP, SP, GN> sm;
     sm.carve(net, mg.N, mg.S, mg.pubx, gnode);
-    if (phase != 2) pred_fwd8_call<HP, SP, MR, GN>(W, gargs(mg), t_val, stash, readout_div, gnode);
+    if (phase != 2) pred_fwd8_call<HP, SP, MR, GN, kFL>(W, gargs(mg), t_val, stash, readout_div, gnode);
     w8::guidance_seed(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
     if (phase == 1) return;
-    pred_bwd8_call<HP, SP, MR, GN>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0, gnode);
+    pred_bwd8_call<HP, SP, MR, GN, kFL>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0, gnode);
     if (dz_ext != nullptr) {  // + the target's direct dependence on z (callback launches are never packed: slot n = node n)
       for (int e = tid; e < mg.N * mg.D; e += kThreads) sGrad[e] += dz_ext[e];
       __syncthreads();
@@ -659,6 +662,8 @@ template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8 = &sampler_kernel_v<V8, HPE, HPP>;
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8s = &sampler_kernel_v<V8S, HPE, HPP>;
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel8s2 = &sampler_kernel_v<V8T<1, false, false, true>, HPE, HPP>;  // (FR: kern8s2_*.hip)
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8h = &sampler_kernel_v<V8H, HPE, HPP>;
 // ... whose predictor runs several rounds of edge tiles (kern8m_*.hip): SP = 0 / 1 / 2 as above

@@ -124,7 +124,7 @@ __device__ __forceinline__ void scatter_runs(f4 (&e)[HP / 16], const TileCols& t
 }
 
 // eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
-template <int HP, int SP = 0, bool GN = false>
+template <int HP, int SP = 0, bool GN = false, bool FL = false>
 __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP, SP, GN>& sm, const float* sZ,
                                             float* sEps, float* sMean /* [4] */, float t_val, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
@@ -216,9 +216,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const float crmax = sm.vec[7 * HP + 1], cdmax = sm.vec[7 * HP + 2];  // max |c_r|, max |c_d| (host)
       {
         const NodeCtxH cx = hctx();
-        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, G, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll, FL>(wb, wbe, G, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
                                                       wave, lane, tw, cx, pf, G + PK, nullptr, sm.pmax);
-        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne>(wb, wbe, G + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne, FL>(wb, wbe, G + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
                                                       nullptr, mg.NC, wave, lane, tw, cx, pf,
                                                       G + 3 * PK, nullptr, sm.qmax);  // node MLP weights travel across the edge phase
       }
@@ -266,7 +266,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       if constexpr (STG) stage_wait();
       else __syncthreads();
       STAMP(ST_MISC);
-      node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne>(wb, wbe, G + 3 * PK, sm.h, xs0, true, G + 4 * PK, sm.agg, xs1, bn1, sm.p, nullptr, nullptr,
+      node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, G + 3 * PK, sm.h, xs0, true, G + 4 * PK, sm.agg, xs1, bn1, sm.p, nullptr, nullptr,
                                               mg.NC, wave, lane, tw, hctx(), pf, G + 5 * PK);
       STAMP(ST_NODE);
       __syncthreads();
@@ -277,7 +277,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         stage_rows(xs0, sm.p, N * LD, wave, lane);
         stage_wait();
       }
-      node_gemm_x<HP, EPI_RESIDUAL_MASK, false, GN, NH, kAheadOne, kAheadOne>(wb, wbe, G + 5 * PK, sm.p, xs0, true, -1, nullptr, nullptr, bn2, sm.h, sm.h, mg.mask,
+      node_gemm_x<HP, EPI_RESIDUAL_MASK, false, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, G + 5 * PK, sm.p, xs0, true, -1, nullptr, nullptr, bn2, sm.h, sm.h, mg.mask,
                                                        mg.NC, wave, lane, tw, hctx(), pf,
                                                        s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
@@ -304,9 +304,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const float crmax = sm.vec[5 * HP], cdmax = sm.vec[5 * HP + 1];  // max |c_r|, max |c_d| (host)
       {
         const NodeCtxH cx = hctx();
-        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, E, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll, FL>(wb, wbe, E, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
                                                       wave, lane, tw, cx, pf, E + PK, nullptr, sm.pmax);
-        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne>(wb, wbe, E + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne, FL>(wb, wbe, E + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
                                                       nullptr, mg.NC, wave, lane, tw, cx, pf, l + 1 < W.L ? lay.gcl(l + 1, 0) : -1, nullptr,
                                                       sm.qmax);
       }

@@ -242,7 +242,7 @@ struct NodeCtxH {
 //   (pf.s[0 .. min(PIN, D))); POUT: chunks of nextW this call loads ahead.
 // The caller guarantees that nobody still reads the split regions when the call starts (a barrier since their last use) and
 // places a barrier between this call's stores to sY and their readers, as for the fp32 form.
-template <int HP, int EPI, bool TWO, int MAXNT, int PIN = kAheadOne, int POUT = kAheadOne>
+template <int HP, int EPI, bool TWO, int MAXNT, int PIN = kAheadOne, int POUT = kAheadOne, bool FL = false>
 __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float* sXa, bool do_split_a, int Wb, const float* sXb,
                                             const float* sBias, float* sY, const float* sRes, const float* sMask, int N, int wave,
                                             int lane, const NodeCtxH& cx, NodePFH<HP>& pf, int nextW = -1, float* gPre = nullptr,
@@ -281,9 +281,12 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
       }
     }
   }
+  // FL: the split passes and the epilogue take their addresses from fresh(lane) (device_common.h): recomputed per call -- some
+  // forty integer instructions -- instead of being hoisted out of the layer loop and spilled; the K loop's offsets stay hoisted.
   if (!(kAblateH & 1)) {
-    if (do_split_a) split_rows_h<HP>(sa, sXa, N, wave, lane);
-    if (TWO && !seq) split_rows_h<HP>(sb, sXb, N, wave, lane);
+    const int ls = FL ? fresh(lane) : lane;
+    if (do_split_a) split_rows_h<HP>(sa, sXa, N, wave, ls);
+    if (TWO && !seq) split_rows_h<HP>(sb, sXb, N, wave, ls);
     if (do_split_a || (TWO && !seq)) lds_barrier();
   }
 
@@ -391,7 +394,7 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
   if constexpr (TWO) {
     if (seq) {
       lds_barrier();  // (every wave is done with the first source's copy; the weight loads in flight stay in flight)
-      split_rows_h<HP>(sb, sXb, N, wave, lane);
+      split_rows_h<HP>(sb, sXb, N, wave, FL ? fresh(lane) : lane);
       lds_barrier();
     }
     source(std::integral_constant<int, 1>{}, sb);
@@ -401,32 +404,33 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
   static_for<D>([&](auto d_tag) {
     if constexpr (decltype(d_tag)::value > kOut - kLate) late(d_tag);
   });
+  const int le = FL ? fresh(lane) : lane, ce = le & 15, ge = le >> 4;
   static_for<MAXNT>([&](auto j_tag) {
     constexpr int j = decltype(j_tag)::value;
     if (j < nt) {
 #pragma unroll
       for (int u = 0; u < NTW; ++u) {
         const int t = wave + kWaves * u;
-        const int nd = j * 16 + c;
+        const int nd = j * 16 + ce;
         f4 yy = y[j][u];
         if (t < T && nd < N) {
-          float* dst = sY + nd * LD + 16 * t + 4 * g;
-          const bool pad = G::odd && cx.ktail && t == T - 1 && g > 0;  // rows 4 .. 15 of the last tile of an H % 16 == 4 width
+          float* dst = sY + nd * LD + 16 * t + 4 * ge;
+          const bool pad = G::odd && cx.ktail && t == T - 1 && ge > 0;  // rows 4 .. 15 of the last tile of an H % 16 == 4 width
           if (pad) yy = splat(0.f);
-          if (gPre != nullptr) stash_store((f4*)(gPre + nd * HP + 16 * t + 4 * g), yy);  // stash: write once, read once
+          if (gPre != nullptr) stash_store((f4*)(gPre + nd * HP + 16 * t + 4 * ge), yy);  // stash: write once, read once
           // the row maxima the edge GEMMs' column scales are bounded with (w8_split.h): one LDS atomic per lane and tile
           if (sMaxOut != nullptr) atomicMax(sMaxOut + nd, umax(umax(absbits(yy[0]), absbits(yy[1])), umax(absbits(yy[2]), absbits(yy[3]))));
           if (!pad) {
             if (EPI == EPI_SILU) yy = silu4(yy);
             if (EPI == EPI_RESIDUAL_MASK) {
-              const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
+              const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * ge);
               yy = (r + yy) * sMask[nd];
             }
             if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
-              const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
+              const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * ge);
               yy = (f4){yy[0] * dsilu_f(r[0]), yy[1] * dsilu_f(r[1]), yy[2] * dsilu_f(r[2]), yy[3] * dsilu_f(r[3])};
             }
-            if (EPI == EPI_ACCUM) yy = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g) + yy;
+            if (EPI == EPI_ACCUM) yy = *(const f4*)(sRes + nd * LD + 16 * t + 4 * ge) + yy;
           }
           *(f4*)dst = yy;
         }
@@ -463,14 +467,20 @@ __device__ __forceinline__ void node_prefetch_x(PF& pf, const WBuf& wb, const WB
 // Xa / Xb: the input rows where they live (LDS, or global memory for the GN kernels); XaS / XbS: their staged copies in the idle
 // weight ring, which only the fp32 form of a GN kernel reads (w8_common.h: stage_rows) -- the fp16 form splits the rows straight
 // from where they are.  split_a = false: the previous call's split copy of Xa is still in place.
-template <int HP, int EPI, bool TWO, bool GN, bool NH, int PIN, int POUT, class PF>
+// FL (node_gemm_h): without it the kernels keep some thirty lane-dependent LDS addresses of the split passes and epilogues alive
+// across every GEMM of a layer loop -- in scratch, read back behind `s_waitcnt vmcnt(0)` one after the other.  Measured on the
+// resident full-ring kernel (same code, same launch, A/B of two libraries): C4 (20 node slots, two column tiles) +2.4 %, batches of
+// 1024 in pairs +2.2 %, but C3 (11 nodes, one column tile: half the epilogue work per reload) -0.4 % -- the recomputation costs
+// what the reloads did.  So FL is on in the kernels that take large molecules (MR, GN, and the FR instantiation of the resident
+// kernel that the host picks for more than 16 node slots) and off in the one C2 / C3 run on.
+template <int HP, int EPI, bool TWO, bool GN, bool NH, int PIN, int POUT, bool FL = false, class PF>
 __device__ __forceinline__ void node_gemm_x(const WBuf& wb, const WBuf& wbe, int Wa, const float* Xa, const float* XaS, bool split_a, int Wb,
                                             const float* Xb, const float* XbS, const float* sBias, float* sY, const float* sRes,
                                             const float* sMask, int N, int wave, int lane, bool tw, const NodeCtxH& cx, PF& pf,
                                             int nextW = -1, float* gPre = nullptr, uint32_t* sMaxOut = nullptr) {
   if constexpr (NH) {
-    node_gemm_h<HP, EPI, TWO, GN ? 3 : 2, PIN, POUT>(wbe, Wa, Xa, split_a, Wb, Xb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre,
-                                                     sMaxOut);
+    node_gemm_h<HP, EPI, TWO, GN ? 3 : 2, PIN, POUT, FL>(wbe, Wa, Xa, split_a, Wb, Xb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre,
+                                                         sMaxOut);
   } else if constexpr (GN) {
     node_gemm_n<HP, EPI, true, 3>(wb, Wa, XaS, Wb, XbS, sBias, sY, sRes, sMask, N, wave, lane, tw, &pf, nextW, gPre);
   } else {

@@ -87,7 +87,7 @@ __host__ __device__ inline int pub_chunk_tiles(int S, long long avail_floats, in
 // MR: the kernel takes graphs of more than one round of eight edge tiles (more than 128 slots).  A separate instantiation: the
 // round loops (and the second copy of the reverse chain that parks du in the stash) cost the single-round kernels 2-4 % when
 // they live in the same function (hipcc's register allocation of the out-of-line phases changes), measured on C3.
-template <int HP, int SP = 0, bool MR = false, bool GN = false>
+template <int HP, int SP = 0, bool MR = false, bool GN = false, bool FL = false>
 __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP, GN>& sm, const float* sZ,
                                              float t_val, float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
@@ -169,9 +169,9 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     STAMP(ST_STAGE);
     {
       const NodeCtxH cx = hctx();
-      node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, Lw.A, h, xs0, true, -1, nullptr, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave,
+      node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll, FL>(wb, wbe, Lw.A, h, xs0, true, -1, nullptr, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave,
                                                     lane, tw, cx, pf, Lw.Bm, nullptr, sm.pmax);
-      node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne>(wb, wbe, Lw.Bm, h, xs0, false, -1, nullptr, nullptr, nullptr, q, nullptr, nullptr, mg.NC,
+      node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne, FL>(wb, wbe, Lw.Bm, h, xs0, false, -1, nullptr, nullptr, nullptr, q, nullptr, nullptr, mg.NC,
                                                     wave, lane, tw, cx, pf, Lw.Wn1h, nullptr, sm.qmax);
     }
     STAMP(ST_NODE);
@@ -269,7 +269,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     if constexpr (STG) stage_wait();
     else __syncthreads();
     STAMP(ST_MISC);
-    node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne>(wb, wbe, Lw.Wn1h, h, xs0, true, Lw.Wn1a, agg, xs1, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane,
+    node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, Lw.Wn1h, h, xs0, true, Lw.Wn1a, agg, xs1, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane,
                                             tw, hctx(), pf, Lw.Wn2, st + 2 * N * HP /* npre -> stash */);
     STAMP(ST_NODE);
     __syncthreads();
@@ -279,7 +279,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       stage_rows(xs0, p, N * LD, wave, lane);
       stage_wait();
     }
-    node_gemm_x<HP, EPI_RESIDUAL_MASK, false, GN, NH, kAheadOne, kAheadOne>(wb, wbe, Lw.Wn2, p, xs0, true, -1, nullptr, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave,
+    node_gemm_x<HP, EPI_RESIDUAL_MASK, false, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, Lw.Wn2, p, xs0, true, -1, nullptr, nullptr, Lw.bn2, h, h, mg.mask, mg.NC, wave,
                                                      lane, tw, hctx(), pf, l + 1 < W.L ? lay.layer(l + 1) : -1);
     if (!last) coord_update(sm, mg, 1.0f, tid);
     STAMP(ST_NODE);
@@ -303,6 +303,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     }
     __syncthreads();
   }
+  STAMP(ST_X0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -312,7 +313,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 //                          B4 = b4: npre (stash) -> dnpre -> dQ
 // pub_ch = 16-feature tiles of du published per chunk into [b0 | b1 | pub] (row = 16 pub_ch + 4 floats per slot)
 // ---------------------------------------------------------------------------------------------
-template <int HP, int SP = 0, bool MR = false, bool GN = false>
+template <int HP, int SP = 0, bool MR = false, bool GN = false, bool FL = false>
 __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP, GN>& sm, const float* stash,
                                               float* sGrad, float readout_div, int pub_ch, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
@@ -325,6 +326,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   const WBuf wbe = SP ? make_wbuf(W.ws, W.ws_bytes) : wb;  // edge-GEMM matrices (w8_split.h)
   const bool tw = W.ktail != 0;                            // H % 16 == 4: the node GEMMs' tail tile (w8_common.h: tail_lane)
   float *B0 = sm.b0, *B1 = sm.b1, *B2 = sm.b2, *dh = sm.b3, *B4 = sm.b4;
+  const int tid_ = tid;  // (phases shadow tid with fresh(tid_): device_common.h)
   float* pub = sm.publish();  // [slots][16 pub_ch + 4]
   const int PLD = 16 * pub_ch + 4;
   const float* estash = stash + pred_stash_node_floats(N, HP, W.L);
@@ -385,41 +387,64 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;
   vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(W.L - 1), HP), PredLayerW::vec_count(HP), tid);
+  STAMP(ST_X1);
   for (int l = W.L - 1; l >= 0; --l) {
     const bool last = l == W.L - 1;
     const PredLayerW Lw(w, lay.layer(l), HP, sm.vec);
-    vec_commit<NV, kThreads>(vpf, sm.vec, PredLayerW::vec_count(HP), tid);
     const float* st = stash + (size_t)l * (3 * N * HP + 4 * N);
     // (a) reload P -> B2, Q -> B1, npre -> B4, x_l ; mask the incoming gradients (h' = (..)*mask, x' = (..)*mask)
-    for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
-      const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
-      const f4 pv = stash_load((const f4*)st + idx), qv = stash_load((const f4*)(st + N * HP) + idx),
-               nv = stash_load((const f4*)(st + 2 * N * HP) + idx);
-      *(f4*)(B2 + n * LD + f) = pv;
-      *(f4*)(B1 + n * LD + f) = qv;
-      *(f4*)(B4 + n * LD + f) = nv;
-      *(f4*)(dh + n * LD + f) = *(const f4*)(dh + n * LD + f) * mg.mask[n];
+    // Every stash read of a thread's first two rounds (all of them up to 19 nodes at HP = 208) and its x row are in flight
+    // before the first is used: the stash of a whole batch lives in HBM, and one round trip after another (a loop of
+    // load - use, then the x rows) cost three HBM latencies per layer -- 4.2 % of a C3 step (profiles/r05d_stamps_*).
+    // Loads of a round that does not exist read the last element instead (no branch around a load: lesson of w8_common.h).
+    {
+      const int tid = fresh(tid_);
+      const int n4 = N * (HP / 4);
+      const f4* sp = (const f4*)st;
+      const f4* sq = (const f4*)(st + N * HP);
+      const f4* sn = (const f4*)(st + 2 * N * HP);
+      const int i0 = tid < n4 ? tid : n4 - 1, i1 = tid + kThreads < n4 ? tid + kThreads : n4 - 1;
+      const f4 xv = gload4((const f4*)(st + 3 * N * HP) + (tid < N ? tid : N - 1));
+      const f4 p0 = stash_load(sp + i0), q0 = stash_load(sq + i0), v0 = stash_load(sn + i0);
+      const f4 p1 = stash_load(sp + i1), q1 = stash_load(sq + i1), v1 = stash_load(sn + i1);
+      vec_commit<NV, kThreads>(vpf, sm.vec, PredLayerW::vec_count(HP), tid);  // (behind the stash reads: both waits overlap)
+      STAMP(ST_GUIDE);
+      auto put = [&](int idx, f4 pv, f4 qv, f4 nv) {
+        const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
+        *(f4*)(B2 + n * LD + f) = pv;
+        *(f4*)(B1 + n * LD + f) = qv;
+        *(f4*)(B4 + n * LD + f) = nv;
+        *(f4*)(dh + n * LD + f) = *(const f4*)(dh + n * LD + f) * mg.mask[n];
+      };
+      if (tid < N) {
+        *(f4*)(sm.x + 4 * tid) = xv;
+        *(f4*)(sm.dx + 4 * tid) = *(const f4*)(sm.dx + 4 * tid) * mg.mask[tid];
+      }
+      if (tid < n4) put(tid, p0, q0, v0);
+      if (tid + kThreads < n4) put(tid + kThreads, p1, q1, v1);
+      for (int idx = tid + 2 * kThreads; idx < n4; idx += kThreads) put(idx, stash_load(sp + idx), stash_load(sq + idx), stash_load(sn + idx));
+      for (int idx = tid + kThreads; idx < N; idx += kThreads) {
+        *(f4*)(sm.x + 4 * idx) = gload4((const f4*)(st + 3 * N * HP) + idx);
+        *(f4*)(sm.dx + 4 * idx) = *(const f4*)(sm.dx + 4 * idx) * mg.mask[idx];
+      }
     }
-    for (int idx = tid; idx < N; idx += kThreads) {
-      *(f4*)(sm.x + 4 * idx) = gload4((const f4*)(st + 3 * N * HP) + idx);
-      *(f4*)(sm.dx + 4 * idx) = *(const f4*)(sm.dx + 4 * idx) * mg.mask[idx];
-    }
+    STAMP(ST_PRED_IO);
     __syncthreads();
     if constexpr (STG) stage_rows(xs0, dh, N * LD, wave, lane);
     compute_geo(sm, mg, 1.0f, tid, false);
     if constexpr (STG) stage_wait();
-    STAMP(ST_STASH);
+    STAMP(ST_BWD_EDGE);
     // (c) dnpre = (Wn2^T dh) * silu'(npre)  (in place in B4)
     // (GN with fp32 node GEMMs: dnpre feeds (d) only -- it is written straight into the second staging area, not to B4 and back)
-    node_gemm_x<HP, EPI_MUL_DSILU, false, GN, NH, kAheadOne, kAheadOne>(wb, wbe, Lw.Wn2t, dh, xs0, true, -1, nullptr, nullptr, nullptr, STG ? xs1 : B4, B4, nullptr,
+    node_gemm_x<HP, EPI_MUL_DSILU, false, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, Lw.Wn2t, dh, xs0, true, -1, nullptr, nullptr, nullptr, STG ? xs1 : B4, B4, nullptr,
                                                  mg.NC, wave, lane, tw, hctx(), pf, Lw.Wn1ht);
     __syncthreads();
     // (d) dh += Wn1h^T dnpre ; dagg = Wn1a^T dnpre -> B0 (h is dead)
     {
       const NodeCtxH cx = hctx();
-      node_gemm_x<HP, EPI_ACCUM, false, GN, NH, kAheadOne, kAheadAll>(wb, wbe, Lw.Wn1ht, B4, xs1, true, -1, nullptr, nullptr, nullptr, dh, dh, nullptr, mg.NC,
+      node_gemm_x<HP, EPI_ACCUM, false, GN, NH, kAheadOne, kAheadAll, FL>(wb, wbe, Lw.Wn1ht, B4, xs1, true, -1, nullptr, nullptr, nullptr, dh, dh, nullptr, mg.NC,
                                                      wave, lane, tw, cx, pf, Lw.Wn1at);
-      node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, 0>(wb, wbe, Lw.Wn1at, B4, xs1, false, -1, nullptr, nullptr, nullptr, B0, nullptr, nullptr,
+      node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, 0, FL>(wb, wbe, Lw.Wn1at, B4, xs1, false, -1, nullptr, nullptr, nullptr, B0, nullptr, nullptr,
                                                     mg.NC, wave, lane, tw, cx, pf);
     }
     __syncthreads();
@@ -542,6 +567,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       }
       STAMP(ST_B_DU);
       __syncthreads();  // every wave is done with P (B2), Q (B1) and dagg (B0): the publish buffer may overwrite B0 / B1
+      STAMP(ST_BWD_BARRIER);
       for (int t0 = 0; t0 < T; t0 += pub_ch) {
         const int t1 = t0 + pub_ch < T ? t0 + pub_ch : T;
         if constexpr (!mr) {
@@ -570,6 +596,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           }
         }
         __syncthreads();
+        STAMP(ST_B_V);
         const int nf4 = (t1 - t0) * 4;  // float4 per slot in this chunk
         for (int idx = tid; idx < N * nf4; idx += kThreads) {
           const int n = idx / nf4, f = 4 * (idx % nf4);
@@ -582,7 +609,9 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           *(f4*)(B2 + n * LD + 16 * t0 + f) = sp;  // dP_n
           *(f4*)(B4 + n * LD + 16 * t0 + f) = sq;  // dQ_n
         }
+        STAMP(ST_B_EV);
         __syncthreads();
+        STAMP(ST_B_CP);
       }
       if (SP != 0 && !RI && l > 0)
         er_start<HP>(ring, wbe, lay.layer(l - 1) + 10 * HP * HP /* Wc1^T of the layer below */, wave, lane);
@@ -607,7 +636,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       stage_rows(xs1, B4, N * LD, wave, lane);
       stage_wait();
     }
-    node_gemm_x<HP, EPI_ACCUM, true, GN, NH, kAheadOne, kAheadOne>(wb, wbe, Lw.At, B2, xs0, true, Lw.Bmt, B4, xs1, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw,
+    node_gemm_x<HP, EPI_ACCUM, true, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, Lw.At, B2, xs0, true, Lw.Bmt, B4, xs1, nullptr, dh, dh, nullptr, mg.NC, wave, lane, tw,
                                              hctx(), pf, l > 0 ? lay.layer(l - 1) + 13 * HP * HP : -1);
     __syncthreads();
     STAMP(ST_BWD_NODE);
