@@ -197,16 +197,16 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       // ------------------------------------------------------------------ GCL (egnn_new.py:42-89)
       const int G = lay.gcl(l, s);  // float offsets into the weight buffer
       const int Wnext_edge = s + 1 < W.S ? lay.gcl(l, s + 1) + 2 * PK : lay.equ(l) + 2 * PK;
-      vec_commit<NV, kThreads>(vpf, sm.vec, 7 * HP + 16, tid);
       if constexpr (STG) stage_rows(xs0, sm.h, N * LD, wave, lane);
-      for (int idx = tid; idx < N * LD; idx += kThreads) {
-        sm.agg[idx] = 0.f;
-        sm.agg1[idx] = 0.f;
+      for (int idx = tid; idx < N * (LD / 4); idx += kThreads) {
+        *(f4*)(sm.agg + 4 * idx) = splat(0.f);
+        *(f4*)(sm.agg1 + 4 * idx) = splat(0.f);
       }
       if (tid < N) {
         sm.pmax[tid] = 0u;
         sm.qmax[tid] = 0u;
       }
+      vec_commit<NV, kThreads>(vpf, sm.vec, 7 * HP + 16, tid);  // (last: the wait for the vectors overlaps the stores above)
       if constexpr (STG) stage_wait();
       else __syncthreads();
       STAMP(ST_STAGE);
