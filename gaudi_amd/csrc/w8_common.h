@@ -466,11 +466,11 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
         if (nd < N) {
           float* dst = sY + nd * LD + 16 * t + 4 * g;
           if (TAIL && u == NTW - 1 && g > 0) {
-            if (gPre != nullptr) stash_store((f4*)(gPre + nd * HP + 16 * t + 4 * g), splat(0.f));
+            if (gPre != nullptr) nstash_store((f4*)(gPre + nd * HP + 16 * t + 4 * g), splat(0.f));
             *(f4*)dst = splat(0.f);
             continue;
           }
-          if (gPre != nullptr) stash_store((f4*)(gPre + nd * HP + 16 * t + 4 * g), y);  // stash: write once, read once
+          if (gPre != nullptr) nstash_store((f4*)(gPre + nd * HP + 16 * t + 4 * g), y);  // stash: write once, read once
           if (EPI == EPI_SILU) y = silu4(y);
           if (EPI == EPI_RESIDUAL_MASK) {
             const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);

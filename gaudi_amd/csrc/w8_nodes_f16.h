@@ -417,7 +417,7 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
           float* dst = sY + nd * LD + 16 * t + 4 * ge;
           const bool pad = G::odd && cx.ktail && t == T - 1 && ge > 0;  // rows 4 .. 15 of the last tile of an H % 16 == 4 width
           if (pad) yy = splat(0.f);
-          if (gPre != nullptr) stash_store((f4*)(gPre + nd * HP + 16 * t + 4 * ge), yy);  // stash: write once, read once
+          if (gPre != nullptr) nstash_store((f4*)(gPre + nd * HP + 16 * t + 4 * ge), yy);  // stash: write once, read once
           // the row maxima the edge GEMMs' column scales are bounded with (w8_split.h): one LDS atomic per lane and tile
           if (sMaxOut != nullptr) atomicMax(sMaxOut + nd, umax(umax(absbits(yy[0]), absbits(yy[1])), umax(absbits(yy[2]), absbits(yy[3]))));
           if (!pad) {

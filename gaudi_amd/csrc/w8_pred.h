@@ -182,8 +182,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     // lane group -- measured 1.5 % slower on C3)
     for (int idx = tid; idx < N * (HP / 4); idx += kThreads) {
       const int n = idx / (HP / 4), f = 4 * (idx % (HP / 4));
-      stash_store((f4*)st + idx, *(const f4*)(p + n * LD + f));
-      stash_store((f4*)(st + N * HP) + idx, *(const f4*)(q + n * LD + f));
+      nstash_store((f4*)st + idx, *(const f4*)(p + n * LD + f));
+      nstash_store((f4*)(st + N * HP) + idx, *(const f4*)(q + n * LD + f));
     }
     STAMP(ST_STASH);
     // Rounds of eight 16-slot tiles.  The kernels that are not MR run exactly one and must compile to what they were before
@@ -400,13 +400,19 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
     {
       const int tid = fresh(tid_);
       const int n4 = N * (HP / 4);
+#ifdef GAUDI_DIAG_HOT_STASH  // (timing experiment only: wrong results)
+      const f4* sp = (const f4*)W.w;
+      const f4* sq = (const f4*)(W.w + N * HP);
+      const f4* sn = (const f4*)(W.w + 2 * N * HP);
+#else
       const f4* sp = (const f4*)st;
       const f4* sq = (const f4*)(st + N * HP);
       const f4* sn = (const f4*)(st + 2 * N * HP);
+#endif
       const int i0 = tid < n4 ? tid : n4 - 1, i1 = tid + kThreads < n4 ? tid + kThreads : n4 - 1;
       const f4 xv = gload4((const f4*)(st + 3 * N * HP) + (tid < N ? tid : N - 1));
-      const f4 p0 = stash_load(sp + i0), q0 = stash_load(sq + i0), v0 = stash_load(sn + i0);
-      const f4 p1 = stash_load(sp + i1), q1 = stash_load(sq + i1), v1 = stash_load(sn + i1);
+      const f4 p0 = nstash_load(sp + i0), q0 = nstash_load(sq + i0), v0 = nstash_load(sn + i0);
+      const f4 p1 = nstash_load(sp + i1), q1 = nstash_load(sq + i1), v1 = nstash_load(sn + i1);
       vec_commit<NV, kThreads>(vpf, sm.vec, PredLayerW::vec_count(HP), tid);  // (behind the stash reads: both waits overlap)
       STAMP(ST_GUIDE);
       auto put = [&](int idx, f4 pv, f4 qv, f4 nv) {
@@ -422,7 +428,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
       }
       if (tid < n4) put(tid, p0, q0, v0);
       if (tid + kThreads < n4) put(tid + kThreads, p1, q1, v1);
-      for (int idx = tid + 2 * kThreads; idx < n4; idx += kThreads) put(idx, stash_load(sp + idx), stash_load(sq + idx), stash_load(sn + idx));
+      for (int idx = tid + 2 * kThreads; idx < n4; idx += kThreads) put(idx, nstash_load(sp + idx), nstash_load(sq + idx), nstash_load(sn + idx));
       for (int idx = tid + kThreads; idx < N; idx += kThreads) {
         *(f4*)(sm.x + 4 * idx) = gload4((const f4*)(st + 3 * N * HP) + idx);
         *(f4*)(sm.dx + 4 * idx) = *(const f4*)(sm.dx + 4 * idx) * mg.mask[idx];
@@ -479,7 +485,11 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         if (!last) {
           f4 cp[T];
           if (tc.active) {
+#ifdef GAUDI_DIAG_HOT_STASH
+            const f4* sc = (const f4*)(W.w + (size_t)tile * (T * 256)) + lane;
+#else
             const f4* sc = (const f4*)(estash + edge_stash_off8(l, tile, 1, S, HP)) + lane;
+#endif
 #pragma unroll
             for (int t = 0; t < T; ++t) cp[t] = stash_load(sc + t * 64);  // silu'(cpre)
             const float phi = gload(pstash + (size_t)l * S + tc.slot);
@@ -505,7 +515,11 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
         if (tc.active) {
           // e = m * a * mask ; a = sigmoid(wa . m + ba)
           f4 ve[T];
+#ifdef GAUDI_DIAG_HOT_STASH
+          const f4* sv = (const f4*)(W.w + (size_t)(8 + tile) * (T * 256)) + lane;
+#else
           const f4* sv = (const f4*)(estash + edge_stash_off8(l, tile, 0, S, HP)) + lane;
+#endif
 #pragma unroll
           for (int t = 0; t < T; ++t) ve[t] = stash_load(sv + t * 64);
           float dadot = 0.f;

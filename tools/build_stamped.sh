@@ -8,4 +8,4 @@ if [ "$1" = "g" ]; then EXTRA="kern8g_fused_192_208.hip -DGAUDI_STAMP_G"; fi
 cd "$(dirname "$0")/../gaudi_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -shared -DGAUDI_STAMPS \
   -o ../libgaudi_hip_stamps.so gaudi_hip.hip kern_edm_192.hip kern_fused_192_208.hip kern8_edm_192.hip kern8_fused_192_208.hip kern8s_edm_192.hip kern8s_fused_192_208.hip kern8h_fused_192_208.hip \
-  -DGAUDI_STAMP_STUBS $EXTRA
+  -DGAUDI_STAMP_STUBS $EXTRA $GAUDI_EXTRA_FLAGS
