@@ -512,7 +512,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                      "frac": frac, "traffic": traffic,
                      "kernel": "sampler_kernel_v<V8T<1,true,true>,192,%s> (V8G: 8 waves, node buffers in a per-workgroup global scratch, several rounds of edge tiles)" % ("208" if guided else "0") if v8g else
                                ("sampler_kernel_v<%s%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
-                                                                    " (MR: several rounds of edge tiles)" if guided and variant != "w4" and int(np.max(units)) > 8 else "",
+                                                                    " (MR: several rounds of edge tiles)" if guided and variant != "w4" and int(np.max(units)) > 8 else
+                                                                    " (FR instantiation: more than 16 node slots, kern8s2_*.hip)" if variant == "w8s" and em_mode == 1 and run_slots > 16 else "",
                                                                     "208" if guided else "0")) if not (variant == "w4" and N > 22) else
                                "sampler_kernel_g<V4G,192,0> + sampler_kernel_g<V4G,0,208> (node buffers in global memory; two launches "
                                "per guided step, averaged together)",
