@@ -152,3 +152,60 @@ def test_weight_sets_the_fp16_images_refuse_run_on_the_fp32_kernels(monkeypatch)
         ref.close()
         monkeypatch.delenv("GAUDI_EDGE_MATH", raising=False)
         assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ the FR kernel instantiation
+@pytest.mark.parametrize("widths", ["tiny", "default"])
+def test_fr_instantiation_of_the_resident_kernel_is_bit_identical(monkeypatch, widths):
+    """Workgroups of more than 16 node slots run the resident full-ring kernel's FR instantiation (kern8s2_*.hip; sampler_kernel.h:
+    V8T<1, false, false, true>): its node GEMMs recompute their lane addresses per call instead of reloading them from scratch --
+    the same arithmetic in the same order.  Guided and unguided chains and the denoiser of 17..20-node hetero molecules must equal
+    the plain instantiation (GAUDI_NO_FR=1) bit for bit, and a teacher-forced guided step must match the oracle."""
+    from gaudi_amd.engine import Engine
+    from gaudi_amd.sampling_edm import build_masks
+    from oracle import gaudi_oracle as O
+    from tests.helpers import rel_err
+    from gaudi_amd import synth
+    dataset, sizes, T = "hetro", [10, 9, 10, 7, 10], 5  # rings: 2 graph nodes per ring -> up to 20 node slots
+    F = synth.num_node_features(dataset)
+    over_e, over_p = (TINY, TINY_P) if widths == "tiny" else ({}, {})
+    eargs = synth.edm_args(dataset=dataset, diffusion_steps=T, **over_e)
+    pargs = synth.pred_args(dataset=dataset, **over_p)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=11, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=12, amplify_coord=True)
+    nm3, em_flat, N = build_masks(sizes, max(sizes), True)
+    B, D = len(sizes), 3 + F
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    assert N > 16
+    w = np.array([0.5, -1.0, 0.25, 0.0, 1.0], np.float32)
+    monkeypatch.delenv("GAUDI_EDGE_MATH", raising=False)
+    monkeypatch.delenv("GAUDI_WAVES", raising=False)
+    out = {}
+    for tag in ("fr", "plain"):
+        if tag == "plain":
+            monkeypatch.setenv("GAUDI_NO_FR", "1")
+        else:
+            monkeypatch.delenv("GAUDI_NO_FR", raising=False)
+        eng = Engine(0)
+        eng.load_edm(eargs, esd)
+        eng.load_predictor(pargs, psd)
+        res = [eng.sample(nm, em, return_z0=True, seed=9, sample_offset=4, target_w=w, scale=0.6),
+               eng.sample(nm, em, return_z0=True, seed=9, sample_offset=4)]
+        assert eng.kernel_variant()[1] == 8 and eng.edge_math()[1] == 1, (eng.kernel_variant(), eng.edge_math())  # resident, full ring
+        assert eng.last_launch_shape()[1] > 16  # (what selects the FR instantiation: gaudi_hip.hip, launch())
+        rng = np.random.default_rng(5)
+        z = O._combined_noise(rng.standard_normal((B, N, D)).astype(np.float32), nm[:, :, None])
+        eps = rng.standard_normal((B, N, D)).astype(np.float32)
+        step = eng.step(2, z, nm, em, eps, target_w=w, scale=0.6)
+        phi = eng.phi(z, np.linspace(0.2, 0.8, B).astype(np.float32), nm[:, :, None], em)
+        out[tag] = (res, step, phi)
+        if tag == "fr":
+            gamma = O.gamma_table("polynomial_2", T, 1e-5)
+            want = O.step_guided(esd, eargs, psd, pargs, gamma, 2, z, nm[:, :, None], em, eps, w, 0.6)
+            assert rel_err(step, want) < 1e-4
+        eng.close()
+    for ra, rb in zip(out["fr"][0], out["plain"][0]):
+        for u, v in zip(ra, rb):
+            if isinstance(u, np.ndarray):
+                assert np.array_equal(u, v)
+    assert np.array_equal(out["fr"][1], out["plain"][1]) and np.array_equal(out["fr"][2], out["plain"][2])
