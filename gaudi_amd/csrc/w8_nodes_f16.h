@@ -106,6 +106,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // their LDS round trips and DPP wait states cover each other.  The caller places a barrier between this and the GEMM's reads.
 // Columns >= N of the last tile are left as they are: a matrix-instruction column depends on its own B column only and those
 // results are never stored.
+// Where column c's inputs 8 g .. 8 g + 7 of a chunk (16 bytes of fp16) sit inside the 1 KiB B unit, in floats.  The readers are the
+// matrix instructions' B operands: lane (c, g) of every wave, 16 bytes each, once per chunk and column tile -- 16 consecutive lanes
+// (one g) must cover 256 consecutive bytes.  The writers are the split pass's rows: one column c per instruction, lanes (chunk, g,
+// half) -- the XOR spreads the four g of a column over the four quads of a 16-bank block, the chunk stride's padding spreads the
+// chunks over the four blocks.  (Through the first version of round 5 the unit was column-major, 4 c + g: a row's store was one
+// contiguous 64 bytes, but the reads of 16 lanes were 64 bytes apart -- four lanes per bank: 0.48 conflict cycles per LDS-active
+// cycle in the GEMM without its split pass, profiles/r05e_lds_conflicts_by_gemm.txt.)
+__host__ __device__ constexpr int nh_bpos(int c, int g) { return (16 * g + (c ^ g)) * 4; }
 struct SplitRowH {
   f4 x;
   uint32_t mx;
@@ -135,11 +143,15 @@ __device__ __forceinline__ void split_row_store(const SplitBufH& sb, const f4 x,
                  l23 = pk_f16((y2 - f23[0]) * kLoScale, (y3 - f23[1]) * kLoScale);
   const int ct = n >> 4, c = n & 15;
   if (m < nc) {
-    float* d = sb.chunk(m) + ct * 512 + (4 * c + g) * 4 + half * 2;
+    float* d = sb.chunk(m) + ct * 512 + nh_bpos(c, g) + half * 2;
     *(u2*)d = (u2){h01, h23};
     *(u2*)(d + 256) = (u2){l01, l23};
   } else if (nh_odd(HP) && lane < HP / 4) {  // inputs 16 (T-1) .. +15, unscaled: the fp32 tail steps
-    *(f4*)(sb.tail(HP) + ct * 256 + c * 16 + 4 * (lane - 4 * (T - 1))) = x;
+    float* d = sb.tail(HP) + ct * 256 + 4 * (lane - 4 * (T - 1)) * 16 + c;  // [input k][column c]: the readers' 64 lanes hit 64 banks
+    d[0] = x[0];
+    d[16] = x[1];
+    d[32] = x[2];
+    d[48] = x[3];
   }
   if (lane == 0) sb.scale(HP)[ct * 16 + c] = inv;
 }
@@ -256,7 +268,7 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
   const int nt = (MAXNT < 2 || N <= 16) ? 1 : (MAXNT < 3 || N <= 32) ? 2 : 3;
   const bool seq = TWO && cx.split_b == cx.split_a;
   const SplitBufH sa{cx.split_a, nt, cx.scales}, sb{cx.split_b, nt, cx.scales + kScaleFloatsH};
-  const int bpos = (4 * c + g) * 4;  // the lane's float offset inside a 1 KiB B unit
+  const int bpos = nh_bpos(c, g);  // the lane's float offset inside a 1 KiB B unit
   const TileLanesH<HP> tl(wave, lane);
   // a matrix that is not there (no next GEMM) is "loaded" with out-of-range lanes too
   const TileLanesH<HP> tl_next(wave, lane, nextW >= 0);
@@ -326,14 +338,14 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
       constexpr int j = decltype(j_tag)::value;
       if (j < nt) {
         if constexpr (G::odd) {  // the tail's fp32 steps: inputs 16 (T-1) + 4 q + g on lane group g, unscaled operands
-          const float* xt = s_.tail(HP) + j * 256 + c * 16 + g;
+          const float* xt = s_.tail(HP) + j * 256 + g * 16 + c;  // [input k = g + 4 q][column c]
 #pragma unroll
           for (int u = 0; u < NTW; ++u) y[j][u] = mfma1(tw[u][0], xt[0], y[j][u]);
           if (!cx.ktail) {
 #pragma unroll
             for (int q = 1; q < 4; ++q)
 #pragma unroll
-              for (int u = 0; u < NTW; ++u) y[j][u] = mfma1(tw[u][q], xt[4 * q], y[j][u]);
+              for (int u = 0; u < NTW; ++u) y[j][u] = mfma1(tw[u][q], xt[64 * q], y[j][u]);
           }
         }
         const float sc = s_.scale(HP)[j * 16 + c] * cx.winv;
