@@ -87,6 +87,7 @@ EXPORTS = {
     "gaudi_host_pack_matrix_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, FP]),
     "gaudi_host_pack_matrix_f16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, FP]),
     "gaudi_host_weight_scale": (C.c_int, [C.c_int, C.POINTER(FP), IP, IP, IP, FP]),
+    "gaudi_host_node_operand_offset": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, IP]),
     "gaudi_profile_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "gaudi_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "gaudi_set_steps_per_launch": (C.c_int, [C.c_void_p, C.c_int]),

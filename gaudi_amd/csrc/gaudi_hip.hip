@@ -2214,6 +2214,13 @@ int gaudi_host_weight_scale(int n, const float* const* blocks, const int32_t* ro
   return GAUDI_OK;
 }
 
+int gaudi_host_node_operand_offset(int column_tiles, int chunk, int tile, int c, int g, int32_t* float_offset_out) {
+  if (column_tiles < 1 || column_tiles > 3 || chunk < 0 || tile < 0 || tile >= column_tiles || c < 0 || c > 15 || g < 0 || g > 3 || !float_offset_out)
+    return GAUDI_E_INVALID;
+  *float_offset_out = chunk * w8::nh_chunk_stride(column_tiles) + tile * 512 + w8::nh_bpos(c, g);
+  return GAUDI_OK;
+}
+
 int gaudi_profile_reset(gaudi_handle* h, int enable) {
   if (!h) return GAUDI_E_INVALID;
   if (h->stream) (void)hipStreamSynchronize(h->stream);

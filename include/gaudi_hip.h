@@ -298,6 +298,12 @@ int gaudi_host_pack_matrix_f16(int H, int ldw, int col0, int HP, int transpose, 
  * entry lies more than 2^12 below the largest of all) -- such a network runs the fp32-instruction kernels. */
 int gaudi_host_weight_scale(int n, const float* const* blocks, const int32_t* rows, const int32_t* cols, const int32_t* ldw,
                             float* scale_out);
+/* LDS layout of the fp16-pair node GEMMs' activation copies (csrc/w8_nodes_f16.h; no reference counterpart: the reference's
+ * node-level nn.Linear calls, egnn_new.py:42-89 / models.py:520-551, have no operand staging).  Float offset, inside the copy of
+ * `column_tiles` tiles of 16 node columns, of the 16 bytes that hold inputs 32 chunk + 8 g .. + 7 of node column c (piece 0; piece 1
+ * lies 256 floats further).  The layout is a performance contract the CPU suite checks: the 16 lanes (c = 0..15) of one g read 256
+ * consecutive bytes, and the 32 lanes of one store pass of a row's split (4 chunks x 4 g x 2 halves) hit 64 different banks. */
+int gaudi_host_node_operand_offset(int column_tiles, int chunk, int tile, int c, int g, int32_t* float_offset_out);
 
 /* Kernel timing with HIP events on the handle's own stream (bench.py roofline).
  * gaudi_profile_reset enables collection; gaudi_profile_get returns the number of step-kernel

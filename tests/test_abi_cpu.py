@@ -268,6 +268,49 @@ def test_host_weight_scale_refusals():
     assert scale(a, (b * 1e-3).astype(np.float32)) == 0  # 1e-5 of the largest matrix
 
 
+def test_node_operand_layout_is_bank_conflict_free():
+    """csrc/w8_nodes_f16.h: nh_bpos -- the LDS position of (node column c, input group g) inside a B unit of the fp16-pair node GEMMs.
+    Readers: the matrix instructions' B operands, 16 bytes per lane, lanes (c = 0..15) of one g in one pass -> must be 256
+    consecutive bytes.  Writers: a row's split, 8 bytes per lane, one pass = 4 chunks x 4 g x 2 halves of one column -> 64
+    different banks (4-byte banks, 64 of them).  Every (chunk, tile, c, g) owns its own 16 bytes.  (the
+    column-major unit of the round's first version put four reading lanes on every bank.)"""
+    lib, L = _lib()
+
+    def off(nct, chunk, tile, c, g):
+        out = np.zeros(1, np.int32)
+        assert lib.gaudi_host_node_operand_offset(nct, chunk, tile, c, g, out.ctypes.data_as(L.IP)) == 0
+        return int(out[0])
+
+    for nct in (1, 2, 3):
+        seen = set()
+        for chunk in range(7):
+            for tile in range(nct):
+                for g in range(4):
+                    lanes = sorted(off(nct, chunk, tile, c, g) for c in range(16))
+                    assert lanes == list(range(lanes[0], lanes[0] + 64, 4)) and lanes[0] % 4 == 0, (nct, chunk, tile, g, lanes)
+                    for c in range(16):
+                        o = off(nct, chunk, tile, c, g)
+                        assert o % 4 == 0 and o not in seen
+                        seen.add(o)
+        # piece 0 and piece 1 (256 floats further) of a tile never overlap another tile or chunk
+        spans = sorted((o, o + 4) for o in seen) + sorted((o + 256, o + 260) for o in seen)
+        spans.sort()
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    # store pass of one row (nct = 1, where the chunk stride is padded for it): chunks m..m+3, all g, both halves -> 64 banks
+    for c in range(16):
+        for m0 in (0, 3):
+            banks = []
+            for m in range(m0, m0 + 4):
+                for g in range(4):
+                    for half in range(2):
+                        o = off(1, m, 0, c, g) + 2 * half
+                        banks += [o % 64, (o + 1) % 64]
+            assert len(set(banks)) == 64, (c, m0)
+    out = np.zeros(1, np.int32)
+    assert lib.gaudi_host_node_operand_offset(4, 0, 0, 0, 0, out.ctypes.data_as(L.IP)) != 0
+    assert lib.gaudi_host_node_operand_offset(1, 0, 0, 16, 0, out.ctypes.data_as(L.IP)) != 0
+
+
 def test_host_split_keeps_non_finite_weights_non_finite():
     """A NaN (any payload, either sign) planted in an edge-GEMM matrix must stay a NaN in every fp16 piece of the split image; an
     infinite weight gives inf in the high piece and NaN = inf - inf below it (the loaders refuse such a network: NodeScale)."""
