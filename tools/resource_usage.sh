@@ -2,7 +2,7 @@
 # Register / scratch usage of the production kernels and their out-of-line phases, from hipcc's own accounting:
 #   tools/resource_usage.sh > profiles/<tag>_resource_usage.txt
 cd "$(dirname "$0")/../gaudi_amd/csrc"
-for tu in kern8s_fused_192_208 kern8s_edm_192 kern8h_fused_192_208 kern8_fused_192_208 kern8_edm_192 kern_fused_192_208 kern_edm_192; do
+for tu in kern8s_fused_192_208 kern8s2_fused_192_208 kern8s_edm_192 kern8m_fused_192_208_h kern8g_fused_192_208 kern8h_fused_192_208 kern8_fused_192_208 kern8_edm_192 kern_fused_192_208 kern_edm_192; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -S --cuda-device-only $tu.hip -o /tmp/ru_$tu.s 2>/dev/null
   python3 - /tmp/ru_$tu.s $tu <<'PY'
 import re, sys
