@@ -119,7 +119,7 @@ def test_nan_scrubbing_vs_reference(golden):
 # ------------------------------------------------------------------------------------------------ g17: NaN in a split matrix
 def test_nan_in_edge_gemm_matrix_vs_reference(golden):
     """A NaN planted in a matrix of the edge-level GEMMs (edge_mlp.2.weight, coord_mlp.0.weight): on the default path these
-    are streamed as three bf16 pieces made by the host (gaudi_hip.hip: bf16_rne, NaN-safe) -- the poisoned weight must act
+    are streamed as pairs of fp16 pieces made by the host (gaudi_hip.hip: pack_matrix_split, NaN-safe) -- the poisoned weight must act
     exactly as it does in the reference: EDM h output NaN / velocity scrubbed / guided step finite; predictor: zeros."""
     from gaudi_amd.engine import Engine
     g = golden("g17_nan_edge_matrix")

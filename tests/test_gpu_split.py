@@ -1,5 +1,5 @@
-"""Edge-level GEMMs on the bf16 matrix pipe with exactly split fp32 operands (gaudi_amd/csrc/w8_split.h), the default of the
-8-wave kernels.  The whole GPU suite runs on it at unchanged tolerances; here: the switch and its fallback, the error of the
+"""GEMMs on the 16-bit matrix pipe with exactly split fp32 operands (gaudi_amd/csrc/w8_split.h, w8_nodes_f16.h: pairs of fp16
+pieces since round 5, three bf16 pieces in rounds 2-4), the default of the 8-wave kernels.  The whole GPU suite runs on it at unchanged tolerances; here: the switch and its fallback, the error of the
 split form against a float64 evaluation next to the error of the fp32 matrix instruction, and the core parity tests repeated
 on GAUDI_EDGE_MATH=fp32 so the fp32-instruction kernels stay covered."""
 import numpy as np
@@ -66,7 +66,7 @@ def test_split_is_the_default_and_env_selects_fp32(monkeypatch, O):
                                                      ("hetro", [5, 3, 4, 2], 64, 60)])
 def test_split_error_vs_float64_is_not_larger_than_the_fp32_instructions(monkeypatch, O, dataset, nodes, nf_e, nf_p):
     """Denoiser output, predictor output and predictor input-gradient of both arithmetic forms against the float64 evaluation
-    of the oracle: the split form (three bf16 pieces per operand, six piece products, fp32 accumulate) must sit at the same
+    of the oracle: the split form (two fp16 pieces per operand, three piece products, fp32 accumulate) must sit at the same
     fp32 rounding level as the fp32 matrix instruction.  Whole-network errors are single draws of rounding noise amplified
     by 9-12 layers (the 4-wave and 8-wave fp32 families differ from each other by up to 1.4x on the same inputs), hence
     the factor 3 (+ a floor of 2e-7 of the tensor's max) and the absolute bar of 1e-5.  For ONE GEMM the split form is the
