@@ -33,7 +33,7 @@ struct EdmDev {
   int F, L, S, attention, use_tanh;
   float coords_range, norm_constant, normf;
   int ktail;  // 8-wave kernels: the last K chunk of every matrix holds 4 valid inputs, packed as ONE k-step (w8_common.h)
-  const float* ws;     // split-bf16 images of the edge-GEMM matrices (w8_split.h) and, in the same buffer, the fp16-pair
+  const float* ws;     // fp16-pair images of the edge-GEMM matrices (w8_split.h) and, in the same buffer, the fp16-pair
   unsigned ws_bytes;   // images of the node-GEMM matrices (w8_nodes_f16.h); nullptr without them
   float hinv;          // 2^-s: descale of the fp16-pair node images (one exponent per network)
 };

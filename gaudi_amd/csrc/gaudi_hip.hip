@@ -73,7 +73,7 @@ struct gaudi_handle {
   gaudi_pred_config pcfg{};
   int HPE = 0, HPP = 0;
   DevBuf edm_w, pred_w, coef_d, edm_w4, pred_w4;  // *_w4: row-major tiles for the 4-wave fallback of an 8-wave handle
-  DevBuf edm_ws, pred_ws;                         // split-bf16 images of the edge-GEMM matrices (w8_split.h)
+  DevBuf edm_ws, pred_ws;                         // fp16-pair images of the edge-GEMM matrices (w8_split.h)
   size_t edm_w_bytes = 0, pred_w_bytes = 0, edm_ws_bytes = 0, pred_ws_bytes = 0;
   float edm_hinv = 0.f, pred_hinv = 0.f;  // 2^-s of the fp16-pair node images inside *_ws (w8_nodes_f16.h); 0: the weight set
                                           // was refused (node_scale) -- its calls run the fp32-instruction kernels
@@ -89,7 +89,7 @@ struct gaudi_handle {
   int steps_per_launch = 25;
   int variant = 8;            // 8 = two waves per SIMD (sampler_kernel8, default), 4 = one wave per SIMD (GAUDI_WAVES=4)
   int run_variant = 4;        // what the CURRENT call runs on (an 8-wave handle falls back to 4 waves for graphs that do not fit)
-  bool split = true;          // 8-wave kernels: edge GEMMs on the bf16 matrix pipe with 3-way split operands (GAUDI_EDGE_MATH=fp32: off)
+  bool split = true;          // 8-wave kernels: GEMMs on the fp16 matrix pipe with operands split into fp16 pairs (GAUDI_EDGE_MATH=fp32: off)
   int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
   bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
   bool run_gn8 = false;       // ... on the 8-wave kernels with node buffers in global memory (V8G, round 4)
@@ -732,7 +732,7 @@ static kernel_fn pick_kernel8(int hpe, int hpp) {
   return f;
 }
 
-// ... and their split-bf16 edge-GEMM versions (kern8s_*.hip); a size without one runs on the fp32-MFMA kernel
+// ... and their split-operand (fp16 pairs) versions (kern8s_*.hip); a size without one runs on the fp32-MFMA kernel
 #ifdef GAUDI_STAMP_STUBS
 #define GAUDI_KERNEL8S_TUS(X) X(edm_192) X(fused_192_208)
 #else
@@ -1073,7 +1073,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   if (!pick_kernel8_mode(hpe, hpp, 0, mr) && !pick_kernel8_mode(hpe, hpp, 1, mr) && !pick_kernel8_mode(hpe, hpp, 2, mr)) return 1;
   const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
   int pubx = 0, pub_ch = 0;
-  // the arithmetic of the edge GEMMs for S edge slots on NS node slots: split-bf16 when the kernel exists and its larger weight
+  // the arithmetic of the edge GEMMs for S edge slots on NS node slots: split operands when the kernel exists and its larger weight
   // ring fits (1 = full ring, 2 = half ring); else fp32 MFMAs (0); else -1 = this call runs on 4 waves
   // the split-operand kernels run their node GEMMs on fp16 pairs: a weight set whose images were refused (NodeScale) keeps the
   // fp32-instruction kernels

@@ -1,4 +1,4 @@
-// kern8h_edm_192.hip -- sampler_kernel8h (8 waves, edge GEMMs on split-bf16 operands with the half-size weight ring: w8_split.h, SplitGeo MODE 2) instantiations [(192, 0)] (own translation unit so the
+// kern8h_edm_192.hip -- sampler_kernel8h (8 waves, edge and node GEMMs on fp16-pair operands with the half-size weight ring: w8_split.h, SplitGeo MODE 2) instantiations [(192, 0)] (own translation unit so the
 // instantiations compile in parallel; looked up by gaudi_hip.hip through gaudi_kern8h_edm_192).
 #include "sampler_kernel.h"
 

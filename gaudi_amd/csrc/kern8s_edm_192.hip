@@ -1,4 +1,4 @@
-// kern8s_edm_192.hip -- sampler_kernel8s (8 waves, edge GEMMs on split-bf16 operands: w8_split.h) instantiations [(192, 0)] (own translation unit so the
+// kern8s_edm_192.hip -- sampler_kernel8s (8 waves, edge and node GEMMs on fp16-pair operands: w8_split.h, w8_nodes_f16.h) instantiations [(192, 0)] (own translation unit so the
 // instantiations compile in parallel; looked up by gaudi_hip.hip through gaudi_kern8s_edm_192).
 #include "sampler_kernel.h"
 

@@ -260,7 +260,8 @@ __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args 
 }
 #endif
 
-// SP: edge GEMMs on the bf16 matrix pipe with three-way split operands (w8_split.h); otherwise fp32 MFMAs
+// SP: edge and node GEMMs on the fp16 matrix pipe with operands split into fp16 pairs (w8_split.h, w8_nodes_f16.h; three bf16 pieces
+//     in rounds 2-4); otherwise fp32 MFMAs
 // MR: the predictor takes graphs of more than one round of eight edge tiles (w8_pred.h); the denoiser always does
 // GN: node buffers in the workgroup's global scratch (V8G, round 4: molecules beyond the LDS limit on the 8-wave kernels)
 // FR: the node GEMMs' split passes and epilogues recompute their lane addresses per call (w8_nodes_f16.h: FL) -- always in the MR

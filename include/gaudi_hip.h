@@ -235,10 +235,11 @@ int gaudi_host_graph_meta8(int B, int N, const float* node_mask, const float* ed
  * kernels' limits: more than 128 edge slots with guidance, a node with more than 32 live edges, LDS).  last_call = what the
  * most recent call ran on. */
 int gaudi_kernel_variant(const gaudi_handle* h, int32_t* configured, int32_t* last_call);
-/* Arithmetic of the edge-level GEMMs (the W2 / Wc1 contractions and their transposes, edm/egnn/egnn_new.py:42-47 and
- * edm/egnn_predictor/gcl.py:225-231) on the 8-wave kernels: 1 = every fp32 operand split exactly into three bf16 pieces, six
- * piece products accumulated in fp32 on the bf16 matrix pipe (error against float64 at the level of the fp32 matrix
- * instruction's: tests/test_gpu_split.py); 0 = v_mfma_f32_16x16x4_f32 (environment GAUDI_EDGE_MATH=fp32 at gaudi_create,
+/* Arithmetic of the GEMMs (edge level: the W2 / Wc1 contractions and their transposes, edm/egnn/egnn_new.py:42-47 and
+ * edm/egnn_predictor/gcl.py:225-231; since round 5 the node-level Linears too) on the 8-wave kernels: 1 = every fp32 operand
+ * as a pair of fp16 pieces behind exact power-of-two scales, three piece products accumulated in fp32 on the fp16 matrix pipe
+ * (rounds 2-4: three bf16 pieces, six products; error against float64 at or below the fp32 matrix instruction's:
+ * tests/test_gpu_split.py, tests/test_gpu_round5.py); 0 = v_mfma_f32_16x16x4_f32 (environment GAUDI_EDGE_MATH=fp32 at gaudi_create,
  * the 4-wave kernels, and the per-call fallback when the LDS weight ring of the split form does not fit).  last_call: 1 =
  * split with the full ring (a 32-input chunk of all output tiles per trip), 2 = split with the half ring (two trips per
  * chunk: molecules whose node buffers leave less LDS), 0 = fp32 instructions. */
