@@ -107,6 +107,135 @@ __global__ __launch_bounds__(512) void k_time(const float* w, unsigned wbytes, i
   if (tid == 0 && blockIdx.x == 0) cyc[gridDim.x * 8] = wall_clock64() - w0;
 }
 
+template <int HP, bool SPLIT>
+static size_t ring_bytes();
+// ---- probe for a "one ring pass for two rounds of edge tiles" kernel (wide groups run their two rounds one
+// after the other, each with its own pass over the weight ring): the chained split GEMM with TWO output tiles sets per wave and trip --
+// every A unit is read from LDS once and multiplied into both sets, the ring traffic and the trip barriers are shared.  NT2 = 1 is the
+// production form (w8::edge_gemm_regs_s), NT2 = 2 the probe; the second set multiplies the same B operand (what is timed is the
+// trip structure, not the numerics).
+template <int HP, int NT, int NT2, class MID>
+__device__ __forceinline__ void rings_mfma_act2(f4* acc0, f4* acc1, const float* slot_lane, const w8::B3& b0, const w8::B3& b1, MID mid) {
+  constexpr int U = w8::SplitGeo<HP, SPLIT_MODE>::kUnit;
+  constexpr int kAhead = NT > 2 ? 2 : 1, kSets = kAhead + 1;
+  f4 a[kSets][w8::kPieces];
+#pragma unroll
+  for (int q = 0; q < kAhead; ++q)
+#pragma unroll
+    for (int p = 0; p < w8::kPieces; ++p) a[q][p] = *(const f4*)(slot_lane + (q * w8::kPieces + p) * U);
+  w8::static_for<NT>([&](auto t_tag) {
+    constexpr int t = decltype(t_tag)::value;
+    constexpr int cur = t % kSets;
+    if (t == NT / 2) {
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t + kAhead < NT) {
+#pragma unroll
+      for (int p = 0; p < w8::kPieces; ++p) a[(t + kAhead) % kSets][p] = *(const f4*)(slot_lane + ((t + kAhead) * w8::kPieces + p) * U);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const w8::u4 ah = __builtin_bit_cast(w8::u4, a[cur][0]), al = __builtin_bit_cast(w8::u4, a[cur][1]);
+      f4 c0 = acc0[t];
+      c0 = w8::mfma_bf(al, b0.h, c0);
+      c0 = w8::mfma_bf(ah, b0.l, c0);
+      c0 = w8::mfma_bf(ah, b0.h, c0);
+      acc0[t] = c0;
+      if constexpr (NT2 == 2) {
+        f4 c1 = acc1[t];
+        c1 = w8::mfma_bf(al, b1.h, c1);
+        c1 = w8::mfma_bf(ah, b1.l, c1);
+        c1 = w8::mfma_bf(ah, b1.h, c1);
+        acc1[t] = c1;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+template <int HP, int NT2>
+__global__ __launch_bounds__(512) void k_time2(const float* w, unsigned wbytes, int nmat, float* out, int gemms, int nactive) {
+  constexpr int T = HP / 16;
+  using G = w8::SplitGeo<HP, SPLIT_MODE>;
+  static_assert(!(G::kTailOK && false), "");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const WBuf wb = make_wbuf(w, wbytes);
+  w8::RingS<HP, SPLIT_MODE> rs;
+  w8::er_init(rs, smem, false, w, 1.0f / kWScale);
+  w8::rings_start(rs, wb, 0, wave, lane);
+  f4 in[T], o0[T], o1[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) in[t] = (f4){0.01f * (lane + t), 0.02f * t, 0.5f, -0.25f};
+  f4 total = splat(0.f);
+  constexpr int MF = G::kMatFloats;
+#pragma unroll 1
+  for (int m = 0; m < gemms; ++m) {
+    const int W = (m % nmat) * MF, nextW = ((m + 1) % nmat) * MF;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      o0[t] = splat(0.f);
+      o1[t] = splat(0.f);
+    }
+    w8::static_for<G::NC>([&](auto m_tag) {
+      constexpr int mc = decltype(m_tag)::value;
+      const w8::B3 bin = w8::split8(in[2 * mc < T ? 2 * mc : 0], in[2 * mc + 1 < T ? 2 * mc + 1 : 0], 1.0f);
+      // (the second set's operand: other registers, so that the two sets are two computations)
+      const w8::B3 bin1 = w8::split8(in[(2 * mc + 3) % T], in[(2 * mc + 5) % T], 0.5f);
+      w8::static_for<G::NH>([&](auto h_tag) {
+        constexpr int h = decltype(h_tag)::value;
+        constexpr int tr = mc * G::NH + h;
+        w8::trip_open(rs, lane);
+        if (wave < nactive)
+          rings_mfma_act2<HP, G::tiles_of(h), NT2>(o0 + h * G::CH, o1 + h * G::CH, rs.slot(rs.par) + lane * 4, bin, bin1,
+                                                   [&] { w8::rings_stage(rs, wb, W, nextW, tr, wave, lane); });
+        else  // a wave without an edge tile: its share of the ring traffic only
+          w8::rings_stage(rs, wb, W, nextW, tr, wave, lane);
+        w8::trip_close(rs, lane);
+      });
+    });
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      total = total + o0[t] + o1[t];
+      in[t] = in[t] + o0[t] * 1e-30f + o1[(t + 1) % T] * 1e-30f;
+    }
+  }
+  out[blockIdx.x * 512 + tid] = total[0] + total[1] + total[2] + total[3];
+}
+template <int HP, int NT2>
+void run_time2(int blocks, int nmat, int nactive = 8) {
+  using G = w8::SplitGeo<HP, SPLIT_MODE>;
+  const size_t wfloats = (size_t)G::kMatFloats * nmat;
+  float *out, *w;
+  hipMalloc(&w, wfloats * 4);
+  {
+    std::vector<uint16_t> h(wfloats * 2);
+    std::mt19937 rng(1);
+    for (auto& v : h) v = f16_rne(0.1f * ((int)(rng() % 2001) - 1000) / 1000.f);
+    hipMemcpy(w, h.data(), wfloats * 4, hipMemcpyHostToDevice);
+  }
+  hipMalloc(&out, blocks * 512 * 4);
+  const int gemms = 200;
+  const size_t lds = ring_bytes<HP, true>();
+  hipFuncSetAttribute((const void*)k_time2<HP, NT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_time2<HP, NT2>), dim3(blocks), dim3(512), lds, 0, w, (unsigned)(wfloats * 4), nmat, out, gemms, nactive);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (hipGetLastError() != hipSuccess) printf("launch error\n");
+  printf("chained split GEMM, %d waves x %d output-tile set(s) per trip (%d edge tiles), HP=%d blocks=%d matrices=%d: %.2f us per GEMM (K=%d) = %.2f us per edge tile\n",
+         nactive, NT2, nactive * NT2, HP, blocks, nmat, ms * 1e3 / gemms, HP, ms * 1e3 / gemms / (NT2 * nactive));
+  hipFree(out);
+  hipFree(w);
+}
+
 // numerics: out[e][o] = sum_k W[o][k] in[e][k] for 128 edge columns (8 waves x 16), chained-GEMM form
 template <int HP, bool SPLIT>
 __global__ __launch_bounds__(512) void k_num(const float* w, unsigned wbytes, const float* in, float* out) {
@@ -276,5 +405,11 @@ int main(int argc, char** argv) {
   run_time<208, false>(7, 256, 48);
   run_time<208, true>(7, 256, 48);
   run_time<208, true>(7, 1, 48);
+  for (int na : {7, 8, 4}) {
+    run_time2<192, 1>(256, 27, na);
+    run_time2<192, 2>(256, 27, na);
+    run_time2<208, 1>(256, 48, na);
+    run_time2<208, 2>(256, 48, na);
+  }
   return 0;
 }
