@@ -51,6 +51,25 @@ constexpr float kLoScale = 2048.f;  // 2^11
 #define GAUDI_NODE_ABLATE 0  // microbenchmark only (timing, wrong results): 1 = no split pass, 2 = no matrix instructions, 4 = no weight loads
 #endif
 constexpr int kAblateH = GAUDI_NODE_ABLATE;
+// microbenchmark only (-DGAUDI_NODE_STAMPS=1): cycle sums of the parts of a node GEMM, per wave (s_memtime waits for lgkmcnt(0): shares, not
+// timings -- DESIGN section 7, lesson 5)
+#ifndef GAUDI_NODE_STAMPS
+#define GAUDI_NODE_STAMPS 0
+#endif
+struct NodeStampH {
+  unsigned long long sum[8], last;
+  __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void mark(int i) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    sum[i] += t - last;
+    last = t;
+  }
+};
+#if GAUDI_NODE_STAMPS
+#define NSTAMP(i) do { if (ns != nullptr) ns->mark(i); } while (0)
+#else
+#define NSTAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ f4 mfma_h(const u4 a, const u4 b, const f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
@@ -258,7 +277,9 @@ template <int HP, int EPI, bool TWO, int MAXNT, int PIN = kAheadOne, int POUT = 
 __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float* sXa, bool do_split_a, int Wb, const float* sXb,
                                             const float* sBias, float* sY, const float* sRes, const float* sMask, int N, int wave,
                                             int lane, const NodeCtxH& cx, NodePFH<HP>& pf, int nextW = -1, float* gPre = nullptr,
-                                            uint32_t* sMaxOut = nullptr /* LDS [N], zeroed: max |y| bits of every node's row */) {
+                                            uint32_t* sMaxOut = nullptr /* LDS [N], zeroed: max |y| bits of every node's row */,
+                                            NodeStampH* ns = nullptr) {
+  (void)ns;
   using G = NodeGeoH<HP>;
   constexpr int T = G::T, LD = HP + 4, NTW = G::NTW, nc = G::nc, D = G::D;
   constexpr int kIn = PIN < D ? PIN : D, kOut = POUT < D ? POUT : D;
@@ -295,11 +316,14 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
   }
   // FL: the split passes and the epilogue take their addresses from fresh(lane) (device_common.h): recomputed per call -- some
   // forty integer instructions -- instead of being hoisted out of the layer loop and spilled; the K loop's offsets stay hoisted.
+  NSTAMP(0);
   if (!(kAblateH & 1)) {
     const int ls = FL ? fresh(lane) : lane;
     if (do_split_a) split_rows_h<HP>(sa, sXa, N, wave, ls);
     if (TWO && !seq) split_rows_h<HP>(sb, sXb, N, wave, ls);
+    NSTAMP(1);
     if (do_split_a || (TWO && !seq)) lds_barrier();
+    NSTAMP(2);
   }
 
   f4 acc0[MAXNT][NTW], acc1[MAXNT][NTW], y[MAXNT][NTW];
@@ -400,9 +424,12 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  NSTAMP(3);
   source(std::integral_constant<int, 0>{}, sa);
+  NSTAMP(4);
   if constexpr (!TWO) late(std::integral_constant<int, kOut - kLate>{});
   fold(sa, ta);
+  NSTAMP(5);
   if constexpr (TWO) {
     if (seq) {
       lds_barrier();  // (every wave is done with the first source's copy; the weight loads in flight stay in flight)
@@ -449,6 +476,7 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
       }
     }
   });
+  NSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ struct Sel<HP, 0> {
   static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tw, int) { w8::node_prefetch<HP>(pf, wb, W, wave, lane, tw); }
   template <int EPI>
   static __device__ __forceinline__ void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sB, float* sY, int N,
-                                              int wave, int lane, bool tw, PF* pf, int nextW, float*, float, bool) {
+                                              int wave, int lane, bool tw, PF* pf, int nextW, float*, float, bool, w8::NodeStampH* = nullptr) {
     w8::node_gemm<HP, EPI, true>(wb, Wa, sXa, Wb, sXb, sB, sY, nullptr, nullptr, N, wave, lane, tw, pf, nextW);
   }
 };
@@ -33,13 +33,16 @@ struct Sel<HP, 3> {
   static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tw, int N) { w8::node_prefetch_h<HP>(pf, wb, W, wave, lane); }
   template <int EPI>
   static __device__ __forceinline__ void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sB, float* sY, int N,
-                                              int wave, int lane, bool tw, PF* pf, int nextW, float* split, float winv, bool seq) {
+                                              int wave, int lane, bool tw, PF* pf, int nextW, float* split, float winv, bool seq,
+                                              w8::NodeStampH* ns = nullptr) {
     const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
     w8::NodeCtxH cx{winv, split + 96, seq ? split + 96 : split + 96 + w8::nh_split_floats(HP, nct), tw, split};
     if (Wb >= 0)
-      w8::node_gemm_h<HP, EPI, true, GAUDI_MB_MAXNT, w8::kAheadAll, w8::kAheadAll>(wb, Wa, sXa, true, Wb, sXb, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW);
+      w8::node_gemm_h<HP, EPI, true, GAUDI_MB_MAXNT, w8::kAheadAll, w8::kAheadAll>(wb, Wa, sXa, true, Wb, sXb, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW,
+                                                                                    nullptr, nullptr, ns);
     else
-      w8::node_gemm_h<HP, EPI, false, GAUDI_MB_MAXNT, w8::kAheadAll, w8::kAheadAll>(wb, Wa, sXa, true, -1, nullptr, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW);
+      w8::node_gemm_h<HP, EPI, false, GAUDI_MB_MAXNT, w8::kAheadAll, w8::kAheadAll>(wb, Wa, sXa, true, -1, nullptr, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW,
+                                                                                     nullptr, nullptr, ns);
   }
 };
 
@@ -59,6 +62,10 @@ __global__ __launch_bounds__(512) void k(const float* w, unsigned wbytes, int nm
   const int MS = (V == 3 ? 1 : 1) * T * T * 256;  // matrix stride in fp32-offset units (the f16 images sit at 2 W)
   typename Sel<HP, V>::PF pf;
   Sel<HP, V>::prefetch(pf, wb, 0, wave, lane, tail != 0, N);
+  w8::NodeStampH st;
+  for (int i = 0; i < 8; ++i) st.sum[i] = 0;
+  st.start();
+  w8::NodeStampH* ns = GAUDI_NODE_STAMPS ? &st : nullptr;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
   for (int m = 0; m < gemms; ++m) {
@@ -66,16 +73,19 @@ __global__ __launch_bounds__(512) void k(const float* w, unsigned wbytes, int nm
     if (two) {
       const int m2 = (m + nmat / 2) % nmat;
       Sel<HP, V>::template gemm<EPI_SILU>(wb, W, (m & 1) ? sY : sX, m2 * MS, (m & 1) ? sY : sX, nullptr, (m & 1) ? sX : sY, N, wave, lane, tail != 0, &pf,
-                                          nextW, sSplit, 1.0f, two == 2);
+                                          nextW, sSplit, 1.0f, two == 2, ns);
     } else {
       Sel<HP, V>::template gemm<EPI_SILU>(wb, W, (m & 1) ? sY : sX, -1, nullptr, nullptr, (m & 1) ? sX : sY, N, wave, lane, tail != 0, &pf, nextW, sSplit,
-                                          1.0f, false);
+                                          1.0f, false, ns);
     }
     __syncthreads();
+    if (GAUDI_NODE_STAMPS) st.mark(7);
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   out[blockIdx.x * 512 + tid] = sX[tid % (R * LD)];
   if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+  if (GAUDI_NODE_STAMPS && lane == 0 && blockIdx.x == 0)
+    for (int i = 0; i < 8; ++i) cyc[gridDim.x * 8 + wave * 8 + i] = st.sum[i];
 }
 
 // numerics: Y[n][o] = bias[o] + sum_k Wa[o][k] Xa[n][k] + sum_k Wb[o][k] Xb[n][k]   (one workgroup, EPI_NONE)
@@ -163,7 +173,7 @@ void run(int N, int blocks, int nmat, int tail, int two = 0) {
   hipMalloc(&w, wfloats * 4);
   hipMemset(w, 0, wfloats * 4);
   hipMalloc(&out, blocks * 512 * 4);
-  hipMalloc(&cyc, blocks * 8 * 8);
+  hipMalloc(&cyc, (blocks * 8 + 64) * 8);
   const int gemms = 600;
   const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
   const size_t lds = (2 * ((N + 15) & ~15) * (HP + 4) + (two == 1 ? 2 : 1) * w8::nh_split_floats(HP, nct) + 96) * 4;
@@ -187,6 +197,16 @@ void run(int N, int blocks, int nmat, int tail, int two = 0) {
   printf("%s HP=%d N=%d blocks=%d matrices=%d (%.1f MB) tail=%d sources=%d%s: %.0f cycles, %.3f us per GEMM call (%d matri%s)\n",
          V ? "node_gemm_h (fp16 pairs)" : "node_gemm   (fp32 MFMA) ", HP, N, blocks, nmat, (double)nmat * T * T * 1024 / 1e6, tail, two ? 2 : 1,
          two == 2 ? " split in turn" : "", mx / gemms, ms * 1e3 / gemms, two ? 2 : 1, two ? "ces" : "x");
+  if (GAUDI_NODE_STAMPS && V == 3) {
+    std::vector<unsigned long long> hs(64);
+    hipMemcpy(hs.data(), cyc + blocks * 8, 64 * 8, hipMemcpyDeviceToHost);
+    printf("    cycles per call by part: prologue loads | split | barrier | init+B | K loop | fold | epilogue | closing barrier\n");
+    for (int wv : {0, 3, 4, 7}) {
+      printf("    wave %d:", wv);
+      for (int i = 0; i < 8; ++i) printf(" %6.0f", (double)hs[wv * 8 + i] / gemms);
+      printf("\n");
+    }
+  }
   hipFree(out);
   hipFree(cyc);
   hipFree(w);
