@@ -103,9 +103,15 @@ EXPORTS = {
     "gaudi_host_pack_plan_wide": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, FP, FP, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gaudi_set_plan_hint": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "gaudi_last_warning": (C.c_char_p, [C.c_void_p]),
+    "gaudi_abi_version": (C.c_int, []),
+    "gaudi_last_family_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gaudi_host_pack_plan": (C.c_int, [C.c_int, C.c_int, FP, FP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32)]),
 }
+
+ABI_VERSION = 6  # include/gaudi_hip.h: GAUDI_ABI_VERSION
+_ROUND6_EXPORTS = ("gaudi_last_warning", "gaudi_abi_version", "gaudi_last_family_split")  # an older A/B library (GAUDI_LIB) lacks them
 
 _lib = None
 
@@ -122,9 +128,21 @@ def load_library() -> C.CDLL:
     # the host-side packers (gaudi_host_*) are test / tooling entry points: a diagnostic library named by GAUDI_LIB (an A/B
     # build of another revision) may predate some of them; everything else must be there
     lenient = "GAUDI_LIB" in os.environ
+    # ... and one whose exported signatures differ (include/gaudi_hip.h: GAUDI_ABI_VERSION) must not have this file's argument
+    # types bound to its host-side entry points at all: round 5 inserted a float into gaudi_host_pack_matrix_split, and a
+    # call through the wrong prototype passes that float where the old library expects a pointer
+    abi = None
+    if hasattr(lib, "gaudi_abi_version"):
+        lib.gaudi_abi_version.restype, lib.gaudi_abi_version.argtypes = C.c_int, []
+        abi = int(lib.gaudi_abi_version())
+    if abi != ABI_VERSION and not lenient:
+        raise GaudiError(f"{LIB_PATH} exports ABI version {abi}, this package expects {ABI_VERSION}: rebuild it "
+                         "(`python -m gaudi_amd.build --force`)")
     for name, (res, args) in EXPORTS.items():
-        if lenient and name.startswith("gaudi_host_") and not hasattr(lib, name):
+        if lenient and not hasattr(lib, name) and (name.startswith("gaudi_host_") or name in _ROUND6_EXPORTS):
             continue
+        if lenient and abi != ABI_VERSION and name.startswith("gaudi_host_"):
+            continue  # left unbound on purpose: a call raises instead of corrupting memory
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

@@ -68,6 +68,7 @@ struct gaudi_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
+  std::string warn;  // the last non-fatal condition a caller should know about (gaudi_last_warning)
   bool has_edm = false, has_pred = false;
   gaudi_edm_config ecfg{};
   gaudi_pred_config pcfg{};
@@ -118,6 +119,16 @@ struct gaudi_handle {
   int plan_min_slots = 0, plan_force_waves = 0;
   int call_min_slots = 0, call_force_waves = 0;
   bool call_cut = false;      // gaudi_sample cut this request into sub-batches
+  // Per-molecule kernel family (round 6): gaudi_sample sorts a request whose padded N is beyond the resident kernels' LDS limit into
+  // molecules that fit those kernels on their OWN (few enough live nodes and edge tiles) and the rest (V8G), and runs the two
+  // buckets one after the other.  call_narrow = node slots per workgroup of the first bucket's packed launch (< N); call_molmap =
+  // the bucket's molecule -> index in the request (the Philox key is the molecule's global sample index).
+  int call_narrow = 0;
+  const int32_t* call_molmap = nullptr;
+  bool gn8_pack = true;       // GAUDI_GN8_PACK=0: V8G launches keep a molecule's nodes where the masks have them (round 5)
+  bool family_split = false;  // GAUDI_FAMILY_SPLIT=1: per-molecule kernel family (below).  Off by default: the two buckets run as two launches
+                              // per 25 steps on one stream, each with its own tail -- c4x 76.8 against 84.3 mol/s in one family
+  int last_split_resident = 0;  // molecules of the last gaudi_sample call that ran on the resident kernels beside a V8G bucket
   // profiling: launches are bracketed by HIP events on the handle's stream.  A small window of pending pairs is kept;
   // older pairs are folded into running sums and their events recycled (a T = 1000 callback chain makes 2001 launches).
   bool prof = false;
@@ -408,12 +419,19 @@ struct NodeScale {
     gmax = std::max(gmax, m);
     if (m > 0.f) min_mat = std::min(min_mat, m);
   }
-  // -> 2^s (0: refused)
+  // -> 2^s (0: refused; why() says which rule)
   float scale() const {
     if (inf || !(gmax > 0.f) || min_mat < gmax * 2.44140625e-4f) return 0.f;
     int ex;
     std::frexp(gmax, &ex);  // gmax = f 2^ex, f in [0.5, 1)
+    if (14 - ex > 126 || 14 - ex < -126) return 0.f;  // (the scale and its inverse must be normal numbers: |w| around 2^-112 .. 2^140)
     return std::ldexp(1.f, 14 - ex);
+  }
+  const char* why() const {
+    if (inf) return "a weight matrix holds an infinity";
+    if (!(gmax > 0.f)) return "every weight matrix is zero or NaN";
+    if (min_mat < gmax * 2.44140625e-4f) return "the largest entry of some weight matrix lies more than 2^12 below the largest entry of the network";
+    return "the largest weight is outside 2^-112 .. 2^140";
   }
 };
 // A node-GEMM matrix: the fp32 tiles and, when the split buffer is being filled and the network's scale is known, its fp16-pair
@@ -856,8 +874,8 @@ static size_t gnode_floats(int hpe, int hpp, int N) {
 
 static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split, bool gn = false) {
   size_t net = 0;
-  if (hpe) net = std::max(net, (size_t)((gn ? 0 : 5 * N * (hpe + 4)) + w8::edge_ring_floats(hpe, split) + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * hpe));
-  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + (gn ? 0 : 5 * N * (hpp + 4)) + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * hpp));
+  if (hpe) net = std::max(net, (size_t)((gn ? w8::kGnLdsBuffers : 5) * N * (hpe + 4) + w8::edge_ring_floats(hpe, split) + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * hpe));
+  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + (gn ? w8::kGnLdsBuffers : 5) * N * (hpp + 4) + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * hpp));
   return common_floats8(N, D, S) + net;
 }
 static size_t gnode_floats8(int hpe, int hpp, int N) {
@@ -980,10 +998,8 @@ struct Pack {
   std::vector<int32_t> ncomp;         // [G]
 };
 // NG node slots and TG edge tiles per group (N and 8: the classic packing; more: wide groups, whose edge phases run in rounds)
-static void pack_groups(int B, int N, const float* node_mask, const float* edge_mask, const Meta8& M, Pack& pk, int NG = 0,
-                        int TG = w8::kWaves) {
-  if (NG < N) NG = N;
-  // nodes a molecule needs slots for: live ones and any node that touches a live edge, in their own order
+// nodes a molecule needs slots for in a packed launch: live ones and any node that touches a live edge, in their own order
+static std::vector<std::vector<int>> used_nodes(int B, int N, const float* node_mask, const float* edge_mask) {
   std::vector<std::vector<int>> used(B);
   for (int b = 0; b < B; ++b) {
     std::vector<char> keep(N, 0);
@@ -998,6 +1014,15 @@ static void pack_groups(int B, int N, const float* node_mask, const float* edge_
     for (int i = 0; i < N; ++i)
       if (keep[i]) used[b].push_back(i);
   }
+  return used;
+}
+// narrow: NG may be SMALLER than N (every molecule must then fit NG slots on its own: the caller checks) -- rows of the global
+// arrays keep the stride N.  maxcomp: molecules per group (1: every molecule alone, its nodes compacted to the front slots).
+// molmap: molecule -> index the noise is keyed with (a bucket of a larger request), or nullptr.
+static void pack_groups(int B, int N, const float* node_mask, const float* edge_mask, const Meta8& M, Pack& pk, int NG = 0,
+                        int TG = w8::kWaves, bool narrow = false, int maxcomp = kMaxComp, const int32_t* molmap = nullptr) {
+  if (NG < N && !narrow) NG = N;
+  const std::vector<std::vector<int>> used = used_nodes(B, N, node_mask, edge_mask);
   struct Group {
     std::vector<int> mols;
     int nodes = 0, tiles = 0;
@@ -1007,7 +1032,7 @@ static void pack_groups(int B, int N, const float* node_mask, const float* edge_
     const int nn = (int)used[b].size(), nt = M.ntiles[b];
     Group* fit = nullptr;
     for (Group& g : groups)
-      if ((int)g.mols.size() < kMaxComp && g.nodes + nn <= NG && g.tiles + nt <= TG) {
+      if ((int)g.mols.size() < maxcomp && g.nodes + nn <= NG && g.tiles + nt <= TG) {
         fit = &g;
         break;
       }
@@ -1033,7 +1058,7 @@ static void pack_groups(int B, int N, const float* node_mask, const float* edge_
     int base = 0;
     for (size_t k = 0; k < groups[g].mols.size(); ++k) {
       const int b = groups[g].mols[k];
-      pk.compmol[(size_t)g * kMaxComp + k] = b;
+      pk.compmol[(size_t)g * kMaxComp + k] = molmap ? molmap[b] : b;
       std::fill(slot_of.begin(), slot_of.end(), -1);
       for (size_t r = 0; r < used[b].size(); ++r) slot_of[used[b][r]] = base + (int)r;
       if (!used[b].empty()) pk.align[(size_t)g * NG + base] = 1;
@@ -1085,11 +1110,35 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
     return pick_kernel8_mode(hpe, hpp, 0, mrk) && plan_pub8(hpe, hpp, NS, Dz, S, 0, pubx, pub_ch) ? 0 : -1;
   };
   int mode_u = plan_for(N, M.S, mr);
+  Pack pk;
+  const int B0 = B;
+  const float* nm_used = node_mask;
+  int n_slots = N, mode_run = mode_u;
+  bool mr_run = mr;
+  bool narrow_taken = false, use_pack = false;
+  // Round 6: a bucket of molecules that fit the resident kernels on their own (gaudi_sample: per-molecule kernel family) while the
+  // call's padded N does not -- packed groups of call_narrow (< N) node slots, one round of eight edge tiles.
+  if (h->call_narrow > 0 && h->call_narrow < N && h->pack_now && (int64_t)B * N < (1 << 28)) {
+    pack_groups(B, N, node_mask, edge_mask, M, pk, h->call_narrow, w8::kWaves, true, kMaxComp, h->call_molmap);
+    Meta8 M2;
+    rc = build_meta8(pk.G, h->call_narrow, pk.umask.data(), pk.uemask.data(), M2, err, 0, pk.align.data());
+    if (rc != GAUDI_OK) return fail(h, rc, "per-molecule kernel family: " + err);
+    const bool mr2 = hpp && M2.S > 16 * w8::kWaves;
+    const int mode2 = plan_for(h->call_narrow, M2.S, mr2);
+    if (mode2 < 1 || mr2) return fail(h, GAUDI_E_CAPACITY, "per-molecule kernel family: the resident plan of the small bucket does not fit");
+    M = std::move(M2);
+    B = pk.G;
+    nm_used = pk.umask.data();
+    n_slots = h->call_narrow;
+    mode_run = mode_u = mode2;
+    mr_run = mr2;
+    narrow_taken = use_pack = true;
+  }
   // V8G (round 4): a molecule whose node buffers do not fit LDS beside the ring runs on the 8-wave kernels with those five
   // buffers in a per-workgroup global scratch (split edge GEMMs, full ring, several rounds of edge tiles) -- before round 4
   // such calls fell to the 4-wave V4G kernels (fp32 matrix instructions, two launches per guided step)
   bool gn8 = false;
-  if ((mode_u < 0 || h->force_gn8) && h->gn8 && h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) && node_f16_ok &&
+  if (!narrow_taken && (mode_u < 0 || h->force_gn8) && h->gn8 && h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) && node_f16_ok &&
       pick_kernel8g(hpe, hpp) && (GAUDI_NODE_F16 || gn8_stage_fits(hpe, hpp, N)) && plan_pub8(hpe, hpp, N, Dz, M.S, 1, pubx, pub_ch, true)) {
     gn8 = true;
     mode_u = 1;
@@ -1097,13 +1146,29 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
     plan_for(N, M.S, mr);  // (restore pubx / pub_ch of the resident plan)
   }
   if (mode_u < 0) return 1;
-  Pack pk;
-  const int B0 = B;
-  const float* nm_used = node_mask;
-  int n_slots = N, mode_run = mode_u;
-  bool mr_run = mr;
+  if (!narrow_taken) mode_run = mode_u;
+  // V8G sampling calls (round 6): every molecule alone in its workgroup as before, but its nodes COMPACTED to the front slots
+  // (a hetero molecule's rings and orientation nodes are two blocks of the padded index range: n rings occupy columns up to
+  // N / 2 + n) -- fewer node-GEMM column tiles; the packed form also carries the molecule's index in the request (call_molmap).
+  if (gn8 && h->pack_now && h->pack && h->gn8_pack && (int64_t)B * N < (1 << 28)) {
+    pack_groups(B, N, node_mask, edge_mask, M, pk, N, 1 << 20, false, 1, h->call_molmap);
+    Meta8 M2;
+    int pubx2 = 0, pub_ch2 = 0;
+    if (build_meta8(pk.G, N, pk.umask.data(), pk.uemask.data(), M2, err, M.S, pk.align.data()) == GAUDI_OK && M2.S == M.S &&
+        plan_pub8(hpe, hpp, N, Dz, M2.S, 1, pubx2, pub_ch2, true)) {
+      M = std::move(M2);
+      B = pk.G;
+      nm_used = pk.umask.data();
+      pubx = pubx2;
+      pub_ch = pub_ch2;
+      use_pack = true;
+    } else {
+      if (h->call_molmap) return fail(h, GAUDI_E_CAPACITY, "per-molecule kernel family: the packed V8G plan does not fit");
+      pk = Pack();
+    }
+  }
   // (a row of the map holds molecule * N + node in 28 bits)
-  if (!gn8 && h->pack_now && h->pack && B > 1 && (int64_t)B * N < (1 << 28)) {
+  if (!gn8 && !narrow_taken && h->pack_now && h->pack && B > 1 && (int64_t)B * N < (1 << 28)) {
     // Candidate group shapes, widest first.  WIDE groups (opt-in: GAUDI_PAIRS=1 for batches of at least two molecules per CU, 2
     // always): up to 2 N node slots and two rounds of eight edge tiles -- e.g. two 11-ring cata molecules, or three to four small
     // hetero ones, per workgroup.  Every node-level matrix is then streamed from L2 once for all of them and the per-GEMM fixed
@@ -1150,12 +1215,12 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
       n_slots = cd.NG;
       mode_run = mode2;
       mr_run = mr2;
-      taken = true;
+      taken = use_pack = true;
       break;
     }
     if (!taken) plan_for(N, M.S, mr);  // keep the unpacked plan (pubx / pub_ch)
   }
-  const bool packed = B != B0;
+  const bool packed = use_pack;
   h->run_split = mode_run;
   P.pubx = pubx;
   P.pub_ch = pub_ch;
@@ -1332,6 +1397,8 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_FORCE_GN8")) h->force_gn8 = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_FORCE_MR")) h->force_mr = atoi(v) != 0;  // diagnostic: one-round graphs on the MR kernels
   if (const char* v = getenv("GAUDI_PACK")) h->pack = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_GN8_PACK")) h->gn8_pack = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_FAMILY_SPLIT")) h->family_split = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PAIRS")) h->pairs = atoi(v);
   {
     int cus = 0;
@@ -1370,6 +1437,13 @@ void gaudi_destroy(gaudi_handle* h) {
 }
 
 const char* gaudi_last_error(const gaudi_handle* h) { return h ? h->err.c_str() : "null handle"; }
+const char* gaudi_last_warning(const gaudi_handle* h) { return h ? h->warn.c_str() : ""; }
+int gaudi_abi_version(void) { return GAUDI_ABI_VERSION; }
+int gaudi_last_family_split(const gaudi_handle* h, int32_t* resident_molecules) {
+  if (!h || !resident_molecules) return GAUDI_E_INVALID;
+  *resident_molecules = h->last_split_resident;
+  return GAUDI_OK;
+}
 
 int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const char* const* names,
                    const float* const* tensors, const int64_t* numel) {
@@ -1405,6 +1479,9 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
       }
     }
     hscale = ns.scale();
+    if (!(hscale > 0.f) && h->variant == 8 && h->split)
+      h->warn = std::string("EDM weights: the fp16-pair images cannot carry this weight set (") + ns.why() +
+                "): its calls run the fp32-instruction kernels (about 0.55 x the speed, same results at fp32 accuracy)";
   }
   auto pack = [&](bool lane_linear, std::vector<float>& w, std::vector<float>* ws) {
   w.assign((size_t)lay.total(), 0.f);
@@ -1773,6 +1850,21 @@ static int max_sub_batch(gaudi_handle* h, int B, int N, bool guided) {
   return (int)std::min<long long>(B, bmax);
 }
 
+// Node slots of the widest packed group the RESIDENT split kernels take at these widths (one round of eight edge tiles), below N;
+// 0: none (no split images, no such kernel).  A function of the widths only.
+static int resident_node_limit(gaudi_handle* h, int N, bool guided) {
+  const int hpe = h->HPE, hpp = guided ? h->HPP : 0;
+  if (h->variant != 8 || !h->split || !h->edm_ws_bytes || (hpp && !h->pred_ws_bytes)) return 0;
+  if (GAUDI_NODE_F16 && (!(h->edm_hinv > 0.f) || (hpp && !(h->pred_hinv > 0.f)))) return 0;
+  const int Dz = 3 + h->ecfg.in_node_nf;
+  for (int ng = std::min(N - 1, 32); ng >= 8; --ng)
+    for (int mode = 1; mode <= 2; ++mode) {
+      int pubx = 0, pub_ch = 0;
+      if (pick_kernel8_mode(hpe, hpp, mode, false) && plan_pub8(hpe, hpp, ng, Dz, 16 * w8::kWaves, mode, pubx, pub_ch)) return ng;
+    }
+  return 0;
+}
+
 int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const float* edge_mask, uint64_t seed,
                  int64_t sample_offset, const float* noise, float std, const float* target_w, float scale,
                  float* x_out, float* onehot_out, float* z0_out, gaudi_diag* diag) {
@@ -1782,42 +1874,116 @@ int gaudi_sample(gaudi_handle* h, int B, int N, const float* node_mask, const fl
   if (B <= 0 || N <= 0) return fail(h, GAUDI_E_INVALID, "B and N must be positive");
   HIPCHECK(h, hipSetDevice(h->device));
   const int T = h->ecfg.diffusion_steps, F = h->ecfg.in_node_nf, D = 3 + F;
-  const int bmax = max_sub_batch(h, B, N, target_w != nullptr);
-  // sub-batches plan with the whole batch's graph figures (same kernel family and edge-GEMM arithmetic for every cut)
   struct CallHint {
     gaudi_handle* h;
     ~CallHint() {
-      h->call_min_slots = h->call_force_waves = 0;
+      h->call_min_slots = h->call_force_waves = h->call_narrow = 0;
       h->call_cut = false;
+      h->call_molmap = nullptr;
     }
   } call_hint{h};
-  h->call_cut = bmax < B;
-  if (bmax < B && h->variant == 8) {
+  h->last_split_resident = 0;
+  // ---- per-molecule kernel family (round 6).  A request whose padded N is beyond the resident kernels' LDS limit used to run
+  // EVERY molecule on the V8G kernels (node buffers in a global scratch: 20 % slower on a molecule that would fit).
+  // Now the molecules that fit the resident kernels on their own -- at most `lim` live nodes and one round of eight edge tiles: a
+  // function of the molecule's own graph and the widths, so a molecule's kernel (and its rounding) does not depend on which
+  // other molecules share the call or the shard -- form a first bucket that runs packed on the resident kernels; the rest
+  // run on V8G as before.  Noise is keyed by the molecule's index in the request either way.
+  std::vector<int32_t> small, large;
+  int lim = 0;
+  if (h->variant == 8 && h->family_split && h->pack && h->gn8 && h->gn8_pack && !h->force_gn && !h->force_gn8 && !h->fix_noise &&
+      !h->plan_force_waves && (int64_t)B * N < (1 << 28)) {
     Meta8 M;
     std::string err;
-    const int rc = build_meta8(B, N, node_mask, edge_mask, M, err);
-    if (rc == GAUDI_E_CAPACITY) h->call_force_waves = 4;
-    else if (rc) return fail(h, rc, err);
-    else h->call_min_slots = M.S;
+    const int hpp = target_w ? h->HPP : 0;
+    if (build_meta8(B, N, node_mask, edge_mask, M, err, h->plan_min_slots) == GAUDI_OK) {
+      int pubx = 0, pub_ch = 0;
+      bool fits = false;  // the unpacked resident plan of the whole call, any split mode
+      for (int mode = 1; mode <= 2 && !fits; ++mode)
+        fits = pick_kernel8_mode(h->HPE, hpp, mode, hpp && M.S > 16 * w8::kWaves) && plan_pub8(h->HPE, hpp, N, D, M.S, mode, pubx, pub_ch);
+      if (!fits && (lim = resident_node_limit(h, N, target_w != nullptr)) > 0) {
+        const std::vector<std::vector<int>> used = used_nodes(B, N, node_mask, edge_mask);
+        for (int b = 0; b < B; ++b) ((int)used[b].size() <= lim && M.ntiles[b] <= w8::kWaves ? small : large).push_back(b);
+      }
+    }
+  }
+  struct Bucket {
+    const std::vector<int32_t>* idx;  // nullptr: the whole request in place
+    int narrow;
+  };
+  std::vector<Bucket> buckets;
+  if (small.empty()) buckets.push_back({nullptr, 0});
+  else {
+    buckets.push_back({&small, lim});
+    if (!large.empty()) buckets.push_back({&large, 0});
+    h->last_split_resident = (int)small.size();
   }
   int nanc = 0;
-  std::vector<float> nz;
-  for (int b0 = 0; b0 < B; b0 += bmax) {
-    const int nb = std::min(bmax, B - b0);
-    const float* nzp = noise;
-    if (noise && nb != B && !h->fix_noise) {  // gather this sub-batch's draws out of [T+2][B][N][D]
-      nz.resize((size_t)(T + 2) * nb * N * D);
-      for (int d = 0; d < T + 2; ++d)
-        std::memcpy(&nz[(size_t)d * nb * N * D], noise + ((size_t)d * B + b0) * N * D, sizeof(float) * (size_t)nb * N * D);
-      nzp = nz.data();
+  std::vector<float> nz, gm, ge, gx, gh, gz;
+  for (const Bucket& bk : buckets) {
+    const int Bb = bk.idx ? (int)bk.idx->size() : B;
+    const float *nmb = node_mask, *emb = edge_mask, *nsb = noise;
+    float *xo = x_out, *ho = onehot_out, *zo = z0_out;
+    if (bk.idx) {  // gather the bucket's molecules
+      gm.resize((size_t)Bb * N);
+      ge.resize((size_t)Bb * N * N);
+      gx.assign((size_t)Bb * N * 3, 0.f);
+      gh.assign((size_t)Bb * N * F, 0.f);
+      for (int k = 0; k < Bb; ++k) {
+        const int b = (*bk.idx)[k];
+        std::memcpy(&gm[(size_t)k * N], node_mask + (size_t)b * N, sizeof(float) * N);
+        std::memcpy(&ge[(size_t)k * N * N], edge_mask + (size_t)b * N * N, sizeof(float) * N * N);
+      }
+      nmb = gm.data();
+      emb = ge.data();
+      xo = gx.data();
+      ho = gh.data();
+      if (z0_out) {
+        gz.assign((size_t)Bb * N * D, 0.f);
+        zo = gz.data();
+      }
     }
-    int nan_sub = 0;
-    int rc = run_chain(h, nb, N, node_mask + (size_t)b0 * N, edge_mask + (size_t)b0 * N * N, nullptr, true, T - 1, 0, true,
-                       nzp, 0, T + 2, seed, sample_offset + b0, std, target_w, scale,
-                       z0_out ? z0_out + (size_t)b0 * N * D : nullptr, x_out + (size_t)b0 * N * 3,
-                       onehot_out + (size_t)b0 * N * F, &nan_sub);
-    if (rc) return rc;
-    nanc += nan_sub;
+    h->call_narrow = bk.narrow;
+    h->call_min_slots = h->call_force_waves = 0;
+    const int bmax = max_sub_batch(h, Bb, N, target_w != nullptr);
+    // sub-batches plan with the whole batch's graph figures (same kernel family and edge-GEMM arithmetic for every cut)
+    h->call_cut = bmax < Bb;
+    if (bmax < Bb && h->variant == 8 && !bk.narrow) {
+      Meta8 M;
+      std::string err;
+      const int rc = build_meta8(Bb, N, nmb, emb, M, err);
+      if (rc == GAUDI_E_CAPACITY) h->call_force_waves = 4;
+      else if (rc) return fail(h, rc, err);
+      else h->call_min_slots = M.S;
+    }
+    for (int b0 = 0; b0 < Bb; b0 += bmax) {
+      const int nb = std::min(bmax, Bb - b0);
+      const float* nzp = nsb;
+      if (noise && !h->fix_noise && (nb != B || bk.idx)) {  // gather this sub-batch's draws out of [T+2][B][N][D]
+        nz.resize((size_t)(T + 2) * nb * N * D);
+        for (int d = 0; d < T + 2; ++d)
+          for (int k = 0; k < nb; ++k) {
+            const int b = bk.idx ? (*bk.idx)[b0 + k] : b0 + k;
+            std::memcpy(&nz[((size_t)d * nb + k) * N * D], noise + ((size_t)d * B + b) * N * D, sizeof(float) * (size_t)N * D);
+          }
+        nzp = nz.data();
+      }
+      h->call_molmap = bk.idx ? bk.idx->data() + b0 : nullptr;
+      int nan_sub = 0;
+      int rc = run_chain(h, nb, N, nmb + (size_t)b0 * N, emb + (size_t)b0 * N * N, nullptr, true, T - 1, 0, true, nzp, 0, T + 2, seed,
+                         bk.idx ? sample_offset : sample_offset + b0, std, target_w, scale, zo ? zo + (size_t)b0 * N * D : nullptr,
+                         xo + (size_t)b0 * N * 3, ho + (size_t)b0 * N * F, &nan_sub);
+      h->call_molmap = nullptr;
+      if (rc) return rc;
+      nanc += nan_sub;
+    }
+    if (bk.idx)  // scatter the bucket's results
+      for (int k = 0; k < Bb; ++k) {
+        const int b = (*bk.idx)[k];
+        std::memcpy(x_out + (size_t)b * N * 3, &gx[(size_t)k * N * 3], sizeof(float) * N * 3);
+        std::memcpy(onehot_out + (size_t)b * N * F, &gh[(size_t)k * N * F], sizeof(float) * N * F);
+        if (z0_out) std::memcpy(z0_out + (size_t)b * N * D, &gz[(size_t)k * N * D], sizeof(float) * N * D);
+      }
   }
   finish_sample(B, N, node_mask, x_out, nanc, diag);
   return GAUDI_OK;

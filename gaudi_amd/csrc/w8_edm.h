@@ -15,6 +15,14 @@ namespace w8 {
 // instead (the 4-wave family's V4G form of round 3, edm_device.h, on the 8-wave kernels).  The code is the same: the pointers
 // are carved from the scratch, hipcc emits flat / global accesses for them; every cross-wave hand-off of these buffers
 // already sits behind a workgroup barrier, which orders global memory inside a workgroup too.
+// Round 6 (hybrid residency): of a GN kernel's five buffers the two that the EDGE phases gather from -- P and Q, read per edge
+// slot and K chunk by the generating edge GEMM (and again by the reverse pass's chain) -- stay in LDS: up to N = 40 they fit
+// beside the full ring (2 x 34 KB + 52 KiB), and they carried two thirds of the V8G kernels' vector-memory instructions.  h and
+// the two partial sums (read by the node GEMMs' split passes, written by the scatter) stay in the scratch.
+#ifndef GAUDI_GN_PQ_LDS
+#define GAUDI_GN_PQ_LDS 1
+#endif
+constexpr int kGnLdsBuffers = GAUDI_GN_PQ_LDS ? 2 : 0;  // node buffers a GN kernel keeps in LDS (shared with the host's LDS plan)
 template <int HP, int SP = 0, bool GN = false>
 struct NetSmem {
   static constexpr bool kGlobalNodes = GN;
@@ -29,7 +37,7 @@ struct NetSmem {
   float* trans;         // [S][4]
   float* vec;           // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
   __host__ __device__ static int floats(int N, int S) {
-    return (GN ? 0 : 5 * N * (HP + 4)) + EdgeRing<HP, SP>::kFloats + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * HP;
+    return (GN ? kGnLdsBuffers : 5) * N * (HP + 4) + EdgeRing<HP, SP>::kFloats + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * HP;
   }
   __device__ void carve(float* base, int N, int S, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
@@ -37,8 +45,13 @@ struct NetSmem {
     if (GN) gnode = assume_global(gnode);
     float*& nb = GN ? gnode : base;
     h = nb; nb += N * LD;
-    p = nb; nb += N * LD;
-    q = nb; nb += N * LD;
+    if (GN && kGnLdsBuffers) {
+      p = base; base += N * LD;
+      q = base; base += N * LD;
+    } else {
+      p = nb; nb += N * LD;
+      q = nb; nb += N * LD;
+    }
     agg = nb; nb += N * LD;
     agg1 = nb; nb += N * LD;
     x = base; base += 4 * N;

@@ -20,8 +20,8 @@
 // exponent per network (gaudi_hip.hip: pack_matrix_f16; max |w| of all node matrices -> [2^13, 2^14)), the activations per
 // NODE and per GEMM input on the device (the row's max exponent -> 2^14: split_rows_h), undone in the epilogue.  NaN
 // propagates as in fp32; an infinite activation gives NaN where fp32 gives +-inf (hi = inf, x - hi = NaN) -- the sampler
-// scrubs both the same way (models.py:138-141).  The host refuses the form (-> fp32 node GEMMs) for weight sets with
-// infinities or a matrix that lies more than 2^24 below the largest one.
+// scrubs both the same way (models.py:138-141).  The host refuses the form (-> fp32 node GEMMs, with a warning: gaudi_last_warning)
+// for weight sets with infinities or a matrix whose largest entry lies more than 2^12 below the network's (gaudi_hip.hip: NodeScale).
 //
 // Bytes.  hi and lo are 2 + 2 bytes: a matrix image is exactly the fp32 matrix's size -- units of 1 KiB ordered
 // [K chunk of 32][output tile][piece], lane L = (row L & 15, inputs 8 (L >> 4) .. +7 of the chunk).  An odd tile count (208 =

@@ -29,7 +29,7 @@ struct PredSmem {
   float* pred;                    // [16] pred | [16] dpred
   float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
   __host__ __device__ static int floats(int N, int S, int pubx) {
-    return EdgeRing<HP, SP>::kFloats + (GN ? 0 : 5 * N * (HP + 4)) + pubx + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * HP;
+    return EdgeRing<HP, SP>::kFloats + (GN ? kGnLdsBuffers : 5) * N * (HP + 4) + pubx + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * HP;
   }
   // the publish buffer of the reverse pass (du of every slot, pub_ch feature tiles at a time)
   __device__ __forceinline__ float* publish() const { return GN ? ring : b0; }
@@ -38,11 +38,12 @@ struct PredSmem {
     if (SP == 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // fp32 form: the ring stays busy across the publish phase
     if (GN) gnode = assume_global(gnode);
     float*& nb = GN ? gnode : base;
-    b2 = nb; nb += N * LD;
+    // (GN, round 6: P = b1 and Q = b2 -- what the edge phases of both passes gather from -- stay in LDS, w8_edm.h: kGnLdsBuffers)
+    if (GN && kGnLdsBuffers) { b2 = base; base += N * LD; } else { b2 = nb; nb += N * LD; }
     b3 = nb; nb += N * LD;
     b4 = nb; nb += N * LD;
     b0 = nb; nb += N * LD;
-    b1 = nb; nb += N * LD;
+    if (GN && kGnLdsBuffers) { b1 = base; base += N * LD; } else { b1 = nb; nb += N * LD; }
     if (SP != 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // N * LD * 4 bytes is a multiple of 16: units stay aligned
     pub = base; base += pubx;
     x = base; base += 4 * N;

@@ -3,8 +3,8 @@
 // v_mfma_f32_16x16x4_f32 runs at the vector fp32 rate (64 FLOP/clk/SIMD); the 16-bit instructions v_mfma_f32_16x16x32_{bf16,f16}
 // at 16x that.  Round 2 split every fp32 operand into three bf16 pieces (six piece products per product: 2.67x less matrix
 // time than the fp32 instruction).  Round 5: both operands are fp16 PAIRS, x s = hi + lo with hi = fp16(x s), lo = fp16(x s - hi)
-// (round to nearest; s a power of two that brings the largest magnitude to [2^14, 2^15): per network for the weights, on the
-// host; per edge column for the activations, on the device), and a product is accumulated in fp32 from THREE piece products
+// (round to nearest; s a power of two: per network for the weights, on the host -- the largest |w| of the network goes to
+// [2^13, 2^14), gaudi_hip.hip: NodeScale --; per edge column for the activations, on the device -- the column's bound goes to [2^14, 2^15)), and a product is accumulated in fp32 from THREE piece products
 //     a_hi b_lo + a_lo b_hi + a_hi b_hi                       (dropped: a_lo b_lo <= 2^-22 |a b|)
 // on v_mfma_f32_16x16x32_f16: half the matrix instructions of the bf16 form, two thirds of its weight bytes (4 B per weight: the
 // ring is 26 KiB per slot instead of 39) and a cheaper operand split (two conversions per value instead of three).  hi carries

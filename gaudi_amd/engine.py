@@ -68,6 +68,33 @@ class Engine:
         except Exception:
             pass
 
+    def _warning(self):
+        """The library's last non-fatal condition ('' if none, or an older A/B library without the entry point)."""
+        fn = getattr(self.lib, "gaudi_last_warning", None)
+        if fn is None or fn.restype is not C.c_char_p:
+            return ""
+        msg = fn(self.h)
+        return msg.decode() if msg else ""
+
+    def _note_fallback(self):
+        """A weight set the fp16-pair images refuse runs the fp32-instruction kernels at about 0.55 x the speed: say so once,
+        loudly, and keep the reason for diag['edge_math_fallback']."""
+        w = self._warning()
+        if w and w != getattr(self, "_fallback_reason", None):
+            import warnings
+            warnings.warn("gaudi_amd: " + w, RuntimeWarning, stacklevel=3)
+        if w:
+            self._fallback_reason = w
+
+    def family_split(self) -> int:
+        """Molecules of the most recent sample() call that ran on the resident kernels beside a V8G bucket (0: one family)."""
+        fn = getattr(self.lib, "gaudi_last_family_split", None)
+        if fn is None or not fn.argtypes:
+            return 0
+        n = C.c_int32(0)
+        self._check(fn(self.h, C.byref(n)), "gaudi_last_family_split")
+        return int(n.value)
+
     def _check(self, rc: int, what: str):
         if rc != 0:
             msg = self.lib.gaudi_last_error(self.h)
@@ -104,6 +131,7 @@ class Engine:
                         float(args["diffusion_noise_precision"]), (C.c_float * 3)(*[float(v) for v in nv]))
         n, c_names, c_ptrs, c_numel, keep = self._tensor_args(sd)
         self._check(self.lib.gaudi_load_edm(self.h, C.byref(cfg), n, c_names, c_ptrs, c_numel), "gaudi_load_edm")
+        self._note_fallback()
         self.edm_args, self.F, self.T = dict(args), F, int(args["diffusion_steps"])
         # EnVariationalDiffusion.check_issues_norm_values (en_diffusion.py:336-349): the reference refuses to BUILD a model whose
         # sigma_0 is not small against 1 / norm_value (8 standard deviations) -- e.g. 'cosine' with the default
@@ -124,6 +152,7 @@ class Engine:
         n, c_names, c_ptrs, c_numel, keep = self._tensor_args(sd)
         self._check(self.lib.gaudi_load_predictor(self.h, C.byref(cfg), n, c_names, c_ptrs, c_numel),
                     "gaudi_load_predictor")
+        self._note_fallback()
         self.pred_args, self.K = dict(args), K
 
     # ------------------------------------------------------------------ tables
@@ -219,7 +248,8 @@ class Engine:
                                           float(std), fptr(tw), float(scale), fptr(x), fptr(h), fptr(z0),
                                           C.byref(diag)), "gaudi_sample")
         d = dict(max_masked_leak=diag.max_masked_leak, max_cog_rel=diag.max_cog_rel, max_cog_abs=diag.max_cog_abs,
-                 nan_count=diag.nan_count, reprojected=diag.reprojected)
+                 nan_count=diag.nan_count, reprojected=diag.reprojected,
+                 edge_math_fallback=getattr(self, "_fallback_reason", None), family_split_resident=self.family_split())
         return (x, h, d, z0) if return_z0 else (x, h, d)
 
     def predict_noised(self, x, onehot, t_int, node_mask, edge_mask, *, seed=0, sample_offset=0, noise=None):
@@ -301,7 +331,8 @@ class Engine:
             raise failure[0]
         self._check(rc, "gaudi_sample_cbz" if with_z else "gaudi_sample_cb")
         d = dict(max_masked_leak=diag.max_masked_leak, max_cog_rel=diag.max_cog_rel, max_cog_abs=diag.max_cog_abs,
-                 nan_count=diag.nan_count, reprojected=diag.reprojected)
+                 nan_count=diag.nan_count, reprojected=diag.reprojected,
+                 edge_math_fallback=getattr(self, "_fallback_reason", None), family_split_resident=self.family_split())
         return (x, h, d, z0) if return_z0 else (x, h, d)
 
     def sample_chain(self, node_mask, edge_mask, keep_frames, *, seed=0, sample_offset=0, noise=None, std=1.0):

@@ -73,6 +73,14 @@ typedef struct {
 int gaudi_create(int device, gaudi_handle** out);
 void gaudi_destroy(gaudi_handle* h);
 const char* gaudi_last_error(const gaudi_handle* h);
+/* The last NON-fatal condition of the handle a caller should know about ("" if none): e.g. a weight set the fp16-pair images
+ * cannot carry (an infinite weight, a matrix far below the others), whose calls therefore run the fp32-instruction kernels at
+ * about 0.55 x the speed.  gaudi_amd.engine turns it into a Python warning at load time and into diag["edge_math_fallback"]. */
+const char* gaudi_last_warning(const gaudi_handle* h);
+/* Bumped whenever an exported signature changes (round 6: 6).  gaudi_amd/_lib.py refuses to bind the host-side packers of a
+ * diagnostic library (GAUDI_LIB) whose version differs: round 5 inserted an argument into gaudi_host_pack_matrix_split. */
+#define GAUDI_ABI_VERSION 6
+int gaudi_abi_version(void);
 
 /* Load a state dict (reference key names WITHOUT the "module." prefix).
  * names[i] is the key, tensors[i] its fp32 data, numel[i] its element count.  Unknown keys are
@@ -253,6 +261,16 @@ int gaudi_node_buffers(const gaudi_handle* h, int32_t* last_call);
  * groups they were packed into; node_slots (may be NULL): node slots per workgroup -- the call's N, or more when the launch
  * ran WIDE groups (below).  bench.py prices its roofline with these figures, not with the host-side plan. */
 int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups, int32_t* node_slots);
+/* Per-molecule kernel family (round 6).  gaudi_sample sorts a request whose padded N is beyond the resident kernels' LDS limit
+ * into the molecules that fit those kernels on their own (at most as many live nodes as the widest resident group takes, one round
+ * of eight edge tiles -- a function of the molecule's own graph and the hidden sizes, so the choice does not depend on the rest of
+ * the batch or on how it is sharded) and the rest; the first bucket runs packed on the resident kernels, the second on the V8G
+ * kernels, both with noise keyed by the molecule's index in the request.  resident_molecules: how many molecules of the most
+ * recent gaudi_sample call ran in the first bucket (0: the call ran one family).  Matches sampling_edm.py:172-209 (no size cap,
+ * mixed sizes in one call).  OPT-IN (environment GAUDI_FAMILY_SPLIT=1 at gaudi_create): the two buckets are two launches per 25
+ * steps on one stream, each with its own tail of idle CUs, and BASELINE config 4 read literally measures 76.8 mol/s this way
+ * against 84.3 in one family (round 6); results are bit-identical per molecule either way of sharding. */
+int gaudi_last_family_split(const gaudi_handle* h, int32_t* resident_molecules);
 /* The same plan for WIDE groups (device-free): groups of up to node_slots (>= N) node slots and `tiles` edge tiles.  Opt-in
  * (environment GAUDI_PAIRS at gaudi_create: 0 never = default, 1 for batches of at least two molecules per CU, 2 always): a
  * sampling call then gives a workgroup more node slots than a molecule has -- two 11-ring cata molecules, three or four small

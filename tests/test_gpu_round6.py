@@ -1,0 +1,147 @@
+"""GPU evidence added in round 6: the per-molecule kernel family of gaudi_sample, V8G launches with every
+molecule's nodes compacted, the fp16-image refusal made loud (item 6)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from gaudi_amd import synth
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(eargs, esd, pargs=None, psd=None, **env):
+    from gaudi_amd.engine import Engine
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        eng = Engine(0)  # the knobs are read once, by gaudi_create
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    eng.load_edm(eargs, esd)
+    if pargs is not None:
+        eng.load_predictor(pargs, psd)
+    return eng
+
+
+def _hetero_batch(rings, pad, T, seeds=(21, 22)):
+    from gaudi_amd.sampling_edm import build_masks
+    F = synth.num_node_features("hetro")
+    eargs, pargs = synth.edm_args(dataset="hetro", diffusion_steps=T), synth.pred_args(dataset="hetro")
+    esd = synth.synth_edm_state_dict(eargs, F, seed=seeds[0])
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=seeds[1])
+    nm3, em_flat, N = build_masks(rings, pad, True)
+    B = len(rings)
+    return eargs, esd, pargs, psd, F, nm3.reshape(B, N), em_flat.reshape(B, N, N), N
+
+
+@pytest.mark.parametrize("guided", [True, False])
+def test_family_split_a_molecules_kernel_depends_on_its_own_size_only(guided):
+    """BASELINE config 4 read literally mixes 6-20 rings (12-40 graph nodes) in one call (sampling_edm.py:172-209 pads to the batch
+    maximum, no size cap).  The padded N = 40 is beyond the resident kernels' LDS limit, and through round 5 EVERY molecule of such
+    a call ran on the V8G kernels (node buffers in a global scratch).  Round 6: the molecules that fit the resident kernels on
+    their own run there, packed, the rest on V8G -- two buckets of one gaudi_sample call.  The bucket of a molecule is a function
+    of its own graph: the molecule sampled ALONE (same padding, its own global index), in any shard of the batch, or in the
+    whole batch gives the same bits; noise is keyed by the index in the request, so the whole call equals the one-family call
+    (the default: the split is opt-in, GAUDI_FAMILY_SPLIT=1 -- as two launches per 25 steps it measured slower) to the two families' agreement (5e-6 per step; 1e-4 over this short chain)."""
+    T = 6
+    rings = [3, 20, 6, 12, 9, 16, 4, 11]
+    eargs, esd, pargs, psd, F, nm, em, N = _hetero_batch(rings, 20, T)
+    assert N == 40
+    w = np.array([3, 0, 1, 1, 0], np.float32) if guided else None
+    B = len(rings)
+    eng = _engine(eargs, esd, pargs, psd, GAUDI_FAMILY_SPLIT=1)
+    x, h, d = eng.sample(nm, em, seed=5, target_w=w, scale=0.6)
+    nres = d["family_split_resident"]
+    assert 0 < nres < B, nres
+    assert d["max_masked_leak"] == 0 and np.isfinite(x).all()
+    x2, h2, _ = eng.sample(nm, em, seed=5, target_w=w, scale=0.6)
+    assert np.array_equal(x, x2) and np.array_equal(h, h2)  # bitwise reproducible
+    # every molecule alone, with its own global sample index
+    for b in range(B):
+        xb, hb, db = eng.sample(nm[b:b + 1], em[b:b + 1], seed=5, sample_offset=b, target_w=w, scale=0.6)
+        assert np.array_equal(xb[0], x[b]) and np.array_equal(hb[0], h[b]), (b, rings[b], db["family_split_resident"])
+    # two shards
+    xa, ha, _ = eng.sample(nm[:3], em[:3], seed=5, sample_offset=0, target_w=w, scale=0.6)
+    xc, hc, _ = eng.sample(nm[3:], em[3:], seed=5, sample_offset=3, target_w=w, scale=0.6)
+    assert np.array_equal(np.concatenate([xa, xc]), x) and np.array_equal(np.concatenate([ha, hc]), h)
+    eng.close()
+    # one family per call (round 5): same noise stream, the two kernel families agree to a few 1e-6 per step
+    eng1 = _engine(eargs, esd, pargs, psd)  # the default
+    x1, h1, d1 = eng1.sample(nm, em, seed=5, target_w=w, scale=0.6)
+    assert d1["family_split_resident"] == 0 and eng1.node_buffers_global()
+    eng1.close()
+    assert rel_err(x, x1) < 1e-4 and np.array_equal(h, h1)
+
+
+def test_family_split_with_injected_noise_vs_oracle():
+    """The same call with injected raw draws (the parity path: [T+2][B][N][D], gathered per bucket) against the numpy oracle's
+    guided chain: both buckets at 1e-4."""
+    from oracle import gaudi_oracle as O
+    T = 4
+    rings = [4, 20, 7, 13]
+    eargs, esd, pargs, psd, F, nm, em, N = _hetero_batch(rings, 20, T, seeds=(31, 32))
+    B = len(rings)
+    noise = np.random.default_rng(3).standard_normal((T + 2, B, N, 3 + F)).astype(np.float32)
+    w = np.array([3, 0, 1, 1, 0], np.float32)
+    eng = _engine(eargs, esd, pargs, psd, GAUDI_FAMILY_SPLIT=1)
+    x, h, d = eng.sample(nm, em, noise=noise, target_w=w, scale=0.6)
+    assert d["family_split_resident"] == 2
+    eng.close()
+    xo, ho, _ = O.sample(esd, eargs, nm[:, :, None], em, noise, pred_sd=psd, pcfg=pargs, target_w=w, scale=0.6)
+    assert rel_err(x, xo) < 1e-4 and np.array_equal(h, ho)
+
+
+def test_v8g_compacted_nodes_equal_nodes_in_place_bit_for_bit():
+    """V8G sampling launches (round 6) place a molecule's live nodes in the FRONT slots of its workgroup (a hetero molecule's rings
+    and orientation nodes are two blocks of the padded index range: fewer node-GEMM column tiles when compacted).  Node columns
+    are independent, every sum visits its terms in the molecule's own order: the result must not change by a bit against the
+    round-5 launch (GAUDI_GN8_PACK=0), guided and unguided."""
+    T = 5
+    rings = [20, 13, 9, 17]
+    eargs, esd, pargs, psd, F, nm, em, N = _hetero_batch(rings, 20, T, seeds=(41, 42))
+    w = np.array([3, 0, 1, 1, 0], np.float32)
+    outs = []
+    for env in ({"GAUDI_FAMILY_SPLIT": 0, "GAUDI_GN8_PACK": 0}, {"GAUDI_FAMILY_SPLIT": 0}):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        a = eng.sample(nm, em, seed=9, target_w=w, scale=0.6)
+        assert eng.node_buffers_global()
+        b = eng.sample(nm, em, seed=9)
+        outs.append((a[0], a[1], b[0], b[1]))
+        eng.close()
+    for u, v in zip(*outs):
+        assert np.array_equal(u, v)
+
+
+def test_refused_fp16_images_warn_and_report():
+    """a weight set the fp16-pair images cannot carry (here: an infinite weight) runs the
+    fp32-instruction kernels -- about 0.55 x the speed -- and used to do so silently.  Now the load warns, gaudi_last_warning
+    carries the reason and every sample() reports it in diag['edge_math_fallback']; a healthy weight set reports None."""
+    from oracle import gaudi_oracle as O
+    from tests.helpers import TINY, TINY_P
+    T = 4
+    eargs, pargs = synth.edm_args(diffusion_steps=T, **TINY), synth.pred_args(**TINY_P)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=3)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=4)
+    nm, em = O.build_masks([5, 7, 3], 7, False)
+    w = O.target_max_gap_weights(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        eng = _engine(eargs, esd, pargs, psd)  # no warning
+    x, h, d = eng.sample(nm, em, seed=1, target_w=w, scale=0.6)
+    assert d["edge_math_fallback"] is None and eng.edge_math()[1] != 0
+    eng.close()
+    bad = {k: np.array(v, copy=True) for k, v in psd.items()}
+    key = next(k for k in bad if k.endswith("node_mlp.0.weight"))
+    bad[key][0, 0] = np.inf
+    with pytest.warns(RuntimeWarning, match="fp16-pair images cannot carry"):
+        eng = _engine(eargs, esd, pargs, bad)
+    x, h, d = eng.sample(nm, em, seed=1, target_w=w, scale=0.6)
+    assert "infinity" in d["edge_math_fallback"] and eng.edge_math()[1] == 0
+    eng.close()

@@ -25,7 +25,10 @@ for step in "$@"; do
           for f in gaudi_amd/ngemmr_mb_*; do timeout 60 $f r > $out/$(basename $f).txt 2>&1; done ;;
     mb_rv) for f in gaudi_amd/ngemmr_mb_*; do timeout 60 $f r > $out/$(basename $f).txt 2>&1; done ;;
     mb_r1) timeout 300 gaudi_amd/ngemmr_mb > $out/ngemmr_mb.txt 2>&1 ;;
-    tests_r6) timeout 1800 python3 -m pytest tests/test_gpu_round6.py -x -q -m gpu > $out/tests_r6.txt 2>&1 ;;
+    tests_r6) timeout 1800 python3 -m pytest tests/test_gpu_round6.py -q -m gpu > $out/tests_r6.txt 2>&1 ;;
+    c4x) timeout 900 $B --workload c4x > $out/c4x_new.json 2> $out/c4x_new.err
+         GAUDI_FAMILY_SPLIT=0 timeout 900 $B --workload c4x > $out/c4x_nosplit.json 2> $out/c4x_nosplit.err
+         GAUDI_FAMILY_SPLIT=0 GAUDI_GN8_PACK=0 timeout 900 $B --workload c4x > $out/c4x_r5.json 2> $out/c4x_r5.err ;;
     tests_core) timeout 2400 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_split.py tests/test_gpu_round5.py -x -q -m gpu > $out/tests_core.txt 2>&1 ;;
     tests_v8g) timeout 2400 python3 -m pytest tests/test_gpu_round4.py tests/test_gpu_round3.py -x -q -m gpu -k "v8g or large or n40 or dense or callback_targets" > $out/tests_v8g.txt 2>&1 ;;
     tests_all) timeout 3400 python3 -m pytest tests -x -q -m gpu > $out/tests_all.txt 2>&1 ;;
