@@ -106,12 +106,14 @@ EXPORTS = {
     "gaudi_last_warning": (C.c_char_p, [C.c_void_p]),
     "gaudi_abi_version": (C.c_int, []),
     "gaudi_last_family_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "gaudi_profile_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "gaudi_last_keep_h": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gaudi_host_pack_plan": (C.c_int, [C.c_int, C.c_int, FP, FP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32)]),
 }
 
 ABI_VERSION = 6  # include/gaudi_hip.h: GAUDI_ABI_VERSION
-_ROUND6_EXPORTS = ("gaudi_last_warning", "gaudi_abi_version", "gaudi_last_family_split")  # an older A/B library (GAUDI_LIB) lacks them
+_ROUND6_EXPORTS = ("gaudi_last_warning", "gaudi_abi_version", "gaudi_last_family_split", "gaudi_profile_clock", "gaudi_last_keep_h")  # an older A/B library (GAUDI_LIB) lacks them
 
 _lib = None
 

@@ -82,7 +82,7 @@ struct gaudi_handle {
   // per-call workspaces
   DevBuf d_mask, d_order, d_edges, d_emask, d_npairs, d_seg, d_zin, d_zout, d_t, d_x, d_h, d_noise, d_nan, d_dpred,
       d_pred, d_tw, d_stash, d_chain, d_sx, d_stype, d_sn, d_sflags, d_sdist, d_sadj, d_saux, d_stab, d_as, d_ncols, d_soff,
-      d_sidx, d_gnode, d_rowmap, d_compmol, d_ncomp;
+      d_sidx, d_gnode, d_rowmap, d_compmol, d_ncomp, d_clock;
   PinBuf p_pred, p_dpred;     // gaudi_sample_cb: pred [B,K] device -> host, dT/dpred [B,K] host -> device, once per step
   PinBuf p_z, p_dz;           // gaudi_sample_cbz: z_s [B,N,D] device -> host, scale * dT/dz host -> device
   DevBuf d_dz;
@@ -125,6 +125,8 @@ struct gaudi_handle {
   // the bucket's molecule -> index in the request (the Philox key is the molecule's global sample index).
   int call_narrow = 0;
   const int32_t* call_molmap = nullptr;
+  bool keep_h = true;         // GAUDI_KEEP_H=0: every node GEMM that reads h splits it again (round 5)
+  int run_hk = 0;             // floats of the kept split copy of h behind the current call's LDS plan (0: none)
   bool gn8_pack = true;       // GAUDI_GN8_PACK=0: V8G launches keep a molecule's nodes where the masks have them (round 5)
   bool family_split = false;  // GAUDI_FAMILY_SPLIT=1: per-molecule kernel family (below).  Off by default: the two buckets run as two launches
                               // per 25 steps on one stream, each with its own tail -- c4x 76.8 against 84.3 mol/s in one family
@@ -933,7 +935,8 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
                     (v8 ? " in the 8-wave family" : ""));
-  const size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split, h->run_gn8) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW, h->run_gn);
+  size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split, h->run_gn8) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW, h->run_gn);
+  if (v8 && P.hk_off) lds = sizeof(float) * ((size_t)P.hk_off + (size_t)h->run_hk);  // the kept split copy of h sits behind the FUSED plan
   if (lds > 160 * 1024)
     return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
   {
@@ -977,7 +980,14 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
     }
   }
 #else
-  hipLaunchKernelGGL(fn, dim3(P.B), dim3(v8 ? w8::kThreads : kThreads), lds, h->stream, P);
+  if (h->prof) {  // profiled launches also leave their clock counters (sampler_kernel.h: KParams::clock_out)
+    KParams PC = P;
+    HIPCHECK(h, h->d_clock.reserve(sizeof(unsigned long long) * 4));
+    PC.clock_out = h->d_clock.as<unsigned long long>();
+    hipLaunchKernelGGL(fn, dim3(P.B), dim3(v8 ? w8::kThreads : kThreads), lds, h->stream, PC);
+  } else {
+    hipLaunchKernelGGL(fn, dim3(P.B), dim3(v8 ? w8::kThreads : kThreads), lds, h->stream, P);
+  }
 #endif
   HIPCHECK(h, hipGetLastError());
   if (h->prof) {
@@ -1267,6 +1277,19 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   h->run_nslots = n_slots;
   h->run_mr = mr_run;
   h->run_gn8 = gn8;
+  // Kept split copy of h (w8_nodes_f16.h: node_ctx_keep): behind everything the plan of BOTH networks needs, when 160 KiB leave the
+  // room -- C2 / C3 do (46 KB free), 20-22 node slots do not.  Same results either way (the copy is a function of h alone).
+  P.hk_off = 0;
+  h->run_hk = 0;
+  if (h->keep_h && GAUDI_NODE_F16 && mode_run >= 1 && !gn8) {
+    const size_t plan = lds_bytes8(hpe, hpp, n_slots, Dz, M.S, pubx, mode_run, false) / sizeof(float);
+    const size_t at = (plan + 3) & ~(size_t)3;
+    const size_t need = (size_t)w8::nh_keep_floats(std::max(hpe, hpp), n_slots);
+    if ((at + need) * sizeof(float) + 1024 <= 160 * 1024) {
+      P.hk_off = (int)at;
+      h->run_hk = (int)need;
+    }
+  }
   if (gn8) {
     const size_t stride = (gnode_floats8(hpe, hpp, N) + 63) / 64 * 64;
     HIPCHECK(h, h->d_gnode.reserve(sizeof(float) * (stride * (size_t)B + 256)));  // (+ the staging copies' 1 KiB read granule)
@@ -1398,6 +1421,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_FORCE_MR")) h->force_mr = atoi(v) != 0;  // diagnostic: one-round graphs on the MR kernels
   if (const char* v = getenv("GAUDI_PACK")) h->pack = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_GN8_PACK")) h->gn8_pack = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_KEEP_H")) h->keep_h = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_FAMILY_SPLIT")) h->family_split = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PAIRS")) h->pairs = atoi(v);
   {
@@ -1439,6 +1463,22 @@ void gaudi_destroy(gaudi_handle* h) {
 const char* gaudi_last_error(const gaudi_handle* h) { return h ? h->err.c_str() : "null handle"; }
 const char* gaudi_last_warning(const gaudi_handle* h) { return h ? h->warn.c_str() : ""; }
 int gaudi_abi_version(void) { return GAUDI_ABI_VERSION; }
+int gaudi_profile_clock(gaudi_handle* h, double* shader_mhz) {
+  if (!h || !shader_mhz) return GAUDI_E_INVALID;
+  *shader_mhz = 0.0;
+  if (!h->d_clock.p) return GAUDI_OK;  // no profiled launch yet
+  HIPCHECK(h, hipSetDevice(h->device));
+  unsigned long long c[4] = {0, 0, 0, 0};
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, hipMemcpy(c, h->d_clock.p, sizeof(c), hipMemcpyDeviceToHost));
+  if (c[3] > c[1] && c[2] > c[0]) *shader_mhz = 100.0 * (double)(c[2] - c[0]) / (double)(c[3] - c[1]);
+  return GAUDI_OK;
+}
+int gaudi_last_keep_h(const gaudi_handle* h, int32_t* lds_floats) {
+  if (!h || !lds_floats) return GAUDI_E_INVALID;
+  *lds_floats = h->run_hk;
+  return GAUDI_OK;
+}
 int gaudi_last_family_split(const gaudi_handle* h, int32_t* resident_molecules) {
   if (!h || !resident_molecules) return GAUDI_E_INVALID;
   *resident_molecules = h->last_split_resident;

@@ -75,6 +75,12 @@ struct KParams {
   const int32_t* rowmap;       // [B][N] node slot -> global row (molecule * N + its node) | component << 28, or -1; nullptr = not packed
   const int32_t* compmol;      // [B][kMaxComp] molecule index of each component
   const int32_t* ncomp;        // [B]
+  // Profiled launches (gaudi_profile_reset(h, 1)): lane 0 of workgroup 0 leaves the shader-clock and the constant 100 MHz
+  // counters at kernel entry [0], [1] and at the end of its last step [2], [3] -- the clock the chip HELD under this kernel's
+  // load (1.7-2.0 GHz against the nominal 2.4 the roofline peaks assume), bench.py: roofline.clock_mhz.  nullptr otherwise.
+  unsigned long long* clock_out;
+  int hk_off;                  // 8-wave split kernels: float offset (from the start of LDS) of the kept split copy of h, 0 = none
+                               // (w8_nodes_f16.h: node_ctx_keep; placed by the host behind the whole plan when 160 KiB leave the room)
 };
 constexpr int kMaxComp = 4;
 
@@ -178,7 +184,7 @@ __device__ __forceinline__ Lds8 carve_lds8(float* smem, int N, int D, int S) {
   return L;
 }
 struct Graph8Args {
-  int N, D, S, NC, ntiles, pubx, pub_ch;
+  int N, D, S, NC, ntiles, pubx, pub_ch, hk;
 };
 __device__ __forceinline__ w8::MolGraph graph8(const Lds8& L, const Graph8Args& a) {
   w8::MolGraph mg;
@@ -186,6 +192,7 @@ __device__ __forceinline__ w8::MolGraph graph8(const Lds8& L, const Graph8Args& 
   mg.ntiles = a.ntiles;
   mg.rounds = (a.ntiles + w8::kWaves - 1) / w8::kWaves;
   mg.pubx = a.pubx; mg.pub_ch = a.pub_ch;
+  mg.hk = a.hk;
   mg.mask = L.sMask; mg.edge = L.sEdge; mg.em = L.sEm; mg.seg = L.sSeg; mg.soff = L.sOff; mg.sidx = L.sIdx;
   mg.row = L.sRow;
   mg.ncomp = __builtin_amdgcn_readfirstlane(L.sCmol[4]);
@@ -207,7 +214,7 @@ __device__ __forceinline__ T* uni(T* p) {
   return (T*)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ Graph8Args uni(const Graph8Args& a) {
-  return Graph8Args{uni(a.N), uni(a.D), uni(a.S), uni(a.NC), uni(a.ntiles), uni(a.pubx), uni(a.pub_ch)};
+  return Graph8Args{uni(a.N), uni(a.D), uni(a.S), uni(a.NC), uni(a.ntiles), uni(a.pubx), uni(a.pub_ch), uni(a.hk)};
 }
 __device__ __forceinline__ EdmDev uni(const EdmDev& w) {
   return EdmDev{uni(w.w), uni(w.w_bytes), uni(w.F), uni(w.L), uni(w.S), uni(w.attention), uni(w.use_tanh), uni(w.coords_range),
@@ -229,6 +236,7 @@ __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, f
   const w8::MolGraph mg = graph8(L, ga);
   w8::NetSmem<HP, SP, GN> sm;
   sm.carve(L.net, ga.N, ga.S, GN ? uni(gnode_) : nullptr);
+  sm.hk = ga.hk ? smem + ga.hk : nullptr;
   w8::edm_forward<HP, SP, GN, FL>(W, mg, sm, L.sZ, L.sEps, L.sMean, t_val, (int)threadIdx.x);
 }
 // the predictor's forward and reverse passes are separate functions too (the reverse pass holds three 52-register
@@ -243,6 +251,7 @@ __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args 
   const w8::MolGraph mg = graph8(L, ga);
   w8::PredSmem<HP, SP, GN> sm;
   sm.carve(L.net, ga.N, ga.S, ga.pubx, GN ? uni(gnode_) : nullptr);
+  sm.hk = ga.hk ? smem + ga.hk : nullptr;
   w8::pred_forward<HP, SP, MR, GN, FL>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
 }
 template <int HP, int SP, bool MR, bool GN = false, bool FL = false>
@@ -295,12 +304,13 @@ struct V8T {
     mg.rounds = (mg.ntiles + w8::kWaves - 1) / w8::kWaves;
     mg.pubx = P.pubx;
     mg.pub_ch = P.pub_ch;
+    mg.hk = P.hk_off;
     mg.mask = sMask; mg.edge = sEdge; mg.em = sEm; mg.seg = sSeg; mg.soff = sOff; mg.sidx = sIdx;
     return base;
   }
   __device__ __forceinline__ static void set_rows(Graph& mg, const int* row, int ncomp, int NR) { mg.row = row; mg.ncomp = ncomp; mg.NR = NR; }
   __device__ __forceinline__ static Graph8Args gargs(const Graph& mg) {
-    return Graph8Args{mg.N, mg.D, mg.S, mg.NC, mg.ntiles, mg.pubx, mg.pub_ch};
+    return Graph8Args{mg.N, mg.D, mg.S, mg.NC, mg.ntiles, mg.pubx, mg.pub_ch, mg.hk};
   }
   static constexpr bool kGlobalNodes = GN;
   template <int HP>
@@ -309,6 +319,7 @@ struct V8T {
 #ifdef GAUDI_STAMPS
     w8::NetSmem<HP, SP, GN> sm;
     sm.carve(net, mg.N, mg.S, GN ? uni(gnode) : nullptr);
+    sm.hk = w8::lds_at(mg.hk);
     w8::edm_forward<HP, SP, GN>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
 #else
     (void)net; (void)sZ; (void)sEps; (void)sMean; (void)tid;
@@ -433,6 +444,10 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
   auto gidx = [=](int n, int d, int W) -> long long { return sRow[n] < 0 ? -1LL : (long long)row_of(sRow[n]) * W + d; };
 
   const int mode = P.mode;
+  if (P.clock_out != nullptr && blockIdx.x == 0 && tid == 0) {
+    P.clock_out[0] = __builtin_readcyclecounter();
+    P.clock_out[1] = __builtin_amdgcn_s_memrealtime();
+  }
 #ifdef GAUDI_STAMPS
   Stamps g_stamps;
   g_stamps.init();
@@ -604,6 +619,10 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
         P.stamps[31] = __builtin_amdgcn_s_memrealtime() - rt0;      // constant 100 MHz
       }
 #endif
+      if (P.clock_out != nullptr && blockIdx.x == 0 && tid == 0) {
+        P.clock_out[2] = __builtin_readcyclecounter();
+        P.clock_out[3] = __builtin_amdgcn_s_memrealtime();
+      }
       if (nan_local) atomicAdd(P.nan_count, nan_local);
       return;
     }

@@ -570,6 +570,7 @@ struct MolGraph {
   int NC;                 // node columns that matter: 1 + last node that is live or touches a live edge (<= N)
   int ntiles, rounds;     // 16-slot tiles of THIS molecule, ceil(ntiles / 8)
   int pubx, pub_ch;       // predictor reverse pass: see w8_pred.h
+  int hk = 0;             // float offset of the kept split copy of h from the start of LDS, 0 = none (w8_nodes_f16.h)
   const float* mask;      // LDS [N]
   const uint32_t* edge;   // LDS [S]  edge words (ew_* above)
   const float* em;        // LDS [S]  edge_mask value (0 for padding slots)
@@ -582,6 +583,11 @@ struct MolGraph {
   int ncomp;
   int NR;                 // rows per molecule of the global arrays (N, or less when the group is wider than a molecule)
 };
+// pointer to float offset `off` of the workgroup's dynamic LDS (0 -> nullptr): the kept split copy of h sits behind the whole plan
+__device__ __forceinline__ float* lds_at(int off) {
+  extern __shared__ __attribute__((aligned(16))) float gaudi_lds_alias[];
+  return off ? gaudi_lds_alias + off : nullptr;
+}
 __device__ __forceinline__ int mg_comp(const MolGraph& mg, int n) { return (mg.row[n] >> 28) & 7; }
 
 }  // namespace w8

@@ -15,12 +15,14 @@ namespace w8 {
 // instead (the 4-wave family's V4G form of round 3, edm_device.h, on the 8-wave kernels).  The code is the same: the pointers
 // are carved from the scratch, hipcc emits flat / global accesses for them; every cross-wave hand-off of these buffers
 // already sits behind a workgroup barrier, which orders global memory inside a workgroup too.
-// Round 6 (hybrid residency): of a GN kernel's five buffers the two that the EDGE phases gather from -- P and Q, read per edge
-// slot and K chunk by the generating edge GEMM (and again by the reverse pass's chain) -- stay in LDS: up to N = 40 they fit
-// beside the full ring (2 x 34 KB + 52 KiB), and they carried two thirds of the V8G kernels' vector-memory instructions.  h and
-// the two partial sums (read by the node GEMMs' split passes, written by the scatter) stay in the scratch.
+// Round 6 experiment (hybrid residency, -DGAUDI_GN_PQ_LDS=1): of a GN kernel's five buffers the two that the EDGE phases gather
+// from -- P and Q, read per edge slot and K chunk by the generating edge GEMM and again by the reverse pass's chain -- stay in LDS
+// (up to N = 40 they fit beside the full ring: 2 x 34 KB + 52 KiB).  Measured on BASELINE config 4 read literally (N = 40, same
+// session): 84.3 against 81.3 mol/s (+3.6 %) -- the gathers were hitting L1 / L2 well enough -- while complete graphs of 27-33 nodes
+// (992 edge slots: 40 KB of per-slot arrays) no longer fit and fall to the 4-wave V4G kernels.  Off: the gain does not pay for a
+// second set of V8G instantiations.
 #ifndef GAUDI_GN_PQ_LDS
-#define GAUDI_GN_PQ_LDS 1
+#define GAUDI_GN_PQ_LDS 0
 #endif
 constexpr int kGnLdsBuffers = GAUDI_GN_PQ_LDS ? 2 : 0;  // node buffers a GN kernel keeps in LDS (shared with the host's LDS plan)
 template <int HP, int SP = 0, bool GN = false>
@@ -36,6 +38,7 @@ struct NetSmem {
   float* d0;            // [S]
   float* trans;         // [S][4]
   float* vec;           // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
+  float* hk = nullptr;  // kept split copy of h (w8_nodes_f16.h: node_ctx_keep), behind the whole plan; nullptr: none
   __host__ __device__ static int floats(int N, int S) {
     return (GN ? kGnLdsBuffers : 5) * N * (HP + 4) + EdgeRing<HP, SP>::kFloats + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * HP;
   }
@@ -198,6 +201,9 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       return NodeCtxH{1.f, nullptr, nullptr, tw, nullptr};
     }
   };
+  // a kept split copy of h (w8_nodes_f16.h: node_ctx_keep): h is split when it has changed, not by every GEMM that reads it
+  const bool keep = NH && sm.hk != nullptr;
+  bool h_kept = false;
   constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next sub-layer's vectors (GCL: 7 HP + 16 floats, EquivariantUpdate: 5 HP), loaded a phase ahead
   vec_prefetch<NV, kThreads>(vpf, wb, lay.gcl(0, 0) + 6 * PK, 7 * HP + 16, tid);
@@ -228,9 +234,10 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const float ba = sm.vec[7 * HP];
       const float crmax = sm.vec[7 * HP + 1], cdmax = sm.vec[7 * HP + 2];  // max |c_r|, max |c_d| (host)
       {
-        const NodeCtxH cx = hctx();
-        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll, FL>(wb, wbe, G, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
+        const NodeCtxH cx = keep ? node_ctx_keep<HP>(hctx(), sm.hk, mg.NC) : hctx();
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll, FL>(wb, wbe, G, sm.h, xs0, !h_kept, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
                                                       wave, lane, tw, cx, pf, G + PK, nullptr, sm.pmax);
+        h_kept = keep;
         node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne, FL>(wb, wbe, G + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
                                                       nullptr, mg.NC, wave, lane, tw, cx, pf,
                                                       G + 3 * PK, nullptr, sm.qmax);  // node MLP weights travel across the edge phase
@@ -279,8 +286,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       if constexpr (STG) stage_wait();
       else __syncthreads();
       STAMP(ST_MISC);
-      node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, G + 3 * PK, sm.h, xs0, true, G + 4 * PK, sm.agg, xs1, bn1, sm.p, nullptr, nullptr,
-                                              mg.NC, wave, lane, tw, hctx(), pf, G + 5 * PK);
+      node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, G + 3 * PK, sm.h, xs0, !h_kept, G + 4 * PK, sm.agg, xs1, bn1, sm.p, nullptr, nullptr,
+                                              mg.NC, wave, lane, tw, keep ? node_ctx_keep<HP>(hctx(), sm.hk, mg.NC) : hctx(), pf, G + 5 * PK);
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
@@ -293,6 +300,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       node_gemm_x<HP, EPI_RESIDUAL_MASK, false, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, G + 5 * PK, sm.p, xs0, true, -1, nullptr, nullptr, bn2, sm.h, sm.h, mg.mask,
                                                        mg.NC, wave, lane, tw, hctx(), pf,
                                                        s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
+      h_kept = false;  // (h has changed)
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
@@ -316,9 +324,10 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
       const float crmax = sm.vec[5 * HP], cdmax = sm.vec[5 * HP + 1];  // max |c_r|, max |c_d| (host)
       {
-        const NodeCtxH cx = hctx();
-        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll, FL>(wb, wbe, E, sm.h, xs0, true, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
+        const NodeCtxH cx = keep ? node_ctx_keep<HP>(hctx(), sm.hk, mg.NC) : hctx();
+        node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll, FL>(wb, wbe, E, sm.h, xs0, !h_kept, -1, nullptr, nullptr, b1, sm.p, nullptr, nullptr, mg.NC,
                                                       wave, lane, tw, cx, pf, E + PK, nullptr, sm.pmax);
+        h_kept = keep;  // (the EquivariantUpdate leaves h alone: the next block's GCL reads the same copy)
         node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne, FL>(wb, wbe, E + PK, sm.h, xs0, false, -1, nullptr, nullptr, nullptr, sm.q, nullptr,
                                                       nullptr, mg.NC, wave, lane, tw, cx, pf, l + 1 < W.L ? lay.gcl(l + 1, 0) : -1, nullptr,
                                                       sm.qmax);

@@ -265,6 +265,7 @@ struct NodeCtxH {
   float* split_b;   // ... of the second source; == split_a: the region holds ONE input, the sources are split in turn
   bool ktail;       // H % 16 == 4: the tail block holds one k-step
   float* scales;    // LDS [2][kScaleFloatsH]: the per-node descale factors of the two sources
+  float* scales_b = nullptr;  // the second source's, when they do not follow the first's (a kept copy of h: node_ctx_keep)
 };
 
 // One node GEMM of the workgroup (all waves call it; N <= 16 MAXNT node columns).
@@ -288,7 +289,7 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
   // column tiles of this call (wave-uniform; the code below branches on it around matrix instructions and LDS traffic only)
   const int nt = (MAXNT < 2 || N <= 16) ? 1 : (MAXNT < 3 || N <= 32) ? 2 : 3;
   const bool seq = TWO && cx.split_b == cx.split_a;
-  const SplitBufH sa{cx.split_a, nt, cx.scales}, sb{cx.split_b, nt, cx.scales + kScaleFloatsH};
+  const SplitBufH sa{cx.split_a, nt, cx.scales}, sb{cx.split_b, nt, cx.scales_b != nullptr ? cx.scales_b : cx.scales + kScaleFloatsH};
   const int bpos = nh_bpos(c, g);  // the lane's float offset inside a 1 KiB B unit
   const TileLanesH<HP> tl(wave, lane);
   // a matrix that is not there (no next GEMM) is "loaded" with out-of-range lanes too
@@ -539,6 +540,18 @@ __device__ __forceinline__ NodeCtxH node_ctx_h(float* region, int cap, int N, fl
   const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
   const int need = nh_split_floats(HP, nct);
   return NodeCtxH{winv, region, 2 * need <= cap ? region + need : region, ktail, scales};
+}
+// Round 6: a KEPT split copy of h.  h feeds P and Q of a layer, the node MLP's first Linear of the same layer and -- in the denoiser,
+// where the EquivariantUpdate leaves h alone (egnn_new.py:119-155) -- P and Q of the next sub-layer: with `keep` (an LDS region of
+// its own behind everything else: nh_keep_floats, placed by the host when the plan leaves the room) h is split once per change
+// instead of once per GEMM that reads it: 2 of the denoiser's 5 split passes per block, 1 of the predictor's 4 per layer.
+// The context of a GEMM whose FIRST source is h: copy and factors in `keep`, a second source (agg) in the phase's usual region.
+__host__ __device__ constexpr int nh_keep_floats(int HP, int N) { return nh_split_floats(HP, N <= 16 ? 1 : N <= 32 ? 2 : 3) + kScaleFloatsH; }
+template <int HP>
+__device__ __forceinline__ NodeCtxH node_ctx_keep(const NodeCtxH& cx, float* keep, int N) {
+  const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
+  return NodeCtxH{cx.winv, keep + kScaleFloatsH, cx.split_a, cx.ktail, keep, cx.scales};
+  (void)nct;
 }
 
 }  // namespace w8

@@ -28,6 +28,7 @@ struct PredSmem {
   float *d0, *trans, *dd0;        // [S], [S][4], [S]
   float* pred;                    // [16] pred | [16] dpred
   float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
+  float* hk = nullptr;            // kept split copy of h (w8_nodes_f16.h: node_ctx_keep), behind the whole plan; nullptr: none
   __host__ __device__ static int floats(int N, int S, int pubx) {
     return EdgeRing<HP, SP>::kFloats + (GN ? kGnLdsBuffers : 5) * N * (HP + 4) + pubx + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * HP;
   }
@@ -145,6 +146,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
       return NodeCtxH{1.f, nullptr, nullptr, tw, nullptr};
     }
   };
+  // a kept split copy of h: P splits it, Q and the node MLP's first Linear read the same copy (w8_nodes_f16.h: node_ctx_keep)
+  const bool keep = NH && sm.hk != nullptr;
   constexpr int NV = (PredLayerW::vec_count(HP) + kThreads - 1) / kThreads;
   VecPF<NV> vpf;  // the next layer's vectors, loaded one node GEMM ahead
   vec_prefetch<NV, kThreads>(vpf, wb, PredLayerW::vec_off(lay.layer(0), HP), PredLayerW::vec_count(HP), tid);
@@ -169,7 +172,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     else __syncthreads();
     STAMP(ST_STAGE);
     {
-      const NodeCtxH cx = hctx();
+      const NodeCtxH cx = keep ? node_ctx_keep<HP>(hctx(), sm.hk, mg.NC) : hctx();
       node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadOne, kAheadAll, FL>(wb, wbe, Lw.A, h, xs0, true, -1, nullptr, nullptr, Lw.b1, p, nullptr, nullptr, mg.NC, wave,
                                                     lane, tw, cx, pf, Lw.Bm, nullptr, sm.pmax);
       node_gemm_x<HP, EPI_NONE, false, GN, NH, kAheadAll, kAheadOne, FL>(wb, wbe, Lw.Bm, h, xs0, false, -1, nullptr, nullptr, nullptr, q, nullptr, nullptr, mg.NC,
@@ -270,8 +273,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
     if constexpr (STG) stage_wait();
     else __syncthreads();
     STAMP(ST_MISC);
-    node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, Lw.Wn1h, h, xs0, true, Lw.Wn1a, agg, xs1, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane,
-                                            tw, hctx(), pf, Lw.Wn2, st + 2 * N * HP /* npre -> stash */);
+    node_gemm_x<HP, EPI_SILU, true, GN, NH, kAheadOne, kAheadOne, FL>(wb, wbe, Lw.Wn1h, h, xs0, !keep, Lw.Wn1a, agg, xs1, Lw.bn1, p, nullptr, nullptr, mg.NC, wave, lane,
+                                            tw, keep ? node_ctx_keep<HP>(hctx(), sm.hk, mg.NC) : hctx(), pf, Lw.Wn2, st + 2 * N * HP /* npre -> stash */);
     STAMP(ST_NODE);
     __syncthreads();
     STAMP(ST_BARRIER);
@@ -722,6 +725,7 @@ __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph
   const int N = mg.N, D = mg.D;
   PredSmem<HP, SP, GN> sm;
   sm.carve(net, N, mg.S, pubx, gnode);
+  sm.hk = lds_at(mg.hk);
   if (phase != 2) pred_forward<HP, SP, MR, GN>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   guidance_seed(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
   if (phase == 1) return;

@@ -86,6 +86,24 @@ class Engine:
         if w:
             self._fallback_reason = w
 
+    def profile_clock_mhz(self) -> float:
+        """Shader clock the chip held during the most recent profiled sampler launch (0.0: none, or an older A/B library)."""
+        fn = getattr(self.lib, "gaudi_profile_clock", None)
+        if fn is None or not fn.argtypes:
+            return 0.0
+        v = C.c_double(0.0)
+        self._check(fn(self.h, C.byref(v)), "gaudi_profile_clock")
+        return float(v.value)
+
+    def keep_h(self) -> int:
+        """Floats of LDS the most recent call gave to a kept split copy of h (0: none)."""
+        fn = getattr(self.lib, "gaudi_last_keep_h", None)
+        if fn is None or not fn.argtypes:
+            return 0
+        n = C.c_int32(0)
+        self._check(fn(self.h, C.byref(n)), "gaudi_last_keep_h")
+        return int(n.value)
+
     def family_split(self) -> int:
         """Molecules of the most recent sample() call that ran on the resident kernels beside a V8G bucket (0: one family)."""
         fn = getattr(self.lib, "gaudi_last_family_split", None)

@@ -261,6 +261,16 @@ int gaudi_node_buffers(const gaudi_handle* h, int32_t* last_call);
  * groups they were packed into; node_slots (may be NULL): node slots per workgroup -- the call's N, or more when the launch
  * ran WIDE groups (below).  bench.py prices its roofline with these figures, not with the host-side plan. */
 int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups, int32_t* node_slots);
+/* Shader clock (MHz) the chip held during the most recent PROFILED sampler launch (gaudi_profile_reset(h, 1)): cycles of the
+ * shader clock over ticks of the constant 100 MHz counter, both read by workgroup 0 at kernel entry and at the end of its last
+ * step.  0 if no profiled launch has run.  The roofline peaks in bench.py assume the nominal 2.4 GHz; under this kernel's load
+ * the chip runs at 1.7-2.0 GHz. */
+int gaudi_profile_clock(gaudi_handle* h, double* shader_mhz);
+/* Floats of LDS the most recent call gave to a KEPT split copy of h (round 6; 0: none -- no room in 160 KiB, a kernel family
+ * without fp16-pair node GEMMs, or GAUDI_KEEP_H=0 at gaudi_create).  With it the node GEMMs that read h (P, Q, the node MLP's first
+ * Linear: edm/egnn/egnn_new.py:59-73,119-128, edm/egnn_predictor/gcl.py:240-250) split it into fp16 pairs once per change of h
+ * instead of once per GEMM; the copy is a function of h alone, results do not change by a bit. */
+int gaudi_last_keep_h(const gaudi_handle* h, int32_t* lds_floats);
 /* Per-molecule kernel family (round 6).  gaudi_sample sorts a request whose padded N is beyond the resident kernels' LDS limit
  * into the molecules that fit those kernels on their own (at most as many live nodes as the widest resident group takes, one round
  * of eight edge tiles -- a function of the molecule's own graph and the hidden sizes, so the choice does not depend on the rest of
