@@ -56,6 +56,9 @@ constexpr int kAblateH = GAUDI_NODE_ABLATE;
 #ifndef GAUDI_NODE_STAMPS
 #define GAUDI_NODE_STAMPS 0
 #endif
+#ifndef GAUDI_NODE_PRIO
+#define GAUDI_NODE_PRIO 1  // 1 = waves 4-7 at s_setprio 1 inside the K loop (kernels with one column tile; round 6), 2 = waves 0-3, 0 = off
+#endif
 struct NodeStampH {
   unsigned long long sum[8], last;
   __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); }
@@ -426,6 +429,15 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
     }
   };
   NSTAMP(3);
+#if GAUDI_NODE_PRIO
+  // Round 6: the second-dispatched half of the workgroup (waves 4-7) loses every issue arbitration by age -- its K loops end last
+  // and everybody waits for them at the closing barrier (MI355X_MICROARCH.md, two waves per SIMD, item 4): one priority step for it
+  // while it streams.  Microbenchmark -0.3 ... -1.9 % per GEMM at one column tile (profiles/r06b_node_gemm_priority.txt); product C3
+  // 206.3 -> 208.1 mol/s.  With TWO column tiles the microbenchmark gains more (-3.7 %) and the product LOSES (C4 245.0 -> 242.2,
+  // pairs -0.2 %): only the kernels that run one column tile (not FL) take the step.  Priority for waves 0-3 instead: nothing.
+  if constexpr (!FL)
+    if ((GAUDI_NODE_PRIO == 1 && wave >= kWaves / 2) || (GAUDI_NODE_PRIO == 2 && wave < kWaves / 2)) __builtin_amdgcn_s_setprio(1);
+#endif
   source(std::integral_constant<int, 0>{}, sa);
   NSTAMP(4);
   if constexpr (!TWO) late(std::integral_constant<int, kOut - kLate>{});
@@ -444,6 +456,9 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
   static_for<D>([&](auto d_tag) {
     if constexpr (decltype(d_tag)::value > kOut - kLate) late(d_tag);
   });
+#if GAUDI_NODE_PRIO
+  if constexpr (!FL) __builtin_amdgcn_s_setprio(0);
+#endif
   const int le = FL ? fresh(lane) : lane, ce = le & 15, ge = le >> 4;
   static_for<MAXNT>([&](auto j_tag) {
     constexpr int j = decltype(j_tag)::value;
