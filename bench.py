@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* = vector fp32 peak
 PEAK_HBM_GBPS = 8000.0
+NOMINAL_CLOCK_MHZ = 2400.0  # the clock the guide's peak figures are quoted at
 
 
 def parse():
@@ -411,6 +412,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
         dist.all_gather(allr, mine)
         per_rank_ms = [[float(v) for v in t_.cpu()] for t_ in allr]
     n_launch, kern_ms, steps_done = eng.profile_get()
+    clock_mhz = eng.profile_clock_mhz()  # shader clock the chip held during the last profiled launch (0: not available)
     eng.profile_reset(False)
     assert x.shape[0] == B * world and np.isfinite(x).all()
     if rank != 0:
@@ -443,6 +445,12 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
             # batch -- the roofline then prices the unpacked launch)
             sys.stderr.write(f"bench.py: the last launch ran {run_groups} workgroups, the host pack plan of the whole batch says {G_}: "
                              "roofline figures use the unpacked launch\n")
+    if v8g and run_groups == B:
+        # V8G sampling launches (round 6) compact a molecule's nodes to the front slots: the node GEMMs produce as many columns as
+        # the molecule USES (live nodes and nodes that touch a live edge), not "1 + the last used index"
+        live = nm > 0
+        ee = (em.reshape(B, N, N) != 0) & (live[:, :, None] | live[:, None, :])
+        ncols = np.minimum(np.asarray(ncols), (live | ee.any(2) | ee.any(1)).sum(1))
     npairs = units
     G = len(ncols)  # workgroups per call: molecules, or groups of molecules when the call packs
     pa = pargs if guided else None
@@ -510,6 +518,11 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                                       "lists in LDS (a complete graph of about 60 nodes)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": frac, "traffic": traffic,
+                     # the peaks above are priced at the nominal 2.4 GHz; under this kernel's load the chip holds less (workgroup 0
+                     # reads the shader-clock and the constant 100 MHz counters at kernel entry and exit: gaudi_profile_clock)
+                     "clock_mhz": clock_mhz or None, "nominal_clock_mhz": NOMINAL_CLOCK_MHZ,
+                     "frac_at_clock": (frac * NOMINAL_CLOCK_MHZ / clock_mhz) if clock_mhz else None,
+                     "parity_rel_err": gate_out["rel_err"] if gate_out is not None else None,
                      "kernel": "sampler_kernel_v<V8T<1,true,true>,192,%s> (V8G: 8 waves, node buffers in a per-workgroup global scratch, several rounds of edge tiles)" % ("208" if guided else "0") if v8g else
                                ("sampler_kernel_v<%s%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
                                                                     " (MR: several rounds of edge tiles)" if guided and variant != "w4" and int(np.max(units)) > 8 else
@@ -631,8 +644,8 @@ def main():
             # the other single-GPU configurations, timed by the same harness (short: one or two calls each)
             sec = {}
             # (every line is gated like the headline: one teacher-forced full-batch step of the engine that is about to be timed
-            # against the C++ port, untimed; the wide-group run of c3_b1024 is bit-equal to launches the tests pin)
-            for wl, b, st, wu, math, gt in (("c2", 256, 2, 1, None, True), ("c4", 1024, 2, 1, None, True), ("c3_b1024", 1024, 2, 1, None, False),
+            # against the C++ port, untimed -- round 6: c3_b1024's wide-group launch too, all 1 024 molecules)
+            for wl, b, st, wu, math, gt in (("c2", 256, 2, 1, None, True), ("c4", 1024, 2, 1, None, True), ("c3_b1024", 1024, 2, 1, None, True),
                                             ("c3_fp32_mfma", 256, 2, 1, "fp32", True), ("c2_fp32_mfma", 256, 2, 1, "fp32", True),
                                             ("c4x", 1024, 1, 1, None, True)):  # BASELINE config 4 read literally: 12-40 graph nodes (V8G kernels)
                 r = run_workload(a, engines, wl.split("_")[0], b, st, wu, rank, world, dev, backend, T, edge_math=math,
@@ -642,6 +655,7 @@ def main():
                            "useful_frac": r["roofline"]["useful_frac"],
                            "fp32_equivalent_frac_of_fp32_peak": r["roofline"]["fp32_equivalent_frac_of_fp32_peak"],
                            "avg_launch_ms": r["roofline"]["avg_launch_ms"], "kernel": r["roofline"]["kernel"],
+                           "clock_mhz": r["roofline"]["clock_mhz"], "frac_at_clock": r["roofline"]["frac_at_clock"],
                            "edge_gemm_math": r["edge_gemm_math"]}
                 if "parity_gate" in r:
                     sec[wl]["parity_gate"] = {k: r["parity_gate"][k] for k in ("rel_err", "tol", "passed")}
@@ -652,7 +666,7 @@ def main():
             # the reference-form call: C3 through sampling_edm.sample_guidance with the closure the
             # reference ships (affine in pred: recognised and run on the fused kernel) and with one that is not (callback path:
             # two launches per step around torch.autograd on the [B,K] leaf)
-            for wl, cl, st, wu in (("c3_closure_linear", "linear", 2, 1), ("c3_closure_nonlinear", "nonlinear", 1, 0)):
+            for wl, cl, st, wu in (("c3_closure_linear", "linear", 2, 1), ("c3_closure_nonlinear", "nonlinear", 1, 1)):
                 try:
                     r = run_workload(a, engines, "c3", 256, st, wu, rank, world, dev, backend, T, closure=cl)
                     sec[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": st,

@@ -403,13 +403,15 @@ static void pack_matrix_f16(float* dst, const float* W, int H, int ldw, int col0
 // One power of two for all matrices of a network (node-level AND edge-level: w8_nodes_f16.h, w8_split.h): the largest finite
 // |w| lands in [2^13, 2^14).  An entry keeps 22 significant bits down to 2^-17 of the largest one in the edge images (lo shares
 // hi's exponent range: one accumulator) and down to 2^-25 in the node images (lo carries its own exponent), with fp16's
-// absolute floor below that.  The form is refused -- the call then runs the fp32-instruction kernels -- when a matrix holds an
-// infinity (fp16 pieces would turn inf x 0 and inf - inf into NaN where the fp32 product keeps inf) or when some matrix lies
-// more than 2^12 below the largest (nothing a trained network shows; kept as a loud boundary rather than a silent loss).
+// absolute floor below that.  The form is refused -- the call then runs the fp32-instruction kernels, and the load says so
+// (gaudi_last_warning) -- when a matrix holds an infinity (fp16 pieces would turn inf x 0 and inf - inf into NaN where the fp32
+// product keeps inf) or when a whole matrix lies below those floors.
 struct NodeScale {
-  float gmax = 0.f, min_mat = INFINITY;
+  // node-level and edge-level matrices apart: the node images carry an entry with 22 bits down to 2^-25 of the scale's top (lo has
+  // its own exponent), the edge images down to 2^-17 (lo shares hi's range)
+  float gmax = 0.f, min_node = INFINITY, min_edge = INFINITY;
   bool inf = false;
-  void see(const float* W, int rows, int ldw, int col0, int cols) {
+  void see(const float* W, int rows, int ldw, int col0, int cols, bool edge = false) {
     if (!W) return;
     float m = 0.f;
     for (int o = 0; o < rows; ++o)
@@ -419,11 +421,18 @@ struct NodeScale {
         else if (a == a) m = std::max(m, a);
       }
     gmax = std::max(gmax, m);
-    if (m > 0.f) min_mat = std::min(min_mat, m);
+    if (m > 0.f) (edge ? min_edge : min_node) = std::min(edge ? min_edge : min_node, m);
   }
+  // Round 6: the rule is as narrow as the images allow.  Through round 5 ANY matrix 2^12 below the network's
+  // largest entry refused the set (one small matrix: the whole network at 0.55 x the speed, silently).  Now: an edge matrix may lie
+  // 2^17 below (its largest entries then still carry 21-22 bits, its error stays at 2^-22 of ITS largest entry -- the norm a GEMM's
+  // error is measured in), a node matrix 2^25; and the refusal is loud (gaudi_last_warning).  One exponent per MATRIX instead was
+  // built and measured: parity-green, 1.0-1.5 % slower on the headline in three forms (profiles/r06c_per_matrix_scale_ab.txt,
+  // tools/experiments/per_matrix_scale.patch).
+  bool too_small() const { return min_edge < gmax * 7.62939453125e-6f /* 2^-17 */ || min_node < gmax * 2.98023223876953125e-8f /* 2^-25 */; }
   // -> 2^s (0: refused; why() says which rule)
   float scale() const {
-    if (inf || !(gmax > 0.f) || min_mat < gmax * 2.44140625e-4f) return 0.f;
+    if (inf || !(gmax > 0.f) || too_small()) return 0.f;
     int ex;
     std::frexp(gmax, &ex);  // gmax = f 2^ex, f in [0.5, 1)
     if (14 - ex > 126 || 14 - ex < -126) return 0.f;  // (the scale and its inverse must be normal numbers: |w| around 2^-112 .. 2^140)
@@ -432,7 +441,8 @@ struct NodeScale {
   const char* why() const {
     if (inf) return "a weight matrix holds an infinity";
     if (!(gmax > 0.f)) return "every weight matrix is zero or NaN";
-    if (min_mat < gmax * 2.44140625e-4f) return "the largest entry of some weight matrix lies more than 2^12 below the largest entry of the network";
+    if (too_small())
+      return "the largest entry of some weight matrix lies more than 2^17 (edge-level matrices; 2^25: node-level) below the largest entry of the network";
     return "the largest weight is outside 2^-112 .. 2^140";
   }
 };
@@ -1511,7 +1521,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
       for (int s = 0; s <= S; ++s) {
         const std::string q = p + "e_block_" + std::to_string(l) + (s < S ? ".gcl_" + std::to_string(s) + "." : ".gcl_equiv.");
         ns.see(T.peek(q + (s < S ? "edge_mlp.0.weight" : "coord_mlp.0.weight"), (int64_t)H * (2 * H + 2)), H, 2 * H + 2, 0, 2 * H);
-        ns.see(T.peek(q + (s < S ? "edge_mlp.2.weight" : "coord_mlp.2.weight"), (int64_t)H * H), H, H, 0, H);
+        ns.see(T.peek(q + (s < S ? "edge_mlp.2.weight" : "coord_mlp.2.weight"), (int64_t)H * H), H, H, 0, H, true);
         if (s < S) {
           ns.see(T.peek(q + "node_mlp.0.weight", (int64_t)H * 2 * H), H, 2 * H, 0, 2 * H);
           ns.see(T.peek(q + "node_mlp.2.weight", (int64_t)H * H), H, H, 0, H);
@@ -2415,7 +2425,7 @@ int gaudi_host_weight_scale(int n, const float* const* blocks, const int32_t* ro
                             float* scale_out) {
   if (n < 1 || !blocks || !rows || !cols || !ldw || !scale_out) return GAUDI_E_INVALID;
   NodeScale ns;
-  for (int i = 0; i < n; ++i) ns.see(blocks[i], rows[i], ldw[i], 0, cols[i]);
+  for (int i = 0; i < n; ++i) ns.see(blocks[i], rows[i], ldw[i], 0, cols[i], true);  // (as edge-level matrices: the stricter floor)
   *scale_out = ns.scale();
   return GAUDI_OK;
 }

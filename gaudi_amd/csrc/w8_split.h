@@ -26,6 +26,10 @@
 // ds_read_b128 per unit.  Units are ordered [m][t][p]; a ring group = the CH tiles x 2 pieces one trip consumes.
 #pragma once
 #include "w8_common.h"
+#ifndef GAUDI_EDGE_PRIO
+#define GAUDI_EDGE_PRIO 0  // experiment (round 6): waves 4-7 at s_setprio 1 inside the generating edge GEMM's trips -- what pays in the node
+                           // GEMMs' K loops LOSES here: C3 208.3 -> 206.1 mol/s, C4 245.1 -> 244.5 (same-session A/B)
+#endif
 
 // (The experiment variants of rounds 2-3 -- LDS-counter trips, register-staged ring, sliced input generation, L2 touches, cache
 // policy bits -- live in tools/experiments/w8_split_variants.h, which only the microbenchmarks include; DESIGN.md section 8
@@ -298,6 +302,9 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
   B3 bin = gen(0), nb = bin;
   static_assert(G::NH <= 3, "at most three trips per K chunk");
   const bool tail = G::kTailOK && ring.ktail;
+#if GAUDI_EDGE_PRIO
+  if (wave >= kWaves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   auto chunk = [&](int m, const B3& bin, B3& nb) {  // consumes `bin`, generates the next chunk into `nb`
     const int mn = m + 1 < G::NC ? m + 1 : m;  // the chunk generated during this one (clamped at the end: no branch)
     auto trip = [&](auto h_tag) {
@@ -335,6 +342,9 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
       trip_close(ring, lane);
     }
   }
+#if GAUDI_EDGE_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   const float dsc = sc.inv * ring.winv;
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = acc[t] * dsc + *(const f4*)(sB2 + 16 * t + 4 * g);

@@ -445,21 +445,34 @@ class GaudiModel:
                 holds, checker = [True], None
                 if fn is not None:
                     # the closure was recognised as affine at three values of t; while the device runs the fused chain, the host
-                    # holds it to that weight vector at every t of the chain (a closure with a guidance window)
+                    # holds it to that weight vector at every t of the chain (a closure with a guidance window).
+                    # NOTE for callers: the closure is evaluated on a helper thread beside the engine call (it only ever sees
+                    # stand-in predictions, never the engine) -- a closure with side effects on shared state must be wrapped in
+                    # PredTarget.  The verdict is cached per (closure, T, weights): repeated calls of design() with the same
+                    # closure pay for it once.
                     import threading
-
-                    def _check_all_t():
-                        try:
-                            holds[0] = affine_gradient_holds(fn, tw, self.T)
-                        except BaseException:
-                            holds[0] = False
-                    checker = threading.Thread(target=_check_all_t, daemon=True)
-                    checker.start()
-                out = self.engine.sample(nm.reshape(B, N), em, seed=seed, sample_offset=off, noise=self.injected_noise, std=std,
-                                         target_w=tw, scale=scale, return_z0=fn is not None)
+                    key = (id(fn), int(self.T), tw.tobytes())
+                    cache = self.__dict__.setdefault("_affine_verdicts", {})
+                    if key in cache and cache[key][0] is fn:
+                        holds[0] = cache[key][1]
+                    else:
+                        def _check_all_t():
+                            try:
+                                holds[0] = affine_gradient_holds(fn, tw, self.T)
+                            except BaseException:
+                                holds[0] = False
+                        checker = threading.Thread(target=_check_all_t, daemon=True)
+                        checker.start()
+                try:
+                    out = self.engine.sample(nm.reshape(B, N), em, seed=seed, sample_offset=off, noise=self.injected_noise, std=std,
+                                             target_w=tw, scale=scale, return_z0=fn is not None)
+                finally:
+                    if checker is not None:  # (joined whether or not the engine call raised)
+                        checker.join()
+                        if len(cache) > 64:
+                            cache.clear()
+                        cache[key] = (fn, holds[0])  # (the closure object is kept: its id cannot be reused while cached)
                 x, h, diag = out[0], out[1], out[2]
-                if checker is not None:
-                    checker.join()
                 if fn is not None and not holds[0]:
                     # not the affine function the probe saw: the fused result is discarded and the SAME call (same noise stream)
                     # runs through the general path, which differentiates the closure at every step

@@ -323,8 +323,10 @@ int gaudi_host_pack_matrix_split(int H, int ldw, int col0, int HP, int transpose
  * UNSCALED, [tile][k-step q][lane (row, g)] = w[row][16 (T - 1) + 4 q + g]. */
 int gaudi_host_pack_matrix_f16(int H, int ldw, int col0, int HP, int transpose, float scale, const float* W, float* packed_out);
 /* The power-of-two scale gaudi_load_edm / gaudi_load_predictor give a network's weight images: the largest finite |w| of the n
- * blocks (rows[i] x cols[i], row stride ldw[i]) lands in [2^13, 2^14).  0: refused (an infinite weight, or a block whose largest
- * entry lies more than 2^12 below the largest of all) -- such a network runs the fp32-instruction kernels. */
+ * blocks (rows[i] x cols[i], row stride ldw[i]) lands in [2^13, 2^14).  0: refused -- an infinite weight, or a block whose largest
+ * entry lies more than 2^17 below the largest of all (the blocks are judged as edge-level matrices; node-level ones may lie 2^25
+ * below: round 6, through round 5 the rule was 2^12 for all) -- such a network runs the fp32-instruction kernels, and the load
+ * leaves a warning (gaudi_last_warning). */
 int gaudi_host_weight_scale(int n, const float* const* blocks, const int32_t* rows, const int32_t* cols, const int32_t* ldw,
                             float* scale_out);
 /* LDS layout of the fp16-pair node GEMMs' activation copies (csrc/w8_nodes_f16.h; no reference counterpart: the reference's

@@ -244,8 +244,9 @@ def test_host_pack_matrix_f16_node_image():
 
 
 def test_host_weight_scale_refusals():
-    """NodeScale (gaudi_hip.hip): an infinite weight, or a matrix whose largest entry lies more than 2^12 below the largest of
-    all, refuses the fp16 images (scale 0: the network runs the fp32-instruction kernels); NaN entries are ignored."""
+    """NodeScale (gaudi_hip.hip): an infinite weight, or a matrix whose largest entry lies more than 2^17 below the largest of
+    all (edge-level matrices; round 6 -- 2^12 through round 5), refuses the fp16 images (scale 0: the network runs the
+    fp32-instruction kernels); NaN entries are ignored."""
     lib, L = _lib()
     rng = np.random.default_rng(5)
     a = rng.standard_normal((8, 8)).astype(np.float32)
@@ -265,7 +266,8 @@ def test_host_weight_scale_refusals():
     assert scale(c, b) == scale(a, b)
     c[1, 1] = np.inf
     assert scale(c, b) == 0
-    assert scale(a, (b * 1e-3).astype(np.float32)) == 0  # 1e-5 of the largest matrix
+    assert scale(a, (b * 1e-3).astype(np.float32)) == scale(a, b)  # 1e-5 of the largest matrix: refused through round 5
+    assert scale(a, (b * 1e-5).astype(np.float32)) == 0  # 1e-7: beyond 2^-17
 
 
 def test_node_operand_layout_is_bank_conflict_free():

@@ -181,3 +181,28 @@ def test_kept_split_copy_of_h_changes_nothing(widths):
         assert np.array_equal(u, v)
     gamma = O.gamma_table("polynomial_2", T, 1e-5)
     assert rel_err(outs[1][4], O.step_guided(esd, eargs, psd, pargs, gamma, 3, z, nm, em, eps, w, 0.6)) < 1e-4
+
+
+def test_half_ring_mode_is_reached_and_checked():
+    """since the fp16-pair ring shrank to 52 KiB the half-ring mode (two trips per K chunk, SplitGeo<HP, 2>) is only
+    reached where 22 node slots leave no room for the full ring -- wide groups (two 11-ring cata molecules per workgroup) -- and
+    no test asserted that it still IS reached.  Forced wide groups at the default widths: edge_math reports mode 2, the result
+    equals the one-molecule-per-workgroup launch (full ring) bit for bit (bench.py gates the same launch shape at 1 024 molecules
+    against the C++ port: secondary.c3_b1024)."""
+    from oracle import gaudi_oracle as O
+    T = 6
+    eargs, pargs = synth.edm_args(diffusion_steps=T), synth.pred_args()
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=51)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=52)
+    nm, em = O.build_masks([11, 11, 11, 9], 11, False)
+    w = O.target_max_gap_weights(5)
+    res = []
+    for env, want in (({"GAUDI_PAIRS": 0}, 1), ({"GAUDI_PAIRS": 2}, 2)):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        x, h, _ = eng.sample(nm, em, seed=4, target_w=w, scale=0.6)
+        assert eng.edge_math()[1] == want, (env, eng.edge_math())
+        wg, slots = eng.last_launch_shape()
+        assert (wg, slots) == ((4, 11) if want == 1 else (2, 22))
+        res.append((x, h))
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
