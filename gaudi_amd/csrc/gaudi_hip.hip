@@ -817,11 +817,15 @@ static kernel_fn pick_kernel8h(int hpe, int hpp) {
   return f;
 }
 // ... and the kernels whose predictor runs several rounds of edge tiles (kern8m_*.hip: graphs of more than 128 slots)
-#ifdef GAUDI_STAMP_STUBS
+#if defined(GAUDI_STAMP_STUBS) && !defined(GAUDI_STAMP_M)
 static kernel_fn pick_kernel8m(int, int, int) { return nullptr; }
+#else
+#ifdef GAUDI_STAMP_STUBS  // tools/build_stamped.sh m: the fused MR half-ring kernel (what wide groups run) with phase stamps
+#define GAUDI_KERNEL8M_TUS(X) X(fused_192_208_h)
 #else
 #define GAUDI_KERNEL8M_TUS(X) \
   X(fused_192_208_s) X(fused_192_208_h) X(fused_192_208_f) X(pred_208_s) X(pred_208_h) X(pred_208_f) X(fused_tiny) X(pred_small)
+#endif
 #define X(name) kernel_fn gaudi_kern8m_##name(int hpe, int hpp, int mode);
 GAUDI_KERNEL8M_TUS(X)
 #undef X

@@ -27,8 +27,9 @@
 #pragma once
 #include "w8_common.h"
 #ifndef GAUDI_EDGE_PRIO
-#define GAUDI_EDGE_PRIO 0  // experiment (round 6): waves 4-7 at s_setprio 1 inside the generating edge GEMM's trips -- what pays in the node
-                           // GEMMs' K loops LOSES here: C3 208.3 -> 206.1 mol/s, C4 245.1 -> 244.5 (same-session A/B)
+#define GAUDI_EDGE_PRIO 0  // experiment (round 6): waves 4-7 at s_setprio 1 inside the trips -- bit 0: the generating edge GEMM, bit 1: the chained
+                           // ones.  What pays in the node GEMMs' K loops LOSES here (same-session A/B, C3 mol/s): generating 208.3 -> 206.1 (C4
+                           // 245.1 -> 244.5), chained 208.1 -> 206.2
 #endif
 
 // (The experiment variants of rounds 2-3 -- LDS-counter trips, register-staged ring, sliced input generation, L2 touches, cache
@@ -302,7 +303,7 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
   B3 bin = gen(0), nb = bin;
   static_assert(G::NH <= 3, "at most three trips per K chunk");
   const bool tail = G::kTailOK && ring.ktail;
-#if GAUDI_EDGE_PRIO
+#if GAUDI_EDGE_PRIO & 1
   if (wave >= kWaves / 2) __builtin_amdgcn_s_setprio(1);
 #endif
   auto chunk = [&](int m, const B3& bin, B3& nb) {  // consumes `bin`, generates the next chunk into `nb`
@@ -342,7 +343,7 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
       trip_close(ring, lane);
     }
   }
-#if GAUDI_EDGE_PRIO
+#if GAUDI_EDGE_PRIO & 1
   __builtin_amdgcn_s_setprio(0);
 #endif
   const float dsc = sc.inv * ring.winv;
@@ -369,6 +370,9 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
   const float se = sc.s;
   static_assert(G::NH <= 3, "at most three trips per K chunk");
   const int c = lane & 15;
+#if GAUDI_EDGE_PRIO & 2
+  if (wave >= kWaves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   auto chunk = [&](auto m_tag) {
     constexpr int m = decltype(m_tag)::value;
     const B3 bin = split8(in[2 * m], 2 * m + 1 < T ? in[2 * m + 1 < T ? 2 * m + 1 : 0] : splat(0.f), se);
@@ -385,6 +389,9 @@ __device__ __forceinline__ void edge_gemm_regs_s(f4 (&out)[HP / 16], const f4 (&
     if constexpr (G::NH > 2) trip(std::integral_constant<int, 2>{});
   };
   auto finish = [&] {  // descale, then bias and the per-row initial value
+#if GAUDI_EDGE_PRIO & 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const float dsc = sc.inv * ring.winv;
 #pragma unroll
     for (int t = 0; t < T; ++t) {

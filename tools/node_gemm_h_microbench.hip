@@ -11,6 +11,12 @@
 #include <vector>
 #include "w8_nodes_f16.h"
 using namespace gaudi;
+#ifndef GAUDI_MB_AHEAD
+#define GAUDI_MB_AHEAD w8::kAheadAll  // chunks that travel ahead of a call; w8::kAheadOne: what most call sites of the kernels use
+#endif
+#ifndef GAUDI_MB_FL
+#define GAUDI_MB_FL false  // true: the FL form (lane addresses recomputed per call: the MR / GN / FR kernels)
+#endif
 #ifndef GAUDI_MB_MAXNT
 #define GAUDI_MB_MAXNT 3  // column tiles per pass the fp16 form is instantiated for (2: the resident kernels; N = 40 runs are skipped)
 #endif
@@ -30,7 +36,7 @@ struct Sel<HP, 0> {
 template <int HP>
 struct Sel<HP, 3> {
   using PF = w8::NodePFH<HP>;
-  static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tw, int N) { w8::node_prefetch_h<HP>(pf, wb, W, wave, lane); }
+  static __device__ __forceinline__ void prefetch(PF& pf, const WBuf& wb, int W, int wave, int lane, bool tw, int N) { w8::node_prefetch_h<HP, GAUDI_MB_AHEAD>(pf, wb, W, wave, lane); }
   template <int EPI>
   static __device__ __forceinline__ void gemm(const WBuf& wb, int Wa, const float* sXa, int Wb, const float* sXb, const float* sB, float* sY, int N,
                                               int wave, int lane, bool tw, PF* pf, int nextW, float* split, float winv, bool seq,
@@ -38,10 +44,10 @@ struct Sel<HP, 3> {
     const int nct = N <= 16 ? 1 : N <= 32 ? 2 : 3;
     w8::NodeCtxH cx{winv, split + 96, seq ? split + 96 : split + 96 + w8::nh_split_floats(HP, nct), tw, split};
     if (Wb >= 0)
-      w8::node_gemm_h<HP, EPI, true, GAUDI_MB_MAXNT, w8::kAheadAll, w8::kAheadAll>(wb, Wa, sXa, true, Wb, sXb, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW,
+      w8::node_gemm_h<HP, EPI, true, GAUDI_MB_MAXNT, GAUDI_MB_AHEAD, GAUDI_MB_AHEAD, GAUDI_MB_FL>(wb, Wa, sXa, true, Wb, sXb, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW,
                                                                                     nullptr, nullptr, ns);
     else
-      w8::node_gemm_h<HP, EPI, false, GAUDI_MB_MAXNT, w8::kAheadAll, w8::kAheadAll>(wb, Wa, sXa, true, -1, nullptr, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW,
+      w8::node_gemm_h<HP, EPI, false, GAUDI_MB_MAXNT, GAUDI_MB_AHEAD, GAUDI_MB_AHEAD, GAUDI_MB_FL>(wb, Wa, sXa, true, -1, nullptr, sB, sY, nullptr, nullptr, N, wave, lane, cx, *pf, nextW,
                                                                                      nullptr, nullptr, ns);
   }
 };
