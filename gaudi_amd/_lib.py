@@ -20,7 +20,7 @@ class EdmConfig(C.Structure):
                 ("inv_sublayers", C.c_int32), ("attention", C.c_int32), ("tanh", C.c_int32),
                 ("coords_range", C.c_float), ("norm_constant", C.c_float), ("normalization_factor", C.c_float),
                 ("diffusion_steps", C.c_int32), ("noise_power", C.c_float), ("noise_precision", C.c_float),
-                ("norm_values", C.c_float * 3)]
+                ("norm_values", C.c_float * 3), ("sin_embedding", C.c_int32)]
 
 
 class PredConfig(C.Structure):
@@ -112,7 +112,7 @@ EXPORTS = {
                                       C.POINTER(C.c_int32)]),
 }
 
-ABI_VERSION = 6  # include/gaudi_hip.h: GAUDI_ABI_VERSION
+ABI_VERSION = 7  # include/gaudi_hip.h: GAUDI_ABI_VERSION
 _ROUND6_EXPORTS = ("gaudi_last_warning", "gaudi_abi_version", "gaudi_last_family_split", "gaudi_profile_clock", "gaudi_last_keep_h")  # an older A/B library (GAUDI_LIB) lacks them
 
 _lib = None

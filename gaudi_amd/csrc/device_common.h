@@ -502,6 +502,7 @@ __device__ __forceinline__ void node_gemm(const WBuf& wb, int Wa, const float* s
 struct EdgeCol {
   int i, j;      // receiving / sending node of the lane's edge column
   float r, d0;   // radial (current x) and d0 (input x) of that edge
+  const float* ft = nullptr;  // sin_embedding checkpoints (EF = 24): the edge's 24 sinusoid features in LDS (edm_device.h)
 };
 
 // u[f] for f = 16cc+4g+q of one edge column
@@ -514,6 +515,22 @@ __device__ __forceinline__ f4 edge_u(const float* p, const float* q, const float
   return *(const f4*)(p + 16 * cc) + *(const f4*)(q + 16 * cc) + crv * r + cdv * d0;
 }
 
+// The same with EF edge features instead of (r, d0): `sin_embedding=True` (edm/egnn/egnn_new.py:269-273,378-391) replaces the two
+// scalar inputs of the first Linear by 2 x 12 sinusoids of sqrt(r), sqrt(d0); the factorised W1 = [A | B | C] then has EF = 24
+// columns C_k (staged in LDS like cr / cd: sC + k HP) and u = P_i + Q_j + sum_k C_k feat_k.  Only the 4-wave kernels carry this
+// form (a K = 24 contraction per value in the stage that generates the edge GEMM's input).
+template <int EF>
+__device__ __forceinline__ f4 edge_u_ef(const float* p, const float* q, const float* sC, int HPv, int g, int cc, const float* ft) {
+  f4 u = *(const f4*)(p + 16 * cc) + *(const f4*)(q + 16 * cc);
+#pragma unroll
+  for (int k4 = 0; k4 < EF / 4; ++k4) {
+    const f4 fv = *(const f4*)(ft + 4 * k4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u = u + *(const f4*)(sC + (4 * k4 + k) * HPv + 16 * cc + 4 * g) * fv[k];
+  }
+  return u;
+}
+
 // "K tail" (8-wave kernels): a hidden size with H % 16 == 4 (196, 36) leaves 4 valid inputs in the last K chunk -- exactly
 // one MFMA k-step.  That chunk is packed with input 16(T-1)+g on lane group g, element 0 (both operands), and costs one
 // MFMA per tile instead of four.  u of the tail chunk for the lane's edge column; p / q point at the row + 4g.
@@ -523,7 +540,9 @@ __device__ __forceinline__ f4 edge_u_tail(const float* p, const float* q, const 
   return (f4){p[f - 4 * g] + q[f - 4 * g] + sCr[f] * r + sCd[f] * d0, 0.f, 0.f, 0.f};
 }
 
-template <int HP, int NE>
+// EF: edge features of the first Linear -- 2: (r, d0) with their columns sCr, sCd; 24 (sin_embedding): sCr = the EF columns [EF][HP],
+// sCd unused, the features come from ec[e].ft
+template <int HP, int NE, int EF = 2>
 __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const WBuf& wb, int W2, const float* sB2,
                                                   const float* sCr, const float* sCd,
                                                   const float* sP, const float* sQ, const EdgeCol (&ec)[NE], int lane) {
@@ -551,7 +570,10 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
   for (int p = 0; p < PF; ++p) wq[p] = ldw4(wb, W2 + 256 * p, lo);
   f4 bin[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) bin[e] = silu4(edge_u(pp[e], qq[e], sCr, sCd, g, 0, ec[e].r, ec[e].d0));
+  for (int e = 0; e < NE; ++e) {
+    if constexpr (EF == 2) bin[e] = silu4(edge_u(pp[e], qq[e], sCr, sCd, g, 0, ec[e].r, ec[e].d0));
+    else bin[e] = silu4(edge_u_ef<EF>(pp[e], qq[e], sCr, HP, g, 0, ec[e].ft));
+  }
   // K loop stays rolled (one 16-feature chunk per trip): the weight tiles of the next chunk are
   // prefetched by the tail of this one (rotating queue) and the next chunk's activations are
   // generated under this chunk's MFMAs.
@@ -578,7 +600,10 @@ __device__ __forceinline__ void edge_gemm_from_pq(f4 (&acc)[NE][HP / 16], const 
       if (t0 == 0) {  // next chunk's activations (clamped on the last trip: no branch), interleaved with group 0
         const int ncc = cc + 1 < T ? cc + 1 : T - 1;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) nb[e] = silu4(edge_u(pp[e], qq[e], sCr, sCd, g, ncc, ec[e].r, ec[e].d0));
+        for (int e = 0; e < NE; ++e) {
+          if constexpr (EF == 2) nb[e] = silu4(edge_u(pp[e], qq[e], sCr, sCd, g, ncc, ec[e].r, ec[e].d0));
+          else nb[e] = silu4(edge_u_ef<EF>(pp[e], qq[e], sCr, HP, g, ncc, ec[e].ft));
+        }
       }
 #if GAUDI_PIN_SCHED
       // Plain scheduling fences in source order: MFMA group | refills of the slots it read | next group ...

@@ -11,16 +11,19 @@ namespace gaudi {
 //          EqU     { A, Bm, W2 (3 PK) | cr, cd, b1, b2, w3 (5 HP) | max|cr|, max|cd| (16) }
 //          (the GCL's 16-float block holds ba, max|cr|, max|cd|: the column maxima bound the split edge GEMMs' scales, w8_split.h)
 // A/Bm/cr/cd are the column blocks of Linear(2H+2 -> H): W1 = [A | Bm | cr | cd].
+//   sin_embedding checkpoints (EF = 24 edge features instead of 2, egnn_new.py:269-273): cr, cd become the EF columns C_0 .. C_23 of
+//   W1 = [A | Bm | C]; the vector blocks grow to (5 + EF) HP + 16 and (3 + EF) HP + 16 floats
 struct EdmLayout {
   int HP, F1, L, S;
+  int EF = 2;  // edge features of the first Linear of every edge / coordinate MLP
   __host__ __device__ int pk() const { return HP * HP; }
   __host__ __device__ int emb_w() const { return 0; }
   __host__ __device__ int emb_b() const { return align16(HP * F1); }
   __host__ __device__ int out_w() const { return emb_b() + HP; }
   __host__ __device__ int out_b() const { return out_w() + align16(F1 * HP); }
   __host__ __device__ int blocks() const { return out_b() + 16; }
-  __host__ __device__ int gcl_size() const { return 6 * pk() + 7 * HP + 16; }
-  __host__ __device__ int equ_size() const { return 3 * pk() + 5 * HP + 16; }
+  __host__ __device__ int gcl_size() const { return 6 * pk() + (5 + EF) * HP + 16; }
+  __host__ __device__ int equ_size() const { return 3 * pk() + (3 + EF) * HP + 16; }
   __host__ __device__ int block_size() const { return S * gcl_size() + equ_size(); }
   __host__ __device__ int gcl(int l, int s) const { return blocks() + l * block_size() + s * gcl_size(); }
   __host__ __device__ int equ(int l) const { return blocks() + l * block_size() + S * gcl_size(); }
@@ -59,9 +62,13 @@ struct MolGraph {
 // cross-wave hand-off of them already sits behind a workgroup barrier, which orders global memory inside a workgroup too).
 // The code is the same: the pointers carry their address space, hipcc emits global loads / stores for them.  Slower, but it
 // lifts the graph-size limit of the library to what the reference accepts (sampling_edm.py:172-209 has no cap).
-template <int HP, bool GN = false>
+// EF = 24 (sin_embedding): the vector block holds the 24 feature columns, and every edge slot its 24 sinusoid features
+// (feat: [4][EW][EF], the d0 half written once per evaluation, the r half once per block)
+template <int HP, bool GN = false, int EF = 2>
 struct NetSmem {
   static constexpr bool kGlobalNodes = GN;
+  static constexpr int kEF = EF;
+  float* feat = nullptr;   // [4][EW][EF] (EF > 2 only)
   float *h, *p, *q, *agg;  // [N][HP+4]
   float* scr;              // [4][16][HP+4]  per-wave transposition scratch
   float *x, *x0;           // [N][4]
@@ -69,8 +76,9 @@ struct NetSmem {
   float* d0;               // [4][EW]
   float* trans;            // [4][EW][4]
   float* vec;              // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
-  __device__ static int floats(int N, int EW) {
-    return (GN ? 0 : 4 * N * (HP + 4)) + kWaves * 16 * (HP + 4) + 8 * N + kWaves * EW * 9 + 8 * HP;
+  __host__ __device__ static int floats(int N, int EW) {
+    return (GN ? 0 : 4 * N * (HP + 4)) + kWaves * 16 * (HP + 4) + 8 * N + kWaves * EW * 9 + (6 + EF) * HP +
+           (EF > 2 ? kWaves * EW * EF : 0);
   }
   __device__ void carve(float* base, int N, int EW, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
@@ -85,9 +93,24 @@ struct NetSmem {
     geo = (f4*)base; base += kWaves * EW * 4;
     d0 = base; base += kWaves * EW;
     trans = base; base += kWaves * EW * 4;
-    vec = base;
+    vec = base; base += (6 + EF) * HP;
+    if (EF > 2) feat = base;
   }
 };
+
+// SinusoidsEmbeddingNew (egnn_new.py:378-391): x -> sqrt(x + 1e-8) * f_k, (sin | cos), f_k = 2 pi 4^k / 15 (k = 0..5) in the fp32
+// values torch builds (oracle/gaudi_oracle.py: sin_frequencies; tests/golden/g22 holds the reference's tensor).  Accurate sinf / cosf:
+// the highest frequency multiplies sqrt(r) by 429.
+__device__ __forceinline__ void sin_features(float x, float* out /* [12] */) {
+  constexpr float kFreq[6] = {4.1887903e-01f, 1.6755161e+00f, 6.7020645e+00f, 2.6808258e+01f, 1.0723303e+02f, 4.2893213e+02f};
+  const float sx = sqrtf(x + 1e-8f);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float e = sx * kFreq[k];
+    out[k] = sinf(e);
+    out[6 + k] = cosf(e);
+  }
+}
 
 __device__ __forceinline__ void edge_ij(uint32_t e, int& i, int& j) { i = e & 255; j = (e >> 8) & 255; }
 
@@ -108,6 +131,10 @@ __device__ __forceinline__ void compute_geo(const SM& sm, const MolGraph& mg, fl
       const float inv = 1.0f / (sqrtf(r + 1e-8f) + norm_constant);
       sm.geo[wave * mg.EW + slot] = (f4){r, dx * inv, dy * inv, dz * inv};
     }
+    if constexpr (SM::kEF > 2) {  // edge_attr = [sin_embedding(r) | sin_embedding(d0)] (egnn_new.py:217-219, 302-303)
+      float* ft = sm.feat + (size_t)(wave * mg.EW + slot) * SM::kEF + (write_d0 ? SM::kEF / 2 : 0);
+      sin_features(r, ft);
+    }
   }
 }
 
@@ -122,6 +149,7 @@ __device__ __forceinline__ void load_cols(const SM& sm, const MolGraph& mg, int 
     geo[e] = sm.geo[s];
     ec[e].r = geo[e][0];
     ec[e].d0 = sm.d0[s];
+    if constexpr (SM::kEF > 2) ec[e].ft = sm.feat + (size_t)s * SM::kEF;
   }
 }
 
@@ -146,7 +174,8 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   constexpr int T = HP / 16;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int N = mg.N, D = mg.D, F = W.F, F1 = F + 1;
-  EdmLayout lay{HP, F1, W.L, W.S};
+  constexpr int EF = SM::kEF;  // edge features: 2, or 24 for sin_embedding checkpoints
+  EdmLayout lay{HP, F1, W.L, W.S, EF};
   const float* __restrict__ w = W.w;
   const WBuf wb = make_wbuf(W.w, W.w_bytes);
 
@@ -174,9 +203,10 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
   compute_geo(sm, mg, 0.f, wave, lane, true);  // d0 of the input coordinates (egnn_new.py:301)
   NodePF<HP> pf;  // first weight tiles of the next node GEMM, loaded ahead of it (device_common.h)
   node_prefetch<HP>(pf, wb, lay.gcl(0, 0), wave, lane);
-  constexpr int NV = (7 * HP + 16 + kThreads - 1) / kThreads;
-  VecPF<NV> vpf;  // the next sub-layer's vectors (GCL: 7 HP + 16 floats, EquivariantUpdate: 5 HP), loaded a phase ahead
-  vec_prefetch(vpf, wb, lay.gcl(0, 0) + 6 * HP * HP, 7 * HP + 16, tid);
+  constexpr int kVG = (5 + EF) * HP + 16, kVE = (3 + EF) * HP;  // floats of a GCL's / an EquivariantUpdate's vector block
+  constexpr int NV = (kVG + kThreads - 1) / kThreads;
+  VecPF<NV> vpf;  // the next sub-layer's vectors, loaded a phase ahead
+  vec_prefetch(vpf, wb, lay.gcl(0, 0) + 6 * HP * HP, kVG, tid);
   STAMP(ST_EDM_IO);
 
   for (int l = 0; l < W.L; ++l) {
@@ -188,12 +218,12 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int V = G + 6 * PK;
       // stage the layer's vectors in LDS (previous readers are behind the barrier that ended the last layer)
       (void)V;
-      vec_commit(vpf, sm.vec, 7 * HP + 16, tid);
+      vec_commit(vpf, sm.vec, kVG, tid);
       __syncthreads();
       STAMP(ST_STAGE);
-      const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *wa = sm.vec + 4 * HP,
-                  *bn1 = sm.vec + 5 * HP, *bn2 = sm.vec + 6 * HP;
-      const float ba = sm.vec[7 * HP];
+      const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + EF * HP, *b2 = sm.vec + (EF + 1) * HP, *wa = sm.vec + (EF + 2) * HP,
+                  *bn1 = sm.vec + (EF + 3) * HP, *bn2 = sm.vec + (EF + 4) * HP;
+      const float ba = sm.vec[(EF + 5) * HP];
       node_gemm<HP, EPI_NONE, true>(wb, G, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, G + PK);
       node_gemm<HP, EPI_NONE, true>(wb, G + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf);
       for (int idx = tid; idx < N * LD; idx += kThreads) sm.agg[idx] = 0.f;
@@ -210,7 +240,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           f4 geo2[2];
           load_cols<SM, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
           f4 acc[2][T];
-          edge_gemm_from_pq<HP, 2>(acc, wb, G + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+          edge_gemm_from_pq<HP, 2, EF>(acc, wb, G + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
           STAMP(ST_EDGE);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
@@ -243,7 +273,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       STAMP(ST_NODE);
       __syncthreads();
       STAMP(ST_BARRIER);
-      vec_prefetch(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK, s + 1 < W.S ? 7 * HP + 16 : 5 * HP, tid);
+      vec_prefetch(vpf, wb, s + 1 < W.S ? lay.gcl(l, s + 1) + 6 * PK : lay.equ(l) + 3 * PK, s + 1 < W.S ? kVG : kVE, tid);
       node_gemm<HP, EPI_RESIDUAL_MASK, true>(wb, G + 5 * PK, sm.p, -1, nullptr, bn2, sm.h, sm.h, mg.mask, mg.NC, wave, lane,
                                              &pf, s + 1 < W.S ? lay.gcl(l, s + 1) : lay.equ(l));
       STAMP(ST_NODE);
@@ -256,10 +286,10 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       const int PK = HP * HP;
       const int V = E + 3 * PK;
       (void)V;
-      vec_commit(vpf, sm.vec, 5 * HP, tid);
+      vec_commit(vpf, sm.vec, kVE, tid);
       __syncthreads();
       STAMP(ST_STAGE);
-      const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + 2 * HP, *b2 = sm.vec + 3 * HP, *w3 = sm.vec + 4 * HP;
+      const float *cr = sm.vec, *cd = sm.vec + HP, *b1 = sm.vec + EF * HP, *b2 = sm.vec + (EF + 1) * HP, *w3 = sm.vec + (EF + 2) * HP;
       node_gemm<HP, EPI_NONE, true>(wb, E, sm.h, -1, nullptr, b1, sm.p, nullptr, nullptr, mg.NC, wave, lane, &pf, E + PK);
       node_gemm<HP, EPI_NONE, true>(wb, E + PK, sm.h, -1, nullptr, nullptr, sm.q, nullptr, nullptr, mg.NC, wave, lane, &pf);
       STAMP(ST_NODE);
@@ -271,7 +301,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
         f4 geo2[2];
         load_cols<SM, 2>(sm, mg, wave, tp * 32, c, ec, mk2, geo2);
         f4 acc[2][T];
-        edge_gemm_from_pq<HP, 2>(acc, wb, E + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
+        edge_gemm_from_pq<HP, 2, EF>(acc, wb, E + 2 * PK, b2, cr, cd, sm.p, sm.q, ec, lane);
         STAMP(ST_EDGE);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -294,7 +324,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
       }
       if (l + 1 < W.L) {
         node_prefetch<HP>(pf, wb, lay.gcl(l + 1, 0), wave, lane);
-        vec_prefetch(vpf, wb, lay.gcl(l + 1, 0) + 6 * HP * HP, 7 * HP + 16, tid);  // travels across the barrier and coord_update
+        vec_prefetch(vpf, wb, lay.gcl(l + 1, 0) + 6 * HP * HP, kVG, tid);  // travels across the barrier and coord_update
       }
       STAMP(ST_EDGE_EPI);
       __syncthreads();

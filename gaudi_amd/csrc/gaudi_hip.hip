@@ -742,6 +742,20 @@ static bool have_kernels_g(int hpe, int hpp) {
 }
 #endif
 
+// the 4-wave kernels of sin_embedding denoisers (kernse_*.hip: 24 edge features instead of 2, edm_device.h); the predictor-only
+// launches of such a handle (no sin_embedding there) take the ordinary kernels
+#ifdef GAUDI_STAMP_STUBS
+static kernel_fn pick_kernel_se(int, int, bool) { return nullptr; }
+#else
+kernel_fn gaudi_kernse_edm(int hpe, int hpp, int gn);
+kernel_fn gaudi_kernse_fused(int hpe, int hpp, int gn);
+static kernel_fn pick_kernel_se(int hpe, int hpp, bool gn) {
+  kernel_fn f = gaudi_kernse_edm(hpe, hpp, gn);
+  if (!f) f = gaudi_kernse_fused(hpe, hpp, gn);
+  return f;
+}
+#endif
+
 // the 8-wave instantiations (kern8_*.hip)
 #ifdef GAUDI_STAMP_STUBS
 #define GAUDI_KERNEL8_TUS(X) X(edm_192) X(fused_192_208)
@@ -878,9 +892,12 @@ static int round_hidden(int H) {
 // dealt to the waves, the longest list rounded up to 32)
 static int dense_ew4(int N) { return std::max(32, ((N + kWaves - 1) / kWaves * (N - 1) + 31) / 32 * 32); }
 
-static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW, bool gn = false) {
+// ef: edge features of the denoiser's first Linears (2, or 24 for sin_embedding: edm_device.h, NetSmem)
+static size_t lds_bytes(int hpe, int hpp, int N, int D, int EW, bool gn = false, int ef = 2) {
   size_t net = 0;
-  if (hpe) net = std::max(net, (size_t)((gn ? 0 : 4 * N * (hpe + 4)) + kWaves * 16 * (hpe + 4) + 8 * N + kWaves * EW * 9 + 8 * hpe));
+  if (hpe)
+    net = std::max(net, (size_t)((gn ? 0 : 4 * N * (hpe + 4)) + kWaves * 16 * (hpe + 4) + 8 * N + kWaves * EW * 9 + (6 + ef) * hpe +
+                                 (ef > 2 ? kWaves * EW * ef : 0)));
   if (hpp) net = std::max(net, (size_t)((gn ? 0 : 5 * N * (hpp + 4)) + kWaves * 16 * (hpp + 4) + 12 * N + kWaves * EW * 10 + 32 + 10 * hpp));
   return sizeof(float) * (common_floats(N, D, EW) + net);
 }
@@ -940,16 +957,19 @@ static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, int sp
 
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
   const bool v8 = h->run_variant == 8;
-  kernel_fn fn = v8 ? (h->run_gn8 ? pick_kernel8g(hpe, hpp) : pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp))
-                    : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
+  const bool se = hpe && h->ecfg.sin_embedding;  // stage_graph keeps such a call on the 4-wave family
+  kernel_fn fn = v8   ? (h->run_gn8 ? pick_kernel8g(hpe, hpp) : pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp))
+                 : se ? pick_kernel_se(hpe, hpp, h->run_gn)
+                      : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
   // two column tiles per node GEMM on the resident full-ring kernel: its FR instantiation (same arithmetic, same results)
   if (v8 && !h->run_gn8 && h->run_split == 1 && !(h->run_mr && hpp) && P.N > 16 && !getenv("GAUDI_NO_FR"))
     if (kernel_fn f2 = pick_kernel8s2(hpe, hpp)) fn = f2;
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
-                    (v8 ? " in the 8-wave family" : ""));
-  size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split, h->run_gn8) : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW, h->run_gn);
+                    (v8 ? " in the 8-wave family" : se ? " among the sin_embedding kernels (hidden sizes 32 and 192, predictor 48 / 208)" : ""));
+  size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split, h->run_gn8)
+                  : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW, h->run_gn, se ? 24 : 2);
   if (v8 && P.hk_off) lds = sizeof(float) * ((size_t)P.hk_off + (size_t)h->run_hk);  // the kept split copy of h sits behind the FUSED plan
   if (lds > 160 * 1024)
     return fail(h, GAUDI_E_CAPACITY, "molecule needs " + std::to_string(lds) + " B of LDS (>160 KiB): N too large");
@@ -1326,7 +1346,9 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   h->run_mr = false;
   h->run_groups = B;
   h->run_nslots = N;
-  if (h->variant == 8 && !h->force_gn) {
+  // a sin_embedding denoiser (24 edge features per first Linear, egnn_new.py:269-273) exists in the 4-wave family only
+  const bool se = hpe && h->ecfg.sin_embedding;
+  if (h->variant == 8 && !h->force_gn && !se) {
     const int rc8 = stage_graph8(h, B, N, node_mask, edge_mask, P, hpe, hpp);
     if (rc8 <= 0) return rc8;
     h->run_variant = 4;  // fall back to the 4-wave kernels for this call
@@ -1376,8 +1398,10 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   // hetero batch of 18-20 nodes fits the resident kernels where the dense graph would not).
   const int Dz = 3 + (hpe ? h->ecfg.in_node_nf : h->pcfg.in_nf);
   const bool part_of_batch = h->plan_min_slots || h->plan_force_waves || h->call_min_slots || h->call_force_waves || h->call_cut;
-  if (h->force_gn || lds_bytes(hpe, hpp, N, Dz, part_of_batch ? std::max(M.EW, dense_ew4(N)) : M.EW) > 160 * 1024) {
-    if (have_kernels_g(hpe, hpp) && lds_bytes(hpe, hpp, N, Dz, M.EW, true) <= 160 * 1024) {
+  const int ef = se ? 24 : 2;
+  const bool have_g = se ? (pick_kernel_se(hpe, 0, true) && (!hpp || pick_kernel_g(0, hpp))) : have_kernels_g(hpe, hpp);
+  if (h->force_gn || lds_bytes(hpe, hpp, N, Dz, part_of_batch ? std::max(M.EW, dense_ew4(N)) : M.EW, false, ef) > 160 * 1024) {
+    if (have_g && lds_bytes(hpe, hpp, N, Dz, M.EW, true, ef) <= 160 * 1024) {
       h->run_gn = true;
       const size_t stride = (gnode_floats(hpe, hpp, N) + 63) / 64 * 64;
       HIPCHECK(h, h->d_gnode.reserve(sizeof(float) * stride * (size_t)B));
@@ -1512,7 +1536,8 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
   if (!HP) return fail(h, GAUDI_E_INVALID, "no kernel instantiated for this hidden size");
   Tensors T;
   for (int i = 0; i < n; ++i) T.m[names[i]] = {tensors[i], numel[i]};
-  EdmLayout lay{HP, F1, L, S};
+  const int EF = cfg->sin_embedding ? 24 : 2;  // edge_feat_nf (egnn_new.py:269-273): 2 x 12 sinusoids of (r, d0), or the two scalars
+  EdmLayout lay{HP, F1, L, S, EF};
   const std::string p = "dynamics.egnn.";
   const int PK = HP * HP;
   // tile layout: lane-linear for the 8-wave kernels, row-major for the 4-wave ones (kept as the fallback of the 8-wave
@@ -1524,7 +1549,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
     for (int l = 0; l < L; ++l) {
       for (int s = 0; s <= S; ++s) {
         const std::string q = p + "e_block_" + std::to_string(l) + (s < S ? ".gcl_" + std::to_string(s) + "." : ".gcl_equiv.");
-        ns.see(T.peek(q + (s < S ? "edge_mlp.0.weight" : "coord_mlp.0.weight"), (int64_t)H * (2 * H + 2)), H, 2 * H + 2, 0, 2 * H);
+        ns.see(T.peek(q + (s < S ? "edge_mlp.0.weight" : "coord_mlp.0.weight"), (int64_t)H * (2 * H + EF)), H, 2 * H + EF, 0, 2 * H);
         ns.see(T.peek(q + (s < S ? "edge_mlp.2.weight" : "coord_mlp.2.weight"), (int64_t)H * H), H, H, 0, H, true);
         if (s < S) {
           ns.see(T.peek(q + "node_mlp.0.weight", (int64_t)H * 2 * H), H, 2 * H, 0, 2 * H);
@@ -1533,7 +1558,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
       }
     }
     hscale = ns.scale();
-    if (!(hscale > 0.f) && h->variant == 8 && h->split)
+    if (!(hscale > 0.f) && h->variant == 8 && h->split && EF == 2)
       h->warn = std::string("EDM weights: the fp16-pair images cannot carry this weight set (") + ns.why() +
                 "): its calls run the fp32-instruction kernels (about 0.55 x the speed, same results at fp32 accuracy)";
   }
@@ -1563,7 +1588,7 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
       pack_vec(&w[lay.out_b()], ob, F1);
     }
   }
-  const int ld1 = 2 * H + 2;
+  const int ld1 = 2 * H + EF;
   for (int l = 0; l < L; ++l) {
     for (int s = 0; s < S; ++s) {
       const std::string q = p + "e_block_" + std::to_string(l) + ".gcl_" + std::to_string(s) + ".";
@@ -1589,16 +1614,15 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
       pack_node_matrix(pn, G + 3 * PK, Wn1, H, 2 * H, 0, HP);
       pack_node_matrix(pn, G + 4 * PK, Wn1, H, 2 * H, H, HP);
       pack_node_matrix(pn, G + 5 * PK, Wn2, H, H, 0, HP);
-      pack_col(V, W1, H, ld1, 2 * H);
-      pack_col(V + HP, W1, H, ld1, 2 * H + 1);
-      pack_vec(V + 2 * HP, b1, H);
-      pack_vec(V + 3 * HP, b2, H);
-      if (wa) pack_vec(V + 4 * HP, wa, H);
-      pack_vec(V + 5 * HP, bn1, H);
-      pack_vec(V + 6 * HP, bn2, H);
-      if (ba) V[7 * HP] = ba[0];
-      V[7 * HP + 1] = col_absmax(W1, H, ld1, 2 * H);      // max |c_r|, max |c_d|: the split edge GEMMs' column scales are
-      V[7 * HP + 2] = col_absmax(W1, H, ld1, 2 * H + 1);  // bounded with them (w8_split.h)
+      for (int k = 0; k < EF; ++k) pack_col(V + k * HP, W1, H, ld1, 2 * H + k);  // c_r, c_d (or the 24 sinusoid columns)
+      pack_vec(V + EF * HP, b1, H);
+      pack_vec(V + (EF + 1) * HP, b2, H);
+      if (wa) pack_vec(V + (EF + 2) * HP, wa, H);
+      pack_vec(V + (EF + 3) * HP, bn1, H);
+      pack_vec(V + (EF + 4) * HP, bn2, H);
+      if (ba) V[(EF + 5) * HP] = ba[0];
+      V[(EF + 5) * HP + 1] = col_absmax(W1, H, ld1, 2 * H);      // max |c_r|, max |c_d|: the split edge GEMMs' column scales are
+      V[(EF + 5) * HP + 2] = col_absmax(W1, H, ld1, 2 * H + 1);  // bounded with them (w8_split.h; EF = 2 only)
     }
     const std::string q = p + "e_block_" + std::to_string(l) + ".gcl_equiv.";
     float* E = &w[lay.equ(l)];
@@ -1612,18 +1636,18 @@ int gaudi_load_edm(gaudi_handle* h, const gaudi_edm_config* cfg, int n, const ch
     pack_node_matrix(pn, E, W1, H, ld1, 0, HP);
     pack_node_matrix(pn, E + PK, W1, H, ld1, H, HP);
     pack_edge_matrix(pe, E + 2 * PK, W2, H, H, 0, HP);
-    pack_col(V, W1, H, ld1, 2 * H);
-    pack_col(V + HP, W1, H, ld1, 2 * H + 1);
-    pack_vec(V + 2 * HP, b1, H);
-    pack_vec(V + 3 * HP, b2, H);
-    pack_vec(V + 4 * HP, w3, H);
-    V[5 * HP] = col_absmax(W1, H, ld1, 2 * H);
-    V[5 * HP + 1] = col_absmax(W1, H, ld1, 2 * H + 1);
+    for (int k = 0; k < EF; ++k) pack_col(V + k * HP, W1, H, ld1, 2 * H + k);
+    pack_vec(V + EF * HP, b1, H);
+    pack_vec(V + (EF + 1) * HP, b2, H);
+    pack_vec(V + (EF + 2) * HP, w3, H);
+    V[(EF + 3) * HP] = col_absmax(W1, H, ld1, 2 * H);
+    V[(EF + 3) * HP + 1] = col_absmax(W1, H, ld1, 2 * H + 1);
   }
   };
   std::vector<float> w, ws;
-  const bool want_split = h->variant == 8 && h->split;
-  pack(h->variant == 8, w, want_split ? &ws : nullptr);
+  // a sin_embedding denoiser only ever runs on the 4-wave kernels (stage_graph): no fp16-pair images, and the row-major pack twice
+  const bool want_split = h->variant == 8 && h->split && EF == 2;
+  pack(h->variant == 8 && EF == 2, w, want_split ? &ws : nullptr);
   if (!T.missing.empty()) return fail(h, GAUDI_E_MISSING, "EDM checkpoint tensor missing or mis-shaped: " + T.missing);
   HIPCHECK(h, h->edm_w.reserve(sizeof(float) * w.size()));
   HIPCHECK(h, hipMemcpy(h->edm_w.p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));

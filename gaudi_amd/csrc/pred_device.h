@@ -43,6 +43,7 @@ struct PredDev {
 template <int HP, bool GN = false>  // GN: node buffers in a per-molecule global scratch (edm_device.h: NetSmem)
 struct PredSmem {
   static constexpr bool kGlobalNodes = GN;
+  static constexpr int kEF = 2;  // the predictor has no sin_embedding (egnn_predictor/models.py:452: edge_attr = d0)
   float *b0, *b1, *b2, *b3, *b4;  // [N][HP+4] node buffers (roles change per phase, see below)
   float* scr;                     // [4][16][HP+4]
   float *x, *x0, *dx;             // [N][4]

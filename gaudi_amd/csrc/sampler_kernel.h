@@ -96,12 +96,13 @@ __device__ __forceinline__ int comp_of(int w) { return (w >> 28) & 7; }
 
 // ---- kernel variants: what differs between the 4-wave kernels (one wave per SIMD, per-wave edge lists, weights streamed
 // per wave) and the 8-wave kernels (two waves per SIMD, flat 16-slot tiles, LDS-shared weight ring) behind one sampler body
-template <bool GN>
+// EF: edge features of the denoiser's first Linears -- 24 for sin_embedding checkpoints (edm_device.h), which only this family runs
+template <bool GN, int EF = 2>
 struct V4T {
   static constexpr int kThreads = gaudi::kThreads;
   static constexpr bool kGlobalNodes = GN;
   using Graph = gaudi::MolGraph;
-  template <int HP> using EdmSmem = gaudi::NetSmem<HP, GN>;
+  template <int HP> using EdmSmem = gaudi::NetSmem<HP, GN, EF>;
   __device__ __forceinline__ static void set_rows(Graph&, const int*, int, int) {}  // the 4-wave kernels are never packed
   __host__ __device__ static int graph_floats(int N, int EW) { return 2 * gaudi::kWaves * EW + align16(N); }
   __device__ __forceinline__ static float* load_graph(const KParams& P, int b, float* base, const float* sMask, Graph& mg, int tid, int wave) {
@@ -127,7 +128,7 @@ struct V4T {
   template <int HP>
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
                                              float* sMean, float t_val, int tid STAMP_DECL, float* gnode) {
-    gaudi::NetSmem<HP, GN> sm;
+    gaudi::NetSmem<HP, GN, EF> sm;
     sm.carve(net, mg.N, mg.EW, gnode);
     gaudi::edm_forward<HP>(W, mg, sm, sZ, sEps, sMean, t_val, tid STAMP_ARGS);
   }
@@ -151,6 +152,8 @@ struct V4T {
 };
 using V4 = V4T<false>;
 using V4G = V4T<true>;  // node buffers in global memory: molecules beyond the LDS limit (N up to 255)
+using V4S = V4T<false, 24>;  // sin_embedding denoiser (kern_se_*.hip)
+using V4GS = V4T<true, 24>;
 
 // ---- out-of-line phases of the 8-wave kernels.  Inlined into one 40k-instruction function, the denoiser, the predictor and
 // its reverse pass are register-allocated together and hipcc spills ~200 VGPRs whose reloads land next to the deep weight
@@ -678,6 +681,10 @@ template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel = &sampler_kernel_v<V4, HPE, HPP>;
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel_g = &sampler_kernel_v<V4G, HPE, HPP>;
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel_se = &sampler_kernel_v<V4S, HPE, HPP>;
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel_gse = &sampler_kernel_v<V4GS, HPE, HPP>;
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8 = &sampler_kernel_v<V8, HPE, HPP>;
 template <int HPE, int HPP>

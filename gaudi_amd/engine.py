@@ -130,8 +130,6 @@ class Engine:
     # ------------------------------------------------------------------ weights
     def load_edm(self, args: dict, state_dict: dict):
         """args: the checkpoint's args.txt namespace (utils/args_edm.py); state_dict: model.pt."""
-        if args.get("sin_embedding", False):
-            raise GaudiError("sin_embedding=True checkpoints are not supported")
         agg = args.get("aggregation_method", "sum")
         if agg not in ("sum", "mean"):
             raise GaudiError(f"unknown aggregation_method {agg!r}")
@@ -146,7 +144,8 @@ class Engine:
                         int(bool(args["attention"])), int(bool(args["tanh"])), float(args["coords_range"]),
                         float(args["norm_constant"]), float(args.get("normalization_factor", 1)) if agg == "sum" else 0.0,
                         int(args["diffusion_steps"]), _noise_power(args["diffusion_noise_schedule"]),
-                        float(args["diffusion_noise_precision"]), (C.c_float * 3)(*[float(v) for v in nv]))
+                        float(args["diffusion_noise_precision"]), (C.c_float * 3)(*[float(v) for v in nv]),
+                        int(bool(args.get("sin_embedding", False))))
         n, c_names, c_ptrs, c_numel, keep = self._tensor_args(sd)
         self._check(self.lib.gaudi_load_edm(self.h, C.byref(cfg), n, c_names, c_ptrs, c_numel), "gaudi_load_edm")
         self._note_fallback()

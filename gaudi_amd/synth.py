@@ -81,6 +81,7 @@ def synth_edm_state_dict(args: dict, in_node_nf: int, seed: int = 0, amplify_coo
     g = _Gen(seed)
     H = args["nf"]
     F1 = in_node_nf + 1  # + time (condition_time=True, models_edm.py:82)
+    EF = 24 if args.get("sin_embedding", False) else 2  # edge features: (r, d0), or 2 x 12 sinusoids of them (egnn_new.py:269-273)
     sd = {}
     sd["buffer"] = np.zeros(1, np.float32)
     if gamma is not None:
@@ -91,14 +92,14 @@ def synth_edm_state_dict(args: dict, in_node_nf: int, seed: int = 0, amplify_coo
     for l in range(args["n_layers"]):
         for s in range(args["inv_sublayers"]):
             q = f"{p}e_block_{l}.gcl_{s}."
-            _linear(sd, g, q + "edge_mlp.0", H, 2 * H + 2)
+            _linear(sd, g, q + "edge_mlp.0", H, 2 * H + EF)
             _linear(sd, g, q + "edge_mlp.2", H, H)
             _linear(sd, g, q + "node_mlp.0", H, 2 * H)
             _linear(sd, g, q + "node_mlp.2", H, H)
             if args["attention"]:
                 _linear(sd, g, q + "att_mlp.0", 1, H)
         q = f"{p}e_block_{l}.gcl_equiv."
-        _linear(sd, g, q + "coord_mlp.0", H, 2 * H + 2)
+        _linear(sd, g, q + "coord_mlp.0", H, 2 * H + EF)
         _linear(sd, g, q + "coord_mlp.2", H, H)
         _coord_head(sd, g, q + "coord_mlp.4.weight", H, amplify_coord)
     return sd

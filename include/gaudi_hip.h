@@ -47,6 +47,9 @@ typedef struct {
   float noise_power;           /* p of "polynomial_<p>" (en_diffusion.py:47-61); 0 = the "cosine" schedule (:64-81,196-197) */
   float noise_precision;       /* args.diffusion_noise_precision                               */
   float norm_values[3];        /* args.normalize_factors                                       */
+  int32_t sin_embedding;       /* args.sin_embedding (egnn_new.py:269-273,378-391): the first Linear of every edge / coordinate MLP
+                                  takes 2 x 12 sinusoids of sqrt(r), sqrt(d0) instead of (r, d0).  Such a denoiser runs on the
+                                  4-wave kernels (hidden sizes 32 and 192; about a third of the 8-wave rate)   (ABI 7)   */
 } gaudi_edm_config;
 
 /* Architecture of EGNN_predictor: cond_prediction/train_cond_predictor.py:183-196. */
@@ -77,9 +80,9 @@ const char* gaudi_last_error(const gaudi_handle* h);
  * cannot carry (an infinite weight, a matrix far below the others), whose calls therefore run the fp32-instruction kernels at
  * about 0.55 x the speed.  gaudi_amd.engine turns it into a Python warning at load time and into diag["edge_math_fallback"]. */
 const char* gaudi_last_warning(const gaudi_handle* h);
-/* Bumped whenever an exported signature changes (round 6: 6).  gaudi_amd/_lib.py refuses to bind the host-side packers of a
+/* Bumped whenever an exported signature or a config struct changes (round 6: 6; 7: gaudi_edm_config.sin_embedding appended).  gaudi_amd/_lib.py refuses to bind the host-side packers of a
  * diagnostic library (GAUDI_LIB) whose version differs: round 5 inserted an argument into gaudi_host_pack_matrix_split. */
-#define GAUDI_ABI_VERSION 6
+#define GAUDI_ABI_VERSION 7
 int gaudi_abi_version(void);
 
 /* Load a state dict (reference key names WITHOUT the "module." prefix).

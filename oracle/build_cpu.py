@@ -104,6 +104,8 @@ class CpuPort:
     def load_edm(self, args, sd):
         if args.get("aggregation_method", "sum") != "sum":
             raise ValueError("the C++ port restates aggregation_method='sum' (the numpy oracle covers 'mean')")
+        if args.get("sin_embedding", False):
+            raise ValueError("the C++ port restates sin_embedding=False (the numpy oracle covers the sinusoid edge features)")
         F = np.asarray(sd["dynamics.egnn.embedding.weight"]).shape[1] - 1
         cfg = EdmCfg(F, int(args["nf"]), int(args["n_layers"]), int(args.get("inv_sublayers", 1)), int(bool(args["attention"])),
                      int(bool(args["tanh"])), float(args["coords_range"]), float(args["norm_constant"]),

@@ -186,6 +186,23 @@ def _coord2diff(x, norm_constant):
     return radial, diff / (norm + x.dtype.type(norm_constant))
 
 
+def sin_frequencies(dtype=F32):
+    """SinusoidsEmbeddingNew.__init__ (egnn_new.py:378-385): 2 pi 4^k / 15, k = 0..5.  torch builds them as
+    ``2 * math.pi * div_factor ** torch.arange(n) / max_res``: the Python double times an int64 tensor gives a float32 tensor (the
+    product rounded to fp32 -- exact here: a power of four), then the fp32 division by 15."""
+    n = int(np.log(15.0 / (15.0 / 2000.0)) / np.log(4.0)) + 1  # 6
+    k = 4.0 ** np.arange(n)
+    # (the tensor is neither a parameter nor a buffer: model.double() leaves it in fp32, and the float64 run of the reference
+    # multiplies by the fp32-rounded frequencies -- the float64 evaluation here does the same)
+    return ((np.float32(2.0 * np.pi) * k.astype(np.float32)) / np.float32(15.0)).astype(dtype)
+
+
+def _sin_embedding(x, dtype):
+    """SinusoidsEmbeddingNew.forward (egnn_new.py:387-391) on [..., 1] -> [..., 12]: sqrt(x + 1e-8) * f, (sin | cos)."""
+    e = np.sqrt(x + dtype(1e-8)) * sin_frequencies(dtype)
+    return np.concatenate([np.sin(e), np.cos(e)], axis=-1).astype(dtype)
+
+
 def _edge_input(h, edge_attr):
     B, N, H = h.shape
     hi = np.broadcast_to(h[:, :, None, :], (B, N, N, H))
@@ -213,6 +230,9 @@ def edm_phi(sd, cfg, z, t, node_mask, edge_mask, dtype=F32):
 
     p = "dynamics.egnn."
     d0, _ = _coord2diff(x, 1.0)  # egnn_new.py:301 (radial only)
+    sin_emb = bool(cfg.get("sin_embedding", False))
+    if sin_emb:
+        d0 = _sin_embedding(d0, dtype)  # egnn_new.py:302-303
     h = _linear(h, sd[p + "embedding.weight"], sd[p + "embedding.bias"])
     x_in = x
     # unsorted_segment_sum (egnn_new.py:403-421): 'sum' divides by normalization_factor; 'mean' by the number of edges of the
@@ -224,6 +244,8 @@ def edm_phi(sd, cfg, z, t, node_mask, edge_mask, dtype=F32):
     for l in range(cfg["n_layers"]):
         bp = f"{p}e_block_{l}."
         radial, cdiff = _coord2diff(x, cfg["norm_constant"])  # egnn_new.py:216
+        if sin_emb:
+            radial = _sin_embedding(radial, dtype)  # :217-218
         edge_attr = np.concatenate([radial, d0], axis=-1)  # :219
         for s in range(cfg["inv_sublayers"]):
             gp = f"{bp}gcl_{s}."

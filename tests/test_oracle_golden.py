@@ -369,3 +369,47 @@ def test_g21_target_with_direct_z_dependence(golden, name):
     x, h, _ = O.sample(esd, eargs, nm, g[name + "_edge_mask"], g[name + "_noise"], std=1.0, pred_sd=psd, pcfg=pargs, scale=0.6,
                        target_z=direct_z_target_grad(nm))
     assert rel_err(x, g[name + "_x"]) < 1e-4 and np.array_equal(h, g[name + "_h"])
+
+
+# ------------------------------------------------------------------------------------------------ sin_embedding (g22)
+def test_g22_sin_embedding_frequencies(golden):
+    """SinusoidsEmbeddingNew (egnn_new.py:378-391): the six frequencies, bit for bit as torch builds them -- also what the float64
+    model multiplies with (`.double()` leaves the fp32-rounded values in place)."""
+    g = golden("g22_sin_embedding")
+    assert np.array_equal(O.sin_frequencies(np.float32), g["frequencies"])
+    assert np.array_equal(O.sin_frequencies(np.float64), g["frequencies"].astype(np.float64))
+
+
+@pytest.mark.parametrize("name", ["cata_tiny", "hetro_tiny", "cata_default"])
+def test_g22_sin_embedding_phi(golden, name):
+    """phi of a sin_embedding=True denoiser against the REFERENCE in float64 (tight) and in fp32 (the embedding multiplies
+    sqrt(r) by up to 429 before sin / cos: fp32 runs of the same network differ among themselves by the reference's own
+    fp32-vs-fp64 spread, which bounds what any fp32 implementation can be held to)."""
+    g = golden("g22_sin_embedding")
+    cfg = json.loads(str(g[name + "_cfg"]))
+    args, sd = edm_from_cfg(cfg, diffusion_steps=cfg["T"])
+    assert args["sin_embedding"]
+    z, t, nm, em = g[name + "_z"], g[name + "_t"][:, 0], g[name + "_node_mask"], g[name + "_edge_mask"]
+    eps64 = O.edm_phi(sd, args, z.astype(np.float64), t.astype(np.float64), nm, em, dtype=np.float64)
+    assert rel_err(eps64, g[name + "_eps64"]) < 1e-10
+    eps = O.edm_phi(sd, args, z, t, nm, em)
+    spread = rel_err(g[name + "_eps"], g[name + "_eps64"])
+    assert rel_err(eps, g[name + "_eps"]) < max(1e-4, 0.5 * spread)
+    assert rel_err(eps, g[name + "_eps64"]) < max(1e-4, 2 * spread)
+    assert np.abs(eps * (1 - nm)).max() == 0
+
+
+def test_g22_sin_embedding_steps(golden):
+    """Teacher-forced unguided and guided steps (default widths, sin_embedding denoiser + ordinary predictor) at s = 999, 400, 0."""
+    g = golden("g22_sin_embedding")
+    name = "cata_default"
+    cfg = json.loads(str(g[name + "_cfg"]))
+    T = cfg["T"]
+    eargs, esd = edm_from_cfg(cfg, diffusion_steps=T)
+    pargs, psd = pred_from_cfg(dict(dataset=cfg["dataset"], wseed=cfg["pseed"]))
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    z, nm, em, eps = g[name + "_z"], g[name + "_node_mask"], g[name + "_edge_mask"], g[name + "_step_noise"]
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    for s in (999, 400, 0):
+        assert rel_err(O.step_unguided(esd, eargs, gamma, s, z, nm, em, eps), g[f"{name}_zs_unguided_s{s}"]) < 1e-5, s
+        assert rel_err(O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6), g[f"{name}_zs_guided_s{s}"]) < 2e-5, s

@@ -7,6 +7,7 @@ injected noise, and only numeric inputs/outputs are stored.  Recipe = SURVEY.md 
 
     python tools/make_golden.py            # rewrites every fixture
 """
+import copy
 import json
 import os
 import sys
@@ -993,6 +994,58 @@ def g20_cosine_and_mean():
     save("g20_cosine_and_mean", **out)
 
 
+def g22_sin_embedding():
+    """`sin_embedding=True` (utils/args_edm.py:33, models_edm.py:78; egnn_new.py:269-273,302-303,217-218,378-391): the two scalar
+    edge features r, d0 become 2 x 12 sinusoids of their square roots, the first Linear of every edge / coordinate MLP takes
+    2 H + 24 inputs.  phi (tiny widths, amplified heads, cata and hetro; default widths, default init), a teacher-forced
+    unguided and guided step at the default widths, run by the reference in fp32 AND float64 (the highest frequency multiplies
+    sqrt(r) by 429: the embedding is ill-conditioned in fp32 by construction -- the float64 run says by how much)."""
+    out = {}
+    from edm.egnn.egnn_new import SinusoidsEmbeddingNew
+    out["frequencies"] = SinusoidsEmbeddingNew().frequencies.numpy().copy()
+    for ci, (name, ds, nodes, mx, over) in enumerate([("cata_tiny", "cata", [4, 11, 7, 2, 11], 11, dict(TINY)),
+                                                      ("hetro_tiny", "hetro", [3, 5, 10, 7], 10, dict(TINY)),
+                                                      ("cata_default", "cata", [11, 9, 11], 11, {})]):
+        F = synth.num_node_features(ds)
+        T = 1000
+        over = dict(over, sin_embedding=True, diffusion_steps=T)
+        amp = "tiny" in name
+        esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=2200 + ci, amplify_coord=amp)
+        a, model = build_ref_edm(ds, esd, **over)
+        nm, em, z = case_inputs(ds, nodes, mx, seed=2220 + ci)
+        B = z.shape[0]
+        t = np.linspace(0.05, 0.95, B).astype(np.float32).reshape(B, 1)
+        with torch.no_grad():
+            eps = model.phi(torch.from_numpy(z), torch.from_numpy(t), torch.from_numpy(nm), torch.from_numpy(em), None).numpy()
+            m64 = copy.deepcopy(model).double()
+            eps64 = m64.phi(torch.from_numpy(z).double(), torch.from_numpy(t).double(), torch.from_numpy(nm).double(),
+                            torch.from_numpy(em).double(), None).numpy()
+        out[f"{name}_z"], out[f"{name}_t"], out[f"{name}_node_mask"], out[f"{name}_edge_mask"] = z, t, nm, em
+        out[f"{name}_eps"], out[f"{name}_eps64"] = eps, eps64
+        cfgd = dict(dataset=ds, T=T, eseed=2200 + ci, nodes=nodes, amp=amp, over={k: v for k, v in over.items() if k != "diffusion_steps"})
+        if name == "cata_default":
+            psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds), F, 5, seed=2210 + ci)
+            pa, pred = build_ref_pred(ds, psd)
+
+            def tf_gap(_in, _nm, _em, _t):
+                return -pred(_in, _nm, _em, _t)[:, 1]
+
+            eps_n = rng_noise(2230 + ci, z.shape)
+            for sidx in (999, 400, 0):
+                s_t = torch.full((B, 1), sidx / T)
+                t_t = torch.full((B, 1), (sidx + 1) / T)
+                with InjectNoise([eps_n]):
+                    zs_u = model.sample_p_zs_given_zt(s_t, t_t, torch.from_numpy(z), torch.from_numpy(nm), torch.from_numpy(em), None)
+                with InjectNoise([eps_n]):
+                    zs_g = model.sample_p_zs_given_zt_guidance(s_t, t_t, torch.from_numpy(z), torch.from_numpy(nm), torch.from_numpy(em),
+                                                               tf_gap, 0.6)
+                out[f"{name}_zs_unguided_s{sidx}"], out[f"{name}_zs_guided_s{sidx}"] = zs_u.numpy(), zs_g.detach().numpy()
+            out[f"{name}_step_noise"] = eps_n
+            cfgd["pseed"] = 2210 + ci
+        out[f"{name}_cfg"] = np.array(json.dumps(cfgd))
+    save("g22_sin_embedding", **out)
+
+
 def direct_z_target_torch(z, pred, nm):
     """-pred[:, 1] + 0.05 * sum over live nodes of |x_n|^2 + 0.02 * sum of the first feature column: depends on z through the
     predictor AND directly (numpy twin: tests/helpers.direct_z_target_grad)."""
@@ -1050,8 +1103,8 @@ def g8_checkpoint_roundtrip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps, g20=g20_cosine_and_mean, g21=g21_direct_z_target)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps, g20=g20_cosine_and_mean, g21=g21_direct_z_target, g22=g22_sin_embedding)
     for w in which:
         fns[w]()
