@@ -230,10 +230,12 @@ def test_sin_embedding_phi_vs_reference(golden, name):
     assert rel_err(eps, g[name + "_eps64"]) < max(1e-4, 2 * spread), (rel_err(eps, g[name + "_eps64"]), spread)
     assert rel_err(eps, g[name + "_eps"]) < max(1e-4, 2 * spread)
     assert np.abs(eps * (1 - nm.reshape(B, N, 1))).max() == 0
-    # forced onto the kernels with the node buffers in global memory (what a large molecule takes): same results
+    # forced onto the kernels with the node buffers in global memory (what a large molecule takes): the same source, a few
+    # multiply-adds contracted differently -- last-bit differences, which the embedding amplifies as it does the reference's own
     eng_g = _engine(eargs, esd, GAUDI_FORCE_GN=1)
     eps_g = eng_g.phi(z, t, nm.reshape(B, N), em.reshape(B, N, N))
-    assert eng_g.node_buffers_global() and rel_err(eps_g, eps) < 1e-5
+    assert eng_g.node_buffers_global() and rel_err(eps_g, eps) < max(1e-5, 0.1 * spread), (rel_err(eps_g, eps), spread)
+    assert rel_err(eps_g, g[name + "_eps64"]) < max(1e-4, 2 * spread)
     eng.close()
     eng_g.close()
 
@@ -264,4 +266,35 @@ def test_sin_embedding_steps_and_chain(golden):
     x2, h2, _ = eng.sample(nm2, em3, seed=3, target_w=w, scale=0.6)
     assert np.isfinite(x).all() and d["nan_count"] == 0 and np.array_equal(x, x2) and np.array_equal(h, h2)
     assert np.abs(x * (1 - nm2[:, :, None])).max() == 0
+    eng.close()
+
+
+def test_sin_embedding_large_molecule_vs_oracle():
+    """A sin_embedding denoiser on a molecule beyond the LDS limit (hetero 20 rings = 40 graph nodes, default widths): the kernels
+    with the node buffers in global memory, the guided step as two launches (denoiser, then predictor) -- phi and a guided
+    teacher-forced step against the oracle (pinned on the reference by g22) at 1e-4."""
+    from oracle import gaudi_oracle as O
+    from gaudi_amd.sampling_edm import build_masks
+    T, s = 1000, 400
+    F = synth.num_node_features("hetro")
+    eargs, pargs = synth.edm_args(dataset="hetro", diffusion_steps=T, sin_embedding=True), synth.pred_args(dataset="hetro")
+    esd = synth.synth_edm_state_dict(eargs, F, seed=61)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=62)
+    rings = [20, 13]
+    nm3, em_flat, N = build_masks(rings, 20, True)
+    B = len(rings)
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    rng = np.random.default_rng(63)
+    z = (rng.standard_normal((B, N, 3 + F)).astype(np.float32)) * nm[:, :, None]
+    z[:, :, :3] -= (z[:, :, :3].sum(1, keepdims=True) / nm.sum(1)[:, None, None]) * nm[:, :, None]
+    eps = rng.standard_normal((B, N, 3 + F)).astype(np.float32)
+    t = np.full(B, np.float32(s + 1) / np.float32(T), np.float32)
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    eng = _engine(eargs, esd, pargs, psd)
+    got = eng.phi(z, t, nm, em)
+    assert eng.kernel_variant()[1] == 4 and eng.node_buffers_global()
+    assert rel_err(got, O.edm_phi(esd, eargs, z, t, nm3, em_flat)) < 1e-4
+    zs = eng.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+    assert rel_err(zs, O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm3, em_flat, eps, w, 0.6)) < 1e-4
     eng.close()
