@@ -93,7 +93,8 @@ struct gaudi_handle {
   bool split = true;          // 8-wave kernels: GEMMs on the fp16 matrix pipe with operands split into fp16 pairs (GAUDI_EDGE_MATH=fp32: off)
   int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
   bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
-  bool run_gn8 = false;       // ... on the 8-wave kernels with node buffers in global memory (V8G, round 4)
+  int run_gn8 = 0;            // ... on the 8-wave kernels with node buffers in global memory (V8G, round 4): 1 all five, 2 P / Q in LDS
+  bool gn8_pq = true;         // GAUDI_GN8_PQ=0: never the P / Q-in-LDS form (kern8gp_*.hip)
   bool gn8 = true;            // GAUDI_GN8=0: molecules beyond the LDS limit go to the 4-wave V4G kernels, as in round 3
   bool force_gn8 = false;     // GAUDI_FORCE_GN8=1: V8G whenever it can run (test knob)
   bool pack = true;           // several small molecules per workgroup in sampling calls (GAUDI_PACK=0: off)
@@ -873,6 +874,23 @@ static kernel_fn pick_kernel8g(int hpe, int hpp) {
   return f;
 }
 #endif
+// ... of which P and Q stay in LDS (kern8gp_*.hip, round 6)
+#ifdef GAUDI_STAMP_STUBS
+static kernel_fn pick_kernel8gp(int, int) { return nullptr; }
+#else
+#define GAUDI_KERNEL8GP_TUS(X) X(fused_192_208) X(edm_192) X(pred_208) X(tiny)
+#define X(name) kernel_fn gaudi_kern8gp_##name(int hpe, int hpp);
+GAUDI_KERNEL8GP_TUS(X)
+#undef X
+static kernel_fn pick_kernel8gp(int hpe, int hpp) {
+  kernel_fn f = nullptr;
+#define X(name) \
+  if (!f) f = gaudi_kern8gp_##name(hpe, hpp);
+  GAUDI_KERNEL8GP_TUS(X)
+#undef X
+  return f;
+}
+#endif
 // mr: the call holds a graph of more than one round of edge tiles AND runs the predictor
 static kernel_fn pick_kernel8_mode(int hpe, int hpp, int mode, bool mr = false) {
   if (mr) return pick_kernel8m(hpe, hpp, mode);
@@ -905,10 +923,11 @@ static size_t gnode_floats(int hpe, int hpp, int N) {
   return std::max((size_t)(hpe ? 4 * N * (hpe + 4) : 0), (size_t)(hpp ? 5 * N * (hpp + 4) : 0));
 }
 
-static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split, bool gn = false) {
+// gn: 0 resident, 1 the five node buffers in global memory, 2 of which P / Q in LDS (w8_edm.h: gn_lds_buffers)
+static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split, int gn = 0) {
   size_t net = 0;
-  if (hpe) net = std::max(net, (size_t)((gn ? w8::kGnLdsBuffers : 5) * N * (hpe + 4) + w8::edge_ring_floats(hpe, split) + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * hpe));
-  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + (gn ? w8::kGnLdsBuffers : 5) * N * (hpp + 4) + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * hpp));
+  if (hpe) net = std::max(net, (size_t)((gn ? w8::gn_lds_buffers(gn) : 5) * N * (hpe + 4) + w8::edge_ring_floats(hpe, split) + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * hpe));
+  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + (gn ? w8::gn_lds_buffers(gn) : 5) * N * (hpp + 4) + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * hpp));
   return common_floats8(N, D, S) + net;
 }
 static size_t gnode_floats8(int hpe, int hpp, int N) {
@@ -931,10 +950,10 @@ static bool node_f16_fits(int hp, int N, int split, bool gn) {
   const int ring = w8::edge_ring_floats(hp, split);
   return w8::nh_split_floats(hp, nct) <= (w8::node_ring_idle(hp, split, gn) ? ring : ring / 2);
 }
-static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pubx, int& pub_ch, bool gn = false) {
+static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pubx, int& pub_ch, int gn = 0) {
   pubx = 0;
   pub_ch = 0;
-  if (!node_f16_fits(hpe, N, split, gn) || !node_f16_fits(hpp, N, split, gn)) return false;
+  if (!node_f16_fits(hpe, N, split, gn != 0) || !node_f16_fits(hpp, N, split, gn != 0)) return false;
   const long long cap = 160 * 1024 / 4 - 64;  // floats (a little headroom for the runtime's own static LDS)
   const long long base = (long long)lds_floats8_base(hpe, hpp, N, D, S, split, gn);
   if (base > cap) return false;
@@ -951,14 +970,14 @@ static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pub
   pubx = (int)std::max(0LL, (long long)S * (16 * pub_ch + 4) - own);
   return true;
 }
-static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, int split, bool gn = false) {
+static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, int split, int gn = 0) {
   return sizeof(float) * (lds_floats8_base(hpe, hpp, N, D, S, split, gn) + (hpp ? pubx : 0));
 }
 
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
   const bool v8 = h->run_variant == 8;
   const bool se = hpe && h->ecfg.sin_embedding;  // stage_graph keeps such a call on the 4-wave family
-  kernel_fn fn = v8   ? (h->run_gn8 ? pick_kernel8g(hpe, hpp) : pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp))
+  kernel_fn fn = v8   ? (h->run_gn8 == 2 ? pick_kernel8gp(hpe, hpp) : h->run_gn8 ? pick_kernel8g(hpe, hpp) : pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp))
                  : se ? pick_kernel_se(hpe, hpp, h->run_gn)
                       : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
   // two column tiles per node GEMM on the resident full-ring kernel: its FR instantiation (same arithmetic, same results)
@@ -1181,10 +1200,15 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   // V8G (round 4): a molecule whose node buffers do not fit LDS beside the ring runs on the 8-wave kernels with those five
   // buffers in a per-workgroup global scratch (split edge GEMMs, full ring, several rounds of edge tiles) -- before round 4
   // such calls fell to the 4-wave V4G kernels (fp32 matrix instructions, two launches per guided step)
-  bool gn8 = false;
+  // Round 6: of the five, P and Q stay in LDS where that plan fits (kern8gp_*.hip; +3.6 % on 40-node molecules) -- a function of
+  // the widths, N and the edge slots the plan is made with (the whole batch's: call_min_slots / plan_min_slots), like the rest
+  int gn8 = 0;
   if (!narrow_taken && (mode_u < 0 || h->force_gn8) && h->gn8 && h->split && (!hpe || h->edm_ws_bytes) && (!hpp || h->pred_ws_bytes) && node_f16_ok &&
-      pick_kernel8g(hpe, hpp) && (GAUDI_NODE_F16 || gn8_stage_fits(hpe, hpp, N)) && plan_pub8(hpe, hpp, N, Dz, M.S, 1, pubx, pub_ch, true)) {
-    gn8 = true;
+      (GAUDI_NODE_F16 || gn8_stage_fits(hpe, hpp, N))) {
+    if (h->gn8_pq && GAUDI_NODE_F16 && pick_kernel8gp(hpe, hpp) && plan_pub8(hpe, hpp, N, Dz, M.S, 1, pubx, pub_ch, 2)) gn8 = 2;
+    else if (pick_kernel8g(hpe, hpp) && plan_pub8(hpe, hpp, N, Dz, M.S, 1, pubx, pub_ch, 1)) gn8 = 1;
+  }
+  if (gn8) {
     mode_u = 1;
   } else if (h->force_gn8 && mode_u >= 0) {
     plan_for(N, M.S, mr);  // (restore pubx / pub_ch of the resident plan)
@@ -1199,7 +1223,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
     Meta8 M2;
     int pubx2 = 0, pub_ch2 = 0;
     if (build_meta8(pk.G, N, pk.umask.data(), pk.uemask.data(), M2, err, M.S, pk.align.data()) == GAUDI_OK && M2.S == M.S &&
-        plan_pub8(hpe, hpp, N, Dz, M2.S, 1, pubx2, pub_ch2, true)) {
+        plan_pub8(hpe, hpp, N, Dz, M2.S, 1, pubx2, pub_ch2, gn8)) {
       M = std::move(M2);
       B = pk.G;
       nm_used = pk.umask.data();
@@ -1342,7 +1366,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   h->run_variant = h->variant;
   h->run_split = 0;
   h->run_gn = false;
-  h->run_gn8 = false;
+  h->run_gn8 = 0;
   h->run_mr = false;
   h->run_groups = B;
   h->run_nslots = N;
@@ -1459,6 +1483,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_FORCE_MR")) h->force_mr = atoi(v) != 0;  // diagnostic: one-round graphs on the MR kernels
   if (const char* v = getenv("GAUDI_PACK")) h->pack = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_GN8_PACK")) h->gn8_pack = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_GN8_PQ")) h->gn8_pq = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_KEEP_H")) h->keep_h = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_FAMILY_SPLIT")) h->family_split = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PAIRS")) h->pairs = atoi(v);
@@ -2404,7 +2429,7 @@ int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups, int32_t* n
 
 int gaudi_node_buffers(const gaudi_handle* h, int32_t* last_call) {
   if (!h || !last_call) return GAUDI_E_INVALID;
-  *last_call = (h->run_gn || h->run_gn8) ? 1 : 0;
+  *last_call = h->run_gn ? 1 : h->run_gn8;  // 0 resident, 1 global scratch, 2 global scratch with P / Q in LDS (8-wave kernels)
   return GAUDI_OK;
 }
 

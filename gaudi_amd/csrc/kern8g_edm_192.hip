@@ -1,4 +1,4 @@
-// kern8g_edm_192.hip -- 8-wave sampler kernels with the node buffers in global memory (sampler_kernel.h: V8T<1, true, true> = V8G, round 4):
+// kern8g_edm_192.hip -- 8-wave sampler kernels with the node buffers in global memory (sampler_kernel.h: V8T<1, true, 1> = V8G, round 4):
 // molecules whose node buffers do not fit 160 KiB of LDS beside the weight ring; split edge GEMMs with the full ring, several
 // rounds of edge tiles in the predictor [EDM only, 192].  Own translation unit (the instantiations compile in parallel); looked up by
 // gaudi_hip.hip through gaudi_kern8g_edm_192.

@@ -229,7 +229,7 @@ __device__ __forceinline__ PredDev uni(const PredDev& w) {
 }
 #ifndef GAUDI_STAMPS
 // GN: the node buffers of the phase live in the workgroup's slice of the global scratch (gnode_), everything else in LDS
-template <int HP, int SP, bool GN = false, bool FL = false>
+template <int HP, int SP, int GN = 0, bool FL = false>
 __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, float t_val_, float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const EdmDev W = uni(W_);
@@ -244,7 +244,7 @@ __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, f
 }
 // the predictor's forward and reverse passes are separate functions too (the reverse pass holds three 52-register
 // operand sets at its peak; allocated together with the forward it spilled twice as much)
-template <int HP, int SP, bool MR, bool GN = false, bool FL = false>
+template <int HP, int SP, bool MR, int GN = 0, bool FL = false>
 __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args ga_, float t_val_, float* stash_, float readout_div_,
                                                          float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -257,7 +257,7 @@ __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args 
   sm.hk = ga.hk ? smem + ga.hk : nullptr;
   w8::pred_forward<HP, SP, MR, GN, FL>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
 }
-template <int HP, int SP, bool MR, bool GN = false, bool FL = false>
+template <int HP, int SP, bool MR, int GN = 0, bool FL = false>
 __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args ga_, float* stash_, float readout_div_, int resume_,
                                                          float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -275,12 +275,13 @@ __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args 
 // SP: edge and node GEMMs on the fp16 matrix pipe with operands split into fp16 pairs (w8_split.h, w8_nodes_f16.h; three bf16 pieces
 //     in rounds 2-4); otherwise fp32 MFMAs
 // MR: the predictor takes graphs of more than one round of eight edge tiles (w8_pred.h); the denoiser always does
-// GN: node buffers in the workgroup's global scratch (V8G, round 4: molecules beyond the LDS limit on the 8-wave kernels)
+// GN: node buffers in the workgroup's global scratch (V8G, round 4: molecules beyond the LDS limit on the 8-wave kernels) -- 1: all
+//     five; 2: P and Q stay in LDS (round 6, w8_edm.h: gn_lds_buffers)
 // FR: the node GEMMs' split passes and epilogues recompute their lane addresses per call (w8_nodes_f16.h: FL) -- always in the MR
 //     and GN kernels; the resident single-round kernel exists in both forms and the host picks by node slots (gaudi_hip.hip)
-template <int SP, bool MR = false, bool GN = false, bool FR = false>
+template <int SP, bool MR = false, int GN = 0, bool FR = false>
 struct V8T {
-  static constexpr bool kFL = MR || GN || FR;
+  static constexpr bool kFL = MR || GN != 0 || FR;
   static constexpr int kThreads = w8::kThreads;
   static constexpr int kSplit = SP;
   using Graph = w8::MolGraph;
@@ -315,7 +316,7 @@ struct V8T {
   __device__ __forceinline__ static Graph8Args gargs(const Graph& mg) {
     return Graph8Args{mg.N, mg.D, mg.S, mg.NC, mg.ntiles, mg.pubx, mg.pub_ch, mg.hk};
   }
-  static constexpr bool kGlobalNodes = GN;
+  static constexpr bool kGlobalNodes = GN != 0;
   template <int HP>
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
                                              float* sMean, float t_val, int tid STAMP_DECL, float* gnode) {
@@ -699,6 +700,9 @@ inline constexpr sampler_fn sampler_kernel8m = &sampler_kernel_v<V8T<SP, true>, 
 // ... and with the node buffers in global memory (kern8g_*.hip: molecules beyond the LDS limit; split edge GEMMs, full ring,
 // several rounds of edge tiles in the predictor)
 template <int HPE, int HPP>
-inline constexpr sampler_fn sampler_kernel8g = &sampler_kernel_v<V8T<1, true, true>, HPE, HPP>;
+inline constexpr sampler_fn sampler_kernel8g = &sampler_kernel_v<V8T<1, true, 1>, HPE, HPP>;
+// ... of which P and Q stay in LDS (kern8gp_*.hip: taken where that plan fits)
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel8gp = &sampler_kernel_v<V8T<1, true, 2>, HPE, HPP>;
 
 }  // namespace gaudi

@@ -542,7 +542,7 @@ __device__ __forceinline__ void node_gemm_n(const WBuf& wb, int Wa, const float*
 // schedule: the compiled code of those kernels is kept identical to what was tuned and measured)
 #define NODE_GEMM(EPI, ...)                                                   \
   do {                                                                        \
-    if constexpr (GN) node_gemm_n<HP, EPI, true, 3>(__VA_ARGS__);             \
+    if constexpr (GN != 0) node_gemm_n<HP, EPI, true, 3>(__VA_ARGS__);        \
     else node_gemm<HP, EPI, true>(__VA_ARGS__);                               \
   } while (0)
 

@@ -15,19 +15,16 @@ namespace w8 {
 // instead (the 4-wave family's V4G form of round 3, edm_device.h, on the 8-wave kernels).  The code is the same: the pointers
 // are carved from the scratch, hipcc emits flat / global accesses for them; every cross-wave hand-off of these buffers
 // already sits behind a workgroup barrier, which orders global memory inside a workgroup too.
-// Round 6 experiment (hybrid residency, -DGAUDI_GN_PQ_LDS=1): of a GN kernel's five buffers the two that the EDGE phases gather
-// from -- P and Q, read per edge slot and K chunk by the generating edge GEMM and again by the reverse pass's chain -- stay in LDS
-// (up to N = 40 they fit beside the full ring: 2 x 34 KB + 52 KiB).  Measured on BASELINE config 4 read literally (N = 40, same
-// session): 84.3 against 81.3 mol/s (+3.6 %) -- the gathers were hitting L1 / L2 well enough -- while complete graphs of 27-33 nodes
-// (992 edge slots: 40 KB of per-slot arrays) no longer fit and fall to the 4-wave V4G kernels.  Off: the gain does not pay for a
-// second set of V8G instantiations.
-#ifndef GAUDI_GN_PQ_LDS
-#define GAUDI_GN_PQ_LDS 0
-#endif
-constexpr int kGnLdsBuffers = GAUDI_GN_PQ_LDS ? 2 : 0;  // node buffers a GN kernel keeps in LDS (shared with the host's LDS plan)
-template <int HP, int SP = 0, bool GN = false>
+// GN = 2 (round 6, hybrid residency: kern8gp_*.hip): of the five buffers the two that the EDGE phases gather from -- P and Q, read per
+// edge slot and K chunk by the generating edge GEMM and again by the reverse pass's chain -- stay in LDS (up to N = 40 they fit
+// beside the full ring: 2 x 34 KB + 52 KiB).  Measured on BASELINE config 4 read literally (N = 40, same session): 84.3 against
+// 81.3 mol/s (+3.6 %) -- the gathers were hitting L1 / L2 well enough.  Complete graphs of 27-33 nodes (992 edge slots: 40 KB of
+// per-slot arrays) do not fit that form: the host plans GN = 2 first and GN = 1 where it does not fit (gaudi_hip.hip: stage_graph8).
+// node buffers a GN kernel keeps in LDS (shared with the host's LDS plan)
+__host__ __device__ constexpr int gn_lds_buffers(int gn) { return gn == 2 ? 2 : 0; }
+template <int HP, int SP = 0, int GN = 0>
 struct NetSmem {
-  static constexpr bool kGlobalNodes = GN;
+  static constexpr bool kGlobalNodes = GN != 0;
   float *h, *p, *q;     // [N][HP+4]
   float *agg, *agg1;    // [N][HP+4] the two partial edge->node sums of a node (its run may straddle two tiles)
   float* ring;          // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats)
@@ -40,7 +37,7 @@ struct NetSmem {
   float* vec;           // [8*HP] the current layer's small vectors (cr, cd, b1, b2, wa/w3, bn1, bn2, ba)
   float* hk = nullptr;  // kept split copy of h (w8_nodes_f16.h: node_ctx_keep), behind the whole plan; nullptr: none
   __host__ __device__ static int floats(int N, int S) {
-    return (GN ? kGnLdsBuffers : 5) * N * (HP + 4) + EdgeRing<HP, SP>::kFloats + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * HP;
+    return (GN ? gn_lds_buffers(GN) : 5) * N * (HP + 4) + EdgeRing<HP, SP>::kFloats + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * HP;
   }
   __device__ void carve(float* base, int N, int S, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
@@ -48,7 +45,7 @@ struct NetSmem {
     if (GN) gnode = assume_global(gnode);
     float*& nb = GN ? gnode : base;
     h = nb; nb += N * LD;
-    if (GN && kGnLdsBuffers) {
+    if (GN == 2) {
       p = base; base += N * LD;
       q = base; base += N * LD;
     } else {
@@ -140,7 +137,7 @@ __device__ __forceinline__ void scatter_runs(f4 (&e)[HP / 16], const TileCols& t
 }
 
 // eps_hat[N][D] (LDS) = EGNN_dynamics._forward(t, z[N][D] (LDS))
-template <int HP, int SP = 0, bool GN = false, bool FL = false>
+template <int HP, int SP = 0, int GN = 0, bool FL = false>
 __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg, const NetSmem<HP, SP, GN>& sm, const float* sZ,
                                             float* sEps, float* sMean /* [4] */, float t_val, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;

@@ -529,7 +529,7 @@ __device__ __forceinline__ void node_prefetch_x(PF& pf, const WBuf& wb, const WB
 // 1024 in pairs +2.2 %, but C3 (11 nodes, one column tile: half the epilogue work per reload) -0.4 % -- the recomputation costs
 // what the reloads did.  So FL is on in the kernels that take large molecules (MR, GN, and the FR instantiation of the resident
 // kernel that the host picks for more than 16 node slots) and off in the one C2 / C3 run on.
-template <int HP, int EPI, bool TWO, bool GN, bool NH, int PIN, int POUT, bool FL = false, class PF>
+template <int HP, int EPI, bool TWO, int GN, bool NH, int PIN, int POUT, bool FL = false, class PF>
 __device__ __forceinline__ void node_gemm_x(const WBuf& wb, const WBuf& wbe, int Wa, const float* Xa, const float* XaS, bool split_a, int Wb,
                                             const float* Xb, const float* XbS, const float* sBias, float* sY, const float* sRes,
                                             const float* sMask, int N, int wave, int lane, bool tw, const NodeCtxH& cx, PF& pf,
@@ -537,7 +537,7 @@ __device__ __forceinline__ void node_gemm_x(const WBuf& wb, const WBuf& wbe, int
   if constexpr (NH) {
     node_gemm_h<HP, EPI, TWO, GN ? 3 : 2, PIN, POUT, FL>(wbe, Wa, Xa, split_a, Wb, Xb, sBias, sY, sRes, sMask, N, wave, lane, cx, pf, nextW, gPre,
                                                          sMaxOut);
-  } else if constexpr (GN) {
+  } else if constexpr (GN != 0) {
     node_gemm_n<HP, EPI, true, 3>(wb, Wa, XaS, Wb, XbS, sBias, sY, sRes, sMask, N, wave, lane, tw, &pf, nextW, gPre);
   } else {
     node_gemm<HP, EPI, true>(wb, Wa, Xa, Wb, Xb, sBias, sY, sRes, sMask, N, wave, lane, tw, &pf, nextW, gPre);

@@ -12,10 +12,10 @@ namespace w8 {
 
 // GN: the five node buffers live in a per-workgroup global scratch (w8_edm.h: NetSmem); the publish buffer of the reverse
 // pass is then [ring | pub] -- split forms only
-template <int HP, int SP = 0, bool GN = false>
+template <int HP, int SP = 0, int GN = 0>
 struct PredSmem {
   static_assert(!GN || SP != 0, "global node buffers: split edge GEMMs only (the fp32 form's publish buffer starts in b0 / b1)");
-  static constexpr bool kGlobalNodes = GN;
+  static constexpr bool kGlobalNodes = GN != 0;
   float *b2, *b3, *b4;            // [N][HP+4] node buffers (roles change per phase, see below)
   float *b0, *b1;                 // [N][HP+4] ... these two open the publish buffer of the reverse pass: [b0 | b1 | (ring) | pub]
   float* ring;                    // weight ring of the edge GEMMs (EdgeRing<HP, SP>::kFloats); split form: idle while du is
@@ -30,7 +30,7 @@ struct PredSmem {
   float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
   float* hk = nullptr;            // kept split copy of h (w8_nodes_f16.h: node_ctx_keep), behind the whole plan; nullptr: none
   __host__ __device__ static int floats(int N, int S, int pubx) {
-    return EdgeRing<HP, SP>::kFloats + (GN ? kGnLdsBuffers : 5) * N * (HP + 4) + pubx + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * HP;
+    return EdgeRing<HP, SP>::kFloats + (GN ? gn_lds_buffers(GN) : 5) * N * (HP + 4) + pubx + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * HP;
   }
   // the publish buffer of the reverse pass (du of every slot, pub_ch feature tiles at a time)
   __device__ __forceinline__ float* publish() const { return GN ? ring : b0; }
@@ -39,12 +39,12 @@ struct PredSmem {
     if (SP == 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // fp32 form: the ring stays busy across the publish phase
     if (GN) gnode = assume_global(gnode);
     float*& nb = GN ? gnode : base;
-    // (GN, round 6: P = b1 and Q = b2 -- what the edge phases of both passes gather from -- stay in LDS, w8_edm.h: kGnLdsBuffers)
-    if (GN && kGnLdsBuffers) { b2 = base; base += N * LD; } else { b2 = nb; nb += N * LD; }
+    // (GN = 2, round 6: P = b1 and Q = b2 -- what the edge phases of both passes gather from -- stay in LDS, w8_edm.h: gn_lds_buffers)
+    if (GN == 2) { b2 = base; base += N * LD; } else { b2 = nb; nb += N * LD; }
     b3 = nb; nb += N * LD;
     b4 = nb; nb += N * LD;
     b0 = nb; nb += N * LD;
-    if (GN && kGnLdsBuffers) { b1 = base; base += N * LD; } else { b1 = nb; nb += N * LD; }
+    if (GN == 2) { b1 = base; base += N * LD; } else { b1 = nb; nb += N * LD; }
     if (SP != 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // N * LD * 4 bytes is a multiple of 16: units stay aligned
     pub = base; base += pubx;
     x = base; base += 4 * N;
@@ -89,7 +89,7 @@ __host__ __device__ inline int pub_chunk_tiles(int S, long long avail_floats, in
 // MR: the kernel takes graphs of more than one round of eight edge tiles (more than 128 slots).  A separate instantiation: the
 // round loops (and the second copy of the reverse chain that parks du in the stash) cost the single-round kernels 2-4 % when
 // they live in the same function (hipcc's register allocation of the out-of-line phases changes), measured on C3.
-template <int HP, int SP = 0, bool MR = false, bool GN = false, bool FL = false>
+template <int HP, int SP = 0, bool MR = false, int GN = 0, bool FL = false>
 __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP, GN>& sm, const float* sZ,
                                              float t_val, float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 //                          B4 = b4: npre (stash) -> dnpre -> dQ
 // pub_ch = 16-feature tiles of du published per chunk into [b0 | b1 | pub] (row = 16 pub_ch + 4 floats per slot)
 // ---------------------------------------------------------------------------------------------
-template <int HP, int SP = 0, bool MR = false, bool GN = false, bool FL = false>
+template <int HP, int SP = 0, bool MR = false, int GN = 0, bool FL = false>
 __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP, GN>& sm, const float* stash,
                                               float* sGrad, float readout_div, int pub_ch, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
@@ -690,7 +690,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 }
 
 // unit-test entry: pred (and optionally grad into sGrad) for z in sZ
-template <int HP, int SP = 0, bool MR = false, bool GN = false>
+template <int HP, int SP = 0, bool MR = false, int GN = 0>
 __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                 float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid STAMP_DECL,
@@ -715,7 +715,7 @@ __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, fl
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 // phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
 // (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
-template <int HP, int SP = 0, bool MR = false, bool GN = false>
+template <int HP, int SP = 0, bool MR = false, int GN = 0>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, float sigma, const float* target_w,
                                                 float scale, float* pred_out, float readout_div, float* stash, int pubx,

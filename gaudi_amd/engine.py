@@ -414,6 +414,13 @@ class Engine:
         self._check(self.lib.gaudi_node_buffers(self.h, C.byref(v)), "gaudi_node_buffers")
         return bool(v.value)
 
+    def node_buffers_form(self) -> int:
+        """0: the most recent call kept its node buffers in LDS; 1: in a global scratch; 2: in a global scratch except P and Q, which
+        stayed in LDS (8-wave kernels, round 6: kern8gp_*.hip -- taken where that plan fits)."""
+        v = C.c_int32()
+        self._check(self.lib.gaudi_node_buffers(self.h, C.byref(v)), "gaudi_node_buffers")
+        return int(v.value)
+
     def last_workgroups(self) -> int:
         """Workgroups of the most recent launch (molecules, or the groups they were packed into)."""
         return self.last_launch_shape()[0]

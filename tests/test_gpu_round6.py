@@ -298,3 +298,79 @@ def test_sin_embedding_large_molecule_vs_oracle():
     zs = eng.step(s, z, nm, em, eps, target_w=w, scale=0.6)
     assert rel_err(zs, O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm3, em_flat, eps, w, 0.6)) < 1e-4
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ V8G with P and Q in LDS
+@pytest.mark.parametrize("widths", ["tiny", "default"])
+def test_v8g_hybrid_residency_agrees_with_all_global(widths):
+    """Round 6: a V8G launch keeps P and Q -- the two node buffers the edge phases gather from -- in LDS where that plan fits
+    (kern8gp_*.hip), the other three in the global scratch as before; GAUDI_GN8_PQ=0 is round 5's all-global form.  Same source,
+    two pointers in another address space: phi, predictor + gradient, a guided step and a guided chain agree to 5e-6 (the bar
+    V8G holds against the resident kernels), each form is reproducible bit for bit, and the form that ran is reported."""
+    from oracle import gaudi_oracle as O
+    from gaudi_amd.sampling_edm import build_masks
+    from tests.helpers import TINY, TINY_P
+    T = 6
+    F = synth.num_node_features("hetro")
+    over_e, over_p = (TINY, TINY_P) if widths == "tiny" else ({}, {})
+    eargs, pargs = synth.edm_args(dataset="hetro", diffusion_steps=T, **over_e), synth.pred_args(dataset="hetro", **over_p)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=21, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=22, amplify_coord=True)
+    rings, pad = ([3, 10, 6, 8], 10) if widths == "tiny" else ([20, 13, 17, 6], 20)  # (the tiny widths' ring holds 20 nodes' split copy, not 40)
+    nm3, em_flat, N = build_masks(rings, pad, True)
+    B = len(rings)
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    rng = np.random.default_rng(4)
+    z = O._combined_noise(rng.standard_normal((B, N, 3 + F)).astype(np.float32), nm3)
+    eps = rng.standard_normal((B, N, 3 + F)).astype(np.float32)
+    t = np.full(B, 0.5, np.float32)
+    w = np.array([3, 0, 1, 1, 0], np.float32)
+    dp = np.broadcast_to(w * np.float32(0.6), (B, 5)).copy()
+    outs = []
+    for env, form in (({"GAUDI_FORCE_GN8": 1}, 2), ({"GAUDI_FORCE_GN8": 1, "GAUDI_GN8_PQ": 0}, 1)):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        phi = eng.phi(z, t, nm, em)
+        assert eng.node_buffers_form() == form and eng.kernel_variant()[1] == 8
+        pred, grad = eng.predictor_grad(z, t, nm, em, dp)
+        assert eng.node_buffers_form() == form
+        zs = eng.step(2, z, nm, em, eps, target_w=w, scale=0.6)
+        assert eng.node_buffers_form() == form
+        x, h, d = eng.sample(nm, em, seed=5, target_w=w, scale=0.6)
+        xb, hb, _ = eng.sample(nm, em, seed=5, target_w=w, scale=0.6)
+        assert eng.node_buffers_form() == form and np.array_equal(x, xb) and np.array_equal(h, hb)
+        outs.append((phi, pred, grad, zs, x))
+        eng.close()
+    for a, b in zip(*outs[:2]):
+        assert rel_err(a, b) < 5e-6, rel_err(a, b)
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    assert rel_err(outs[0][0], O.edm_phi(esd, eargs, z, t, nm3, em_flat)) < 1e-4
+    assert rel_err(outs[0][3], O.step_guided(esd, eargs, psd, pargs, gamma, 2, z, nm3, em_flat, eps, w, 0.6)) < 1e-4
+
+
+def test_v8g_hybrid_falls_back_to_all_global_where_it_does_not_fit():
+    """A complete graph of 30 nodes at the default widths (870 edge slots: 35 KB of per-slot arrays) does not leave room for P and Q
+    beside the ring: the call runs the all-global V8G form (8 waves) -- not the 4-wave kernels, as the compile-time switch of the
+    first experiment did -- and the sparse 40-node hetero molecule beside it in another call runs the hybrid."""
+    from oracle import gaudi_oracle as O
+    eargs, pargs = synth.edm_args(diffusion_steps=1000), synth.pred_args()
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=41, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=42, amplify_coord=True)
+    N = 30
+    nm, em = O.build_masks([N, N - 7], N, False)
+    rng = np.random.default_rng(N)
+    z = O._combined_noise(rng.standard_normal((2, N, 4)).astype(np.float32), nm)
+    eps = rng.standard_normal((2, N, 4)).astype(np.float32)
+    w = O.target_max_gap_weights(5)
+    gamma = O.gamma_table("polynomial_2", 1000, 1e-5)
+    eng = _engine(eargs, esd, pargs, psd)
+    zs = eng.step(300, z, nm, em, eps, target_w=w, scale=0.6)
+    assert eng.kernel_variant()[1] == 8 and eng.node_buffers_form() == 1
+    assert rel_err(zs, O.step_guided(esd, eargs, psd, pargs, gamma, 300, z, nm, em, eps, w, 0.6)) < 1e-4
+    eng.close()
+    eargs, esd, pargs, psd, F, nm, em, N = _hetero_batch([20, 12], 20, 1000)
+    eng = _engine(eargs, esd, pargs, psd)
+    rng = np.random.default_rng(1)
+    z = O._combined_noise(rng.standard_normal((2, N, 3 + F)).astype(np.float32), nm[:, :, None])
+    eng.step(300, z, nm, em, rng.standard_normal((2, N, 3 + F)).astype(np.float32), target_w=np.array([0, -1, 0, 0, 0], np.float32), scale=0.6)
+    assert eng.kernel_variant()[1] == 8 and eng.node_buffers_form() == 2
+    eng.close()
