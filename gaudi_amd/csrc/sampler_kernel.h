@@ -523,6 +523,7 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
           if (split != 2) {
             // ---- z_s = z_t/alpha_ts - c*eps + sigma*noise ; x part mean-removed (en_diffusion.py:831-852)
             combined_noise(T - s, 1.0f);
+            STAMP(ST_X2);
             for (int e = tid; e < N * D; e += kThreads) {
               float ep = sEps[e];
               if (guided) {  // eps_t.nan_to_num(0.)  (en_diffusion.py:881)
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(V::kThreads) void sampler_kernel_v(const KParams P)
             sZ[n * D + d] = sZ[n * D + d] - mean_of(n, d) * sMask[n];
           }
           __syncthreads();
+          STAMP(ST_X3);
           if (guided) {
             // `if torch.isnan(zs).any(): zs = zs.nan_to_num(0.)` (en_diffusion.py:933-934): NaN -> 0 and +-inf -> +-FLT_MAX.
             // The reference tests the whole batch; a workgroup sees one molecule (or a few, as components), so the trigger

@@ -17,6 +17,7 @@ ab() {  # ab <name> <bench args...>: variant libraries named in GAUDI_VARIANTS, 
 for step in "$@"; do
   case $step in
     ab_c3) ab c3 ;;
+    ab_c3_nogate) ab c3 --no-parity-gate ;;
     ab_c2) ab c2 --workload c2 ;;
     ab_c4) ab c4 --workload c4 ;;
     ab_c4x) ab c4x --workload c4x --diffusion-steps 200 ;;
