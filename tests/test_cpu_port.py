@@ -124,3 +124,24 @@ def test_molecule_groups_do_not_change_a_molecule():
             assert np.array_equal(a, b)
     want = O.step_guided(esd, eargs, psd, pargs, gamma, 40, z, nm3, em, eps, w, 0.6)
     assert rel_err(outs[0][0], want) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["cata_tiny_att0_tanh1", "hetro_tiny_att1_tanh0", "hetro_tiny_att0_tanh0", "cata_default_att0_tanh0"])
+def test_attention_and_tanh_switches_vs_reference(golden, port, name):
+    """`--attention False` / `--tanh False` on both networks (g23): the C++ port carries the switches too."""
+    from tests.test_oracle_golden import _g23_case
+    g = golden("g23_attention_tanh_flags")
+    cfg, eargs, esd, pargs, psd = _g23_case(g, name)
+    port.load_edm(eargs, esd)
+    port.load_predictor(pargs, psd)
+    z, t, nm, em, eps = (g[f"{name}_{k}"] for k in ("z", "t", "node_mask", "edge_mask", "step_noise"))
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    assert rel_err(port.phi(z, t[:, 0], nm, em), g[name + "_eps"]) < 1e-5
+    pred, grad = port.predictor(z, t[:, 0], nm, em, dpred=w * np.float32(0.6))
+    assert rel_err(pred, g[name + "_pred"]) < 1e-5 and rel_err(grad, g[name + "_grad_gap"]) < 2e-5
+    gamma = O.gamma_table("polynomial_2", cfg["T"], 1e-5)
+    s = cfg["s"]
+    c = O.step_coefficients(gamma, s, s + 1)
+    t_val = np.float32(np.float32(s + 1) / np.float32(cfg["T"]))
+    assert rel_err(port.step(c, t_val, z, nm, em, eps), g[name + "_zs_unguided"]) < 1e-5
+    assert rel_err(port.step(c, t_val, z, nm, em, eps, target_w=w, scale=0.6), g[name + "_zs_guided"]) < 2e-5

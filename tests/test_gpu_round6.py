@@ -374,3 +374,36 @@ def test_v8g_hybrid_falls_back_to_all_global_where_it_does_not_fit():
     eng.step(300, z, nm, em, rng.standard_normal((2, N, 3 + F)).astype(np.float32), target_w=np.array([0, -1, 0, 0, 0], np.float32), scale=0.6)
     assert eng.kernel_variant()[1] == 8 and eng.node_buffers_form() == 2
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ attention / tanh switches (g23)
+G23_NAMES = [f"{ds}_tiny_att{a}_tanh{t}" for a, t in ((0, 1), (1, 0), (0, 0)) for ds in ("cata", "hetro")] + ["cata_default_att0_tanh0"]
+
+
+@pytest.mark.parametrize("family", ["8 waves, fp16 pairs", "8 waves, fp32 instructions", "4 waves", "global node buffers"])
+@pytest.mark.parametrize("name", G23_NAMES)
+def test_attention_and_tanh_switches_vs_reference(golden, name, family):
+    """`--attention False` / `--tanh False` (utils/args_edm.py:29-30, cond_prediction/prediction_args.py:44-45) are constructor
+    switches of both networks that no fixture exercised through round 5 (every golden had the defaults True / True).  g23: the
+    REFERENCE's phi, predictor + input gradient and teacher-forced unguided / guided step for the three other combinations, on
+    every kernel family, at 1e-4."""
+    from tests.test_oracle_golden import _g23_case
+    g = golden("g23_attention_tanh_flags")
+    cfg, eargs, esd, pargs, psd = _g23_case(g, name)
+    env = {"8 waves, fp16 pairs": {}, "8 waves, fp32 instructions": {"GAUDI_EDGE_MATH": "fp32"}, "4 waves": {"GAUDI_WAVES": 4},
+           "global node buffers": {"GAUDI_FORCE_GN8": 1}}[family]
+    z, t, nm, em, eps = (g[f"{name}_{k}"] for k in ("z", "t", "node_mask", "edge_mask", "step_noise"))
+    B, N = z.shape[:2]
+    nm2, em3 = nm.reshape(B, N), em.reshape(B, N, N)
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    eng = _engine(eargs, esd, pargs, psd, **env)
+    assert rel_err(eng.phi(z, t[:, 0], nm2, em3), g[name + "_eps"]) < 1e-4
+    assert eng.kernel_variant()[1] == (4 if family == "4 waves" else 8)
+    pred, grad = eng.predictor_grad(z, t[:, 0], nm2, em3, np.broadcast_to(w * np.float32(0.6), (B, 5)).copy())
+    assert rel_err(pred, g[name + "_pred"]) < 1e-4 and rel_err(grad, g[name + "_grad_gap"]) < 1e-4
+    assert np.abs(grad * (1 - nm2[:, :, None])).max() == 0
+    assert rel_err(eng.step(cfg["s"], z, nm2, em3, eps), g[name + "_zs_unguided"]) < 1e-4
+    assert rel_err(eng.step(cfg["s"], z, nm2, em3, eps, target_w=w, scale=0.6), g[name + "_zs_guided"]) < 1e-4
+    if family == "global node buffers":
+        assert eng.node_buffers_global()
+    eng.close()

@@ -413,3 +413,37 @@ def test_g22_sin_embedding_steps(golden):
     for s in (999, 400, 0):
         assert rel_err(O.step_unguided(esd, eargs, gamma, s, z, nm, em, eps), g[f"{name}_zs_unguided_s{s}"]) < 1e-5, s
         assert rel_err(O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm, em, eps, w, 0.6), g[f"{name}_zs_guided_s{s}"]) < 2e-5, s
+
+
+# ------------------------------------------------------------------------------------------------ attention / tanh switches (g23)
+def _g23_case(g, name):
+    cfg = json.loads(str(g[name + "_cfg"]))
+    ds = cfg["dataset"]
+    F = synth.num_node_features(ds)
+    eargs = synth.edm_args(dataset=ds, diffusion_steps=cfg["T"], **cfg["over_e"])
+    pargs = synth.pred_args(dataset=ds, **cfg["over_p"])
+    esd = synth.synth_edm_state_dict(eargs, F, seed=cfg["eseed"], amplify_coord=cfg["amp"])
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=cfg["pseed"], amplify_coord=cfg["amp"])
+    return cfg, eargs, esd, pargs, psd
+
+
+G23_NAMES = [f"{ds}_tiny_att{a}_tanh{t}" for a, t in ((0, 1), (1, 0), (0, 0)) for ds in ("cata", "hetro")] + ["cata_default_att0_tanh0"]
+
+
+@pytest.mark.parametrize("name", G23_NAMES)
+def test_g23_attention_and_tanh_switches(golden, name):
+    """`--attention False` / `--tanh False` (utils/args_edm.py:29-30, prediction_args.py:44-45) on both networks: phi, predictor +
+    input gradient, teacher-forced unguided and guided step against the reference."""
+    g = golden("g23_attention_tanh_flags")
+    assert json.loads(str(g["names"])) == G23_NAMES
+    cfg, eargs, esd, pargs, psd = _g23_case(g, name)
+    z, t, nm, em, eps = (g[f"{name}_{k}"] for k in ("z", "t", "node_mask", "edge_mask", "step_noise"))
+    B = z.shape[0]
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    dp = np.broadcast_to(w * np.float32(0.6), (B, 5)).copy()
+    gamma = O.gamma_table("polynomial_2", cfg["T"], 1e-5)
+    assert rel_err(O.edm_phi(esd, eargs, z, t[:, 0], nm, em), g[name + "_eps"]) < 1e-5
+    pred, grad = O.predictor_grad(psd, pargs, z, nm, em, t[:, 0], dp)
+    assert rel_err(pred, g[name + "_pred"]) < 1e-5 and rel_err(grad, g[name + "_grad_gap"]) < 2e-5
+    assert rel_err(O.step_unguided(esd, eargs, gamma, cfg["s"], z, nm, em, eps), g[name + "_zs_unguided"]) < 1e-5
+    assert rel_err(O.step_guided(esd, eargs, psd, pargs, gamma, cfg["s"], z, nm, em, eps, w, 0.6), g[name + "_zs_guided"]) < 2e-5

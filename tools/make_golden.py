@@ -1046,6 +1046,56 @@ def g22_sin_embedding():
     save("g22_sin_embedding", **out)
 
 
+def g23_attention_tanh_flags():
+    """`--attention False` / `--tanh False` (utils/args_edm.py:29-30, cond_prediction/prediction_args.py:44-45; egnn_new.py:53-57,117-125,
+    egnn_predictor/gcl.py): the edge gate and the tanh bound of the coordinate update are constructor switches of BOTH networks.
+    Every combination other than the default (True, True), on both networks at once: phi, predictor + input gradient, a
+    teacher-forced unguided and guided step -- tiny widths (amplified heads, cata and hetro) and the default widths (cata)."""
+    out = {}
+    T = 1000
+    cases = []
+    for att, th in ((False, True), (True, False), (False, False)):
+        tag = f"att{int(att)}_tanh{int(th)}"
+        cases.append((f"cata_tiny_{tag}", "cata", [4, 11, 7, 2, 11], 11, dict(TINY), dict(TINY_P), True, att, th))
+        cases.append((f"hetro_tiny_{tag}", "hetro", [3, 5, 10, 7], 10, dict(TINY), dict(TINY_P), True, att, th))
+    cases.append(("cata_default_att0_tanh0", "cata", [11, 9, 11], 11, {}, {}, False, False, False))
+    for ci, (name, ds, nodes, mx, over_e, over_p, amp, att, th) in enumerate(cases):
+        F = synth.num_node_features(ds)
+        over_e = dict(over_e, attention=att, tanh=th, diffusion_steps=T)
+        over_p = dict(over_p, attention=att, tanh=th)
+        esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over_e), F, seed=2300 + ci, amplify_coord=amp)
+        psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **over_p), F, 5, seed=2350 + ci, amplify_coord=amp)
+        a, model = build_ref_edm(ds, esd, **over_e)
+        pa, pred = build_ref_pred(ds, psd, **over_p)
+        assert ("dynamics.egnn.e_block_0.gcl_0.att_mlp.0.weight" in esd) == att
+        nm, em, z = case_inputs(ds, nodes, mx, seed=2320 + ci)
+        B = z.shape[0]
+        t = np.linspace(0.05, 0.95, B).astype(np.float32).reshape(B, 1)
+        tnm, tem = torch.from_numpy(nm), torch.from_numpy(em)
+        with torch.no_grad():
+            out[f"{name}_eps"] = model.phi(torch.from_numpy(z), torch.from_numpy(t), tnm, tem, None).numpy()
+        zt = torch.from_numpy(z).requires_grad_()
+        p = pred(zt, tnm, tem, torch.from_numpy(t))
+        out[f"{name}_pred"] = p.detach().numpy()
+        out[f"{name}_grad_gap"] = torch.autograd.grad((0.6 * -p[:, 1]).sum(), zt)[0].numpy()
+
+        def tf_gap(_in, _nm, _em, _t):
+            return -pred(_in, _nm, _em, _t)[:, 1]
+
+        s = 400
+        eps_n = rng_noise(2340 + ci, z.shape)
+        s_t, t_t = torch.full((B, 1), s / T), torch.full((B, 1), (s + 1) / T)
+        with InjectNoise([eps_n]), torch.no_grad():
+            out[f"{name}_zs_unguided"] = model.sample_p_zs_given_zt(s_t, t_t, torch.from_numpy(z), tnm, tem, None).numpy()
+        with InjectNoise([eps_n]):
+            out[f"{name}_zs_guided"] = model.sample_p_zs_given_zt_guidance(s_t, t_t, torch.from_numpy(z), tnm, tem, tf_gap, 0.6).detach().numpy()
+        out[f"{name}_z"], out[f"{name}_t"], out[f"{name}_node_mask"], out[f"{name}_edge_mask"], out[f"{name}_step_noise"] = z, t, nm, em, eps_n
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, T=T, s=s, eseed=2300 + ci, pseed=2350 + ci, amp=amp,
+                                                      over_e={k: v for k, v in over_e.items() if k != "diffusion_steps"}, over_p=over_p)))
+    out["names"] = np.array(json.dumps([c[0] for c in cases]))
+    save("g23_attention_tanh_flags", **out)
+
+
 def direct_z_target_torch(z, pred, nm):
     """-pred[:, 1] + 0.05 * sum over live nodes of |x_n|^2 + 0.02 * sum of the first feature column: depends on z through the
     predictor AND directly (numpy twin: tests/helpers.direct_z_target_grad)."""
@@ -1105,6 +1155,6 @@ def g8_checkpoint_roundtrip():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps, g20=g20_cosine_and_mean, g21=g21_direct_z_target, g22=g22_sin_embedding)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps, g20=g20_cosine_and_mean, g21=g21_direct_z_target, g22=g22_sin_embedding, g23=g23_attention_tanh_flags)
     for w in which:
         fns[w]()
