@@ -407,3 +407,31 @@ def test_attention_and_tanh_switches_vs_reference(golden, name, family):
     if family == "global node buffers":
         assert eng.node_buffers_global()
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ non-default scalars (g24)
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_scalar_hyperparameters_away_from_their_defaults_vs_reference(golden, name):
+    """polynomial_3 with precision 1e-4, normalize_factors [2, 3, 5], coords_range 7 (denoiser) and 4 (predictor), norm_constant 2,
+    normalization_factor 2, inv_sublayers 2 -- every scalar of args.txt the path reads, away from its default at once (golden g24:
+    the reference's gamma table, phi, predictor + gradient, guided T = 50 chain through sample_guidance) on 8 and 4 waves."""
+    from tests.test_oracle_golden import _g24_case
+    g = golden("g24_scalar_hyperparameters")
+    cfg, eargs, esd, pargs, psd = _g24_case(g, name, chain=False)
+    c_cfg, c_eargs, c_esd, c_pargs, c_psd = _g24_case(g, name, chain=True)
+    z, t, nm, em = g[name + "_z"], g[name + "_t"][:, 0], g[name + "_node_mask"], g[name + "_edge_mask"]
+    B, N = z.shape[:2]
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    for env in ({}, {"GAUDI_WAVES": 4}):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        assert np.allclose(eng.gamma(), g[f"gamma_T{cfg['T']}"], rtol=3e-7, atol=0)
+        assert rel_err(eng.phi(z, t, nm.reshape(B, N), em.reshape(B, N, N)), g[name + "_eps"]) < 1e-4
+        pred, grad = eng.predictor_grad(z, t, nm.reshape(B, N), em.reshape(B, N, N), np.broadcast_to(w * np.float32(0.6), (B, 5)).copy())
+        assert rel_err(pred, g[name + "_pred"]) < 1e-4 and rel_err(grad, g[name + "_grad_gap"]) < 1e-4
+        eng.close()
+        eng = _engine(c_eargs, c_esd, c_pargs, c_psd, **env)
+        cnm = g[name + "_chain_node_mask"]
+        Bc, Nc = cnm.shape[0], cnm.shape[1]
+        x, h, d = eng.sample(cnm.reshape(Bc, Nc), g[name + "_chain_edge_mask"].reshape(Bc, Nc, Nc), noise=g[name + "_noise"], target_w=w, scale=0.6)
+        assert rel_err(x, g[name + "_x_guided"]) < 1e-4 and np.array_equal(h, g[name + "_h_guided"])
+        eng.close()

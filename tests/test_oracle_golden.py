@@ -447,3 +447,48 @@ def test_g23_attention_and_tanh_switches(golden, name):
     assert rel_err(pred, g[name + "_pred"]) < 1e-5 and rel_err(grad, g[name + "_grad_gap"]) < 2e-5
     assert rel_err(O.step_unguided(esd, eargs, gamma, cfg["s"], z, nm, em, eps), g[name + "_zs_unguided"]) < 1e-5
     assert rel_err(O.step_guided(esd, eargs, psd, pargs, gamma, cfg["s"], z, nm, em, eps, w, 0.6), g[name + "_zs_guided"]) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ non-default scalars (g24)
+def _g24_case(g, name, chain):
+    cfg = cfg_of(g, name)
+    ds = cfg["dataset"]
+    F = synth.num_node_features(ds)
+    eargs = synth.edm_args(dataset=ds, diffusion_steps=cfg["T"], **cfg["over_e"])
+    pargs = synth.pred_args(dataset=ds, **cfg["over_p"])
+    esd = synth.synth_edm_state_dict(eargs, F, seed=cfg["chain_eseed" if chain else "eseed"], amplify_coord=not chain)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=cfg["chain_pseed" if chain else "pseed"], amplify_coord=not chain)
+    return cfg, eargs, esd, pargs, psd
+
+
+@pytest.mark.parametrize("name", ["cata", "hetro"])
+def test_g24_scalar_hyperparameters(golden, name):
+    """polynomial_3 / precision 1e-4 / normalize_factors [2, 3, 5] / coords_range 7 and 4 / norm_constant 2 / normalization_factor 2 /
+    inv_sublayers 2, all at once: the reference's gamma tables (bit-exact), coefficients, phi, predictor + gradient, and a guided
+    T = 50 chain through sample_guidance (golden g24)."""
+    g = golden("g24_scalar_hyperparameters")
+    for T in (50, 1000):
+        gamma = O.gamma_table("polynomial_3", T, 1e-4)
+        assert np.array_equal(gamma, g[f"gamma_T{T}"])
+        for row in g[f"coef_T{T}"]:
+            s = int(row[0])
+            c = O.step_coefficients(gamma, s, s + 1)
+            got = [c["alpha_ts"], c["sigma2_ts"], c["eps_coef"], c["sigma"], c["sigma_s"], c["sigma_t"]]
+            # sigma2_t|s = -expm1(softplus(gamma_s) - softplus(gamma_t)) is a difference of two fp32 numbers near 1e-4 that differ by
+            # 2e-9 at s = 0 of this schedule: the reference's own value carries a 0.3 % rounding error there (an ulp or two of its
+            # softplus: 3e-11 absolute), which no other libm reproduces; the bounds below are that error carried into each
+            # quantity (eps_coef = sigma2 / alpha / sigma_t with sigma_t = 1e-2; sigma ~ sqrt(sigma2): d = 3e-11 / (2 * 4.5e-5)) --
+            # what the step adds with them is 2e-7 * eps and 4.5e-5 * noise
+            for k, (a_, r_) in enumerate(zip(got, row[1:7])):
+                assert abs(a_ - r_) <= 1e-5 * abs(r_) + (1e-9, 3e-11, 3e-9, 4e-7, 1e-9, 1e-9)[k], (T, s, k, a_, r_)
+    cfg, eargs, esd, pargs, psd = _g24_case(g, name, chain=False)
+    assert eargs["coords_range"] == 7.0 and pargs["coords_range"] == 4.0 and eargs["inv_sublayers"] == 2
+    z, t, nm, em = g[name + "_z"], g[name + "_t"][:, 0], g[name + "_node_mask"], g[name + "_edge_mask"]
+    assert rel_err(O.edm_phi(esd, eargs, z, t, nm, em), g[name + "_eps"]) < 1e-5
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    pred, grad = O.predictor_grad(psd, pargs, z, nm, em, t, np.broadcast_to(w * np.float32(0.6), (z.shape[0], 5)).copy())
+    assert rel_err(pred, g[name + "_pred"]) < 1e-5 and rel_err(grad, g[name + "_grad_gap"]) < 2e-5
+    cfg, eargs, esd, pargs, psd = _g24_case(g, name, chain=True)
+    x, h, _ = O.sample(esd, eargs, g[name + "_chain_node_mask"], g[name + "_chain_edge_mask"], g[name + "_noise"], std=1.0,
+                       pred_sd=psd, pcfg=pargs, target_w=w, scale=0.6)
+    assert rel_err(x, g[name + "_x_guided"]) < 1e-4 and np.array_equal(h, g[name + "_h_guided"])

@@ -1096,6 +1096,71 @@ def g23_attention_tanh_flags():
     save("g23_attention_tanh_flags", **out)
 
 
+def g24_scalar_hyperparameters():
+    """Every scalar hyper-parameter of the path away from its default at once (utils/args_edm.py, prediction_args.py):
+    diffusion_noise_schedule 'polynomial_3' with diffusion_noise_precision 1e-4 (en_diffusion.py:47-61,191-218), normalize_factors
+    [2, 3, 5] (:384-415), coords_range 7 (denoiser, egnn_new.py:290) and 4 (predictor, egnn_predictor/models.py:515), norm_constant 2,
+    normalization_factor 2, inv_sublayers 2: gamma / coefficient tables, phi, predictor + gradient (amplified heads), and a guided
+    T = 50 chain through sample_guidance on default-init weights, injected noise."""
+    out = {}
+    sched = dict(diffusion_noise_schedule="polynomial_3", diffusion_noise_precision=1e-4, normalize_factors=[2, 3, 5])
+    for T in (50, 1000):
+        sd = synth.synth_edm_state_dict(synth.edm_args(nf=8, n_layers=1), 1, seed=0)
+        a, model = build_ref_edm("cata", sd, nf=8, n_layers=1, diffusion_steps=T, **sched)
+        out[f"gamma_T{T}"] = model.gamma.gamma.numpy().copy()
+        rows = []
+        for s in ([0, 1, T // 2, T - 2, T - 1]):
+            st = torch.full((1, 1), s) / T
+            tt = (torch.full((1, 1), s) + 1) / T
+            gs, gt = model.gamma(st), model.gamma(tt)
+            zt = torch.zeros(1, 1, 1)
+            s2, s_ts, a_ts = model.sigma_and_alpha_t_given_s(gt, gs, zt)
+            sig_s, sig_t = model.sigma(gs, zt), model.sigma(gt, zt)
+            rows.append([s, a_ts.item(), s2.item(), (s2 / a_ts / sig_t).item(), (s_ts * sig_s / sig_t).item(),
+                         sig_s.item(), sig_t.item(), tt.item()])
+        out[f"coef_T{T}"] = np.array(rows, dtype=np.float64)
+    T = 50
+    arch_e = dict(nf=32, n_layers=2, inv_sublayers=2, coords_range=7.0, norm_constant=2.0, normalization_factor=2.0)
+    arch_p = dict(TINY_P, coords_range=4.0)
+    for ci, (name, ds, nodes, mx) in enumerate([("cata", "cata", [4, 11, 7, 2, 11], 11), ("hetro", "hetro", [3, 5, 10, 7], 10)]):
+        F = synth.num_node_features(ds)
+        over = dict(diffusion_steps=T, **sched, **arch_e)
+        esd = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=2400 + ci, amplify_coord=True)
+        a, model = build_ref_edm(ds, esd, **over)
+        psd = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **arch_p), F, 5, seed=2410 + ci, amplify_coord=True)
+        pa, pred = build_ref_pred(ds, psd, **arch_p)
+        nm, em, z = case_inputs(ds, nodes, mx, seed=2420 + ci)
+        B = z.shape[0]
+        t = np.linspace(0.05, 0.95, B).astype(np.float32).reshape(B, 1)
+        tnm, tem = torch.from_numpy(nm), torch.from_numpy(em)
+        with torch.no_grad():
+            out[f"{name}_eps"] = model.phi(torch.from_numpy(z), torch.from_numpy(t), tnm, tem, None).numpy()
+        zt = torch.from_numpy(z).requires_grad_()
+        p = pred(zt, tnm, tem, torch.from_numpy(t))
+        out[f"{name}_pred"] = p.detach().numpy()
+        out[f"{name}_grad_gap"] = torch.autograd.grad((0.6 * -p[:, 1]).sum(), zt)[0].numpy()
+        out[f"{name}_z"], out[f"{name}_t"], out[f"{name}_node_mask"], out[f"{name}_edge_mask"] = z, t, nm, em
+
+        esd_c = synth.synth_edm_state_dict(synth.edm_args(dataset=ds, **over), F, seed=2440 + ci)
+        a_c, model_c = build_ref_edm(ds, esd_c, **over)
+        psd_c = synth.synth_predictor_state_dict(synth.pred_args(dataset=ds, **arch_p), F, 5, seed=2450 + ci)
+        pa_c, pred_c = build_ref_pred(ds, psd_c, **arch_p)
+
+        def tf_gap(_in, _nm, _em, _t):
+            return -pred_c(_in, _nm, _em, _t)[:, 1]
+
+        n = torch.tensor(nodes)
+        Nn = max(nodes) * (2 if ds != "cata" else 1)
+        noise = rng_noise(2430 + ci, (T + 2, len(nodes), Nn, 3 + F))
+        with InjectNoise(list(noise)):
+            x, h, nm2, em2 = ref_sampling.sample_guidance(a_c, model_c, tf_gap, n, scale=0.6, std=1.0)
+        out[f"{name}_noise"], out[f"{name}_x_guided"], out[f"{name}_h_guided"] = noise, x.numpy(), h.numpy().astype(np.float32)
+        out[f"{name}_chain_node_mask"], out[f"{name}_chain_edge_mask"] = nm2.numpy(), em2.numpy()
+        out[f"{name}_cfg"] = np.array(json.dumps(dict(dataset=ds, T=T, eseed=2400 + ci, pseed=2410 + ci, chain_eseed=2440 + ci,
+                                                      chain_pseed=2450 + ci, nodes=nodes, over_e=dict(sched, **arch_e), over_p=arch_p)))
+    save("g24_scalar_hyperparameters", **out)
+
+
 def direct_z_target_torch(z, pred, nm):
     """-pred[:, 1] + 0.05 * sum over live nodes of |x_n|^2 + 0.02 * sum of the first feature column: depends on z through the
     predictor AND directly (numpy twin: tests/helpers.direct_z_target_grad)."""
@@ -1155,6 +1220,6 @@ def g8_checkpoint_roundtrip():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
     fns = dict(g1=g1_schedule, g2=g2_masks, g3=g3_phi, g4=g4_predictor, g5=g5_steps, g6=g6_decode,
-               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps, g20=g20_cosine_and_mean, g21=g21_direct_z_target, g22=g22_sin_embedding, g23=g23_attention_tanh_flags)
+               g7=g7_end_to_end, g8=g8_checkpoint_roundtrip, g9=g9_sample_chain, g10=g10_nonlinear_target, g11=g11_stability, g12=g12_ring_count_sampler, g13=g13_noised_predictor, g14=g14_long_chains, g15=g15_nan_scrub, g16=g16_fix_noise, g17=g17_nan_in_edge_gemm_matrix, g18=g18_large_molecules, g19=g19_amplified_default_steps, g20=g20_cosine_and_mean, g21=g21_direct_z_target, g22=g22_sin_embedding, g23=g23_attention_tanh_flags, g24=g24_scalar_hyperparameters)
     for w in which:
         fns[w]()
