@@ -75,9 +75,6 @@ struct PredSmem {
   }
 };
 
-__device__ __forceinline__ f4 dsilu4(f4 u) {
-  return (f4){dsilu_f(u[0]), dsilu_f(u[1]), dsilu_f(u[2]), dsilu_f(u[3])};
-}
 __device__ __forceinline__ float dot4(f4 a, f4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
 // float offsets of one layer's tensors inside the packed weight buffer

@@ -478,7 +478,7 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
           }
           if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
             const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
-            y = (f4){y[0] * dsilu_f(r[0]), y[1] * dsilu_f(r[1]), y[2] * dsilu_f(r[2]), y[3] * dsilu_f(r[3])};
+            y = y * dsilu4(r);
           }
           if (EPI == EPI_ACCUM) y = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g) + y;
           *(f4*)dst = y;

@@ -483,7 +483,7 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
             }
             if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
               const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * ge);
-              yy = (f4){yy[0] * dsilu_f(r[0]), yy[1] * dsilu_f(r[1]), yy[2] * dsilu_f(r[2]), yy[3] * dsilu_f(r[3])};
+              yy = yy * dsilu4(r);
             }
             if (EPI == EPI_ACCUM) yy = *(const f4*)(sRes + nd * LD + 16 * t + 4 * ge) + yy;
           }

@@ -239,13 +239,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           float sdot = 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            f4 sl, ds;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float d;
-              sl[q] = silu_dsilu_f(cp[t][q], d);
-              ds[q] = d;
-            }
+            const f4 sg = sigmoid4(cp[t]);  // silu and silu' from one sigmoid, four values per packed instruction
+            const f4 ds = sg * (splat(1.0f) + cp[t] * (splat(1.0f) - sg)), sl = cp[t] * sg;
             stash_store(sc + t * 64, ds);
             sdot += dot4(sl, *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
           }

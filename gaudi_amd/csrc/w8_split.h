@@ -86,8 +86,19 @@ __device__ __forceinline__ P3 split2(float a, float b) {  // (already scaled)
   return r;
 }
 __device__ __forceinline__ B3 split8(const f4 lo, const f4 hi, float s) {
-  const P3 p0 = split2(lo[0] * s, lo[1] * s), p1 = split2(lo[2] * s, lo[3] * s), p2 = split2(hi[0] * s, hi[1] * s),
-           p3 = split2(hi[2] * s, hi[3] * s);
+  // the scaled values on the VECTORS (packed multiplies, two values per instruction; exact: s is a power of two); the remainder as
+  // fma(x, s, -hi) so that it stays ONE v_fma_mix_f32 that reads the fp16 piece directly (x * s - hi written on the packed product
+  // costs a v_cvt_f32_f16 and a v_sub_f32 instead).  Same values either way.
+  const f4 ls = lo * s, hs = hi * s;
+  auto sp = [s](float a, float b, float as, float bs) {
+    P3 r;
+    r.h = pk_f16(as, bs);
+    const f2 f = unpk_f16(r.h);
+    r.l = pk_f16(__builtin_fmaf(a, s, -f[0]), __builtin_fmaf(b, s, -f[1]));
+    return r;
+  };
+  const P3 p0 = sp(lo[0], lo[1], ls[0], ls[1]), p1 = sp(lo[2], lo[3], ls[2], ls[3]), p2 = sp(hi[0], hi[1], hs[0], hs[1]),
+           p3 = sp(hi[2], hi[3], hs[2], hs[3]);
   B3 r;
   r.h = (u4){p0.h, p1.h, p2.h, p3.h};
   r.l = (u4){p0.l, p1.l, p2.l, p3.l};
