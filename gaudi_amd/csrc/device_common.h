@@ -90,21 +90,29 @@ __device__ __forceinline__ float silu_dsilu_f(float x, float& d) {
   d = s * (1.0f + x * (1.0f - s));
   return x * s;
 }
+__device__ __forceinline__ f4 silu4(f4 u) {
+  f4 r;
+  r[0] = silu_f(u[0]); r[1] = silu_f(u[1]); r[2] = silu_f(u[2]); r[3] = silu_f(u[3]);
+  return r;
+}
+__device__ __forceinline__ f4 dsilu4(f4 u) { return (f4){dsilu_f(u[0]), dsilu_f(u[1]), dsilu_f(u[2]), dsilu_f(u[3])}; }
 __device__ __forceinline__ f4 splat(float v) { return (f4){v, v, v, v}; }
-// Four values at once.  The multiplies and adds are written on the VECTOR so that hipcc selects the packed fp32 instructions
-// (v_pk_mul_f32 / v_pk_add_f32: two values per issue slot -- a SIMD's time is the sum of its instructions); only the
-// transcendentals stay one per value.  Same operations on the same operands as the scalar forms above: bit-identical results
-// (__expf(-x) = v_exp_f32(x * -log2(e)), the constant below).
-__device__ __forceinline__ f4 sigmoid4(f4 x) {
+// The same, four values at once, for the 8-wave kernels (round 6).  The multiplies and adds are written on the VECTOR so that hipcc
+// selects the packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32: two values per issue slot); only the transcendentals stay one per
+// value.  Same operations on the same operands as the scalar forms above: bit-identical results (__expf(-x) = v_exp_f32(x * -log2(e)),
+// the constant below).  The 4-wave kernels keep the scalar forms: with these, the V4G predictor at the default widths (kerng_pred.hip,
+// <0, 208>: the instantiation on the register cliff, sampler_kernel.h) returned a wrong input gradient (2.6 %) -- found by
+// test_global_node_buffer_kernels_agree_with_the_lds_kernels.
+__device__ __forceinline__ f4 sigmoid4v(f4 x) {
   const f4 e = x * splat(-1.4426950408889634f);
   const f4 d = (f4){__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]), __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} +
                splat(1.0f);
   return (f4){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
 }
-__device__ __forceinline__ f4 silu4(f4 u) { return u * sigmoid4(u); }
+__device__ __forceinline__ f4 silu4v(f4 u) { return u * sigmoid4v(u); }
 // silu'(x) = s * (1 + x * (1 - s))
-__device__ __forceinline__ f4 dsilu4(f4 x) {
-  const f4 s = sigmoid4(x);
+__device__ __forceinline__ f4 dsilu4v(f4 x) {
+  const f4 s = sigmoid4v(x);
   return s * (splat(1.0f) + x * (splat(1.0f) - s));
 }
 

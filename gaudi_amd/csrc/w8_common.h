@@ -191,9 +191,9 @@ __device__ __forceinline__ void edge_gemm_pq(f4 (&acc)[HP / 16], Ring<HP>& ring,
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = *(const f4*)(sB2 + 16 * t + 4 * g);
   const bool ktail = ring.ktail;
-  auto gen = [&](int cc) { return silu4(edge_u(pp, qq, sCr, sCd, g, cc, r, d0)); };  // silu(u) of input chunk cc, B layout
+  auto gen = [&](int cc) { return silu4v(edge_u(pp, qq, sCr, sCd, g, cc, r, d0)); };  // silu(u) of input chunk cc, B layout
   auto gen_last = [&] {  // ... of the last chunk: one k-step when the matrix carries a K tail
-    return ktail ? silu4(edge_u_tail(pp, qq, sCr, sCd, g, T, r, d0)) : gen(T - 1);
+    return ktail ? silu4v(edge_u_tail(pp, qq, sCr, sCd, g, T, r, d0)) : gen(T - 1);
   };
   f4 bin = T > 1 ? gen(0) : gen_last(), nb = bin;
   // one trip; NQ k-steps; `last_next`: the chunk generated for the next trip is the last one
@@ -471,14 +471,14 @@ __device__ __forceinline__ void node_gemm_body(const WBuf& wb, int Wa, const flo
             continue;
           }
           if (gPre != nullptr) nstash_store((f4*)(gPre + nd * HP + 16 * t + 4 * g), y);  // stash: write once, read once
-          if (EPI == EPI_SILU) y = silu4(y);
+          if (EPI == EPI_SILU) y = silu4v(y);
           if (EPI == EPI_RESIDUAL_MASK) {
             const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
             y = (r + y) * sMask[nd];
           }
           if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
             const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g);
-            y = y * dsilu4(r);
+            y = y * dsilu4v(r);
           }
           if (EPI == EPI_ACCUM) y = *(const f4*)(sRes + nd * LD + 16 * t + 4 * g) + y;
           *(f4*)dst = y;

@@ -256,7 +256,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           float sdot = 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            const f4 m = silu4(acc[t]);
+            const f4 m = silu4v(acc[t]);
             acc[t] = m;
             const f4 wv = *(const f4*)(wa + 16 * t + 4 * g);
             sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
@@ -346,7 +346,7 @@ __device__ __forceinline__ void edm_forward(const EdmDev& W, const MolGraph& mg,
           float sdot = 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            const f4 m = silu4(acc[t]);
+            const f4 m = silu4v(acc[t]);
             const f4 wv = *(const f4*)(w3 + 16 * t + 4 * g);
             sdot += m[0] * wv[0] + m[1] * wv[1] + m[2] * wv[2] + m[3] * wv[3];
           }

@@ -476,14 +476,14 @@ __device__ __forceinline__ void node_gemm_h(const WBuf& wh, int Wa, const float*
           // the row maxima the edge GEMMs' column scales are bounded with (w8_split.h): one LDS atomic per lane and tile
           if (sMaxOut != nullptr) atomicMax(sMaxOut + nd, umax(umax(absbits(yy[0]), absbits(yy[1])), umax(absbits(yy[2]), absbits(yy[3]))));
           if (!pad) {
-            if (EPI == EPI_SILU) yy = silu4(yy);
+            if (EPI == EPI_SILU) yy = silu4v(yy);
             if (EPI == EPI_RESIDUAL_MASK) {
               const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * ge);
               yy = (r + yy) * sMask[nd];
             }
             if (EPI == EPI_MUL_DSILU) {  // y * silu'(pre-activation stored in sRes); in place is safe
               const f4 r = *(const f4*)(sRes + nd * LD + 16 * t + 4 * ge);
-              yy = yy * dsilu4(r);
+              yy = yy * dsilu4v(r);
             }
             if (EPI == EPI_ACCUM) yy = *(const f4*)(sRes + nd * LD + 16 * t + 4 * ge) + yy;
           }

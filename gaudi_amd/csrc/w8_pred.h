@@ -216,7 +216,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
         float sdot = 0.f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const f4 m = silu4(acc[t]);
+          const f4 m = silu4v(acc[t]);
           acc[t] = m;
           sdot += dot4(m, *(const f4*)(Lw.wa + 16 * t + 4 * g));
         }
@@ -239,7 +239,7 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
           float sdot = 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            const f4 sg = sigmoid4(cp[t]);  // silu and silu' from one sigmoid, four values per packed instruction
+            const f4 sg = sigmoid4v(cp[t]);  // silu and silu' from one sigmoid, four values per packed instruction
             const f4 ds = sg * (splat(1.0f) + cp[t] * (splat(1.0f) - sg)), sl = cp[t] * sg;
             stash_store(sc + t * 64, ds);
             sdot += dot4(sl, *(const f4*)(Lw.wc2 + 16 * t + 4 * g));
@@ -523,13 +523,13 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
           for (int t = 0; t < T; ++t) ve[t] = stash_load(sv + t * 64);
           float dadot = 0.f;
 #pragma unroll
-          for (int t = 0; t < T; ++t) dadot += dot4(de[t], silu4(ve[t]));
+          for (int t = 0; t < T; ++t) dadot += dot4(de[t], silu4v(ve[t]));
           const float da = reduce_groups(dadot) * tc.mk;
           const float ds = W.attention ? da * a * (1.0f - a) : 0.f;
           const float am = a * tc.mk;
 #pragma unroll
           for (int t = 0; t < T; ++t)  // dv = (de*a*mask + ds*wa) * silu'(v)
-            de[t] = (de[t] * am + *(const f4*)(Lw.wa + 16 * t + 4 * g) * ds) * dsilu4(ve[t]);
+            de[t] = (de[t] * am + *(const f4*)(Lw.wa + 16 * t + 4 * g) * ds) * dsilu4v(ve[t]);
         }
         STAMP(ST_B_DV);
         // next edge GEMM of the chain: Wc1^T of layer l-1 (W2^T when that layer is ... never the last), none after layer 0
@@ -548,7 +548,7 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const f4 u = edge_u(pp, qq, Lw.cr, Lw.cd, g, t, gg[0], d0v);
-          du[t] = du[t] * dsilu4(u);
+          du[t] = du[t] * dsilu4v(u);
           drdot += dot4(du[t], *(const f4*)(Lw.cr + 16 * t + 4 * g));
           dd0dot += dot4(du[t], *(const f4*)(Lw.cd + 16 * t + 4 * g));
         }

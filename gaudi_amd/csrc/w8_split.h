@@ -307,8 +307,8 @@ __device__ __forceinline__ void edge_gemm_pq_s(f4 (&acc)[HP / 16], RingS<HP, MOD
   const Pow2Scale sc = scale_for(absbits(ubound));
   const float se = sc.s;
   auto gen = [&](int m) {  // split silu(u) of K chunk m (tiles 2m, 2m+1; an odd T leaves the upper half of the last chunk 0)
-    const f4 lo = silu4(edge_u(pp, qq, sCr, sCd, g, 2 * m, r, d0));
-    const f4 hi = 2 * m + 1 < T ? silu4(edge_u(pp, qq, sCr, sCd, g, 2 * m + 1 < T ? 2 * m + 1 : 0, r, d0)) : splat(0.f);
+    const f4 lo = silu4v(edge_u(pp, qq, sCr, sCd, g, 2 * m, r, d0));
+    const f4 hi = 2 * m + 1 < T ? silu4v(edge_u(pp, qq, sCr, sCd, g, 2 * m + 1 < T ? 2 * m + 1 : 0, r, d0)) : splat(0.f);
     return split8(lo, hi, se);
   };
   B3 bin = gen(0), nb = bin;
