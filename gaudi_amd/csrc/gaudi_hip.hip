@@ -93,6 +93,7 @@ struct gaudi_handle {
   bool split = true;          // 8-wave kernels: GEMMs on the fp16 matrix pipe with operands split into fp16 pairs (GAUDI_EDGE_MATH=fp32: off)
   int run_split = 0;          // ... and how the CURRENT call uses them: 1 = full weight ring, 2 = half ring, 0 = fp32 instructions
   bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
+  bool run_two = false;       // ... and its guided steps are two launches (denoiser-only kernel, then predictor-only kernel): no fused instantiation
   int run_gn8 = 0;            // ... on the 8-wave kernels with node buffers in global memory (V8G, round 4): 1 all five, 2 P / Q in LDS
   bool gn8_pq = true;         // GAUDI_GN8_PQ=0: never the P / Q-in-LDS form (kern8gp_*.hip)
   bool gn8 = true;            // GAUDI_GN8=0: molecules beyond the LDS limit go to the 4-wave V4G kernels, as in round 3
@@ -749,9 +750,11 @@ static bool have_kernels_g(int hpe, int hpp) {
 static kernel_fn pick_kernel_se(int, int, bool) { return nullptr; }
 #else
 kernel_fn gaudi_kernse_edm(int hpe, int hpp, int gn);
+kernel_fn gaudi_kernse_edm_more(int hpe, int hpp, int gn);
 kernel_fn gaudi_kernse_fused(int hpe, int hpp, int gn);
 static kernel_fn pick_kernel_se(int hpe, int hpp, bool gn) {
   kernel_fn f = gaudi_kernse_edm(hpe, hpp, gn);
+  if (!f) f = gaudi_kernse_edm_more(hpe, hpp, gn);
   if (!f) f = gaudi_kernse_fused(hpe, hpp, gn);
   return f;
 }
@@ -986,7 +989,7 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
   if (!fn)
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
-                    (v8 ? " in the 8-wave family" : se ? " among the sin_embedding kernels (hidden sizes 32 and 192, predictor 48 / 208)" : ""));
+                    (v8 ? " in the 8-wave family" : se ? " among the sin_embedding kernels" : ""));
   size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split, h->run_gn8)
                   : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW, h->run_gn, se ? 24 : 2);
   if (v8 && P.hk_off) lds = sizeof(float) * ((size_t)P.hk_off + (size_t)h->run_hk);  // the kept split copy of h sits behind the FUSED plan
@@ -1366,6 +1369,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   h->run_variant = h->variant;
   h->run_split = 0;
   h->run_gn = false;
+  h->run_two = false;
   h->run_gn8 = 0;
   h->run_mr = false;
   h->run_groups = B;
@@ -1433,6 +1437,9 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
       P.gnode_stride = (long long)stride;
     }
   }
+  // Guided steps as two launches: the V4G kernels have no fused instantiation, and a sin_embedding denoiser has one at the tiny and the
+  // default width pairs only -- every other width runs its denoiser-only kernel followed by the ordinary predictor-only kernel
+  h->run_two = h->run_gn || (se && hpp && !pick_kernel_se(hpe, hpp, false));
   return GAUDI_OK;
 }
 
@@ -1845,8 +1852,8 @@ static int run_chain(gaudi_handle* h, int B, int N, const float* node_mask, cons
   }
   float* zin = h->d_zin.as<float>();
   float* zout = h->d_zout.as<float>();
-  if (h->run_gn && target_w) {
-    // Large molecules (V4G kernels), guided: every reverse step is two launches -- the EDM-only kernel runs the step up to
+  if (h->run_two && target_w) {
+    // Large molecules (V4G kernels) and sin_embedding denoisers without a fused kernel, guided: every reverse step is two launches -- the EDM-only kernel runs the step up to
     // z_s before guidance (split = 1: denoise, update with noise), the predictor-only kernel the guidance update, the
     // projection and the NaN scrub (MODE_GUIDE) -- then one decode pass.
     for (int s = s_hi; s >= s_lo; --s) {
@@ -2160,7 +2167,7 @@ static int sample_cb_impl(gaudi_handle* h, int B, int N, const float* node_mask,
   // Large molecules (V4G kernels: node buffers in global memory) have no fused EDM + predictor instantiation (DESIGN.md
   // 7.12): phase A is the EDM-only kernel (split = 1: z_t -> z_s before guidance) followed by the predictor-only kernel's
   // forward half (MODE_GUIDE, split = 1), phase B the predictor-only kernel's second half (MODE_GUIDE, split = 2).
-  const bool gn = h->run_gn;
+  const bool gn = h->run_two;
   // GAUDI_DEBUG_CB: where a callback step's host time goes (enqueue / wait for pred / the caller's function)
   const bool dbg_cb = getenv("GAUDI_DEBUG_CB") != nullptr;
   double t_enq = 0, t_wait = 0, t_user = 0;

@@ -49,7 +49,8 @@ typedef struct {
   float norm_values[3];        /* args.normalize_factors                                       */
   int32_t sin_embedding;       /* args.sin_embedding (egnn_new.py:269-273,378-391): the first Linear of every edge / coordinate MLP
                                   takes 2 x 12 sinusoids of sqrt(r), sqrt(d0) instead of (r, d0).  Such a denoiser runs on the
-                                  4-wave kernels (hidden sizes 32 and 192; about a third of the 8-wave rate)   (ABI 7)   */
+                                  4-wave kernels (about 0.4 x the 8-wave rate; fused with the predictor at the tiny and the default
+                                  width pairs, two launches per guided step elsewhere)   (ABI 7)   */
 } gaudi_edm_config;
 
 /* Architecture of EGNN_predictor: cond_prediction/train_cond_predictor.py:183-196. */

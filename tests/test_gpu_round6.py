@@ -435,3 +435,40 @@ def test_scalar_hyperparameters_away_from_their_defaults_vs_reference(golden, na
         x, h, d = eng.sample(cnm.reshape(Bc, Nc), g[name + "_chain_edge_mask"].reshape(Bc, Nc, Nc), noise=g[name + "_noise"], target_w=w, scale=0.6)
         assert rel_err(x, g[name + "_x_guided"]) < 1e-4 and np.array_equal(h, g[name + "_h_guided"])
         eng.close()
+
+
+@pytest.mark.parametrize("nf", [64, 196])
+def test_sin_embedding_other_widths_guided_as_two_launches(nf):
+    """A sin_embedding denoiser has a fused (denoiser + predictor) kernel at the tiny and the default width pairs only; at every other
+    hidden size of the 4-wave family it runs on its denoiser-only kernel and a guided step is two launches (denoiser, then the ordinary
+    predictor-only kernel: the path large molecules take).  phi, a guided teacher-forced step and a short guided chain against the
+    oracle (pinned on the reference for sin_embedding by g22) at 1e-4."""
+    from oracle import gaudi_oracle as O
+    from tests.helpers import TINY_P
+    T, s = 8, 3
+    ds = "hetro"
+    F = synth.num_node_features(ds)
+    eargs = synth.edm_args(dataset=ds, diffusion_steps=T, sin_embedding=True, nf=nf, n_layers=2)
+    pargs = synth.pred_args(dataset=ds, **TINY_P)
+    esd = synth.synth_edm_state_dict(eargs, F, seed=71)
+    psd = synth.synth_predictor_state_dict(pargs, F, 5, seed=72)
+    nm3, em_flat = O.build_masks([3, 5, 4], 5, True)
+    B, N = nm3.shape[0], nm3.shape[1]
+    nm, em = nm3.reshape(B, N), em_flat.reshape(B, N, N)
+    rng = np.random.default_rng(73)
+    z = O._combined_noise(rng.standard_normal((B, N, 3 + F)).astype(np.float32), nm3)
+    eps = rng.standard_normal((B, N, 3 + F)).astype(np.float32)
+    t = np.full(B, np.float32(s + 1) / np.float32(T), np.float32)
+    w = np.array([0, -1, 0, 0, 0], np.float32)
+    gamma = O.gamma_table("polynomial_2", T, 1e-5)
+    eng = _engine(eargs, esd, pargs, psd)
+    assert rel_err(eng.phi(z, t, nm, em), O.edm_phi(esd, eargs, z, t, nm3, em_flat)) < 1e-4
+    assert eng.kernel_variant()[1] == 4 and not eng.node_buffers_global()
+    assert rel_err(eng.step(s, z, nm, em, eps), O.step_unguided(esd, eargs, gamma, s, z, nm3, em_flat, eps)) < 1e-4
+    zs = eng.step(s, z, nm, em, eps, target_w=w, scale=0.6)
+    assert rel_err(zs, O.step_guided(esd, eargs, psd, pargs, gamma, s, z, nm3, em_flat, eps, w, 0.6)) < 1e-4
+    noise = rng.standard_normal((T + 2, B, N, 3 + F)).astype(np.float32)
+    x, h, d = eng.sample(nm, em, noise=noise, target_w=w, scale=0.6)
+    xo, ho, _ = O.sample(esd, eargs, nm3, em_flat, noise, std=1.0, pred_sd=psd, pcfg=pargs, target_w=w, scale=0.6)
+    assert rel_err(x, xo) < 1e-4 and np.array_equal(h, ho)
+    eng.close()
