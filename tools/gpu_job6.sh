@@ -34,6 +34,12 @@ for step in "$@"; do
            GAUDI_GN8_PQ=0 timeout 900 $B --workload c4x > $out/c4x_allglobal_$rep.json 2> $out/c4x_allglobal_$rep.err
            timeout 900 $B --workload c4x > $out/c4x_hybrid_$rep.json 2> $out/c4x_hybrid_$rep.err
          done ;;
+    xcd) for rep in 1 2; do
+           for wl in c4x c4; do
+             GAUDI_XCD_ORDER=0 timeout 900 $B --workload $wl > $out/${wl}_plain_$rep.json 2> $out/${wl}_plain_$rep.err
+             GAUDI_XCD_ORDER=1 timeout 900 $B --workload $wl > $out/${wl}_xcd_$rep.json 2> $out/${wl}_xcd_$rep.err
+           done
+         done ;;
     tests_core) timeout 2400 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_split.py tests/test_gpu_round5.py -x -q -m gpu > $out/tests_core.txt 2>&1 ;;
     tests_v8g) timeout 2400 python3 -m pytest tests/test_gpu_round4.py tests/test_gpu_round3.py -x -q -m gpu -k "v8g or large or n40 or dense or callback_targets" > $out/tests_v8g.txt 2>&1 ;;
     tests_all) timeout 3400 python3 -m pytest tests -x -q -m gpu > $out/tests_all.txt 2>&1 ;;
