@@ -95,6 +95,8 @@ struct gaudi_handle {
   bool run_gn = false;        // the CURRENT call runs on the 4-wave kernels with node buffers in global memory (large molecules)
   bool run_two = false;       // ... and its guided steps are two launches (denoiser-only kernel, then predictor-only kernel): no fused instantiation
   int run_gn8 = 0;            // ... on the 8-wave kernels with node buffers in global memory (V8G, round 4): 1 all five, 2 P / Q in LDS
+  bool run_pg = false;        // ... a wide-group launch on the FULL ring with the predictor's fifth node buffer in the global scratch (kern8mp_*.hip)
+  bool wide_full = true;      // GAUDI_WIDE_FULL=0: wide groups that do not fit the full ring run on the half ring (round 5)
   bool gn8_pq = true;         // GAUDI_GN8_PQ=0: never the P / Q-in-LDS form (kern8gp_*.hip)
   bool gn8 = true;            // GAUDI_GN8=0: molecules beyond the LDS limit go to the 4-wave V4G kernels, as in round 3
   bool force_gn8 = false;     // GAUDI_FORCE_GN8=1: V8G whenever it can run (test knob)
@@ -894,6 +896,13 @@ static kernel_fn pick_kernel8gp(int hpe, int hpp) {
   return f;
 }
 #endif
+// ... and the wide-group kernels on the full ring (kern8mp_fused.hip, round 6)
+#ifdef GAUDI_STAMP_STUBS
+static kernel_fn pick_kernel8mp(int, int) { return nullptr; }
+#else
+kernel_fn gaudi_kern8mp_fused(int hpe, int hpp);
+static kernel_fn pick_kernel8mp(int hpe, int hpp) { return gaudi_kern8mp_fused(hpe, hpp); }
+#endif
 // mr: the call holds a graph of more than one round of edge tiles AND runs the predictor
 static kernel_fn pick_kernel8_mode(int hpe, int hpp, int mode, bool mr = false) {
   if (mr) return pick_kernel8m(hpe, hpp, mode);
@@ -926,11 +935,14 @@ static size_t gnode_floats(int hpe, int hpp, int N) {
   return std::max((size_t)(hpe ? 4 * N * (hpe + 4) : 0), (size_t)(hpp ? 5 * N * (hpp + 4) : 0));
 }
 
-// gn: 0 resident, 1 the five node buffers in global memory, 2 of which P / Q in LDS (w8_edm.h: gn_lds_buffers)
+// gn: 0 resident, 1 the five node buffers in global memory, 2 of which P / Q in LDS (w8_edm.h: gn_lds_buffers); 3 (round 6: wide
+// groups on the full ring) the resident kernels with the PREDICTOR's fifth node buffer in global memory (w8_pred.h: PredSmem, PG)
 static size_t lds_floats8_base(int hpe, int hpp, int N, int D, int S, int split, int gn = 0) {
   size_t net = 0;
+  const int pbuf = gn == 3 ? 4 : 5;
+  if (gn == 3) gn = 0;
   if (hpe) net = std::max(net, (size_t)((gn ? w8::gn_lds_buffers(gn) : 5) * N * (hpe + 4) + w8::edge_ring_floats(hpe, split) + 8 * N + 2 * align4(N) + 96 + S * 9 + 8 * hpe));
-  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + (gn ? w8::gn_lds_buffers(gn) : 5) * N * (hpp + 4) + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * hpp));
+  if (hpp) net = std::max(net, (size_t)(w8::edge_ring_floats(hpp, split) + (gn ? w8::gn_lds_buffers(gn) : pbuf) * N * (hpp + 4) + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * hpp));
   return common_floats8(N, D, S) + net;
 }
 static size_t gnode_floats8(int hpe, int hpp, int N) {
@@ -956,9 +968,11 @@ static bool node_f16_fits(int hp, int N, int split, bool gn) {
 static bool plan_pub8(int hpe, int hpp, int N, int D, int S, int split, int& pubx, int& pub_ch, int gn = 0) {
   pubx = 0;
   pub_ch = 0;
+  const int gn_lds = gn;  // (3: the resident kernels' planning with four predictor buffers in LDS)
+  if (gn == 3) gn = 0;
   if (!node_f16_fits(hpe, N, split, gn != 0) || !node_f16_fits(hpp, N, split, gn != 0)) return false;
   const long long cap = 160 * 1024 / 4 - 64;  // floats (a little headroom for the runtime's own static LDS)
-  const long long base = (long long)lds_floats8_base(hpe, hpp, N, D, S, split, gn);
+  const long long base = (long long)lds_floats8_base(hpe, hpp, N, D, S, split, gn_lds);
   if (base > cap) return false;
   if (!hpp) return true;
   const int T = hpp / 16;
@@ -980,7 +994,7 @@ static size_t lds_bytes8(int hpe, int hpp, int N, int D, int S, int pubx, int sp
 static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long steps) {
   const bool v8 = h->run_variant == 8;
   const bool se = hpe && h->ecfg.sin_embedding;  // stage_graph keeps such a call on the 4-wave family
-  kernel_fn fn = v8   ? (h->run_gn8 == 2 ? pick_kernel8gp(hpe, hpp) : h->run_gn8 ? pick_kernel8g(hpe, hpp) : pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp))
+  kernel_fn fn = v8   ? (h->run_pg && hpe && hpp ? pick_kernel8mp(hpe, hpp) : h->run_gn8 == 2 ? pick_kernel8gp(hpe, hpp) : h->run_gn8 ? pick_kernel8g(hpe, hpp) : pick_kernel8_mode(hpe, hpp, h->run_split, h->run_mr && hpp))
                  : se ? pick_kernel_se(hpe, hpp, h->run_gn)
                       : h->run_gn ? pick_kernel_g(hpe, hpp) : pick_kernel(hpe, hpp);
   // two column tiles per node GEMM on the resident full-ring kernel: its FR instantiation (same arithmetic, same results)
@@ -990,7 +1004,7 @@ static int launch(gaudi_handle* h, const KParams& P, int hpe, int hpp, long long
     return fail(h, GAUDI_E_INVALID,
                 "no kernel instantiated for padded hidden sizes (" + std::to_string(hpe) + "," + std::to_string(hpp) + ")" +
                     (v8 ? " in the 8-wave family" : se ? " among the sin_embedding kernels" : ""));
-  size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split, h->run_gn8)
+  size_t lds = v8 ? lds_bytes8(hpe, hpp, P.N, 3 + P.F, P.EW, P.pubx, h->run_split, h->run_pg && hpe && hpp ? 3 : h->run_gn8)
                   : lds_bytes(hpe, hpp, P.N, 3 + P.F, P.EW, h->run_gn, se ? 24 : 2);
   if (v8 && P.hk_off) lds = sizeof(float) * ((size_t)P.hk_off + (size_t)h->run_hk);  // the kept split copy of h sits behind the FUSED plan
   if (lds > 160 * 1024)
@@ -1181,7 +1195,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   const float* nm_used = node_mask;
   int n_slots = N, mode_run = mode_u;
   bool mr_run = mr;
-  bool narrow_taken = false, use_pack = false;
+  bool narrow_taken = false, use_pack = false, pg_run = false;
   // Round 6: a bucket of molecules that fit the resident kernels on their own (gaudi_sample: per-molecule kernel family) while the
   // call's padded N does not -- packed groups of call_narrow (< N) node slots, one round of eight edge tiles.
   if (h->call_narrow > 0 && h->call_narrow < N && h->pack_now && (int64_t)B * N < (1 << 28)) {
@@ -1278,8 +1292,20 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
       // a packed launch has more edge slots per workgroup; it must keep the ARITHMETIC the unpacked plan has -- split operands
       // (full or half ring: the same sums in the same order) or fp32 instructions -- because the plan of a sharded batch is the
       // same on every rank (gaudi_set_plan_hint) and packing must not move a rank off it
-      const int mode2 = plan_for(cd.NG, M2.S, mr2);
+      int mode2 = plan_for(cd.NG, M2.S, mr2);
       if (mode2 < 0 || (mode2 != 0) != (mode_u != 0)) continue;
+      // Round 6: a wide group that fits the HALF ring only (two cata-11 molecules at the default widths: five predictor buffers of 22
+      // node slots + the 52 KiB ring are 171 KB) runs on the FULL ring with the predictor's fifth node buffer in the workgroup's global
+      // scratch (kern8mp_fused.hip) -- the same sums in the same order, one trip per K chunk instead of two
+      pg_run = false;
+      if (wide && mode2 == 2 && mr2 && h->wide_full && hpe && hpp && pick_kernel8mp(hpe, hpp)) {
+        if (plan_pub8(hpe, hpp, cd.NG, Dz, M2.S, 1, pubx, pub_ch, 3)) {
+          mode2 = 1;
+          pg_run = true;
+        } else {
+          plan_for(cd.NG, M2.S, mr2);  // (restore pubx / pub_ch of the half-ring plan)
+        }
+      }
       M = std::move(M2);
       B = pk.G;
       nm_used = pk.umask.data();
@@ -1289,7 +1315,10 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
       taken = use_pack = true;
       break;
     }
-    if (!taken) plan_for(N, M.S, mr);  // keep the unpacked plan (pubx / pub_ch)
+    if (!taken) {
+      pg_run = false;
+      plan_for(N, M.S, mr);  // keep the unpacked plan (pubx / pub_ch)
+    }
   }
   const bool packed = use_pack;
   h->run_split = mode_run;
@@ -1297,7 +1326,7 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   P.pub_ch = pub_ch;
   if (getenv("GAUDI_DEBUG_PLAN"))
     fprintf(stderr, "[plan] molecules=%d workgroups=%d N=%d node slots=%d S=%d split=%d mr=%d pub_ch=%d pubx=%d lds=%zu\n", B0, B, N, n_slots,
-            M.S, h->run_split, gn8 ? 2 : (int)mr_run, pub_ch, pubx, lds_bytes8(hpe, hpp, n_slots, Dz, M.S, pubx, h->run_split, gn8));
+            M.S, h->run_split, gn8 ? 2 : pg_run ? 3 : (int)mr_run, pub_ch, pubx, lds_bytes8(hpe, hpp, n_slots, Dz, M.S, pubx, h->run_split, pg_run ? 3 : gn8));
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = d.reserve(bytes);
     if (e != hipSuccess) return e;
@@ -1338,11 +1367,12 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
   h->run_nslots = n_slots;
   h->run_mr = mr_run;
   h->run_gn8 = gn8;
+  h->run_pg = pg_run;
   // Kept split copy of h (w8_nodes_f16.h: node_ctx_keep): behind everything the plan of BOTH networks needs, when 160 KiB leave the
   // room -- C2 / C3 do (46 KB free), 20-22 node slots do not.  Same results either way (the copy is a function of h alone).
   P.hk_off = 0;
   h->run_hk = 0;
-  if (h->keep_h && GAUDI_NODE_F16 && mode_run >= 1 && !gn8) {
+  if (h->keep_h && GAUDI_NODE_F16 && mode_run >= 1 && !gn8 && !pg_run) {
     const size_t plan = lds_bytes8(hpe, hpp, n_slots, Dz, M.S, pubx, mode_run, false) / sizeof(float);
     const size_t at = (plan + 3) & ~(size_t)3;
     const size_t need = (size_t)w8::nh_keep_floats(std::max(hpe, hpp), n_slots);
@@ -1350,6 +1380,12 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
       P.hk_off = (int)at;
       h->run_hk = (int)need;
     }
+  }
+  if (pg_run) {  // one [node slots][hpp + 4] buffer per workgroup
+    const size_t stride = ((size_t)n_slots * (hpp + 4) + 63) / 64 * 64;
+    HIPCHECK(h, h->d_gnode.reserve(sizeof(float) * (stride * (size_t)B + 256)));
+    P.gnode = h->d_gnode.as<float>();
+    P.gnode_stride = (long long)stride;
   }
   if (gn8) {
     const size_t stride = (gnode_floats8(hpe, hpp, N) + 63) / 64 * 64;
@@ -1371,6 +1407,7 @@ static int stage_graph(gaudi_handle* h, int B, int N, const float* node_mask, co
   h->run_gn = false;
   h->run_two = false;
   h->run_gn8 = 0;
+  h->run_pg = false;
   h->run_mr = false;
   h->run_groups = B;
   h->run_nslots = N;
@@ -1491,6 +1528,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_PACK")) h->pack = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_GN8_PACK")) h->gn8_pack = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_GN8_PQ")) h->gn8_pq = atoi(v) != 0;
+  if (const char* v = getenv("GAUDI_WIDE_FULL")) h->wide_full = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_KEEP_H")) h->keep_h = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_FAMILY_SPLIT")) h->family_split = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PAIRS")) h->pairs = atoi(v);
@@ -2436,7 +2474,8 @@ int gaudi_last_workgroups(const gaudi_handle* h, int32_t* workgroups, int32_t* n
 
 int gaudi_node_buffers(const gaudi_handle* h, int32_t* last_call) {
   if (!h || !last_call) return GAUDI_E_INVALID;
-  *last_call = h->run_gn ? 1 : h->run_gn8;  // 0 resident, 1 global scratch, 2 global scratch with P / Q in LDS (8-wave kernels)
+  // 0 resident, 1 global scratch, 2 global scratch with P / Q in LDS (8-wave kernels), 3 resident except the predictor's fifth buffer
+  *last_call = h->run_gn ? 1 : h->run_pg ? 3 : h->run_gn8;
   return GAUDI_OK;
 }
 

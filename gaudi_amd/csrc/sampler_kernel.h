@@ -244,7 +244,7 @@ __device__ __attribute__((noinline)) void edm8_call(EdmDev W_, Graph8Args ga_, f
 }
 // the predictor's forward and reverse passes are separate functions too (the reverse pass holds three 52-register
 // operand sets at its peak; allocated together with the forward it spilled twice as much)
-template <int HP, int SP, bool MR, int GN = 0, bool FL = false>
+template <int HP, int SP, bool MR, int GN = 0, bool FL = false, bool PG = false>
 __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args ga_, float t_val_, float* stash_, float readout_div_,
                                                          float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -252,12 +252,12 @@ __device__ __attribute__((noinline)) void pred_fwd8_call(PredDev W_, Graph8Args 
   const Graph8Args ga = uni(ga_);
   const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
   const w8::MolGraph mg = graph8(L, ga);
-  w8::PredSmem<HP, SP, GN> sm;
-  sm.carve(L.net, ga.N, ga.S, ga.pubx, GN ? uni(gnode_) : nullptr);
+  w8::PredSmem<HP, SP, GN, PG> sm;
+  sm.carve(L.net, ga.N, ga.S, ga.pubx, (GN || PG) ? uni(gnode_) : nullptr);
   sm.hk = ga.hk ? smem + ga.hk : nullptr;
   w8::pred_forward<HP, SP, MR, GN, FL>(W, mg, sm, L.sZ, uni(t_val_), uni(stash_), uni(readout_div_), (int)threadIdx.x);
 }
-template <int HP, int SP, bool MR, int GN = 0, bool FL = false>
+template <int HP, int SP, bool MR, int GN = 0, bool FL = false, bool PG = false>
 __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args ga_, float* stash_, float readout_div_, int resume_,
                                                          float* gnode_ = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -265,8 +265,8 @@ __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args 
   const Graph8Args ga = uni(ga_);
   const Lds8 L = carve_lds8(smem, ga.N, ga.D, ga.S);
   const w8::MolGraph mg = graph8(L, ga);
-  w8::PredSmem<HP, SP, GN> sm;
-  sm.carve(L.net, ga.N, ga.S, ga.pubx, GN ? uni(gnode_) : nullptr);
+  w8::PredSmem<HP, SP, GN, PG> sm;
+  sm.carve(L.net, ga.N, ga.S, ga.pubx, (GN || PG) ? uni(gnode_) : nullptr);
   w8::pred_backward<HP, SP, MR, GN, FL>(W, mg, sm, uni(stash_), L.sEps /* grad */, uni(readout_div_), ga.pub_ch, (int)threadIdx.x,
                         uni(resume_) ? L.sZ : nullptr);
 }
@@ -279,7 +279,8 @@ __device__ __attribute__((noinline)) void pred_bwd8_call(PredDev W_, Graph8Args 
 //     five; 2: P and Q stay in LDS (round 6, w8_edm.h: gn_lds_buffers)
 // FR: the node GEMMs' split passes and epilogues recompute their lane addresses per call (w8_nodes_f16.h: FL) -- always in the MR
 //     and GN kernels; the resident single-round kernel exists in both forms and the host picks by node slots (gaudi_hip.hip)
-template <int SP, bool MR = false, int GN = 0, bool FR = false>
+// PG: the predictor keeps ONE node buffer in the workgroup's global scratch (w8_pred.h: PredSmem) -- wide groups on the full ring
+template <int SP, bool MR = false, int GN = 0, bool FR = false, bool PG = false>
 struct V8T {
   static constexpr bool kFL = MR || GN != 0 || FR;
   static constexpr int kThreads = w8::kThreads;
@@ -316,7 +317,7 @@ struct V8T {
   __device__ __forceinline__ static Graph8Args gargs(const Graph& mg) {
     return Graph8Args{mg.N, mg.D, mg.S, mg.NC, mg.ntiles, mg.pubx, mg.pub_ch, mg.hk};
   }
-  static constexpr bool kGlobalNodes = GN != 0;
+  static constexpr bool kGlobalNodes = GN != 0 || PG;  // (the kernel passes its slice of the global scratch)
   template <int HP>
   __device__ __forceinline__ static void edm(const EdmDev& W, const Graph& mg, float* net, const float* sZ, float* sEps,
                                              float* sMean, float t_val, int tid STAMP_DECL, float* gnode) {
@@ -337,16 +338,16 @@ struct V8T {
                                                const float* dpred_ext, float* gnode, const float* dz_ext) {
 #ifdef GAUDI_STAMPS
     (void)dz_ext;  // (the stamped diagnostic build times the fused step only)
-    w8::guidance_update<HP, SP, MR, GN>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
-                                        mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext, GN ? uni(gnode) : nullptr);
+    w8::guidance_update<HP, SP, MR, GN, PG>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, sigma, target_w, scale, pred_out, readout_div, stash,
+                                            mg.pubx, mg.pub_ch, tid STAMP_ARGS, phase, dpred_ext, (GN || PG) ? uni(gnode) : nullptr);
 #else
     (void)sTmp;
-    w8::PredSmem<HP, SP, GN> sm;
+    w8::PredSmem<HP, SP, GN, PG> sm;
     sm.carve(net, mg.N, mg.S, mg.pubx, gnode);
-    if (phase != 2) pred_fwd8_call<HP, SP, MR, GN, kFL>(W, gargs(mg), t_val, stash, readout_div, gnode);
+    if (phase != 2) pred_fwd8_call<HP, SP, MR, GN, kFL, PG>(W, gargs(mg), t_val, stash, readout_div, gnode);
     w8::guidance_seed(W, sm, target_w, scale, pred_out, tid, phase, dpred_ext);
     if (phase == 1) return;
-    pred_bwd8_call<HP, SP, MR, GN, kFL>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0, gnode);
+    pred_bwd8_call<HP, SP, MR, GN, kFL, PG>(W, gargs(mg), stash, readout_div, phase == 2 ? 1 : 0, gnode);
     if (dz_ext != nullptr) {  // + the target's direct dependence on z (callback launches are never packed: slot n = node n)
       for (int e = tid; e < mg.N * mg.D; e += kThreads) sGrad[e] += dz_ext[e];
       __syncthreads();
@@ -358,7 +359,7 @@ struct V8T {
   __device__ __forceinline__ static void pred_entry(const PredDev& W, const Graph& mg, float* net, float* sZ, float* sGrad,
                                                     float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                     float* pred_out, float readout_div, float* stash, int tid STAMP_DECL, float* gnode) {
-    w8::predictor_entry<HP, SP, MR, GN>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
+    w8::predictor_entry<HP, SP, MR, GN, PG>(W, mg, net, sZ, sGrad, sTmp, sMean, t_val, dpred, want_grad, pred_out, readout_div, stash, mg.pubx,
                             mg.pub_ch, tid STAMP_ARGS, gnode);
   }
 };
@@ -703,6 +704,9 @@ inline constexpr sampler_fn sampler_kernel8m = &sampler_kernel_v<V8T<SP, true>, 
 // several rounds of edge tiles in the predictor)
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8g = &sampler_kernel_v<V8T<1, true, 1>, HPE, HPP>;
+// ... wide groups on the FULL ring: several rounds of edge tiles, the predictor's fifth node buffer in the global scratch (kern8mp_*.hip)
+template <int HPE, int HPP>
+inline constexpr sampler_fn sampler_kernel8mp = &sampler_kernel_v<V8T<1, true, 0, false, true>, HPE, HPP>;
 // ... of which P and Q stay in LDS (kern8gp_*.hip: taken where that plan fits)
 template <int HPE, int HPP>
 inline constexpr sampler_fn sampler_kernel8gp = &sampler_kernel_v<V8T<1, true, 2>, HPE, HPP>;

@@ -12,8 +12,14 @@ namespace w8 {
 
 // GN: the five node buffers live in a per-workgroup global scratch (w8_edm.h: NetSmem); the publish buffer of the reverse
 // pass is then [ring | pub] -- split forms only
-template <int HP, int SP = 0, int GN = 0>
+// PG (round 6, wide groups): ONE of the five node buffers -- b4: the second partial edge->node sums of the forward pass, dnpre / dQ in
+// the reverse pass -- lives in the workgroup's global scratch, everything else as in the resident kernels (GN = 0).  Two cata-11
+// molecules per workgroup (22 node slots, 256 edge slots) then fit beside the FULL weight ring at the default widths, where five
+// resident buffers leave room for the half ring only (two trips per K chunk: -6.6 % measured on pairs that fit both,
+// tools/ring_mode_ab.sh).
+template <int HP, int SP = 0, int GN = 0, bool PG = false>
 struct PredSmem {
+  static_assert(!(PG && GN != 0), "PG is a variant of the resident kernels");
   static_assert(!GN || SP != 0, "global node buffers: split edge GEMMs only (the fp32 form's publish buffer starts in b0 / b1)");
   static constexpr bool kGlobalNodes = GN != 0;
   float *b2, *b3, *b4;            // [N][HP+4] node buffers (roles change per phase, see below)
@@ -30,19 +36,19 @@ struct PredSmem {
   float* vec;                     // [10*HP] the current layer's vectors (cr,cd,b1,b2,wa,bc1,wc2,bn1,bn2,ba)
   float* hk = nullptr;            // kept split copy of h (w8_nodes_f16.h: node_ctx_keep), behind the whole plan; nullptr: none
   __host__ __device__ static int floats(int N, int S, int pubx) {
-    return EdgeRing<HP, SP>::kFloats + (GN ? gn_lds_buffers(GN) : 5) * N * (HP + 4) + pubx + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * HP;
+    return EdgeRing<HP, SP>::kFloats + (GN ? gn_lds_buffers(GN) : PG ? 4 : 5) * N * (HP + 4) + pubx + 12 * N + 2 * align4(N) + 96 + S * 10 + 32 + 10 * HP;
   }
   // the publish buffer of the reverse pass (du of every slot, pub_ch feature tiles at a time)
   __device__ __forceinline__ float* publish() const { return GN ? ring : b0; }
   __device__ void carve(float* base, int N, int S, int pubx, float* gnode = nullptr) {
     constexpr int LD = HP + 4;
     if (SP == 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // fp32 form: the ring stays busy across the publish phase
-    if (GN) gnode = assume_global(gnode);
+    if (GN || PG) gnode = assume_global(gnode);
     float*& nb = GN ? gnode : base;
     // (GN = 2, round 6: P = b1 and Q = b2 -- what the edge phases of both passes gather from -- stay in LDS, w8_edm.h: gn_lds_buffers)
     if (GN == 2) { b2 = base; base += N * LD; } else { b2 = nb; nb += N * LD; }
     b3 = nb; nb += N * LD;
-    b4 = nb; nb += N * LD;
+    if (PG) { b4 = gnode; gnode += N * LD; } else { b4 = nb; nb += N * LD; }
     b0 = nb; nb += N * LD;
     if (GN == 2) { b1 = base; base += N * LD; } else { b1 = nb; nb += N * LD; }
     if (SP != 0) { ring = base; base += EdgeRing<HP, SP>::kFloats; }  // N * LD * 4 bytes is a multiple of 16: units stay aligned
@@ -89,8 +95,8 @@ __host__ __device__ inline int pub_chunk_tiles(int S, long long avail_floats, in
 // MR: the kernel takes graphs of more than one round of eight edge tiles (more than 128 slots).  A separate instantiation: the
 // round loops (and the second copy of the reverse chain that parks du in the stash) cost the single-round kernels 2-4 % when
 // they live in the same function (hipcc's register allocation of the out-of-line phases changes), measured on C3.
-template <int HP, int SP = 0, bool MR = false, int GN = 0, bool FL = false>
-__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP, GN>& sm, const float* sZ,
+template <int HP, int SP = 0, bool MR = false, int GN = 0, bool FL = false, class SM = PredSmem<HP, SP, GN>>
+__device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& mg, const SM& sm, const float* sZ,
                                              float t_val, float* stash, float readout_div, int tid STAMP_DECL) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -312,8 +318,8 @@ __device__ __forceinline__ void pred_forward(const PredDev& W, const MolGraph& m
 //                          B4 = b4: npre (stash) -> dnpre -> dQ
 // pub_ch = 16-feature tiles of du published per chunk into [b0 | b1 | pub] (row = 16 pub_ch + 4 floats per slot)
 // ---------------------------------------------------------------------------------------------
-template <int HP, int SP = 0, bool MR = false, int GN = 0, bool FL = false>
-__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const PredSmem<HP, SP, GN>& sm, const float* stash,
+template <int HP, int SP = 0, bool MR = false, int GN = 0, bool FL = false, class SM = PredSmem<HP, SP, GN>>
+__device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& mg, const SM& sm, const float* stash,
                                               float* sGrad, float readout_div, int pub_ch, int tid STAMP_DECL, const float* sZin = nullptr) {
   constexpr int LD = HP + 4;
   constexpr int T = HP / 16;
@@ -685,13 +691,13 @@ __device__ __forceinline__ void pred_backward(const PredDev& W, const MolGraph& 
 }
 
 // unit-test entry: pred (and optionally grad into sGrad) for z in sZ
-template <int HP, int SP = 0, bool MR = false, int GN = 0>
+template <int HP, int SP = 0, bool MR = false, int GN = 0, bool PG = false>
 __device__ __forceinline__ void predictor_entry(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, const float* dpred, bool want_grad,
                                                 float* pred_out, float readout_div, float* stash, int pubx, int pub_ch, int tid STAMP_DECL,
                                                 float* gnode = nullptr) {
   (void)sTmp; (void)sMean;
-  PredSmem<HP, SP, GN> sm;
+  PredSmem<HP, SP, GN, PG> sm;
   sm.carve(net, mg.N, mg.S, pubx, gnode);
   pred_forward<HP, SP, MR, GN>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);
   if (tid < W.K) {
@@ -710,7 +716,7 @@ __device__ __forceinline__ void guidance_apply(const MolGraph& mg, float* sZ, fl
 // guidance of one reverse step (en_diffusion.py:899-920): z_s <- z_s - sigma * P(clip(grad))
 // phase 0: fused (target linear in pred: dT/dpred = target_w);  phase 1: predictor forward only, pred -> pred_out
 // (the host evaluates an arbitrary target on it);  phase 2: reverse pass + update with dT/dpred = dpred_ext.
-template <int HP, int SP = 0, bool MR = false, int GN = 0>
+template <int HP, int SP = 0, bool MR = false, int GN = 0, bool PG = false>
 __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph& mg, float* net, float* sZ, float* sGrad,
                                                 float* sTmp, float* sMean, float t_val, float sigma, const float* target_w,
                                                 float scale, float* pred_out, float readout_div, float* stash, int pubx,
@@ -718,7 +724,7 @@ __device__ __forceinline__ void guidance_update(const PredDev& W, const MolGraph
                                                 float* gnode = nullptr) {
   (void)sTmp;
   const int N = mg.N, D = mg.D;
-  PredSmem<HP, SP, GN> sm;
+  PredSmem<HP, SP, GN, PG> sm;
   sm.carve(net, N, mg.S, pubx, gnode);
   sm.hk = lds_at(mg.hk);
   if (phase != 2) pred_forward<HP, SP, MR, GN>(W, mg, sm, sZ, t_val, stash, readout_div, tid STAMP_ARGS);

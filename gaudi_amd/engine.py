@@ -412,11 +412,12 @@ class Engine:
         on 8 waves, the V4G kernels on 4 -- kernel_variant() tells which)."""
         v = C.c_int32()
         self._check(self.lib.gaudi_node_buffers(self.h, C.byref(v)), "gaudi_node_buffers")
-        return bool(v.value)
+        return v.value in (1, 2)
 
     def node_buffers_form(self) -> int:
         """0: the most recent call kept its node buffers in LDS; 1: in a global scratch; 2: in a global scratch except P and Q, which
-        stayed in LDS (8-wave kernels, round 6: kern8gp_*.hip -- taken where that plan fits)."""
+        stayed in LDS (8-wave kernels, round 6: kern8gp_*.hip -- taken where that plan fits); 3: in LDS except ONE of the predictor's
+        five (wide groups on the full weight ring, round 6: kern8mp_fused.hip)."""
         v = C.c_int32()
         self._check(self.lib.gaudi_node_buffers(self.h, C.byref(v)), "gaudi_node_buffers")
         return int(v.value)

@@ -260,7 +260,9 @@ int gaudi_edge_math(const gaudi_handle* h, int32_t* configured, int32_t* last_ca
  * scratch -- molecules beyond the LDS limit (about 22 graph nodes at the default widths; the reference has no cap,
  * sampling_edm.py:172-209): the V8G kernels (8 waves, round 4) or, for graphs outside the 8-wave kernels' limits and with
  * GAUDI_GN8=0, the V4G kernels (4 waves; gaudi_kernel_variant tells which); 2 = the V8G kernels' hybrid form (round 6): the global
- * scratch holds three of the five buffers, P and Q stay in LDS (taken where that plan fits; GAUDI_GN8_PQ=0 turns it off). */
+ * scratch holds three of the five buffers, P and Q stay in LDS (taken where that plan fits; GAUDI_GN8_PQ=0 turns it off); 3 = a WIDE
+ * group (two molecules per workgroup) on the full weight ring: everything in LDS except one of the predictor's five buffers
+ * (round 6; GAUDI_WIDE_FULL=0: the half ring with all five in LDS, as in round 5 -- the same bits). */
 int gaudi_node_buffers(const gaudi_handle* h, int32_t* last_call);
 /* Workgroups the most recent kernel launch of the handle ran: the molecules of the call (or of its last sub-batch), or the
  * groups they were packed into; node_slots (may be NULL): node slots per workgroup -- the call's N, or more when the launch

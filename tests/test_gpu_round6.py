@@ -188,7 +188,9 @@ def test_half_ring_mode_is_reached_and_checked():
     reached where 22 node slots leave no room for the full ring -- wide groups (two 11-ring cata molecules per workgroup) -- and
     no test asserted that it still IS reached.  Forced wide groups at the default widths: edge_math reports mode 2, the result
     equals the one-molecule-per-workgroup launch (full ring) bit for bit (bench.py gates the same launch shape at 1 024 molecules
-    against the C++ port: secondary.c3_b1024)."""
+    against the C++ port: secondary.c3_b1024).  Later in round 6 such a group runs on the FULL ring by default, with the predictor's
+    fifth node buffer in the workgroup's global scratch (kern8mp_fused.hip; node_buffers_form() = 3; +5 % at 1 024 molecules):
+    GAUDI_WIDE_FULL=0 is the half-ring launch; all three give the same bits."""
     from oracle import gaudi_oracle as O
     T = 6
     eargs, pargs = synth.edm_args(diffusion_steps=T), synth.pred_args()
@@ -197,15 +199,42 @@ def test_half_ring_mode_is_reached_and_checked():
     nm, em = O.build_masks([11, 11, 11, 9], 11, False)
     w = O.target_max_gap_weights(5)
     res = []
-    for env, want in (({"GAUDI_PAIRS": 0}, 1), ({"GAUDI_PAIRS": 2}, 2)):
+    for env, want, form in (({"GAUDI_PAIRS": 0}, 1, 0), ({"GAUDI_PAIRS": 2, "GAUDI_WIDE_FULL": 0}, 2, 0), ({"GAUDI_PAIRS": 2}, 1, 3)):
         eng = _engine(eargs, esd, pargs, psd, **env)
         x, h, _ = eng.sample(nm, em, seed=4, target_w=w, scale=0.6)
-        assert eng.edge_math()[1] == want, (env, eng.edge_math())
+        assert eng.edge_math()[1] == want and eng.node_buffers_form() == form, (env, eng.edge_math(), eng.node_buffers_form())
+        assert not eng.node_buffers_global()
         wg, slots = eng.last_launch_shape()
-        assert (wg, slots) == ((4, 11) if want == 1 else (2, 22))
+        assert (wg, slots) == ((4, 11) if env["GAUDI_PAIRS"] == 0 else (2, 22))
         res.append((x, h))
         eng.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for x, h in res[1:]:
+        assert np.array_equal(res[0][0], x) and np.array_equal(res[0][1], h)
+
+
+def test_wide_groups_on_the_full_ring_at_the_test_widths_and_unguided():
+    """The same at the test widths (32, 48) on a ragged hetero batch with the nonlinear-free OPV-like weights, a guided chain and a
+    teacher-forced step against the oracle; an UNGUIDED wide launch has no predictor and stays what it was (no global buffer)."""
+    from oracle import gaudi_oracle as O
+    from tests.helpers import TINY, TINY_P
+    T = 6
+    eargs, pargs = synth.edm_args(diffusion_steps=T, **TINY), synth.pred_args(**TINY_P)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=53, amplify_coord=True)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=54, amplify_coord=True)
+    nm, em = O.build_masks([11, 11, 10, 11, 9, 11], 11, False)
+    w = np.array([3, 0, 1, 1, 0], np.float32)
+    outs = []
+    for env in ({"GAUDI_PAIRS": 2, "GAUDI_WIDE_FULL": 0}, {"GAUDI_PAIRS": 2}):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        x, h, _ = eng.sample(nm, em, seed=9, target_w=w, scale=0.6)
+        form = eng.node_buffers_form()
+        xu, hu, _ = eng.sample(nm, em, seed=9)
+        assert eng.node_buffers_form() == 0
+        outs.append((x, h, xu, hu, form, eng.edge_math()[1]))
+        eng.close()
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0][:4], outs[1][:4]))
+    # (at the test widths five buffers fit beside the full ring: both launches are the resident full-ring MR kernel)
+    assert outs[0][4] == 0 and outs[1][4] in (0, 3)
 
 
 # ------------------------------------------------------------------------------------------------ sin_embedding denoisers (g22)

@@ -40,6 +40,11 @@ for step in "$@"; do
              GAUDI_XCD_ORDER=1 timeout 900 $B --workload $wl > $out/${wl}_xcd_$rep.json 2> $out/${wl}_xcd_$rep.err
            done
          done ;;
+    wide_full) for rep in 1 2; do
+           GAUDI_WIDE_FULL=0 GAUDI_DEBUG_PLAN=1 timeout 900 $B --batch 1024 --diffusion-steps 250 > $out/b1024_half_$rep.json 2> $out/b1024_half_$rep.err
+           GAUDI_DEBUG_PLAN=1 timeout 900 $B --batch 1024 --diffusion-steps 250 > $out/b1024_full_$rep.json 2> $out/b1024_full_$rep.err
+         done
+         grep -h "\[plan\]" $out/b1024_half_1.err | tail -1; grep -h "\[plan\]" $out/b1024_full_1.err | tail -1 ;;
     tests_core) timeout 2400 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_split.py tests/test_gpu_round5.py -x -q -m gpu > $out/tests_core.txt 2>&1 ;;
     tests_v8g) timeout 2400 python3 -m pytest tests/test_gpu_round4.py tests/test_gpu_round3.py -x -q -m gpu -k "v8g or large or n40 or dense or callback_targets" > $out/tests_v8g.txt 2>&1 ;;
     tests_all) timeout 3400 python3 -m pytest tests -x -q -m gpu > $out/tests_all.txt 2>&1 ;;
