@@ -431,6 +431,7 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
     em_mode = eng.edge_math()[1]  # 0 fp32 instructions, 1 split operands (full LDS weight ring), 2 split (half ring)
     variant = "w4" if wv == 4 else ("w8s" if em_mode else "w8")
     v8g = wv == 8 and eng.node_buffers_global()  # molecules beyond the LDS limit on the 8-wave kernels (node buffers in global memory)
+    nb_form = eng.node_buffers_form()  # 2: V8G with P / Q in LDS; 3: a wide group on the full ring, one predictor buffer in global memory
     # workgroups of the launches that actually ran (molecules, or the groups the call packed them into): the issued-instruction
     # model below must describe THAT launch, so the host-side plan is only used when it agrees with it
     run_groups, run_slots = eng.last_launch_shape()
@@ -523,7 +524,8 @@ def run_workload(a, eng_cache, workload, B, steps, warmup, rank, world, dev, bac
                      "clock_mhz": clock_mhz or None, "nominal_clock_mhz": NOMINAL_CLOCK_MHZ,
                      "frac_at_clock": (frac * NOMINAL_CLOCK_MHZ / clock_mhz) if clock_mhz else None,
                      "parity_rel_err": gate_out["rel_err"] if gate_out is not None else None,
-                     "kernel": "sampler_kernel_v<V8T<1,true,true>,192,%s> (V8G: 8 waves, node buffers in a per-workgroup global scratch, several rounds of edge tiles)" % ("208" if guided else "0") if v8g else
+                     "kernel": "sampler_kernel_v<V8T<1,true,%d>,192,%s> (V8G: 8 waves, node buffers in a per-workgroup global scratch%s, several rounds of edge tiles)" % (nb_form, "208" if guided else "0", " except P and Q" if nb_form == 2 else "") if v8g else
+                               "sampler_kernel_v<V8T<1,true,0,false,true>,192,208> (wide groups on the full ring: several rounds of edge tiles, one of the predictor's five node buffers in a per-workgroup global scratch)" if nb_form == 3 else
                                ("sampler_kernel_v<%s%s,192,%s>" % ({"w4": "V4", "w8": "V8", "w8s": "V8H" if em_mode == 2 else "V8S"}[variant],
                                                                     " (MR: several rounds of edge tiles)" if guided and variant != "w4" and int(np.max(units)) > 8 else
                                                                     " (FR instantiation: more than 16 node slots, kern8s2_*.hip)" if variant == "w8s" and em_mode == 1 and run_slots > 16 else "",
