@@ -1266,10 +1266,16 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
     // (pairs == 1, the default: when the batch holds at least two molecules per CU AND the classic shape packs next to nothing --
     // cata molecules fill their N slots; a hetero batch whose small molecules already share workgroups gains nothing from the
     // second round: C4 -0.9 %, C3 at 1 024 molecules +2.6 %, C2 at 1 024 +6.7 % with the fp16-pair node GEMMs, profiles/r05c_*)
+    // Round 6: "pays" is decided by ROUNDS of workgroups on the chip -- a workgroup of two molecules takes 1.81 x one molecule's time
+    // (111.5 against 2 x 30.8 ms per launch, profiles/r06h_wide_pairs*), so pairs win where they save enough rounds: 257-512 and
+    // 769-1024 molecules on 256 CUs (2 -> 1.8 and 4 -> 3.6 round-times), not 513-768 (3 -> 3.6).  Same bits either way.
     bool want_wide = h->pairs == 2;
-    if (h->pairs == 1 && B >= 2 * h->num_cus) {
-      pack_groups(B, N, node_mask, edge_mask, M, pk, N, w8::kWaves);
-      want_wide = (long long)pk.G * 10 >= (long long)B * 9;
+    if (h->pairs == 1 && B > h->num_cus) {
+      const long long cus = std::max(1, h->num_cus), r_solo = (B + cus - 1) / cus, r_wide = ((B + 1) / 2 + cus - 1) / cus;
+      if (r_wide * 185 < r_solo * 100) {
+        pack_groups(B, N, node_mask, edge_mask, M, pk, N, w8::kWaves);
+        want_wide = (long long)pk.G * 10 >= (long long)B * 9;
+      }
     }
     if (want_wide)
       for (int ng = std::min(2 * N, 32); ng > N; --ng) {
