@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <queue>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -101,6 +103,7 @@ struct gaudi_handle {
   bool gn8 = true;            // GAUDI_GN8=0: molecules beyond the LDS limit go to the 4-wave V4G kernels, as in round 3
   bool force_gn8 = false;     // GAUDI_FORCE_GN8=1: V8G whenever it can run (test knob)
   bool pack = true;           // several small molecules per workgroup in sampling calls (GAUDI_PACK=0: off)
+  int pairs_cap = -1;         // GAUDI_PAIRS_CAP: two-molecule groups of a wide launch (-1: chosen by wide_plan below; experiments)
   int pairs = 1;              // wide groups (more node slots than a molecule has, two rounds of edge tiles: e.g. two 11-ring cata
                               // molecules per workgroup): 0 = never, 1 = when the batch holds at least two molecules per CU and the
                               // classic packing shares next to nothing (default since round 5: the fp16-pair node GEMMs made the
@@ -1099,8 +1102,10 @@ static std::vector<std::vector<int>> used_nodes(int B, int N, const float* node_
 // narrow: NG may be SMALLER than N (every molecule must then fit NG slots on its own: the caller checks) -- rows of the global
 // arrays keep the stride N.  maxcomp: molecules per group (1: every molecule alone, its nodes compacted to the front slots).
 // molmap: molecule -> index the noise is keyed with (a bucket of a larger request), or nullptr.
+// max_multi: groups that may hold more than one molecule (a MIXED wide launch: pairs first, the rest alone in the same kernel).
 static void pack_groups(int B, int N, const float* node_mask, const float* edge_mask, const Meta8& M, Pack& pk, int NG = 0,
-                        int TG = w8::kWaves, bool narrow = false, int maxcomp = kMaxComp, const int32_t* molmap = nullptr) {
+                        int TG = w8::kWaves, bool narrow = false, int maxcomp = kMaxComp, const int32_t* molmap = nullptr,
+                        int max_multi = INT_MAX) {
   if (NG < N && !narrow) NG = N;
   const std::vector<std::vector<int>> used = used_nodes(B, N, node_mask, edge_mask);
   struct Group {
@@ -1108,12 +1113,14 @@ static void pack_groups(int B, int N, const float* node_mask, const float* edge_
     int nodes = 0, tiles = 0;
   };
   std::vector<Group> groups;
+  int multi = 0;
   for (int b : M.order) {  // heaviest first
     const int nn = (int)used[b].size(), nt = M.ntiles[b];
     Group* fit = nullptr;
     for (Group& g : groups)
-      if ((int)g.mols.size() < maxcomp && g.nodes + nn <= NG && g.tiles + nt <= TG) {
+      if ((int)g.mols.size() < maxcomp && g.nodes + nn <= NG && g.tiles + nt <= TG && (g.mols.size() > 1 || multi < max_multi)) {
         fit = &g;
+        if (g.mols.size() == 1) ++multi;
         break;
       }
     if (!fit) {
@@ -1269,14 +1276,49 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
     // Round 6: "pays" is decided by ROUNDS of workgroups on the chip -- a workgroup of two molecules takes 1.81 x one molecule's time
     // (111.5 against 2 x 30.8 ms per launch, profiles/r06h_wide_pairs*), so pairs win where they save enough rounds: 257-512 and
     // 769-1024 molecules on 256 CUs (2 -> 1.8 and 4 -> 3.6 round-times), not 513-768 (3 -> 3.6).  Same bits either way.
+    // MIXED launches: with p two-molecule groups and B - 2 p single ones in the same wide kernel (heaviest first: the pairs), the
+    // makespan on the chip's CUs is what a list schedule gives -- wide_plan tries p = every multiple of the CU count and "all pairs",
+    // and takes the wide kernel where its best beats ceil(B / CUs) rounds of the one-molecule kernel: 640 molecules run as 256 pairs +
+    // 128 single ones (2.84 round-times against 3), 1 024 as 512 pairs, 256 one per workgroup.
     bool want_wide = h->pairs == 2;
+    int max_multi = INT_MAX;
     if (h->pairs == 1 && B > h->num_cus) {
-      const long long cus = std::max(1, h->num_cus), r_solo = (B + cus - 1) / cus, r_wide = ((B + 1) / 2 + cus - 1) / cus;
-      if (r_wide * 185 < r_solo * 100) {
+      const int cus = std::max(1, h->num_cus);
+      const double solo = (double)((B + cus - 1) / cus);
+      auto makespan = [&](int p) {  // list schedule of p jobs of kPair and B - 2 p jobs of kAlone on `cus` machines, longest first
+        // (measured at the default widths, profiles/r06k_wide_group_rule.txt: a pair 2 228 ms, a molecule alone in the wide kernel 1 325 ms,
+        // the one-molecule kernel 1 236 ms per 1 000 steps)
+        const double kPair = 1.81, kAlone = 1.07;
+        std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+        for (int c = 0; c < cus; ++c) free_at.push(0.0);
+        double end = 0.0;
+        auto run = [&](int n, double cost) {
+          for (int k = 0; k < n; ++k) {
+            const double t = free_at.top() + cost;
+            free_at.pop();
+            free_at.push(t);
+            end = std::max(end, t);
+          }
+        };
+        run(p, kPair);
+        run(B - 2 * p, kAlone);
+        return end;
+      };
+      double best = solo * 0.995;  // (the one-molecule kernel unless the wide one is clearly ahead)
+      int best_p = -1;
+      for (int p = cus; p <= B / 2 + cus - 1; p += cus) {
+        const int pp = std::min(p, B / 2);
+        const double m = makespan(pp);
+        if (m < best) { best = m; best_p = pp; }
+      }
+      if (h->pairs_cap >= 0) best_p = std::min(h->pairs_cap, B / 2);
+      if (best_p >= 0) {
         pack_groups(B, N, node_mask, edge_mask, M, pk, N, w8::kWaves);
         want_wide = (long long)pk.G * 10 >= (long long)B * 9;
+        max_multi = best_p;
       }
     }
+    if (want_wide && h->pairs_cap >= 0) max_multi = h->pairs_cap;  // (experiments)
     if (want_wide)
       for (int ng = std::min(2 * N, 32); ng > N; --ng) {
         const long long cap = 160 * 1024 / 4 - 64;
@@ -1287,8 +1329,8 @@ static int stage_graph8(gaudi_handle* h, int B, int N, const float* node_mask, c
     bool taken = false;
     for (const Cand& cd : cands) {
       const bool wide = cd.NG > N;
-      pack_groups(B, N, node_mask, edge_mask, M, pk, cd.NG, cd.TG);
-      if (pk.G >= B) continue;
+      pack_groups(B, N, node_mask, edge_mask, M, pk, cd.NG, cd.TG, false, kMaxComp, nullptr, wide ? max_multi : INT_MAX);
+      if (pk.G >= B && !(wide && h->pairs_cap == 0)) continue;  // (GAUDI_PAIRS_CAP=0: every molecule alone in the wide kernel -- diagnostic)
       Meta8 M2;
       rc = build_meta8(pk.G, cd.NG, pk.umask.data(), pk.uemask.data(), M2, err, wide ? 0 : M.S, pk.align.data());
       if (rc != GAUDI_OK) continue;
@@ -1538,6 +1580,7 @@ int gaudi_create(int device, gaudi_handle** out) {
   if (const char* v = getenv("GAUDI_KEEP_H")) h->keep_h = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_FAMILY_SPLIT")) h->family_split = atoi(v) != 0;
   if (const char* v = getenv("GAUDI_PAIRS")) h->pairs = atoi(v);
+  if (const char* v = getenv("GAUDI_PAIRS_CAP")) h->pairs_cap = atoi(v);
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cus = cus;

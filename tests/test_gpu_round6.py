@@ -501,3 +501,29 @@ def test_sin_embedding_other_widths_guided_as_two_launches(nf):
     xo, ho, _ = O.sample(esd, eargs, nm3, em_flat, noise, std=1.0, pred_sd=psd, pcfg=pargs, target_w=w, scale=0.6)
     assert rel_err(x, xo) < 1e-4 and np.array_equal(h, ho)
     eng.close()
+
+
+def test_mixed_wide_launch_pairs_first_then_single_molecules():
+    """Batch sizes between the rounds of the chip's CUs: 640 cata molecules on 256 CUs run as ONE launch of 256 two-molecule groups and
+    128 single ones in the same wide kernel (a list schedule of 2.9 round-times against 3 for one molecule per workgroup and 3.6 for
+    320 pairs: gaudi_hip.hip, stage_graph8) -- and every molecule gets the bits it gets alone in its workgroup."""
+    from oracle import gaudi_oracle as O
+    from tests.helpers import TINY, TINY_P
+    T = 3
+    eargs, pargs = synth.edm_args(diffusion_steps=T, **TINY), synth.pred_args(**TINY_P)
+    esd = synth.synth_edm_state_dict(eargs, 1, seed=81)
+    psd = synth.synth_predictor_state_dict(pargs, 1, 5, seed=82)
+    B = 640
+    nm, em = O.build_masks([11] * B, 11, False)
+    w = O.target_max_gap_weights(5)
+    res = []
+    for env, groups in (({"GAUDI_PAIRS": 0}, B), ({}, 384), ({"GAUDI_PAIRS": 2}, 320)):
+        eng = _engine(eargs, esd, pargs, psd, **env)
+        x, h, _ = eng.sample(nm, em, seed=6, target_w=w, scale=0.6)
+        wg, slots = eng.last_launch_shape()
+        # (384 on the 256 CUs of an MI355X; the forced forms do not depend on the CU count)
+        assert wg == groups or (not env and wg in (B, 320)), (env, wg, slots)
+        res.append((x, h))
+        eng.close()
+    for x, h in res[1:]:
+        assert np.array_equal(res[0][0], x) and np.array_equal(res[0][1], h)
